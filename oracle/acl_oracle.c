@@ -1,0 +1,961 @@
+/* acl_oracle.c -- TEST INFRASTRUCTURE, NOT PART OF THE PRODUCT. See acl_oracle.h.
+ *
+ * Scalar restatement of the reference CPU decoder. Every function cites the reference lines it follows
+ * (paths relative to /root/reference/includes/acl). fp32 arithmetic is written one IEEE operation at a
+ * time in the reference's order; compile with -ffp-contract=off so none of it is fused.
+ */
+#include "acl_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * Binary layout (core/impl/compressed_headers.h:51-131,171-197,219-325,404-439)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t size, hash; } raw_buffer_header_t;
+typedef struct { uint32_t tag; uint16_t version; uint8_t algorithm_type, track_type; uint32_t num_tracks, num_samples; float sample_rate; uint32_t misc_packed; } tracks_header_t;
+typedef struct { uint32_t animated_pose_bit_size, animated_rotation_bit_size, animated_translation_bit_size, segment_data; } segment_header_t;
+typedef struct
+{
+	uint32_t num_segments, num_animated_variable_sub_tracks, num_animated_rotation_sub_tracks, num_animated_translation_sub_tracks, num_animated_scale_sub_tracks;
+	uint32_t num_constant_rotation_samples, num_constant_translation_samples, num_constant_scale_samples;
+	uint32_t database_header_offset, segment_headers_offset, sub_track_types_offset, constant_track_data_offset, clip_range_data_offset;
+} transform_tracks_header_t;
+
+#define TAG_COMPRESSED_TRACKS 0xac11ac11u
+#define VERSION_FIRST 7
+#define VERSION_V02_01_99_1 9
+#define VERSION_LATEST 10
+#define TRACK_TYPE_QVVF 12
+#define ROTATION_DROP_W_VARIABLE 3
+#define VECTOR_VARIABLE 1
+
+static const tracks_header_t* get_tracks_header(const void* blob) { return (const tracks_header_t*)((const uint8_t*)blob + 8); }
+static const transform_tracks_header_t* get_transform_header(const void* blob) { return (const transform_tracks_header_t*)((const uint8_t*)blob + 32); }
+
+static int hdr_has_scale(const tracks_header_t* h) { return (h->misc_packed & 1u) != 0; }
+static uint32_t hdr_default_scale(const tracks_header_t* h) { return (h->misc_packed >> 1) & 1u; }
+static uint32_t hdr_scale_format(const tracks_header_t* h) { return (h->misc_packed >> 2) & 1u; }
+static uint32_t hdr_translation_format(const tracks_header_t* h) { return (h->misc_packed >> 3) & 1u; }
+static uint32_t hdr_rotation_format(const tracks_header_t* h) { return (h->misc_packed >> 4) & 15u; }
+static int hdr_has_database(const tracks_header_t* h) { return (h->misc_packed & (1u << 8)) != 0; }
+static int hdr_has_stripped_keyframes(const tracks_header_t* h) { return (h->misc_packed & (1u << 10)) != 0; }
+static int hdr_is_wrap_optimized(const tracks_header_t* h) { return (h->misc_packed & (1u << 30)) != 0; }
+
+static uint32_t load_u32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t load_u64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static float load_f32(const uint8_t* p) { float v; memcpy(&v, p, 4); return v; }
+static uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
+static uint64_t bswap64(uint64_t v) { return ((uint64_t)bswap32((uint32_t)v) << 32) | bswap32((uint32_t)(v >> 32)); }
+static float bits_to_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t float_to_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static const uint8_t* align_ptr(const uint8_t* base, const uint8_t* p, uint32_t alignment)
+{
+	/* blobs are 16 byte aligned, so aligning the offset from the blob start equals aligning the pointer */
+	const uint64_t offset = (uint64_t)(p - base);
+	return base + ((offset + (alignment - 1)) & ~(uint64_t)(alignment - 1));
+}
+
+/* core/bit_manip_utils.h:86-202 */
+static uint32_t count_set_bits(uint32_t v) { uint32_t c = 0; while (v) { v &= v - 1; c++; } return c; }
+static uint32_t count_leading_zeros(uint32_t v) { uint32_t c = 0; if (v == 0) return 32; while ((v & 0x80000000u) == 0) { v <<= 1; c++; } return c; }
+static uint32_t count_trailing_zeros(uint32_t v) { uint32_t c = 0; if (v == 0) return 32; while ((v & 1u) == 0) { v >>= 1; c++; } return c; }
+
+/* core/hash.h:86-99 */
+uint32_t aclo_hash32(const void* data, uint64_t size)
+{
+	const uint8_t* bytes = (const uint8_t*)data;
+	uint32_t acc = 2166136261u;
+	uint64_t i;
+	for (i = 0; i < size; ++i)
+		acc = (acc ^ bytes[i]) * 16777619u;
+	return acc;
+}
+
+uint32_t aclo_num_tracks(const void* blob) { return get_tracks_header(blob)->num_tracks; }
+uint32_t aclo_num_samples(const void* blob) { return get_tracks_header(blob)->num_samples; }
+float aclo_sample_rate(const void* blob) { return get_tracks_header(blob)->sample_rate; }
+
+/* compressed_tracks::get_looping_policy (core/impl/compressed_tracks.impl.h:140-147) */
+static int resolve_looping_policy(const tracks_header_t* header, int looping_policy)
+{
+	if (looping_policy != ACLO_LOOP_AS_COMPRESSED)
+		return looping_policy;
+	if (header->version <= VERSION_FIRST)
+		return ACLO_LOOP_CLAMP;
+	return hdr_is_wrap_optimized(header) ? ACLO_LOOP_WRAP : ACLO_LOOP_CLAMP;
+}
+
+/* compressed_tracks::get_finite_duration (core/impl/compressed_tracks.impl.h:102-122), calculate_finite_duration (core/impl/time_utils.impl.h:102-112) */
+float aclo_finite_duration(const void* blob, int looping_policy)
+{
+	const tracks_header_t* header = get_tracks_header(blob);
+	uint32_t num_samples = header->num_samples;
+	looping_policy = resolve_looping_policy(header, looping_policy);
+	if (looping_policy == ACLO_LOOP_WRAP && num_samples != 0)
+		num_samples++;
+	if (num_samples <= 1)
+		return 0.0f;
+	return (float)(num_samples - 1) / header->sample_rate;
+}
+
+/* compressed_tracks::is_valid (core/impl/compressed_tracks.impl.h:278-301) */
+int aclo_is_valid(const void* blob, uint64_t blob_size, int check_hash)
+{
+	const raw_buffer_header_t* buffer_header = (const raw_buffer_header_t*)blob;
+	const tracks_header_t* header;
+	if (blob == NULL)
+		return 1;
+	if (((uintptr_t)blob & 15u) != 0)
+		return 2;	/* Invalid alignment */
+	if (blob_size < 32 + sizeof(transform_tracks_header_t))
+		return 3;
+	header = get_tracks_header(blob);
+	if (header->tag != TAG_COMPRESSED_TRACKS)
+		return 4;	/* Invalid tag */
+	if (header->algorithm_type != 0)
+		return 5;	/* Invalid algorithm type */
+	if (header->version < VERSION_FIRST || header->version > VERSION_LATEST)
+		return 6;	/* Invalid algorithm version */
+	if (buffer_header->size > blob_size)
+		return 7;
+	if (check_hash && aclo_hash32((const uint8_t*)blob + 8, buffer_header->size - 8) != buffer_header->hash)
+		return 8;	/* Invalid hash */
+	/* scope of this restatement: qvvf tracks with the variable formats (decompression_settings.h:211-232) */
+	if (header->track_type != TRACK_TYPE_QVVF)
+		return 9;
+	if (header->num_tracks != 0 && (hdr_rotation_format(header) != ROTATION_DROP_W_VARIABLE || hdr_translation_format(header) != VECTOR_VARIABLE || (hdr_has_scale(header) && hdr_scale_format(header) != VECTOR_VARIABLE)))
+		return 10;
+	return 0;
+}
+
+void aclo_default_options(aclo_options* options)
+{
+	memset(options, 0, sizeof(*options));
+	options->looping_policy = ACLO_LOOP_AS_COMPRESSED;
+	options->normalization = ACLO_NORMALIZE_LERP_ONLY;		/* default_transform_decompression_settings (decompression_settings.h:227) */
+	options->per_track_rounding = 0;						/* decompression_settings.h:231 */
+	options->default_rotation_mode = ACLO_DEFAULT_CONSTANT;	/* core/track_writer.h:161-163 */
+	options->default_translation_mode = ACLO_DEFAULT_CONSTANT;
+	options->default_scale_mode = ACLO_DEFAULT_LEGACY;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Interpolation helpers (core/impl/interpolation_utils.impl.h)
+ * ---------------------------------------------------------------------------------------------- */
+float aclo_apply_rounding_policy(float alpha, int rounding_policy)
+{
+	/* :261-278 */
+	switch (rounding_policy)
+	{
+	default:
+	case ACLO_ROUND_NONE:
+	case ACLO_ROUND_PER_TRACK:
+		return alpha;
+	case ACLO_ROUND_FLOOR:
+		return 0.0f;
+	case ACLO_ROUND_CEIL:
+		return 1.0f;
+	case ACLO_ROUND_NEAREST:
+		return floorf(alpha + 0.5f);
+	}
+}
+
+static void find_samples_with_rate(uint32_t num_samples, float sample_rate, float sample_time, int rounding_policy, int looping_policy,
+	uint32_t* out_index0, uint32_t* out_index1, float* out_alpha)
+{
+	/* :143-201 (shared tail of :56-117) */
+	const uint32_t last_sample_index = num_samples - 1;
+	float sample_index = sample_time * sample_rate;
+	uint32_t sample_index0 = (uint32_t)sample_index;
+	const uint32_t next_sample_index = sample_index0 + 1;
+	uint32_t sample_index1;
+	float interpolation_alpha;
+
+	if (looping_policy == ACLO_LOOP_CLAMP)
+		sample_index1 = next_sample_index < last_sample_index ? next_sample_index : last_sample_index;
+	else
+	{
+		if (sample_index0 > last_sample_index)
+		{
+			/* sampling the repeating first sample with full weight */
+			sample_index = 0.0f;
+			sample_index0 = 0;
+			sample_index1 = 0;
+		}
+		else
+			sample_index1 = next_sample_index >= num_samples ? 0 : next_sample_index;
+	}
+
+	interpolation_alpha = sample_index - (float)sample_index0;
+
+	*out_index0 = sample_index0;
+	*out_index1 = sample_index1;
+	*out_alpha = aclo_apply_rounding_policy(interpolation_alpha, rounding_policy);
+}
+
+void aclo_find_linear_interpolation_samples_with_sample_rate(uint32_t num_samples, float sample_rate, float sample_time,
+	int rounding_policy, int looping_policy, uint32_t* out_index0, uint32_t* out_index1, float* out_alpha)
+{
+	find_samples_with_rate(num_samples, sample_rate, sample_time, rounding_policy, looping_policy, out_index0, out_index1, out_alpha);
+}
+
+void aclo_find_linear_interpolation_samples_with_duration(uint32_t num_samples, float duration, float sample_time,
+	int rounding_policy, int looping_policy, uint32_t* out_index0, uint32_t* out_index1, float* out_alpha)
+{
+	/* :56-117 */
+	const uint32_t last_sample_index = num_samples - 1;
+	float sample_rate;
+	if (duration == 0.0f)
+		sample_rate = 0.0f;
+	else if (looping_policy == ACLO_LOOP_CLAMP)
+		sample_rate = (float)last_sample_index / duration;
+	else
+		sample_rate = (float)num_samples / duration;
+	find_samples_with_rate(num_samples, sample_rate, sample_time, rounding_policy, looping_policy, out_index0, out_index1, out_alpha);
+}
+
+float aclo_find_linear_interpolation_alpha(float sample_index, uint32_t index0, uint32_t index1, int rounding_policy, int looping_policy)
+{
+	/* :224-253 */
+	float interpolation_alpha;
+	(void)looping_policy;
+
+	if (rounding_policy == ACLO_ROUND_FLOOR)
+		return 0.0f;
+	else if (rounding_policy == ACLO_ROUND_CEIL)
+		return 1.0f;
+	else if (index0 == index1)
+		return 0.0f;
+
+	if (index0 < index1)
+		interpolation_alpha = (sample_index - (float)index0) / (float)(index1 - index0);
+	else
+		interpolation_alpha = sample_index - (float)index0;
+
+	if (rounding_policy == ACLO_ROUND_NONE || rounding_policy == ACLO_ROUND_PER_TRACK)
+		return interpolation_alpha;
+	return floorf(interpolation_alpha + 0.5f);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Bit unpackers (math/vector4_packing.h)
+ * ---------------------------------------------------------------------------------------------- */
+void aclo_unpack_vector3_uXX(uint32_t num_bits, const uint8_t* data, uint32_t bit_offset, float out[3])
+{
+	/* :921-1035: three unaligned big-endian 32 bit windows, shift, mask, int -> float, scale by 1/(2^n - 1) */
+	const uint32_t bit_shift = 32 - num_bits;
+	const uint32_t mask = (1u << num_bits) - 1;
+	const float inv_max_value = num_bits == 0 ? 1.0f : (1.0f / (float)((1 << num_bits) - 1));
+	int c;
+	for (c = 0; c < 3; ++c)
+	{
+		const uint32_t byte_offset = bit_offset / 8;
+		const uint32_t window = bswap32(load_u32(data + byte_offset));
+		const uint32_t value = (window >> (bit_shift - (bit_offset % 8))) & mask;
+		out[c] = (float)value * inv_max_value;
+		bit_offset += num_bits;
+	}
+}
+
+void aclo_unpack_vector3_96(const uint8_t* data, uint32_t bit_offset, float out[3])
+{
+	/* :479-599: three big-endian IEEE floats starting at an arbitrary bit */
+	const uint32_t byte_offset = bit_offset / 8;
+	const uint32_t shift_offset = bit_offset % 8;
+	int c;
+	for (c = 0; c < 3; ++c)
+	{
+		uint64_t v = bswap64(load_u64(data + byte_offset + 4 * (uint32_t)c));
+		v <<= shift_offset;
+		v >>= 32;
+		out[c] = bits_to_float((uint32_t)v);
+	}
+}
+
+void aclo_unpack_vector3_u48(const uint8_t* data, float out[3])
+{
+	/* :628-653: three little-endian u16, scaled by 1/65535 */
+	int c;
+	for (c = 0; c < 3; ++c)
+	{
+		const uint32_t v = (uint32_t)data[c * 2] | ((uint32_t)data[c * 2 + 1] << 8);
+		out[c] = (float)v * (1.0f / 65535.0f);
+	}
+}
+
+void aclo_unpack_vector3_u24(const uint8_t* data, float out[3])
+{
+	/* :781-818: three u8, scaled by 1/255 */
+	int c;
+	for (c = 0; c < 3; ++c)
+		out[c] = (float)data[c] * (1.0f / 255.0f);
+}
+
+void aclo_memcpy_bits(void* dest, uint64_t dest_bit_offset, const void* src, uint64_t src_bit_offset, uint64_t num_bits)
+{
+	/* core/memory_utils.h:295-335: MSB-first bit copy */
+	uint8_t* d = (uint8_t*)dest;
+	const uint8_t* s = (const uint8_t*)src;
+	uint64_t i;
+	for (i = 0; i < num_bits; ++i)
+	{
+		const uint64_t sb = src_bit_offset + i, db = dest_bit_offset + i;
+		const uint8_t bit = (uint8_t)((s[sb >> 3] >> (7 - (sb & 7))) & 1u);
+		d[db >> 3] = (uint8_t)((d[db >> 3] & ~(0x80u >> (db & 7))) | (bit << (7 - (db & 7))));
+	}
+}
+
+void aclo_pack_vector3_uXX(const float in[3], uint32_t num_bits, uint8_t* out_data)
+{
+	/* math/vector4_packing.h:828-858 with pack_scalar_unsigned (math/scalar_packing.h:42-48): round half away from zero */
+	const float max_value = (float)((1u << num_bits) - 1);
+	uint64_t bit_offset = 0;
+	int c;
+	memset(out_data, 0, 16);
+	for (c = 0; c < 3; ++c)
+	{
+		const uint32_t q = (uint32_t)floorf(in[c] * max_value + 0.5f);
+		const uint32_t be = bswap32(q << (32 - num_bits));
+		aclo_memcpy_bits(out_data, bit_offset, &be, 0, num_bits);
+		bit_offset += num_bits;
+	}
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * seek_v0 (decompression/impl/decompression.transform.h:206-563)
+ * ---------------------------------------------------------------------------------------------- */
+static void get_segment_data(const void* blob, const transform_tracks_header_t* th, const segment_header_t* sh,
+	const uint8_t** out_format, const uint8_t** out_range, const uint8_t** out_animated)
+{
+	/* core/impl/compressed_headers.h:309-324 */
+	const uint8_t* base = (const uint8_t*)blob;
+	const uint8_t* format_per_track_data = (const uint8_t*)th + sh->segment_data;
+	const uint8_t* range_data = align_ptr(base, format_per_track_data + th->num_animated_variable_sub_tracks, 2);
+	const uint32_t range_data_size = th->num_segments > 1 ? 6 * th->num_animated_variable_sub_tracks : 0;
+	*out_format = format_per_track_data;
+	*out_range = range_data;
+	*out_animated = align_ptr(base, range_data + range_data_size, 4);
+}
+
+int aclo_seek(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, aclo_seek_result* out)
+{
+	const tracks_header_t* header = get_tracks_header(blob);
+	const transform_tracks_header_t* th = get_transform_header(blob);
+	const uint8_t* tbase = (const uint8_t*)th;
+	const int looping_policy = resolve_looping_policy(header, options->looping_policy);
+	const float clip_duration = aclo_finite_duration(blob, looping_policy);
+	const uint32_t num_segments = th->num_segments;
+	const int has_database = hdr_has_database(header);
+	const aclo_database* db = options->database;
+	const int has_stripped_keyframes = has_database || hdr_has_stripped_keyframes(header);
+	const uint32_t segment_header_size = has_stripped_keyframes ? 20u : 16u;
+	const uint8_t* segment_headers = tbase + th->segment_headers_offset;
+	uint32_t key_frame0, key_frame1, segment_key_frame0, segment_key_frame1;
+	uint32_t segment_index0 = 0, segment_index1 = 0;
+	float alpha;
+	const uint8_t* db_animated_track_data0 = NULL;
+	const uint8_t* db_animated_track_data1 = NULL;
+	const segment_header_t* segment_header0;
+	const segment_header_t* segment_header1;
+
+	memset(out, 0, sizeof(*out));
+	if (header->num_tracks == 0)
+		return 1;
+
+	/* :215-216 clamp (scalar_clamp = min(max(t, 0), duration)) */
+	sample_time = sample_time > 0.0f ? sample_time : 0.0f;
+	sample_time = sample_time < clip_duration ? sample_time : clip_duration;
+
+	/* :240 */
+	find_samples_with_rate(header->num_samples, header->sample_rate, sample_time, rounding_policy, looping_policy, &key_frame0, &key_frame1, &alpha);
+
+	if (num_segments == 1)
+	{
+		/* :267-371 */
+		if (has_stripped_keyframes)
+		{
+			uint32_t sample_indices0 = load_u32(segment_headers + 16);
+			uint32_t sample_indices1;
+			const float sample_index = alpha + (float)key_frame0;
+			uint64_t medium0 = 0, low0 = 0;
+			uint32_t candidates;
+
+			if (db != NULL)
+			{
+				const uint8_t* tracks_db_header = tbase + th->database_header_offset;
+				const uint8_t* db_clip_header = db->clip_segment_headers + load_u32(tracks_db_header);
+				const uint8_t* db_segment_headers = db_clip_header + 8;
+				medium0 = load_u64(db_segment_headers + 0);
+				low0 = load_u64(db_segment_headers + 8);
+				sample_indices0 |= (uint32_t)medium0;
+				sample_indices0 |= (uint32_t)low0;
+			}
+
+			candidates = sample_indices0 & (0xFFFFFFFFu << (31 - key_frame0));
+			key_frame0 = 31 - count_trailing_zeros(candidates);
+			candidates = sample_indices0 & (0xFFFFFFFFu >> key_frame1);
+			key_frame1 = count_leading_zeros(candidates);
+
+			alpha = aclo_find_linear_interpolation_alpha(sample_index, key_frame0, key_frame1, ACLO_ROUND_NONE, looping_policy);
+
+			sample_indices0 = load_u32(segment_headers + 16);
+			sample_indices1 = sample_indices0;
+
+			if (db != NULL)
+			{
+				const uint64_t bit0 = (uint64_t)1 << (31 - key_frame0);
+				const uint64_t bit1 = (uint64_t)1 << (31 - key_frame1);
+				if ((medium0 & bit0) != 0) { sample_indices0 = (uint32_t)medium0; db_animated_track_data0 = db->bulk_data[0] + (uint32_t)(medium0 >> 32); }
+				else if ((low0 & bit0) != 0) { sample_indices0 = (uint32_t)low0; db_animated_track_data0 = db->bulk_data[1] + (uint32_t)(low0 >> 32); }
+				if ((medium0 & bit1) != 0) { sample_indices1 = (uint32_t)medium0; db_animated_track_data1 = db->bulk_data[0] + (uint32_t)(medium0 >> 32); }
+				else if ((low0 & bit1) != 0) { sample_indices1 = (uint32_t)low0; db_animated_track_data1 = db->bulk_data[1] + (uint32_t)(low0 >> 32); }
+			}
+
+			segment_key_frame0 = count_set_bits(~(0xFFFFFFFFu >> key_frame0) & sample_indices0);
+			segment_key_frame1 = count_set_bits(~(0xFFFFFFFFu >> key_frame1) & sample_indices1);
+		}
+		else
+		{
+			segment_key_frame0 = key_frame0;
+			segment_key_frame1 = key_frame1;
+		}
+	}
+	else
+	{
+		/* :372-521 */
+		const uint8_t* segment_start_indices = tbase + 52;
+		const uint32_t approx_num_samples_per_segment = header->num_samples / num_segments;
+		const uint32_t approx_segment_index = key_frame0 / approx_num_samples_per_segment;
+		const uint32_t start_segment_index = approx_segment_index > 0 ? (approx_segment_index - 1) : 0;
+		const uint32_t end_segment_index = start_segment_index + 4;
+		uint32_t segment_index;
+
+		for (segment_index = start_segment_index; segment_index < end_segment_index; ++segment_index)
+		{
+			if (key_frame0 < load_u32(segment_start_indices + 4 * segment_index))
+			{
+				segment_index0 = segment_index - 1;
+				if (key_frame1 == 0)	/* wrapping is supported and we wrapped: use the first segment */
+					segment_index1 = 0;
+				else
+					segment_index1 = key_frame1 < load_u32(segment_start_indices + 4 * segment_index) ? segment_index0 : segment_index;
+				break;
+			}
+		}
+
+		segment_key_frame0 = key_frame0 - load_u32(segment_start_indices + 4 * segment_index0);
+		segment_key_frame1 = key_frame1 - load_u32(segment_start_indices + 4 * segment_index1);
+
+		if (has_stripped_keyframes)
+		{
+			const uint8_t* h0 = segment_headers + 20 * segment_index0;
+			const uint8_t* h1 = segment_headers + 20 * segment_index1;
+			uint32_t sample_indices0 = load_u32(h0 + 16);
+			uint32_t sample_indices1 = load_u32(h1 + 16);
+			const float sample_index = alpha + (float)key_frame0;
+			uint64_t medium0 = 0, medium1 = 0, low0 = 0, low1 = 0;
+			uint32_t candidates, clip_key_frame0, clip_key_frame1;
+
+			if (db != NULL)
+			{
+				const uint8_t* tracks_db_header = tbase + th->database_header_offset;
+				const uint8_t* db_clip_header = db->clip_segment_headers + load_u32(tracks_db_header);
+				const uint8_t* db_segment_headers = db_clip_header + 8;
+				medium0 = load_u64(db_segment_headers + 16 * segment_index0 + 0);
+				low0 = load_u64(db_segment_headers + 16 * segment_index0 + 8);
+				sample_indices0 |= (uint32_t)medium0;
+				sample_indices0 |= (uint32_t)low0;
+				medium1 = load_u64(db_segment_headers + 16 * segment_index1 + 0);
+				low1 = load_u64(db_segment_headers + 16 * segment_index1 + 8);
+				sample_indices1 |= (uint32_t)medium1;
+				sample_indices1 |= (uint32_t)low1;
+			}
+
+			candidates = sample_indices0 & (0xFFFFFFFFu << (31 - segment_key_frame0));
+			segment_key_frame0 = 31 - count_trailing_zeros(candidates);
+			candidates = sample_indices1 & (0xFFFFFFFFu >> segment_key_frame1);
+			segment_key_frame1 = count_leading_zeros(candidates);
+
+			clip_key_frame0 = load_u32(segment_start_indices + 4 * segment_index0) + segment_key_frame0;
+			clip_key_frame1 = load_u32(segment_start_indices + 4 * segment_index1) + segment_key_frame1;
+			key_frame0 = clip_key_frame0;
+			key_frame1 = clip_key_frame1;
+
+			alpha = aclo_find_linear_interpolation_alpha(sample_index, clip_key_frame0, clip_key_frame1, ACLO_ROUND_NONE, looping_policy);
+
+			sample_indices0 = load_u32(h0 + 16);
+			sample_indices1 = load_u32(h1 + 16);
+
+			if (db != NULL)
+			{
+				const uint64_t bit0 = (uint64_t)1 << (31 - segment_key_frame0);
+				const uint64_t bit1 = (uint64_t)1 << (31 - segment_key_frame1);
+				if ((medium0 & bit0) != 0) { sample_indices0 = (uint32_t)medium0; db_animated_track_data0 = db->bulk_data[0] + (uint32_t)(medium0 >> 32); }
+				else if ((low0 & bit0) != 0) { sample_indices0 = (uint32_t)low0; db_animated_track_data0 = db->bulk_data[1] + (uint32_t)(low0 >> 32); }
+				if ((medium1 & bit1) != 0) { sample_indices1 = (uint32_t)medium1; db_animated_track_data1 = db->bulk_data[0] + (uint32_t)(medium1 >> 32); }
+				else if ((low1 & bit1) != 0) { sample_indices1 = (uint32_t)low1; db_animated_track_data1 = db->bulk_data[1] + (uint32_t)(low1 >> 32); }
+			}
+
+			segment_key_frame0 = count_set_bits(~(0xFFFFFFFFu >> segment_key_frame0) & sample_indices0);
+			segment_key_frame1 = count_set_bits(~(0xFFFFFFFFu >> segment_key_frame1) & sample_indices1);
+		}
+	}
+
+	segment_header0 = (const segment_header_t*)(segment_headers + (uint64_t)segment_header_size * segment_index0);
+	segment_header1 = (const segment_header_t*)(segment_headers + (uint64_t)segment_header_size * segment_index1);
+
+	/* :530-562 */
+	out->sample_time = sample_time;
+	out->interpolation_alpha = alpha;
+	out->key_frames[0] = key_frame0;
+	out->key_frames[1] = key_frame1;
+	out->segment_indices[0] = segment_index0;
+	out->segment_indices[1] = segment_index1;
+	out->segment_key_frames[0] = segment_key_frame0;
+	out->segment_key_frames[1] = segment_key_frame1;
+	out->uses_single_segment = segment_header0 == segment_header1;
+
+	get_segment_data(blob, th, segment_header0, &out->format_per_track_data[0], &out->segment_range_data[0], &out->animated_track_data[0]);
+	get_segment_data(blob, th, segment_header1, &out->format_per_track_data[1], &out->segment_range_data[1], &out->animated_track_data[1]);
+
+	if (has_database)
+	{
+		if (db_animated_track_data0 != NULL)
+			out->animated_track_data[0] = db_animated_track_data0;
+		if (db_animated_track_data1 != NULL)
+			out->animated_track_data[1] = db_animated_track_data1;
+	}
+
+	out->key_frame_bit_offsets[0] = segment_key_frame0 * segment_header0->animated_pose_bit_size;
+	out->key_frame_bit_offsets[1] = segment_key_frame1 * segment_header1->animated_pose_bit_size;
+	out->animated_rotation_bit_size[0] = segment_header0->animated_rotation_bit_size;
+	out->animated_rotation_bit_size[1] = segment_header1->animated_rotation_bit_size;
+	out->animated_translation_bit_size[0] = segment_header0->animated_translation_bit_size;
+	out->animated_translation_bit_size[1] = segment_header1->animated_translation_bit_size;
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Arithmetic core (math/quatf.h, decompression/impl/animated_track_cache.transform.h)
+ * ---------------------------------------------------------------------------------------------- */
+/* math/quatf.h:135-147: w = sqrt(|((1 - x*x) - y*y) - z*z|) */
+static float quat_from_positive_w(float x, float y, float z)
+{
+	float result = 1.0f - (x * x);
+	result = result - (y * y);
+	result = result - (z * z);
+	return sqrtf(fabsf(result));
+}
+
+/* math/quatf.h:200-211 */
+static void quat_normalize(float q[4])
+{
+	float dot = q[0] * q[0];
+	float len, inv_len;
+	dot = (q[1] * q[1]) + dot;
+	dot = (q[2] * q[2]) + dot;
+	dot = (q[3] * q[3]) + dot;
+	len = sqrtf(dot);
+	inv_len = 1.0f / len;
+	q[0] = q[0] * inv_len;
+	q[1] = q[1] * inv_len;
+	q[2] = q[2] * inv_len;
+	q[3] = q[3] * inv_len;
+}
+
+/* math/quatf.h:170-196 */
+static void quat_lerp_no_normalization(const float q0[4], const float q1[4], float alpha, float out[4])
+{
+	float dot = q0[0] * q1[0];
+	uint32_t bias;
+	int c;
+	dot = (q0[1] * q1[1]) + dot;
+	dot = (q0[2] * q1[2]) + dot;
+	dot = (q0[3] * q1[3]) + dot;
+	bias = float_to_bits(dot) & 0x80000000u;
+	for (c = 0; c < 4; ++c)
+	{
+		const float end_with_bias = bits_to_float(float_to_bits(q1[c]) ^ bias);
+		const float start_part = q0[c] - (q0[c] * alpha);	/* vector_neg_mul_sub(start, alpha, start) */
+		out[c] = (end_with_bias * alpha) + start_part;		/* vector_mul_add(end, alpha, start_part) */
+	}
+}
+
+/* rtm::vector_lerp, stable form */
+static void vector_lerp3(const float v0[3], const float v1[3], float alpha, float out[3])
+{
+	int c;
+	for (c = 0; c < 3; ++c)
+	{
+		const float start_part = v0[c] - (v0[c] * alpha);
+		out[c] = (v1[c] * alpha) + start_part;
+	}
+}
+
+typedef struct
+{
+	const tracks_header_t* header;
+	const transform_tracks_header_t* th;
+	const aclo_seek_result* seek;
+	uint32_t raw_num_bits;		/* 31 from v02_01_99_1 on, 32 before (animated_track_cache.transform.h:523) */
+	int has_segments;
+} decode_ctx_t;
+
+/* Bits a sub-track occupies per component in the animated pose (count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192) */
+static uint32_t stored_bits(const decode_ctx_t* ctx, uint32_t num_bits) { return num_bits == ctx->raw_num_bits ? 32u : num_bits; }
+
+/* One animated rotation sample of one key frame, whole-pose flavour: unpack_animated_quat (:515-687) + remap_segment_range_data4 (:302-350)
+ * + remap_clip_range_data4 (:391-466). 'index' is the ordinal among animated rotations, 'bit_offset' the sub-track's bit position. */
+static void unpack_rotation_sample(const decode_ctx_t* ctx, int key, uint32_t index, uint32_t bit_offset, float out_xyz[3])
+{
+	const uint32_t group = index / 4, lane = index % 4;
+	const uint32_t num_rotations = ctx->th->num_animated_rotation_sub_tracks;
+	const uint32_t group_size = (num_rotations - group * 4) < 4 ? (num_rotations - group * 4) : 4;
+	const uint8_t* format_per_track_data = ctx->seek->format_per_track_data[key];
+	const uint8_t* segment_range_data = ctx->seek->segment_range_data[key] + (uint64_t)group * 24 + lane;
+	const uint8_t* clip_range_data = (const uint8_t*)ctx->th + ctx->th->clip_range_data_offset + (uint64_t)group * 96 + (uint64_t)lane * 4;
+	const uint32_t num_bits = format_per_track_data[index];
+	int ignore_segment, ignore_clip, c;
+
+	if (num_bits == 0)
+	{
+		/* constant in this segment: 16 bit sample hidden in the segment range bytes, hi/lo split across the SOA rows (:552-588) */
+		const uint32_t x = ((uint32_t)segment_range_data[0] << 8) | segment_range_data[4];
+		const uint32_t y = ((uint32_t)segment_range_data[8] << 8) | segment_range_data[12];
+		const uint32_t z = ((uint32_t)segment_range_data[16] << 8) | segment_range_data[20];
+		out_xyz[0] = (float)x * (1.0f / 65535.0f);
+		out_xyz[1] = (float)y * (1.0f / 65535.0f);
+		out_xyz[2] = (float)z * (1.0f / 65535.0f);
+		ignore_segment = 1;
+		ignore_clip = 0;
+	}
+	else if (num_bits == ctx->raw_num_bits)
+	{
+		aclo_unpack_vector3_96(ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		ignore_segment = 1;
+		ignore_clip = 1;
+	}
+	else
+	{
+		aclo_unpack_vector3_uXX(num_bits, ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		ignore_segment = 0;
+		ignore_clip = 0;
+	}
+
+	if (ctx->has_segments)
+	{
+		/* ignored lanes still go through the multiply-add with extent 1 and min 0 (:316-349) */
+		for (c = 0; c < 3; ++c)
+		{
+			const float range_min = ignore_segment ? 0.0f : (float)segment_range_data[c * 4] * (1.0f / 255.0f);
+			const float range_extent = ignore_segment ? 1.0f : (float)segment_range_data[12 + c * 4] * (1.0f / 255.0f);
+			out_xyz[c] = (out_xyz[c] * range_extent) + range_min;
+		}
+	}
+
+	for (c = 0; c < 3; ++c)
+	{
+		const float range_min = ignore_clip ? 0.0f : load_f32(clip_range_data + (uint64_t)group_size * 4 * (uint32_t)c);
+		const float range_extent = ignore_clip ? 1.0f : load_f32(clip_range_data + (uint64_t)group_size * 4 * (3 + (uint32_t)c));
+		out_xyz[c] = (out_xyz[c] * range_extent) + range_min;
+	}
+}
+
+/* One animated translation/scale sample of one key frame: unpack_animated_vector3 (:871-990).
+ * 'format_index' indexes format_per_track_data, 'range_index' is the ordinal within the translation (or scale) sub-tracks,
+ * range bases point at the first translation (or scale) entry. */
+static void unpack_vector3_sample(const decode_ctx_t* ctx, int key, uint32_t format_index, const uint8_t* segment_range_base, const uint8_t* clip_range_base,
+	uint32_t range_index, uint32_t bit_offset, float out_xyz[3])
+{
+	const uint32_t num_bits = ctx->seek->format_per_track_data[key][format_index];
+	const uint8_t* segment_range_data = segment_range_base + (uint64_t)range_index * 6;
+	const uint8_t* clip_range_data = clip_range_base + (uint64_t)range_index * 24;
+	int ignore_segment, ignore_clip, c;
+
+	if (num_bits == 0)
+	{
+		aclo_unpack_vector3_u48(segment_range_data, out_xyz);
+		ignore_segment = 1;
+		ignore_clip = 0;
+	}
+	else if (num_bits == ctx->raw_num_bits)
+	{
+		aclo_unpack_vector3_96(ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		ignore_segment = 1;
+		ignore_clip = 1;
+	}
+	else
+	{
+		aclo_unpack_vector3_uXX(num_bits, ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		ignore_segment = 0;
+		ignore_clip = 0;
+	}
+
+	if (ctx->has_segments && !ignore_segment)
+	{
+		float range_min[3], range_extent[3];
+		aclo_unpack_vector3_u24(segment_range_data, range_min);
+		aclo_unpack_vector3_u24(segment_range_data + 3, range_extent);
+		for (c = 0; c < 3; ++c)
+			out_xyz[c] = (out_xyz[c] * range_extent[c]) + range_min[c];
+	}
+
+	if (!ignore_clip)
+	{
+		for (c = 0; c < 3; ++c)
+			out_xyz[c] = (out_xyz[c] * load_f32(clip_range_data + 12 + 4 * c)) + load_f32(clip_range_data + 4 * c);
+	}
+}
+
+/* sub-track class of track 'index' (core/impl/compressed_headers.h:214-224) */
+static uint32_t sub_track_type(const uint8_t* types, uint32_t index)
+{
+	return (load_u32(types + 4 * (index / 16)) >> ((15 - (index % 16)) * 2)) & 3u;
+}
+
+static void write_default(const aclo_options* options, int kind, uint8_t mode, uint32_t track_index, const tracks_header_t* header, float* qvv)
+{
+	/* decompression.transform.h:575-675, 883-985, 1203-1310, 1643-1680 */
+	float* dst = qvv + kind * 4;
+	if (mode == ACLO_DEFAULT_SKIPPED)
+		return;
+	if (mode == ACLO_DEFAULT_VARIABLE && options->default_values != NULL)
+	{
+		const float* src = options->default_values + (uint64_t)track_index * 12 + kind * 4;
+		dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = kind == 0 ? src[3] : 0.0f;
+		return;
+	}
+	if (mode == ACLO_DEFAULT_CONSTANT && options->default_values != NULL)
+	{
+		const float* src = options->default_values + kind * 4;
+		dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = kind == 0 ? src[3] : 0.0f;
+		return;
+	}
+	if (kind == 0) { dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 1.0f; }
+	else if (kind == 1) { dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 0.0f; }
+	else
+	{
+		/* legacy scale = the blob's default scale bit, otherwise 1 (core/track_writer.h:169) */
+		const float scale = mode == ACLO_DEFAULT_LEGACY ? (float)hdr_default_scale(header) : 1.0f;
+		dst[0] = scale; dst[1] = scale; dst[2] = scale; dst[3] = 0.0f;
+	}
+}
+
+/* Shared worker: decodes every track (track_filter < 0) or only one. 'single' selects decompress_track_v0's variations. */
+static int decode_pose(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, int track_filter, float* out)
+{
+	const tracks_header_t* header = get_tracks_header(blob);
+	const transform_tracks_header_t* th = get_transform_header(blob);
+	const uint8_t* tbase = (const uint8_t*)th;
+	const uint32_t num_tracks = header->num_tracks;
+	const uint32_t num_entries = (num_tracks + 15) / 16;
+	const int has_scale = hdr_has_scale(header);
+	const uint8_t* rotation_types = tbase + th->sub_track_types_offset;
+	const uint8_t* translation_types = rotation_types + 4 * num_entries;
+	const uint8_t* scale_types = translation_types + 4 * num_entries;
+	const uint8_t* constant_rotations = tbase + th->constant_track_data_offset;
+	const uint8_t* constant_translations = constant_rotations + 12 * (uint64_t)th->num_constant_rotation_samples;
+	const uint8_t* constant_scales = constant_translations + 12 * (uint64_t)th->num_constant_translation_samples;
+	const uint32_t num_rotations_padded = (th->num_animated_rotation_sub_tracks + 3) & ~3u;
+	const uint8_t* clip_range_rotations = tbase + th->clip_range_data_offset;
+	const uint8_t* clip_range_translations = clip_range_rotations + 24 * (uint64_t)th->num_animated_rotation_sub_tracks;
+	const uint8_t* clip_range_scales = clip_range_translations + 24 * (uint64_t)th->num_animated_translation_sub_tracks;
+	const int single = track_filter >= 0;
+	aclo_seek_result seek;
+	decode_ctx_t ctx;
+	uint32_t track_index;
+	uint32_t constant_counts[3] = { 0, 0, 0 };
+	uint32_t animated_counts[3] = { 0, 0, 0 };
+	uint32_t bit_offsets[3][2];
+	int key, kind;
+
+	if (num_tracks == 0)
+		return 1;
+	if (single && (uint32_t)track_filter >= num_tracks)
+		return 2;
+	if (aclo_seek(blob, sample_time, rounding_policy, options, &seek) != 0)
+		return 1;
+
+	ctx.header = header;
+	ctx.th = th;
+	ctx.seek = &seek;
+	ctx.raw_num_bits = header->version >= VERSION_V02_01_99_1 ? 31u : 32u;
+	ctx.has_segments = th->num_segments > 1;
+
+	/* animated_track_cache_v0::initialize (animated_track_cache.transform.h:1223-1314) */
+	for (key = 0; key < 2; ++key)
+	{
+		bit_offsets[0][key] = seek.key_frame_bit_offsets[key];
+		bit_offsets[1][key] = bit_offsets[0][key] + seek.animated_rotation_bit_size[key];
+		bit_offsets[2][key] = bit_offsets[1][key] + seek.animated_translation_bit_size[key];
+	}
+
+	for (track_index = 0; track_index < num_tracks; ++track_index)
+	{
+		const int wanted = !single || track_index == (uint32_t)track_filter;
+		float* qvv = single ? out : out + (uint64_t)track_index * 12;
+
+		for (kind = 0; kind < 3; ++kind)
+		{
+			const uint8_t* types = kind == 0 ? rotation_types : (kind == 1 ? translation_types : scale_types);
+			const uint32_t type = (kind == 2 && !has_scale) ? 0u : sub_track_type(types, track_index);
+			const uint8_t default_mode = kind == 0 ? options->default_rotation_mode : (kind == 1 ? options->default_translation_mode : options->default_scale_mode);
+
+			if (type == 0)
+			{
+				if (wanted)
+					write_default(options, kind, default_mode, track_index, header, qvv);
+			}
+			else if (type == 1)
+			{
+				const uint32_t index = constant_counts[kind]++;
+				if (!wanted)
+					continue;
+
+				if (kind == 0)
+				{
+					/* constant_track_cache_v0::unpack_rotation_group (constant_track_cache.transform.h:113-205): SOA groups of 4, last group unpadded */
+					const uint32_t group = index / 4, lane = index % 4;
+					const uint32_t left = th->num_constant_rotation_samples - group * 4;
+					const uint32_t group_size = left < 4 ? left : 4;
+					const uint8_t* group_data = constant_rotations + (uint64_t)group * 48;
+					float q[4];
+					q[0] = load_f32(group_data + 4 * (uint64_t)(group_size * 0 + lane));
+					q[1] = load_f32(group_data + 4 * (uint64_t)(group_size * 1 + lane));
+					q[2] = load_f32(group_data + 4 * (uint64_t)(group_size * 2 + lane));
+					q[3] = quat_from_positive_w(q[0], q[1], q[2]);
+					if (options->normalization == ACLO_NORMALIZE_ALWAYS)
+						quat_normalize(q);
+					qvv[0] = q[0]; qvv[1] = q[1]; qvv[2] = q[2]; qvv[3] = q[3];
+				}
+				else
+				{
+					/* consume_translation / consume_scale (constant_track_cache.transform.h:297-302,328-333) */
+					const uint8_t* src = (kind == 1 ? constant_translations : constant_scales) + (uint64_t)index * 12;
+					qvv[kind * 4 + 0] = load_f32(src + 0);
+					qvv[kind * 4 + 1] = load_f32(src + 4);
+					qvv[kind * 4 + 2] = load_f32(src + 8);
+					qvv[kind * 4 + 3] = 0.0f;
+				}
+			}
+			else
+			{
+				const uint32_t index = animated_counts[kind]++;
+				const uint32_t format_index = kind == 0 ? index : (kind == 1 ? num_rotations_padded + index : num_rotations_padded + th->num_animated_translation_sub_tracks + index);
+				uint32_t sample_bit_offsets[2];
+				float alpha = seek.interpolation_alpha;
+				int policy = ACLO_ROUND_NONE;
+
+				for (key = 0; key < 2; ++key)
+				{
+					sample_bit_offsets[key] = bit_offsets[kind][key];
+					bit_offsets[kind][key] += stored_bits(&ctx, seek.format_per_track_data[key][format_index]) * 3;
+				}
+
+				if (!wanted)
+					continue;
+
+				if (options->per_track_rounding)
+				{
+					/* track_writer::get_rounding_policy (core/track_writer.h:97): per track only when seeking with per_track */
+					policy = rounding_policy;
+					if (rounding_policy == ACLO_ROUND_PER_TRACK)
+						policy = options->track_rounding != NULL ? options->track_rounding[track_index] : ACLO_ROUND_NONE;
+
+					/* decompress_track_v0 folds the policy into alpha and always interpolates (decompression.transform.h:1975-1983) */
+					if (single)
+					{
+						alpha = aclo_apply_rounding_policy(alpha, policy);
+						policy = ACLO_ROUND_NONE;
+					}
+				}
+
+				if (kind == 0)
+				{
+					float q0[4], q1[4], result[4];
+					unpack_rotation_sample(&ctx, 0, index, sample_bit_offsets[0], q0);
+					unpack_rotation_sample(&ctx, 1, index, sample_bit_offsets[1], q1);
+					q0[3] = quat_from_positive_w(q0[0], q0[1], q0[2]);
+					q1[3] = quat_from_positive_w(q1[0], q1[1], q1[2]);
+
+					/* animated_track_cache.transform.h:1463-1473 (whole pose only) */
+					if (!single && options->normalization == ACLO_NORMALIZE_ALWAYS && options->per_track_rounding)
+					{
+						quat_normalize(q0);
+						quat_normalize(q1);
+					}
+
+					if (policy == ACLO_ROUND_FLOOR)
+						memcpy(result, q0, sizeof(result));
+					else if (policy == ACLO_ROUND_CEIL)
+						memcpy(result, q1, sizeof(result));
+					else if (policy == ACLO_ROUND_NEAREST)
+						memcpy(result, seek.interpolation_alpha < 0.5f ? q0 : q1, sizeof(result));
+					else
+					{
+						/* :1604-1616 */
+						quat_lerp_no_normalization(q0, q1, alpha, result);
+						if (options->normalization >= ACLO_NORMALIZE_LERP_ONLY)
+							quat_normalize(result);
+					}
+					qvv[0] = result[0]; qvv[1] = result[1]; qvv[2] = result[2]; qvv[3] = result[3];
+				}
+				else
+				{
+					const uint8_t* clip_range_base = kind == 1 ? clip_range_translations : clip_range_scales;
+					const uint32_t range_entries_before = kind == 1 ? num_rotations_padded : num_rotations_padded + th->num_animated_translation_sub_tracks;
+					float v0[3], v1[3], result[3];
+					unpack_vector3_sample(&ctx, 0, format_index, seek.segment_range_data[0] + (uint64_t)range_entries_before * 6, clip_range_base, index, sample_bit_offsets[0], v0);
+					unpack_vector3_sample(&ctx, 1, format_index, seek.segment_range_data[1] + (uint64_t)range_entries_before * 6, clip_range_base, index, sample_bit_offsets[1], v1);
+
+					/* unpack_translation_group (:1774-1836) */
+					if (policy == ACLO_ROUND_FLOOR)
+						memcpy(result, v0, sizeof(result));
+					else if (policy == ACLO_ROUND_CEIL)
+						memcpy(result, v1, sizeof(result));
+					else if (policy == ACLO_ROUND_NEAREST)
+						memcpy(result, seek.interpolation_alpha < 0.5f ? v0 : v1, sizeof(result));
+					else
+						vector_lerp3(v0, v1, alpha, result);
+
+					qvv[kind * 4 + 0] = result[0];
+					qvv[kind * 4 + 1] = result[1];
+					qvv[kind * 4 + 2] = result[2];
+					qvv[kind * 4 + 3] = 0.0f;
+				}
+			}
+		}
+	}
+
+	return 0;
+}
+
+int aclo_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out_pose)
+{
+	aclo_options defaults;
+	if (options == NULL) { aclo_default_options(&defaults); options = &defaults; }
+	return decode_pose(blob, sample_time, rounding_policy, options, -1, out_pose);
+}
+
+int aclo_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_qvv)
+{
+	aclo_options defaults;
+	if (options == NULL) { aclo_default_options(&defaults); options = &defaults; }
+	if ((int32_t)track_index < 0)
+		return 2;
+	return decode_pose(blob, sample_time, rounding_policy, options, (int)track_index, out_qvv);
+}
+
+int aclo_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, float* out, uint64_t pose_stride_floats)
+{
+	uint32_t i;
+	for (i = 0; i < count; ++i)
+	{
+		const int result = aclo_decompress_tracks(blobs[clip_indices[i]], sample_times[i], rounding_policy, options, out + (uint64_t)i * pose_stride_floats);
+		if (result != 0)
+			return result;
+	}
+	return 0;
+}

@@ -1,0 +1,166 @@
+"""TEST INFRASTRUCTURE -- ctypes bindings of the CPU oracle (oracle/libacloracle.so) and, when present, of the
+reference's own decoder built from /root/reference (oracle/_ref/libaclref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(acl_amd/) never does.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_PATH = os.path.join(_HERE, "libacloracle.so")
+REF_PATH = os.path.join(_HERE, "_ref", "libaclref.so")
+REF_ASSERT_PATH = os.path.join(_HERE, "_ref", "libaclref_assert.so")
+
+ROUND_NONE, ROUND_FLOOR, ROUND_CEIL, ROUND_NEAREST, ROUND_PER_TRACK = 0, 1, 2, 3, 4
+LOOP_CLAMP, LOOP_WRAP, LOOP_AS_COMPRESSED = 0, 1, 2
+NORMALIZE_NEVER, NORMALIZE_LERP_ONLY, NORMALIZE_ALWAYS = 0, 1, 2
+DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY = 0, 1, 2, 3
+
+
+class Database(ctypes.Structure):
+    _fields_ = [("clip_segment_headers", ctypes.c_void_p), ("bulk_data", ctypes.c_void_p * 2)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [
+        ("looping_policy", ctypes.c_uint8), ("normalization", ctypes.c_uint8), ("per_track_rounding", ctypes.c_uint8),
+        ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8),
+        ("default_values", ctypes.c_void_p), ("track_rounding", ctypes.c_void_p), ("database", ctypes.POINTER(Database)),
+    ]
+
+
+class SeekResult(ctypes.Structure):
+    _fields_ = [
+        ("sample_time", ctypes.c_float), ("interpolation_alpha", ctypes.c_float),
+        ("key_frames", ctypes.c_uint32 * 2), ("segment_indices", ctypes.c_uint32 * 2), ("segment_key_frames", ctypes.c_uint32 * 2),
+        ("key_frame_bit_offsets", ctypes.c_uint32 * 2),
+        ("format_per_track_data", ctypes.c_void_p * 2), ("segment_range_data", ctypes.c_void_p * 2), ("animated_track_data", ctypes.c_void_p * 2),
+        ("animated_rotation_bit_size", ctypes.c_uint32 * 2), ("animated_translation_bit_size", ctypes.c_uint32 * 2),
+        ("uses_single_segment", ctypes.c_uint8),
+    ]
+
+
+_oracle = None
+_ref = {}
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_PATH):
+            raise RuntimeError(f"{ORACLE_PATH} is missing: run `make -C oracle` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(ORACLE_PATH)
+        vp, f32, i32, u32, u64 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
+        lib.aclo_default_options.argtypes = [ctypes.POINTER(Options)]
+        lib.aclo_is_valid.argtypes = [vp, u64, i32]
+        lib.aclo_hash32.argtypes = [vp, u64]
+        lib.aclo_hash32.restype = u32
+        lib.aclo_num_tracks.argtypes = [vp]
+        lib.aclo_num_tracks.restype = u32
+        lib.aclo_num_samples.argtypes = [vp]
+        lib.aclo_num_samples.restype = u32
+        lib.aclo_sample_rate.argtypes = [vp]
+        lib.aclo_sample_rate.restype = f32
+        lib.aclo_finite_duration.argtypes = [vp, i32]
+        lib.aclo_finite_duration.restype = f32
+        pu32, pf32 = ctypes.POINTER(u32), ctypes.POINTER(f32)
+        lib.aclo_find_linear_interpolation_samples_with_sample_rate.argtypes = [u32, f32, f32, i32, i32, pu32, pu32, pf32]
+        lib.aclo_find_linear_interpolation_samples_with_duration.argtypes = [u32, f32, f32, i32, i32, pu32, pu32, pf32]
+        lib.aclo_find_linear_interpolation_alpha.argtypes = [f32, u32, u32, i32, i32]
+        lib.aclo_find_linear_interpolation_alpha.restype = f32
+        lib.aclo_apply_rounding_policy.argtypes = [f32, i32]
+        lib.aclo_apply_rounding_policy.restype = f32
+        lib.aclo_unpack_vector3_uXX.argtypes = [u32, vp, u32, vp]
+        lib.aclo_unpack_vector3_96.argtypes = [vp, u32, vp]
+        lib.aclo_unpack_vector3_u48.argtypes = [vp, vp]
+        lib.aclo_unpack_vector3_u24.argtypes = [vp, vp]
+        lib.aclo_pack_vector3_uXX.argtypes = [vp, u32, vp]
+        lib.aclo_memcpy_bits.argtypes = [vp, u64, vp, u64, u64]
+        lib.aclo_seek.argtypes = [vp, f32, i32, ctypes.POINTER(Options), ctypes.POINTER(SeekResult)]
+        lib.aclo_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
+        lib.aclo_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]
+        lib.aclo_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, i32, ctypes.POINTER(Options), vp, u64]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref(asserting=False):
+    return os.path.exists(REF_ASSERT_PATH if asserting else REF_PATH)
+
+
+def ref(asserting=False):
+    """The reference's own decoder (oracle/_ref/libaclref*.so). Raises if it was never built."""
+    key = bool(asserting)
+    if key not in _ref:
+        path = REF_ASSERT_PATH if asserting else REF_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: it is built from /root/reference by `make -C oracle ref`")
+        lib = ctypes.CDLL(path)
+        vp, f32, i32, u32 = ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_uint32
+        lib.aclref_is_valid.argtypes = [vp, i32]
+        lib.aclref_get_duration.argtypes = [vp, i32]
+        lib.aclref_get_duration.restype = f32
+        lib.aclref_get_num_tracks.argtypes = [vp]
+        lib.aclref_get_num_tracks.restype = u32
+        lib.aclref_get_num_samples.argtypes = [vp]
+        lib.aclref_get_num_samples.restype = u32
+        lib.aclref_decompress.argtypes = [vp, f32, i32, i32, i32, i32, i32, vp, vp, vp]
+        lib.aclref_decompress_many.argtypes = [vp, vp, u32, i32, i32, i32, i32, vp]
+        lib.aclref_bench.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp]
+        lib.aclref_bench.restype = ctypes.c_double
+        _ref[key] = lib
+    return _ref[key]
+
+
+def default_options(**overrides):
+    options = Options()
+    oracle().aclo_default_options(ctypes.byref(options))
+    for key, value in overrides.items():
+        setattr(options, key, value)
+    return options
+
+
+def _ptr(array):
+    return array.ctypes.data if array is not None else None
+
+
+def oracle_decompress_tracks(blob, sample_time, rounding=ROUND_NONE, options=None, out=None):
+    """seek + decompress_tracks through the C restatement. Returns [num_tracks, 12] float32."""
+    lib = oracle()
+    num_tracks = lib.aclo_num_tracks(blob.ctypes.data)
+    if out is None:
+        out = np.zeros((num_tracks, 12), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    result = lib.aclo_decompress_tracks(blob.ctypes.data, ctypes.c_float(sample_time), rounding, ctypes.byref(options), out.ctypes.data)
+    if result != 0:
+        raise RuntimeError(f"aclo_decompress_tracks failed: {result}")
+    return out
+
+
+def oracle_decompress_track(blob, sample_time, track_index, rounding=ROUND_NONE, options=None):
+    lib = oracle()
+    out = np.zeros(12, dtype=np.float32)
+    if options is None:
+        options = default_options()
+    result = lib.aclo_decompress_track(blob.ctypes.data, ctypes.c_float(sample_time), rounding, ctypes.byref(options), track_index, out.ctypes.data)
+    if result != 0:
+        raise RuntimeError(f"aclo_decompress_track failed: {result}")
+    return out
+
+
+def ref_decompress(blob, sample_time, rounding=ROUND_NONE, looping=-1, settings=0, default_mode=0, track_index=-1,
+                   defaults=None, track_rounding=None, out=None, asserting=False):
+    """seek + decompress_tracks (track_index < 0) or decompress_track through the reference's own headers."""
+    lib = ref(asserting)
+    num_tracks = lib.aclref_get_num_tracks(blob.ctypes.data)
+    if out is None:
+        out = np.zeros((num_tracks, 12), dtype=np.float32)
+    result = lib.aclref_decompress(blob.ctypes.data, ctypes.c_float(sample_time), rounding, looping, settings, default_mode, track_index,
+                                   out.ctypes.data, _ptr(defaults), _ptr(track_rounding))
+    if result != 0:
+        raise RuntimeError(f"aclref_decompress failed: {result}")
+    return out
