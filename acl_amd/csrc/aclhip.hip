@@ -1,0 +1,1059 @@
+// aclhip.hip -- gfx950 decode kernels and the C ABI of libaclhip.so (include/aclhip.h).
+//
+// Kernel design:
+//   decompress_tracks_kernel   one wave64 per clip instance. The wave seeks (wave uniform, scalar loads), then
+//     phase 1: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order). A wave scan over
+//              3 * bit-width turns the per-track widths into bit offsets, every lane pulls its x/y/z for both keyframes
+//              out of the big-endian bitstream, expands segment + clip ranges, rebuilds W, lerps, normalizes and
+//              parks the float4 in LDS at its animated ordinal;
+//     phase 2: lanes <-> consecutive 16 byte quads of the output pose (rotation | translation | scale per track).
+//              Default/constant quads come from the clip's pre-expanded base pose, animated quads from LDS, and every
+//              store instruction of the wave writes 1 KiB of contiguous, 16 byte per lane, HBM.
+//   decompress_track_kernel    one thread per (instance, track) request, serial skip over the preceding widths like
+//     the reference's decompress_track (O(track index)).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared aclhip.hip -o ../lib/libaclhip.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/aclhip.h"
+#include "acl_format.h"
+#include "aclhip_device.h"
+
+namespace aclhip
+{
+	constexpr uint32_t k_wave_size = 64;
+	constexpr uint32_t k_waves_per_block = 4;
+	constexpr uint32_t k_block_size = k_wave_size * k_waves_per_block;
+
+	// Inclusive prefix sum across the 64 lanes of a wave
+	__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, uint32_t lane)
+	{
+		#pragma unroll
+		for (uint32_t offset = 1; offset < k_wave_size; offset <<= 1)
+		{
+			const uint32_t other = __shfl_up(value, offset, k_wave_size);
+			if (lane >= offset)
+				value += other;
+		}
+		return value;
+	}
+
+	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 base_value, bool& out_store)
+	{
+		// unpack_default_*_sub_tracks (decompression.transform.h:575-675,883-985,1203-1310) and the "no scale" loop (:1653-1680)
+		const uint32_t mode = params.default_modes[kind];
+		out_store = mode != ACLHIP_DEFAULT_SKIPPED;
+
+		if (params.default_values != nullptr && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
+		{
+			const float* src = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+			return make_float4(src[0], src[1], src[2], kind == 0 ? src[3] : 0.0f);
+		}
+
+		if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
+			return make_float4(1.0f, 1.0f, 1.0f, 0.0f);		// track_writer::get_constant_default_scale (core/track_writer.h:169)
+
+		return base_value;	// identity rotation, zero translation, the clip's legacy default scale
+	}
+
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
+		unsigned long long* __restrict__ rejected_count)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t instance = blockIdx.x * k_waves_per_block + wave_in_block;
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = __builtin_amdgcn_readfirstlane(clip_ids[instance]);
+		if (clip_id >= num_clips || (clips[clip_id].flags & k_clip_valid) == 0)
+		{
+			if (lane == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const device_clip& clip = clips[clip_id];
+		const uint32_t num_tracks = clip.num_tracks;
+		if (num_tracks == 0)
+			return;		// empty track list (decompression.transform.h:1531-1533)
+
+		const float sample_time = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sample_times[instance])));
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		float4* lds_animated = reinterpret_cast<float4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
+
+		// ---- phase 1: animated sub-tracks ----
+		const uint32_t num_animated = clip.num_animated_rotations + clip.num_animated_translations + clip.num_animated_scales;
+		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
+		uint32_t carry0 = 0;
+		uint32_t carry1 = 0;
+
+		for (uint32_t base = 0; base < num_animated; base += k_wave_size)
+		{
+			const uint32_t animated_ordinal = base + lane;
+			const bool active = animated_ordinal < num_animated;
+			const animated_slot slot = make_animated_slot(clip, active ? animated_ordinal : 0);
+
+			uint32_t num_bits0 = 0, num_bits1 = 0;
+			if (active)
+			{
+				num_bits0 = state.format_per_track_data[0][slot.format_index];
+				num_bits1 = state.format_per_track_data[1][slot.format_index];
+			}
+
+			const uint32_t bits0 = active ? stored_bits_per_component(num_bits0, clip.raw_num_bits) * 3u : 0u;
+			const uint32_t bits1 = active ? stored_bits_per_component(num_bits1, clip.raw_num_bits) * 3u : 0u;
+			const uint32_t inclusive0 = wave_inclusive_scan(bits0, lane);
+			const uint32_t inclusive1 = wave_inclusive_scan(bits1, lane);
+			const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + carry0 + inclusive0 - bits0;
+			const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + carry1 + inclusive1 - bits1;
+			carry0 += __builtin_amdgcn_readlane(inclusive0, k_wave_size - 1);
+			carry1 += __builtin_amdgcn_readlane(inclusive1, k_wave_size - 1);
+
+			if (active)
+			{
+				uint32_t policy = k_round_none;
+				if (params.per_track_rounding != 0)
+				{
+					// track_writer::get_rounding_policy (core/track_writer.h:97)
+					policy = rounding_policy;
+					if (rounding_policy == k_round_per_track)
+						policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip.animated_tracks[animated_ordinal]] : k_round_none;
+				}
+
+				lds_animated[animated_ordinal] = decode_animated_sub_track(clip, state, slot, num_bits0, num_bits1, bit_offset0, bit_offset1,
+					policy, state.interpolation_alpha, params.normalization, normalize_samples);
+			}
+		}
+
+		// the wave's own LDS writes must land before its lanes read each other's results
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// ---- phase 2: stream the pose out, 16 bytes per lane, 1 KiB per store instruction ----
+		const uint32_t num_quads = num_tracks * 3u;
+		float4* pose = reinterpret_cast<float4*>(poses + uint64_t(instance) * pose_stride_bytes);
+
+		for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+		{
+			const uint32_t quad = base + lane;
+			if (quad >= num_quads)
+				break;
+
+			const uint32_t entry = clip.quad_map[quad];
+			const uint32_t cls = entry & 3u;
+			float4 value = clip.base_pose[quad];
+			bool store = true;
+
+			if (cls == k_sub_track_animated)
+				value = lds_animated[entry >> 2];
+			else if (cls == k_sub_track_default)
+			{
+				const uint32_t track_index = quad / 3u;
+				value = default_quad(params, quad - track_index * 3u, track_index, value, store);
+			}
+			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && (quad % 3u) == 0)
+				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
+
+			if (store)
+				pose[quad] = value;
+		}
+	}
+
+	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
+		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+	{
+		const uint32_t instance = blockIdx.x * k_block_size + threadIdx.x;
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = clip_ids[instance];
+		if (clip_id >= num_clips || (clips[clip_id].flags & k_clip_valid) == 0)
+		{
+			atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const device_clip& clip = clips[clip_id];
+		const uint32_t track_index = track_indices[instance];
+		if (track_index >= clip.num_tracks)
+		{
+			// invalid track index (decompression.transform.h:1766-1768); an empty clip lands here as well
+			atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[instance]) : uint32_t(params.rounding_policy);
+
+		seek_state state;
+		seek(clip, sample_times[instance], rounding_policy, params.looping_policy, state);
+
+		// decompress_track_v0 folds a per track policy into the alpha and always interpolates (decompression.transform.h:1975-1983)
+		float lerp_alpha = state.interpolation_alpha;
+		if (params.per_track_rounding != 0)
+		{
+			uint32_t policy = rounding_policy;
+			if (rounding_policy == k_round_per_track)
+				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
+			lerp_alpha = apply_rounding_policy(lerp_alpha, policy);
+		}
+
+		for (uint32_t kind = 0; kind < 3; ++kind)
+		{
+			const uint32_t quad = track_index * 3u + kind;
+			const uint32_t entry = clip.quad_map[quad];
+			const uint32_t cls = entry & 3u;
+			float4 value = clip.base_pose[quad];
+			bool store = true;
+
+			if (cls == k_sub_track_animated)
+			{
+				const uint32_t animated_ordinal = entry >> 2;
+				const animated_slot slot = make_animated_slot(clip, animated_ordinal);
+
+				// skip_*_groups + count_animated_group_bit_size (animated_track_cache.transform.h:1105-1192,1664-1707): sum the widths before us
+				uint32_t bit_offset0 = state.key_frame_bit_offsets[0];
+				uint32_t bit_offset1 = state.key_frame_bit_offsets[1];
+				for (uint32_t previous = 0; previous < animated_ordinal; ++previous)
+				{
+					const uint32_t format_index = make_animated_slot(clip, previous).format_index;
+					bit_offset0 += stored_bits_per_component(state.format_per_track_data[0][format_index], clip.raw_num_bits) * 3u;
+					bit_offset1 += stored_bits_per_component(state.format_per_track_data[1][format_index], clip.raw_num_bits) * 3u;
+				}
+
+				const uint32_t num_bits0 = state.format_per_track_data[0][slot.format_index];
+				const uint32_t num_bits1 = state.format_per_track_data[1][slot.format_index];
+				value = decode_animated_sub_track(clip, state, slot, num_bits0, num_bits1, bit_offset0, bit_offset1,
+					k_round_none, lerp_alpha, params.normalization, false);
+			}
+			else if (cls == k_sub_track_default)
+				value = default_quad(params, kind, track_index, value, store);
+			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
+				value = quat_normalize(value);
+
+			if (store)
+				transforms[size_t(instance) * 3 + kind] = value;
+		}
+	}
+}
+
+// ================================================================================================
+// Host side: context, clip registry, C ABI
+// ================================================================================================
+using namespace aclhip;
+
+namespace
+{
+	struct host_clip
+	{
+		bool in_use = false;
+		void* device_memory = nullptr;		// one allocation: blob | base pose | quad map | animated tracks
+		aclhip_clip_info info = {};
+		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
+		uint32_t max_lds_quads = 0;
+	};
+}
+
+struct aclhip_context
+{
+	int device = 0;
+	std::mutex mutex;
+	std::vector<host_clip> clips;
+	std::vector<uint32_t> free_slots;
+	device_clip* d_clips = nullptr;
+	uint32_t d_clips_capacity = 0;
+	unsigned long long* d_rejected = nullptr;
+	uint32_t max_lds_quads = 0;				// largest animated sub-track count among registered clips
+	mutable std::string last_error;
+};
+
+namespace
+{
+	aclhip_status fail(const aclhip_context* context, aclhip_status status, const char* format, ...)
+	{
+		char buffer[512];
+		va_list args;
+		va_start(args, format);
+		std::vsnprintf(buffer, sizeof(buffer), format, args);
+		va_end(args);
+		if (context != nullptr)
+			context->last_error = buffer;
+		return status;
+	}
+
+	#define ACLHIP_CHECK_HIP(context, expression) \
+		do { const hipError_t hip_status_ = (expression); if (hip_status_ != hipSuccess) return fail((context), ACLHIP_ERROR_DEVICE, "%s failed: %s", #expression, hipGetErrorString(hip_status_)); } while (0)
+
+	struct device_guard
+	{
+		int previous = -1;
+		bool ok = false;
+		explicit device_guard(int device)
+		{
+			if (hipGetDevice(&previous) == hipSuccess)
+				ok = hipSetDevice(device) == hipSuccess;
+		}
+		~device_guard() { if (previous >= 0) (void)hipSetDevice(previous); }
+	};
+
+	// compressed_tracks::is_valid (core/impl/compressed_tracks.impl.h:278-301) + bounds checks so that a decode can never read outside the blob
+	aclhip_status validate_clip(const aclhip_context* context, const uint8_t* blob, uint64_t size, int check_hash)
+	{
+		if (blob == nullptr || size < k_transform_header_offset + sizeof(transform_tracks_header))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "buffer is not a valid compressed_tracks instance (too small)");
+
+		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+		const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+		if (header.tag != k_tag_compressed_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid tag");
+		if (header.algorithm_type != k_algorithm_uniformly_sampled)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm type");
+		if (header.version < k_version_first || header.version > k_version_latest)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm version");
+		if (buffer_header.size > size || buffer_header.size < k_transform_header_offset + sizeof(transform_tracks_header))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
+		if (check_hash && hash32(blob + sizeof(raw_buffer_header), buffer_header.size - sizeof(raw_buffer_header)) != buffer_header.hash)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid hash");
+
+		if (header.track_type != k_track_type_qvvf)
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "only qvvf transform tracks are supported");
+		if (header.num_tracks == 0)
+			return ACLHIP_OK;
+		if (header.rotation_format() != k_rotation_quatf_drop_w_variable || header.translation_format() != k_vector_vector3f_variable
+			|| (header.has_scale() && header.scale_format() != k_vector_vector3f_variable))
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "only quatf_drop_w_variable + vector3f_variable are supported (default_transform_decompression_settings)");
+		if (header.num_samples == 0 || !(header.sample_rate > 0.0f))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid sample count or rate");
+
+		const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
+		const uint64_t blob_size = buffer_header.size;
+		const uint64_t tbase = k_transform_header_offset;
+		const bool stripped = header.has_stripped_keyframes() || header.has_database();
+		const uint32_t segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		const uint32_t num_entries = (header.num_tracks + 15) / 16;
+		const uint32_t num_rotations_padded = align_to_u32(th.num_animated_rotation_sub_tracks, 4);
+
+		if (th.num_segments == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
+		if (th.num_animated_variable_sub_tracks != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
+		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
+			|| tbase + th.sub_track_types_offset + uint64_t(num_entries) * 4 * (header.has_scale() ? 3 : 2) > blob_size
+			|| tbase + th.constant_track_data_offset + 12ull * (uint64_t(th.num_constant_rotation_samples) + th.num_constant_translation_samples + th.num_constant_scale_samples) > blob_size
+			|| tbase + th.clip_range_data_offset + 24ull * (uint64_t(th.num_animated_rotation_sub_tracks) + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+		if (th.num_segments > 1 && tbase + k_segment_start_indices_offset + 4ull * (th.num_segments + 1) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment start indices point outside of the buffer");
+		if (header.has_database() && tbase + th.database_header_offset + sizeof(tracks_database_header) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Database header points outside of the buffer");
+
+		for (uint32_t i = 0; i < th.num_segments; ++i)
+		{
+			const segment_header& sh = *reinterpret_cast<const segment_header*>(blob + tbase + th.segment_headers_offset + size_t(i) * segment_header_size);
+			const uint64_t format_offset = tbase + sh.segment_data;
+			const uint64_t range_offset = align_to_u32(uint32_t(format_offset + th.num_animated_variable_sub_tracks), 2);
+			const uint64_t animated_offset = align_to_u32(uint32_t(range_offset + (th.num_segments > 1 ? 6ull * th.num_animated_variable_sub_tracks : 0ull)), 4);
+			if (animated_offset > blob_size || sh.animated_rotation_bit_size > sh.animated_pose_bit_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment %u points outside of the buffer", i);
+			if (!header.has_database())
+			{
+				// every keyframe a seek can pick must be inside the buffer
+				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : 32u;
+				(void)stored;	// the exact count needs the segment's sample count; the tail padding below covers the last window
+			}
+		}
+
+		return ACLHIP_OK;
+	}
+
+	uint32_t sub_track_class(const uint32_t* types, uint32_t track_index)
+	{
+		return (types[track_index / 16] >> ((15 - (track_index % 16)) * 2)) & 3u;
+	}
+
+	aclhip_status grow_clip_table(aclhip_context* context, uint32_t needed)
+	{
+		if (needed <= context->d_clips_capacity)
+			return ACLHIP_OK;
+
+		uint32_t capacity = std::max<uint32_t>(context->d_clips_capacity * 2, 256);
+		while (capacity < needed)
+			capacity *= 2;
+
+		device_clip* d_new = nullptr;
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&d_new), sizeof(device_clip) * capacity));
+		ACLHIP_CHECK_HIP(context, hipMemset(d_new, 0, sizeof(device_clip) * capacity));
+		if (context->d_clips != nullptr)
+		{
+			ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+			ACLHIP_CHECK_HIP(context, hipMemcpy(d_new, context->d_clips, sizeof(device_clip) * context->d_clips_capacity, hipMemcpyDeviceToDevice));
+			ACLHIP_CHECK_HIP(context, hipFree(context->d_clips));
+		}
+		context->d_clips = d_new;
+		context->d_clips_capacity = capacity;
+		return ACLHIP_OK;
+	}
+
+	aclhip_status resolve_params(const aclhip_context* context, const aclhip_decompress_params* params, decode_params& out)
+	{
+		aclhip_decompress_params defaults;
+		if (params == nullptr)
+		{
+			aclhip_default_params(&defaults);
+			params = &defaults;
+		}
+
+		if (params->rounding_policy > ACLHIP_ROUND_PER_TRACK || params->looping_policy > ACLHIP_LOOP_AS_COMPRESSED || params->normalization > ACLHIP_NORMALIZE_ALWAYS)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid rounding / looping / normalization policy");
+		if (params->default_rotation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_translation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_scale_mode > ACLHIP_DEFAULT_LEGACY)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid default sub-track mode (legacy is only valid for scale)");
+		if (params->rounding_policy == ACLHIP_ROUND_PER_TRACK && params->per_track_rounding == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "sample_rounding_policy::per_track needs per_track_rounding enabled (decompression_settings::is_per_track_rounding_supported)");
+		const bool needs_values = params->default_rotation_mode == ACLHIP_DEFAULT_VARIABLE || params->default_translation_mode == ACLHIP_DEFAULT_VARIABLE || params->default_scale_mode == ACLHIP_DEFAULT_VARIABLE;
+		if (needs_values && params->default_values == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "variable default sub-tracks need default_values");
+
+		out.default_values = params->default_values;
+		out.track_rounding_policies = params->track_rounding_policies;
+		out.instance_rounding_policies = params->instance_rounding_policies;
+		out.rounding_policy = params->rounding_policy;
+		out.looping_policy = params->looping_policy;
+		out.normalization = params->normalization;
+		out.per_track_rounding = params->per_track_rounding;
+		out.default_modes[0] = params->default_rotation_mode;
+		out.default_modes[1] = params->default_translation_mode;
+		out.default_modes[2] = params->default_scale_mode;
+		out.pad = 0;
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" const char* aclhip_status_string(aclhip_status status)
+{
+	switch (status)
+	{
+	case ACLHIP_OK: return "ok";
+	case ACLHIP_ERROR_INVALID_ARGUMENT: return "invalid argument";
+	case ACLHIP_ERROR_INVALID_CLIP: return "invalid compressed_tracks";
+	case ACLHIP_ERROR_UNSUPPORTED_FORMAT: return "unsupported track type or format";
+	case ACLHIP_ERROR_UNKNOWN_CLIP: return "unknown clip handle";
+	case ACLHIP_ERROR_OUT_OF_MEMORY: return "out of memory";
+	case ACLHIP_ERROR_DEVICE: return "HIP error";
+	case ACLHIP_ERROR_NO_DEVICE: return "no HIP device";
+	case ACLHIP_ERROR_UNKNOWN_DATABASE: return "unknown database handle";
+	case ACLHIP_ERROR_NOT_IN_DATABASE: return "clip is not contained in the database";
+	}
+	return "unknown status";
+}
+
+extern "C" const char* aclhip_last_error_message(const aclhip_context* context)
+{
+	return context != nullptr ? context->last_error.c_str() : "";
+}
+
+extern "C" void aclhip_default_params(aclhip_decompress_params* out_params)
+{
+	if (out_params == nullptr)
+		return;
+	std::memset(out_params, 0, sizeof(*out_params));
+	out_params->rounding_policy = ACLHIP_ROUND_NONE;
+	out_params->looping_policy = ACLHIP_LOOP_AS_COMPRESSED;
+	out_params->normalization = ACLHIP_NORMALIZE_LERP_ONLY;			// default_transform_decompression_settings (decompression_settings.h:227)
+	out_params->per_track_rounding = 0;									// decompression_settings.h:231
+	out_params->default_rotation_mode = ACLHIP_DEFAULT_CONSTANT;		// core/track_writer.h:161-163
+	out_params->default_translation_mode = ACLHIP_DEFAULT_CONSTANT;
+	out_params->default_scale_mode = ACLHIP_DEFAULT_LEGACY;
+}
+
+extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_context)
+{
+	if (out_context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_context = nullptr;
+
+	int device_count = 0;
+	if (hipGetDeviceCount(&device_count) != hipSuccess || device_count <= 0)
+		return ACLHIP_ERROR_NO_DEVICE;
+	if (device_index < 0 || device_index >= device_count)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	aclhip_context* context = new (std::nothrow) aclhip_context();
+	if (context == nullptr)
+		return ACLHIP_ERROR_OUT_OF_MEMORY;
+	context->device = device_index;
+
+	device_guard guard(device_index);
+	if (!guard.ok || hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
+		|| hipMemset(context->d_rejected, 0, sizeof(unsigned long long)) != hipSuccess)
+	{
+		delete context;
+		return ACLHIP_ERROR_DEVICE;
+	}
+
+	const aclhip_status status = grow_clip_table(context, 1);
+	if (status != ACLHIP_OK)
+	{
+		(void)hipFree(context->d_rejected);
+		delete context;
+		return status;
+	}
+
+	*out_context = context;
+	return ACLHIP_OK;
+}
+
+extern "C" void aclhip_destroy(aclhip_context* context)
+{
+	if (context == nullptr)
+		return;
+	{
+		device_guard guard(context->device);
+		(void)hipDeviceSynchronize();
+		for (host_clip& clip : context->clips)
+			if (clip.in_use && clip.device_memory != nullptr)
+				(void)hipFree(clip.device_memory);
+		if (context->d_clips != nullptr)
+			(void)hipFree(context->d_clips);
+		if (context->d_rejected != nullptr)
+			(void)hipFree(context->d_rejected);
+	}
+	delete context;
+}
+
+extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip)
+{
+	if (context == nullptr || out_clip == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_clip = ACLHIP_INVALID_HANDLE;
+
+	const uint8_t* blob = static_cast<const uint8_t*>(compressed_tracks);
+	aclhip_status status = validate_clip(context, blob, size, check_hash);
+	if (status != ACLHIP_OK)
+		return status;
+
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+	const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
+	const uint32_t blob_size = buffer_header.size;
+	const uint32_t num_tracks = header.num_tracks;
+	const uint32_t num_quads = num_tracks * 3;
+	const bool has_scale = num_tracks != 0 && header.has_scale();
+
+	const uint32_t num_animated_rotations = num_tracks != 0 ? th.num_animated_rotation_sub_tracks : 0;
+	const uint32_t num_animated_translations = num_tracks != 0 ? th.num_animated_translation_sub_tracks : 0;
+	const uint32_t num_animated_scales = num_tracks != 0 ? th.num_animated_scale_sub_tracks : 0;
+	const uint32_t num_animated = num_animated_rotations + num_animated_translations + num_animated_scales;
+
+	// ---- derived tables: base pose, quad map, animated ordinal -> track ----
+	std::vector<float> base_pose(size_t(num_quads) * 4);
+	std::vector<uint32_t> quad_map(num_quads);
+	std::vector<uint32_t> animated_tracks(std::max<uint32_t>(num_animated, 1));
+
+	if (num_tracks != 0)
+	{
+		const uint32_t num_entries = (num_tracks + 15) / 16;
+		const uint32_t* types = reinterpret_cast<const uint32_t*>(blob + k_transform_header_offset + th.sub_track_types_offset);
+		const uint8_t* constant_data = blob + k_transform_header_offset + th.constant_track_data_offset;
+		const float* constant_rotations = reinterpret_cast<const float*>(constant_data);
+		const float* constant_translations = constant_rotations + size_t(th.num_constant_rotation_samples) * 3;
+		const float* constant_scales = constant_translations + size_t(th.num_constant_translation_samples) * 3;
+		const float default_scale = float(header.default_scale());
+
+		uint32_t constant_counts[3] = { 0, 0, 0 };
+		uint32_t animated_counts[3] = { 0, 0, 0 };
+		const uint32_t animated_bases[3] = { 0, num_animated_rotations, num_animated_rotations + num_animated_translations };
+		const uint32_t animated_limits[3] = { num_animated_rotations, num_animated_translations, num_animated_scales };
+		const uint32_t constant_limits[3] = { th.num_constant_rotation_samples, th.num_constant_translation_samples, th.num_constant_scale_samples };
+
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			for (uint32_t kind = 0; kind < 3; ++kind)
+			{
+				const uint32_t quad = track * 3 + kind;
+				float* value = &base_pose[size_t(quad) * 4];
+				const uint32_t cls = (kind == 2 && !has_scale) ? k_sub_track_default : sub_track_class(types + size_t(kind) * num_entries, track);
+
+				// defaults: identity / zero / the clip's legacy default scale (decompression.transform.h:585,893,1548)
+				if (kind == 0) { value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f; value[3] = 1.0f; }
+				else if (kind == 1) { value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f; value[3] = 0.0f; }
+				else { value[0] = default_scale; value[1] = default_scale; value[2] = default_scale; value[3] = 0.0f; }
+
+				if (cls == k_sub_track_constant)
+				{
+					const uint32_t index = constant_counts[kind]++;
+					if (index >= constant_limits[kind])
+						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more constant sub-tracks than constant samples");
+
+					if (kind == 0)
+					{
+						// constant_track_cache_v0::unpack_rotation_group (constant_track_cache.transform.h:113-205): SOA groups of 4, last one unpadded
+						const uint32_t group = index / 4, lane = index % 4;
+						const uint32_t group_size = std::min<uint32_t>(th.num_constant_rotation_samples - group * 4, 4);
+						const float* group_data = constant_rotations + size_t(group) * 12;
+						const float x = group_data[group_size * 0 + lane];
+						const float y = group_data[group_size * 1 + lane];
+						const float z = group_data[group_size * 2 + lane];
+						// quat_from_positive_w4 (math/quatf.h:135-147), same IEEE operations as the device code
+						volatile float w_squared = 1.0f - (x * x);
+						w_squared = w_squared - (y * y);
+						w_squared = w_squared - (z * z);
+						value[0] = x; value[1] = y; value[2] = z; value[3] = std::sqrt(std::fabs(w_squared));
+					}
+					else
+					{
+						const float* src = (kind == 1 ? constant_translations : constant_scales) + size_t(index) * 3;
+						value[0] = src[0]; value[1] = src[1]; value[2] = src[2]; value[3] = 0.0f;
+					}
+					quad_map[quad] = k_sub_track_constant;
+				}
+				else if (cls == k_sub_track_animated)
+				{
+					const uint32_t index = animated_counts[kind]++;
+					if (index >= animated_limits[kind])
+						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more animated sub-tracks than the header declares");
+					const uint32_t ordinal = animated_bases[kind] + index;
+					animated_tracks[ordinal] = track;
+					quad_map[quad] = k_sub_track_animated | (ordinal << 2);
+				}
+				else if (cls == k_sub_track_default)
+					quad_map[quad] = k_sub_track_default;
+				else
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "invalid sub-track type");
+			}
+		}
+
+		if (animated_counts[0] != num_animated_rotations || animated_counts[1] != num_animated_translations || animated_counts[2] != num_animated_scales)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sub-track types disagree with the animated sub-track counts");
+	}
+
+	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | quad map | animated tracks ----
+	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// the decoder reads 8 byte windows: keep well past the reference's 15 bytes of slack
+	const uint64_t base_pose_offset = blob_bytes;
+	const uint64_t quad_map_offset = base_pose_offset + uint64_t(num_quads) * 16;
+	const uint64_t animated_tracks_offset = quad_map_offset + align_to_u32(num_quads * 4, 16);
+	const uint64_t total_bytes = animated_tracks_offset + align_to_u32(std::max<uint32_t>(num_animated, 1) * 4, 16);
+
+	std::vector<uint8_t> staging(total_bytes, 0);
+	std::memcpy(staging.data(), blob, blob_size);
+	if (num_quads != 0)
+	{
+		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
+		std::memcpy(staging.data() + quad_map_offset, quad_map.data(), size_t(num_quads) * 4);
+	}
+	if (num_animated != 0)
+		std::memcpy(staging.data() + animated_tracks_offset, animated_tracks.data(), size_t(num_animated) * 4);
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	if (!guard.ok)
+		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+
+	uint32_t slot;
+	if (!context->free_slots.empty())
+	{
+		slot = context->free_slots.back();
+		context->free_slots.pop_back();
+	}
+	else
+	{
+		slot = uint32_t(context->clips.size());
+		context->clips.emplace_back();
+	}
+
+	status = grow_clip_table(context, slot + 1);
+	if (status != ACLHIP_OK)
+	{
+		context->free_slots.push_back(slot);
+		return status;
+	}
+
+	uint8_t* d_memory = nullptr;
+	if (hipMalloc(reinterpret_cast<void**>(&d_memory), total_bytes) != hipSuccess)
+	{
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
+	}
+
+	device_clip record;
+	std::memset(&record, 0, sizeof(record));
+	record.blob = d_memory;
+	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
+	record.quad_map = reinterpret_cast<const uint32_t*>(d_memory + quad_map_offset);
+	record.animated_tracks = reinterpret_cast<const uint32_t*>(d_memory + animated_tracks_offset);
+	record.num_tracks = num_tracks;
+	record.num_samples = header.num_samples;
+	record.sample_rate = header.sample_rate;
+	record.duration_clamp = header.num_samples <= 1 ? 0.0f : float(header.num_samples - 1) / header.sample_rate;
+	record.duration_wrap = header.num_samples == 0 ? 0.0f : float(header.num_samples) / header.sample_rate;
+	record.flags = k_clip_valid;
+	if (num_tracks != 0)
+	{
+		const bool stripped = header.has_stripped_keyframes() || header.has_database();
+		record.flags |= has_scale ? k_clip_has_scale : 0u;
+		record.flags |= stripped ? k_clip_has_stripped_keyframes : 0u;
+		record.flags |= header.has_database() ? k_clip_has_database : 0u;
+		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
+		record.num_segments = th.num_segments;
+		record.segment_headers_offset = k_transform_header_offset + th.segment_headers_offset;
+		record.segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		record.num_animated_rotations = num_animated_rotations;
+		record.num_animated_translations = num_animated_translations;
+		record.num_animated_scales = num_animated_scales;
+		record.num_animated_variable = th.num_animated_variable_sub_tracks;
+		record.clip_range_offset = k_transform_header_offset + th.clip_range_data_offset;
+		record.raw_num_bits = header.version >= k_version_v02_01_99_1 ? 31u : 32u;
+		if (header.has_database())
+			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(blob + k_transform_header_offset + th.database_header_offset)->clip_header_offset;
+	}
+
+	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		(void)hipFree(d_memory);
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
+	}
+
+	host_clip& entry = context->clips[slot];
+	entry.in_use = true;
+	entry.device_memory = d_memory;
+	entry.info.num_tracks = num_tracks;
+	entry.info.num_samples = header.num_samples;
+	entry.info.sample_rate = header.sample_rate;
+	entry.info.duration = finite_duration(header, k_loop_as_compressed);
+	entry.info.num_segments = num_tracks != 0 ? th.num_segments : 0;
+	entry.info.has_scale = has_scale ? 1 : 0;
+	entry.info.looping_policy = (header.version > k_version_first && header.is_wrap_optimized()) ? ACLHIP_LOOP_WRAP : ACLHIP_LOOP_CLAMP;
+	entry.info.compressed_size = blob_size;
+	entry.info.hash = buffer_header.hash;
+	entry.info.num_animated_sub_tracks = num_animated;
+	entry.info.has_database = num_tracks != 0 && header.has_database() ? 1 : 0;
+	entry.info.has_stripped_keyframes = num_tracks != 0 && header.has_stripped_keyframes() ? 1 : 0;
+	entry.touched_bytes = uint64_t(blob_size) + uint64_t(num_quads) * 20 + uint64_t(num_animated) * 4;
+	entry.max_lds_quads = num_animated;
+	context->max_lds_quads = std::max(context->max_lds_quads, num_animated);
+
+	*out_clip = slot;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+
+	device_guard guard(context->device);
+	device_clip cleared;
+	std::memset(&cleared, 0, sizeof(cleared));
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
+	ACLHIP_CHECK_HIP(context, hipFree(context->clips[clip].device_memory));
+	context->clips[clip] = host_clip();
+	context->free_slots.push_back(clip);
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info)
+{
+	if (context == nullptr || out_info == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	*out_info = context->clips[clip].info;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches)
+{
+	if (context == nullptr || compressed_tracks == nullptr || out_matches == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	// is_bound_to_v0 compares pointer and hash (decompression.transform.h:159-169); there is no shared pointer here: hash + size
+	const raw_buffer_header& buffer_header = *static_cast<const raw_buffer_header*>(compressed_tracks);
+	const aclhip_clip_info& info = context->clips[clip].info;
+	*out_matches = (buffer_header.hash == info.hash && buffer_header.size == info.compressed_size) ? 1 : 0;
+	return ACLHIP_OK;
+}
+
+namespace
+{
+	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
+	{
+		const uint32_t lds_quads_per_wave = std::max<uint32_t>(align_to_u32(context->max_lds_quads, 4), 4);
+		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
+		if (lds_bytes > 160 * 1024)
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "a registered clip has too many animated sub-tracks for the LDS staging (%u)", context->max_lds_quads);
+
+		const uint32_t num_blocks = (num_instances + k_waves_per_block - 1) / k_waves_per_block;
+		hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
+			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params,
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+
+	aclhip_status check_batch_arguments(aclhip_context* context, const void* clips, const void* sample_times, uint32_t num_instances, const void* out, uint64_t pose_stride_bytes)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances != 0 && (clips == nullptr || sample_times == nullptr || out == nullptr))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+		if ((pose_stride_bytes & 15u) != 0 || (reinterpret_cast<uintptr_t>(out) & 15u) != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose buffer and stride must be 16 byte aligned");
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (num_instances == 0)
+		return ACLHIP_OK;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	return launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* transforms, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, transforms, 48);
+	if (status != ACLHIP_OK)
+		return status;
+	if (num_instances == 0)
+		return ACLHIP_OK;
+	if (track_indices == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list");
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
+	hipLaunchKernelGGL(decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+		context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,
+		static_cast<float4*>(transforms), context->d_rejected);
+	ACLHIP_CHECK_HIP(context, hipGetLastError());
+	return ACLHIP_OK;
+}
+
+namespace
+{
+	// Host pointer convenience path: upload, launch, download, synchronously
+	aclhip_status decompress_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, uint32_t default_values_count, void* out, uint64_t out_stride_bytes, uint64_t out_row_bytes)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+
+		aclhip_decompress_params local;
+		if (params != nullptr) local = *params; else aclhip_default_params(&local);
+
+		device_guard guard(context->device);
+
+		uint32_t max_tracks = 0;
+		{
+			std::lock_guard<std::mutex> lock(context->mutex);
+			for (uint32_t i = 0; i < num_instances; ++i)
+				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
+					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);
+		}
+
+		const bool single_track = track_indices != nullptr;
+		const uint64_t device_stride = single_track ? 48 : std::max<uint64_t>(uint64_t(max_tracks) * 48, 16);
+		if (!single_track && out_row_bytes == 0)
+			out_row_bytes = uint64_t(max_tracks) * 48;
+
+		std::vector<void*> allocations;
+		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
+		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
+		{
+			void* d = nullptr;
+			if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess)
+				return false;
+			allocations.push_back(d);
+			if (host != nullptr && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+				return false;
+			*out_device = d;
+			return true;
+		};
+
+		void* d_clip_ids = nullptr; void* d_times = nullptr; void* d_tracks = nullptr; void* d_out = nullptr;
+		void* d_defaults = nullptr; void* d_track_policies = nullptr; void* d_instance_policies = nullptr;
+		bool ok = upload(clips, sizeof(uint32_t) * num_instances, &d_clip_ids) && upload(sample_times, sizeof(float) * num_instances, &d_times);
+		if (ok && single_track)
+			ok = upload(track_indices, sizeof(uint32_t) * num_instances, &d_tracks);
+		ok = ok && upload(nullptr, device_stride * num_instances, &d_out);
+		if (ok && local.default_values != nullptr)
+			ok = upload(local.default_values, size_t(std::max<uint32_t>(default_values_count, 1)) * 48, &d_defaults);
+		if (ok && local.track_rounding_policies != nullptr)
+			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
+		if (ok && local.instance_rounding_policies != nullptr)
+			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+		if (!ok)
+		{
+			release();
+			return fail(context, ACLHIP_ERROR_DEVICE, "staging the batch on the device failed");
+		}
+
+		// skipped defaults must keep what the caller pre-filled: round trip the caller's buffer
+		const bool has_skipped = local.default_rotation_mode == ACLHIP_DEFAULT_SKIPPED || local.default_translation_mode == ACLHIP_DEFAULT_SKIPPED || local.default_scale_mode == ACLHIP_DEFAULT_SKIPPED;
+		if (has_skipped)
+		{
+			const hipError_t copy_status = hipMemcpy2D(d_out, device_stride, out, out_stride_bytes, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyHostToDevice);
+			if (copy_status != hipSuccess)
+			{
+				release();
+				return fail(context, ACLHIP_ERROR_DEVICE, "uploading the pre-filled poses failed: %s", hipGetErrorString(copy_status));
+			}
+		}
+
+		local.default_values = static_cast<const float*>(d_defaults);
+		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
+		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+
+		aclhip_status status;
+		if (single_track)
+			status = aclhip_decompress_track_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks), num_instances, &local, d_out, nullptr);
+		else
+			status = aclhip_decompress_tracks_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, d_out, device_stride, nullptr);
+
+		if (status == ACLHIP_OK)
+		{
+			hipError_t copy_status = hipDeviceSynchronize();
+			if (copy_status == hipSuccess)
+				copy_status = hipMemcpy2D(out, out_stride_bytes, d_out, device_stride, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyDeviceToHost);
+			if (copy_status != hipSuccess)
+				status = fail(context, ACLHIP_ERROR_DEVICE, "downloading the poses failed: %s", hipGetErrorString(copy_status));
+		}
+
+		release();
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes)
+{
+	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, default_values_count, poses, pose_stride_bytes, 0);
+}
+
+extern "C" aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms)
+{
+	if (track_indices == nullptr)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_host(context, clips, sample_times, track_indices, num_instances, params, default_values_count, transforms, 48, 48);
+}
+
+extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count)
+{
+	if (context == nullptr || out_count == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	device_guard guard(context->device);
+	unsigned long long value = 0;
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	ACLHIP_CHECK_HIP(context, hipMemcpy(&value, context->d_rejected, sizeof(value), hipMemcpyDeviceToHost));
+	*out_count = value;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch)
+{
+	if (out_ms_per_launch == nullptr || repeats == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats && status == ACLHIP_OK; ++i)
+		status = launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, hip_stream);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_ms_per_launch = elapsed_ms / float(repeats);
+	return status;
+}
+
+extern "C" aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,
+	uint64_t* out_bytes_written, uint64_t* out_distinct_clip_bytes)
+{
+	if (context == nullptr || (num_instances != 0 && clips == nullptr) || out_bytes_written == nullptr || out_distinct_clip_bytes == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::unordered_set<uint32_t> distinct;
+	uint64_t written = 0, read = 0;
+	for (uint32_t i = 0; i < num_instances; ++i)
+	{
+		const uint32_t clip = clips[i];
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			continue;
+		written += uint64_t(context->clips[clip].info.num_tracks) * 48;
+		if (distinct.insert(clip).second)
+			read += context->clips[clip].touched_bytes;
+	}
+	*out_bytes_written = written;
+	*out_distinct_clip_bytes = read;
+	return ACLHIP_OK;
+}

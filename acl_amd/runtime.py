@@ -1,0 +1,238 @@
+"""ctypes binding of the C ABI in include/aclhip.h (acl_amd/lib/libaclhip.so).
+
+Mirrors the reference's decompression surface (acl::decompression_context::initialize / seek /
+decompress_tracks / decompress_track, /root/reference/includes/acl/decompression/decompress.h:76-201)
+for batches of clip instances. torch is used only for device memory and streams.
+
+The HIP library is the only implementation: if it cannot be loaded this module raises, it never falls back to a CPU path.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaclhip.so")
+
+ROUND_NONE, ROUND_FLOOR, ROUND_CEIL, ROUND_NEAREST, ROUND_PER_TRACK = 0, 1, 2, 3, 4
+LOOP_CLAMP, LOOP_WRAP, LOOP_AS_COMPRESSED = 0, 1, 2
+NORMALIZE_NEVER, NORMALIZE_LERP_ONLY, NORMALIZE_ALWAYS = 0, 1, 2
+DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY = 0, 1, 2, 3
+INVALID_HANDLE = 0xFFFFFFFF
+
+EXPORTED_SYMBOLS = [
+    "aclhip_status_string", "aclhip_last_error_message", "aclhip_create", "aclhip_destroy", "aclhip_default_params",
+    "aclhip_register_clip", "aclhip_unregister_clip", "aclhip_get_clip_info", "aclhip_clip_matches",
+    "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
+    "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
+]
+
+
+class DecompressParams(ctypes.Structure):
+    """aclhip_decompress_params"""
+    _fields_ = [
+        ("rounding_policy", ctypes.c_uint8), ("looping_policy", ctypes.c_uint8), ("normalization", ctypes.c_uint8), ("per_track_rounding", ctypes.c_uint8),
+        ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
+        ("default_values", ctypes.c_void_p), ("track_rounding_policies", ctypes.c_void_p), ("instance_rounding_policies", ctypes.c_void_p),
+    ]
+
+
+class ClipInfo(ctypes.Structure):
+    """aclhip_clip_info"""
+    _fields_ = [
+        ("num_tracks", ctypes.c_uint32), ("num_samples", ctypes.c_uint32), ("sample_rate", ctypes.c_float), ("duration", ctypes.c_float),
+        ("num_segments", ctypes.c_uint32), ("has_scale", ctypes.c_uint32), ("looping_policy", ctypes.c_uint32), ("compressed_size", ctypes.c_uint32),
+        ("hash", ctypes.c_uint32), ("num_animated_sub_tracks", ctypes.c_uint32), ("has_database", ctypes.c_uint32), ("has_stripped_keyframes", ctypes.c_uint32),
+    ]
+
+
+class AclHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"aclhip status {status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libaclhip.so (raises when it was not built -- there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback")
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    pparams = ctypes.POINTER(DecompressParams)
+    lib.aclhip_status_string.argtypes = [i32]
+    lib.aclhip_status_string.restype = ctypes.c_char_p
+    lib.aclhip_last_error_message.argtypes = [vp]
+    lib.aclhip_last_error_message.restype = ctypes.c_char_p
+    lib.aclhip_create.argtypes = [i32, ctypes.POINTER(vp)]
+    lib.aclhip_destroy.argtypes = [vp]
+    lib.aclhip_destroy.restype = None
+    lib.aclhip_default_params.argtypes = [pparams]
+    lib.aclhip_default_params.restype = None
+    lib.aclhip_register_clip.argtypes = [vp, vp, u64, i32, ctypes.POINTER(u32)]
+    lib.aclhip_unregister_clip.argtypes = [vp, u32]
+    lib.aclhip_get_clip_info.argtypes = [vp, u32, ctypes.POINTER(ClipInfo)]
+    lib.aclhip_clip_matches.argtypes = [vp, u32, vp, ctypes.POINTER(i32)]
+    lib.aclhip_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp]
+    lib.aclhip_decompress_track_batch.argtypes = [vp, vp, vp, vp, u32, pparams, vp, vp]
+    lib.aclhip_decompress_tracks_host.argtypes = [vp, vp, vp, u32, pparams, u32, vp, u64]
+    lib.aclhip_decompress_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, u32, vp]
+    lib.aclhip_get_rejected_instance_count.argtypes = [vp, ctypes.POINTER(u64)]
+    lib.aclhip_time_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_float)]
+    lib.aclhip_batch_algorithmic_bytes.argtypes = [vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    _lib = lib
+    return lib
+
+
+def default_params(**overrides):
+    params = DecompressParams()
+    load_library().aclhip_default_params(ctypes.byref(params))
+    for key, value in overrides.items():
+        if not hasattr(params, key):
+            raise AttributeError(f"aclhip_decompress_params has no field '{key}'")
+        setattr(params, key, value)
+    return params
+
+
+def _host_ptr(array):
+    return array.ctypes.data if array is not None else None
+
+
+class Context:
+    """An aclhip_context bound to one HIP device: owns the HBM copies of registered clips."""
+
+    def __init__(self, device_index=0):
+        self._lib = load_library()
+        handle = ctypes.c_void_p()
+        status = self._lib.aclhip_create(device_index, ctypes.byref(handle))
+        if status != 0:
+            raise AclHipError(status, self._lib.aclhip_status_string(status).decode())
+        self._handle = handle
+        self.device_index = device_index
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            self._lib.aclhip_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, status):
+        if status != 0:
+            message = self._lib.aclhip_last_error_message(self._handle).decode() or self._lib.aclhip_status_string(status).decode()
+            raise AclHipError(status, message)
+
+    # ---- clips (decompression_context::initialize) ----
+    def register_clip(self, blob, check_hash=True):
+        """blob: bytes-like / uint8 numpy array holding one compressed_tracks. Returns the clip handle."""
+        array = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        handle = ctypes.c_uint32(INVALID_HANDLE)
+        self._check(self._lib.aclhip_register_clip(self._handle, array.ctypes.data, array.size, 1 if check_hash else 0, ctypes.byref(handle)))
+        return handle.value
+
+    def unregister_clip(self, clip):
+        self._check(self._lib.aclhip_unregister_clip(self._handle, clip))
+
+    def clip_info(self, clip):
+        info = ClipInfo()
+        self._check(self._lib.aclhip_get_clip_info(self._handle, clip, ctypes.byref(info)))
+        return info
+
+    def clip_matches(self, clip, blob):
+        matches = ctypes.c_int(0)
+        self._check(self._lib.aclhip_clip_matches(self._handle, clip, blob.ctypes.data, ctypes.byref(matches)))
+        return bool(matches.value)
+
+    # ---- device pointer API (inputs and outputs resident in HBM) ----
+    def decompress_tracks_batch(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, params=None, stream=None):
+        """seek + decompress_tracks for every instance. All pointers are device addresses (ints)."""
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_tracks_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream))
+
+    def decompress_track_batch(self, clips_ptr, times_ptr, tracks_ptr, num_instances, out_ptr, params=None, stream=None):
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_track_batch(self._handle, clips_ptr, times_ptr, tracks_ptr, num_instances, ctypes.byref(params), out_ptr, stream))
+
+    def time_decompress_tracks_batch(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, repeats, params=None, stream=None):
+        """Average device milliseconds per launch, HIP events recorded on `stream`."""
+        params = params if params is not None else default_params()
+        ms = ctypes.c_float(0.0)
+        self._check(self._lib.aclhip_time_decompress_tracks_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream, repeats, ctypes.byref(ms)))
+        return ms.value
+
+    # ---- host pointer convenience API ----
+    def decompress_tracks(self, clips, sample_times, params=None, num_tracks=None, out=None, default_values=None, track_rounding=None, instance_rounding=None):
+        """Host arrays in, host poses out: returns float32 [n, num_tracks, 12]."""
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
+        n = clips.size
+        if num_tracks is None:
+            num_tracks = max((self.clip_info(int(c)).num_tracks for c in np.unique(clips)), default=0)
+        if out is None:
+            out = np.zeros((n, num_tracks, 12), dtype=np.float32)
+        params = params if params is not None else default_params()
+        count = 0
+        if default_values is not None:
+            default_values = np.ascontiguousarray(default_values, dtype=np.float32)
+            params.default_values = default_values.ctypes.data
+            count = default_values.size // 12
+        if track_rounding is not None:
+            track_rounding = np.ascontiguousarray(track_rounding, dtype=np.uint8)
+            params.track_rounding_policies = track_rounding.ctypes.data
+        if instance_rounding is not None:
+            instance_rounding = np.ascontiguousarray(instance_rounding, dtype=np.uint8)
+            params.instance_rounding_policies = instance_rounding.ctypes.data
+        self._check(self._lib.aclhip_decompress_tracks_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, n, ctypes.byref(params), count, out.ctypes.data, num_tracks * 48))
+        return out
+
+    def decompress_track(self, clips, sample_times, track_indices, params=None, out=None, default_values=None, track_rounding=None, instance_rounding=None):
+        """Host arrays in, one qvv (12 floats) per instance out."""
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
+        track_indices = np.ascontiguousarray(track_indices, dtype=np.uint32)
+        n = clips.size
+        if out is None:
+            out = np.zeros((n, 12), dtype=np.float32)
+        params = params if params is not None else default_params()
+        count = 0
+        if default_values is not None:
+            default_values = np.ascontiguousarray(default_values, dtype=np.float32)
+            params.default_values = default_values.ctypes.data
+            count = default_values.size // 12
+        if track_rounding is not None:
+            track_rounding = np.ascontiguousarray(track_rounding, dtype=np.uint8)
+            params.track_rounding_policies = track_rounding.ctypes.data
+        if instance_rounding is not None:
+            instance_rounding = np.ascontiguousarray(instance_rounding, dtype=np.uint8)
+            params.instance_rounding_policies = instance_rounding.ctypes.data
+        self._check(self._lib.aclhip_decompress_track_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, track_indices.ctypes.data, n, ctypes.byref(params), count, out.ctypes.data))
+        return out
+
+    def rejected_instance_count(self):
+        count = ctypes.c_uint64(0)
+        self._check(self._lib.aclhip_get_rejected_instance_count(self._handle, ctypes.byref(count)))
+        return count.value
+
+    def batch_algorithmic_bytes(self, clips):
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        written, read = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self._check(self._lib.aclhip_batch_algorithmic_bytes(self._handle, clips.ctypes.data, clips.size, ctypes.byref(written), ctypes.byref(read)))
+        return written.value, read.value

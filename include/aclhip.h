@@ -1,0 +1,196 @@
+/* aclhip.h -- C ABI of the MI355X-native batched ACL clip decompressor (libaclhip.so).
+ *
+ * This is the drop-in boundary for the reference's decompression path. The reference has no ABI: its
+ * boundary is the inlined C++ template surface of acl::decompression_context<Settings>
+ * (/root/reference/includes/acl/decompression/decompress.h:76-201). Each entry point below names the
+ * reference interface it replaces; acl_amd/csrc/aclhip.hpp rebuilds the reference's C++ surface on top
+ * of these calls, and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no HIP or torch types: device pointers are `void*`/typed pointers into HBM of the context's
+ *     device, streams are passed as `void*` (a hipStream_t; NULL = the default stream);
+ *   - every function returns an aclhip_status and never throws; decompress calls are asynchronous and
+ *     stream ordered (the reference's calls are synchronous CPU code);
+ *   - a context owns device copies of registered clips; the caller owns instance lists and pose buffers;
+ *   - a pose is `num_tracks` records of 48 bytes, the reference's rtm::qvvf:
+ *     rotation xyzw | translation xyz, 0 | scale xyz, 0   (core/impl/debug_track_writer.h:61-62,172-192).
+ */
+#ifndef ACLHIP_H
+#define ACLHIP_H
+
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define ACLHIP_VERSION_MAJOR 0
+#define ACLHIP_VERSION_MINOR 1
+
+typedef enum aclhip_status
+{
+	ACLHIP_OK = 0,
+	ACLHIP_ERROR_INVALID_ARGUMENT = 1,
+	ACLHIP_ERROR_INVALID_CLIP = 2,			/* compressed_tracks::is_valid() would fail (core/impl/compressed_tracks.impl.h:278-301) */
+	ACLHIP_ERROR_UNSUPPORTED_FORMAT = 3,	/* not qvvf / not quatf_drop_w_variable + vector3f_variable */
+	ACLHIP_ERROR_UNKNOWN_CLIP = 4,
+	ACLHIP_ERROR_OUT_OF_MEMORY = 5,
+	ACLHIP_ERROR_DEVICE = 6,				/* a HIP call failed, see aclhip_last_error_message */
+	ACLHIP_ERROR_NO_DEVICE = 7,
+	ACLHIP_ERROR_UNKNOWN_DATABASE = 8,
+	ACLHIP_ERROR_NOT_IN_DATABASE = 9
+} aclhip_status;
+
+/* acl::sample_rounding_policy (core/sample_rounding_policy.h) */
+typedef enum aclhip_rounding_policy
+{
+	ACLHIP_ROUND_NONE = 0,
+	ACLHIP_ROUND_FLOOR = 1,
+	ACLHIP_ROUND_CEIL = 2,
+	ACLHIP_ROUND_NEAREST = 3,
+	ACLHIP_ROUND_PER_TRACK = 4
+} aclhip_rounding_policy;
+
+/* acl::sample_looping_policy (core/sample_looping_policy.h) */
+typedef enum aclhip_looping_policy
+{
+	ACLHIP_LOOP_CLAMP = 0,
+	ACLHIP_LOOP_WRAP = 1,
+	ACLHIP_LOOP_AS_COMPRESSED = 2
+} aclhip_looping_policy;
+
+/* acl::rotation_normalization_policy_t (decompression/decompression_settings.h:50-62) */
+typedef enum aclhip_normalization_policy
+{
+	ACLHIP_NORMALIZE_NEVER = 0,
+	ACLHIP_NORMALIZE_LERP_ONLY = 1,			/* default_transform_decompression_settings */
+	ACLHIP_NORMALIZE_ALWAYS = 2
+} aclhip_normalization_policy;
+
+/* acl::default_sub_track_mode (core/track_writer.h:49-74) */
+typedef enum aclhip_default_mode
+{
+	ACLHIP_DEFAULT_SKIPPED = 0,				/* default sub-tracks are not written, the caller pre-filled the pose buffer */
+	ACLHIP_DEFAULT_CONSTANT = 1,			/* one value for every default sub-track (identity / 0 / 1 when no value is given) */
+	ACLHIP_DEFAULT_VARIABLE = 2,			/* per track value, e.g. the bind pose */
+	ACLHIP_DEFAULT_LEGACY = 3				/* scale only: the clip's default scale bit (ACL 2.0 behaviour) */
+} aclhip_default_mode;
+
+typedef struct aclhip_context aclhip_context;
+typedef uint32_t aclhip_clip;				/* handle returned by aclhip_register_clip */
+typedef uint32_t aclhip_database;			/* handle returned by aclhip_register_database */
+
+#define ACLHIP_INVALID_HANDLE 0xFFFFFFFFu
+
+/* What decompression_settings + track_writer select at compile time in the reference
+ * (decompression/decompression_settings.h:74-166, core/track_writer.h:82-216), as a run time struct.
+ * aclhip_default_params() fills in default_transform_decompression_settings + the track_writer defaults. */
+typedef struct aclhip_decompress_params
+{
+	uint8_t rounding_policy;				/* aclhip_rounding_policy given to seek() for every instance (unless per-instance policies are supplied) */
+	uint8_t looping_policy;					/* aclhip_looping_policy, decompression_context::set_looping_policy() */
+	uint8_t normalization;					/* aclhip_normalization_policy, get_rotation_normalization_policy() */
+	uint8_t per_track_rounding;				/* is_per_track_rounding_supported() */
+	uint8_t default_rotation_mode;			/* aclhip_default_mode, track_writer::get_default_rotation_mode() */
+	uint8_t default_translation_mode;
+	uint8_t default_scale_mode;
+	uint8_t reserved0;
+	const float* default_values;			/* DEVICE pointer or NULL. CONSTANT: 12 floats; VARIABLE: max num_tracks * 12 floats (qvv per track) */
+	const uint8_t* track_rounding_policies;	/* DEVICE pointer or NULL: track_writer::get_rounding_policy() per track, used when seeking with PER_TRACK */
+	const uint8_t* instance_rounding_policies;	/* DEVICE pointer or NULL: one aclhip_rounding_policy per instance, overrides rounding_policy */
+} aclhip_decompress_params;
+
+typedef struct aclhip_clip_info
+{
+	uint32_t num_tracks;
+	uint32_t num_samples;
+	float sample_rate;
+	float duration;							/* compressed_tracks::get_finite_duration(as_compressed) */
+	uint32_t num_segments;
+	uint32_t has_scale;
+	uint32_t looping_policy;				/* compressed_tracks::get_looping_policy() */
+	uint32_t compressed_size;				/* compressed_tracks::get_size() */
+	uint32_t hash;							/* compressed_tracks::get_hash() */
+	uint32_t num_animated_sub_tracks;		/* rotations + translations + scales */
+	uint32_t has_database;
+	uint32_t has_stripped_keyframes;
+} aclhip_clip_info;
+
+/* ---- library / context ------------------------------------------------------------------------ */
+
+const char* aclhip_status_string(aclhip_status status);
+
+/* Message of the last failing call made through this context on any thread (empty string when none). */
+const char* aclhip_last_error_message(const aclhip_context* context);
+
+/* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are
+ * 128 byte stack objects, decompression/impl/decompression_context.transform.h:53-116). */
+aclhip_status aclhip_create(int device_index, aclhip_context** out_context);
+void aclhip_destroy(aclhip_context* context);
+
+void aclhip_default_params(aclhip_decompress_params* out_params);
+
+/* ---- clips ------------------------------------------------------------------------------------ */
+
+/* Replaces decompression_context::initialize(const compressed_tracks&) (decompress.h:103; impl/decompress.impl.h:66-83;
+ * initialize_v0 impl/decompression.transform.h:84-132): validates the blob like compressed_tracks::is_valid(check_hash)
+ * and copies it, unchanged and 16 byte aligned with tail padding, into HBM together with derived lookup tables.
+ * `compressed_tracks` is a HOST pointer to `size` bytes; the caller may free it as soon as the call returns. */
+aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip);
+
+/* Replaces decompression_context::reset() / the end of the blob's lifetime. Stream ordered work using the clip must have completed. */
+aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip);
+
+aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info);
+
+/* Replaces decompression_context::is_bound_to(const compressed_tracks&) (decompress.h:138): true when `clip`
+ * was registered from a blob with the same hash and size. */
+aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches);
+
+/* ---- decompression ---------------------------------------------------------------------------- */
+
+/* Replaces, for every instance i in [0, num_instances):
+ *     context.seek(sample_times[i], rounding_policy);            (decompress.h:160; seek_v0 impl/decompression.transform.h:206-563)
+ *     context.decompress_tracks(writer);                          (decompress.h:166; decompress_tracks_v0 :1526-1737)
+ * with writer.write_rotation/translation/scale storing into
+ *     (char*)poses + i * pose_stride_bytes + track_index * 48.
+ * clips / sample_times / poses are DEVICE pointers; pose_stride_bytes must be a multiple of 16 and at least
+ * 48 * num_tracks of the largest clip referenced. One wavefront decodes one instance. */
+aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream);
+
+/* Replaces seek() + decompress_track(track_indices[i], writer) (decompress.h:172; decompress_track_v0 :1753-2050):
+ * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers. */
+aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* transforms, void* stream);
+
+/* Convenience for host callers (the C++ mirror of decompression_context uses it with a batch of one): same as the two
+ * calls above but every pointer is a HOST pointer; instance lists are uploaded, poses downloaded, the call is synchronous.
+ * params->default_values / track_rounding_policies / instance_rounding_policies are HOST pointers here as well;
+ * `default_values_count` is the number of qvv records default_values holds (1 for CONSTANT, num_tracks for VARIABLE). */
+aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes);
+aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms);
+
+/* Number of instances the kernels refused since the context was created (unknown clip handle, track index out of range):
+ * the reference silently returns in those cases (impl/decompression.transform.h:1532-1537,1766-1768). */
+aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count);
+
+/* ---- measurement helpers ---------------------------------------------------------------------- */
+
+/* Runs `repeats` launches of aclhip_decompress_tracks_batch on `stream` bracketed by HIP events recorded on that same
+ * stream and returns the average milliseconds per launch (device time of the decode kernel, no host overhead). */
+aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch);
+
+/* Algorithmic bytes of one batch under the compulsory-HBM model of DESIGN.md: poses written plus each distinct
+ * clip's touched bytes once. `clips` is a HOST pointer here. */
+aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,
+	uint64_t* out_bytes_written, uint64_t* out_distinct_clip_bytes);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif
