@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- poses/sec of the batched clip decompressor (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one launch of aclhip_decompress_tracks_batch (seek + decompress_tracks for every instance of the
+batch). Inputs (registered clips, instance lists) and the pose buffer are resident in HBM before the timed region.
+Workloads (BASELINE.json configs):
+    one_clip   64k instances of one CMU-shaped 100-bone clip, random sample times       (configs[1], the default)
+    256_clips  64k instances drawn from 256 distinct 100-bone clips                      (configs[2])
+    cinematic  64k instances per GPU of a 300-bone rig with scale, multi-segment         (configs[3], per GPU shard)
+With N > 1 every rank decodes its own shard of instances (weak scaling, no data-path collective); rank 0 prints ONE
+JSON line with the whole-job poses/sec, the roofline of the decode kernel and, at N = 1, the CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3 TB/s achievable)
+INSTANCES_PER_GPU = 65536
+
+
+def build_workload(name, rank):
+    """Returns (list of SyntheticClip, instance->clip index array, sample times) for this rank's shard."""
+    from acl_amd import synth
+
+    rng = np.random.default_rng(1000 + rank)
+    if name == "one_clip":
+        clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
+        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+    elif name == "256_clips":
+        clips = []
+        spec_rng = np.random.default_rng(3)
+        for i in range(256):
+            animated = spec_rng.uniform(0.25, 0.5)
+            clips.append(synth.build_clip(
+                seed=300 + i, num_tracks=100, num_samples=int(spec_rng.integers(31, 601)), sample_rate=30.0,
+                rotation_default=0.02, rotation_constant=float(0.98 - animated),
+                wrap=int(spec_rng.uniform() < 0.1), strip_keyframes=int(spec_rng.uniform() < 0.1),
+                min_bits=int(spec_rng.integers(5, 10)), max_bits=int(spec_rng.integers(12, 19))))
+        clip_indices = rng.integers(0, 256, size=INSTANCES_PER_GPU).astype(np.uint32)
+    elif name == "cinematic":
+        clips = [synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,
+                                  scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)]
+        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+    else:
+        raise ValueError(f"unknown workload {name}")
+
+    durations = np.array([c.duration for c in clips], dtype=np.float32)
+    times = (rng.uniform(0.0, 1.0, size=clip_indices.size).astype(np.float32) * durations[clip_indices]).astype(np.float32)
+    return clips, clip_indices, times
+
+
+def cpu_baseline(clips, clip_indices, times, max_tracks):
+    """Times the reference's own decoder (oracle/_ref, kind "reference") -- or the C restatement (kind "port") when the
+    reference build is absent -- on a bounded sample of the same instance list, on this box's host cores."""
+    import ctypes
+    from oracle import bindings as ob  # cpu_baseline leg: the oracle is the baseline being measured here, never the product
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sample = min(clip_indices.size, 65536)
+    indices = np.ascontiguousarray(clip_indices[:sample], dtype=np.uint32)
+    sample_times = np.ascontiguousarray(times[:sample], dtype=np.float32)
+
+    if ob.have_ref():
+        lib = ob.ref()
+        blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
+        # calibrate so that the timed part is roughly 15-25 s of CPU work in total (about 2-3 s of wall time on all cores)
+        probe = lib.aclref_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, min(sample, 8192), max_tracks, cores, 1, None)
+        per_pose = probe / min(sample, 8192)
+        repeats = int(max(1, min(400, 2.5 / max(per_pose * sample, 1e-9))))
+        seconds = lib.aclref_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, max_tracks, cores, repeats, None)
+        return {"value": sample / seconds, "unit": "poses/s", "cores": cores, "kind": "reference",
+                "sample": f"{sample} instances of the same list, seek+decompress_tracks, reference headers (AVX2 build, benchmark settings), "
+                          f"{cores} threads, warm cache, best of {repeats} passes"}
+
+    lib = ob.oracle()
+    options = ob.default_options()
+    sample = min(sample, 16384)
+    out = np.zeros((sample, max_tracks * 12), dtype=np.float32)
+    blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        lib.aclo_decompress_tracks_batch(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, 0, ctypes.byref(options), out.ctypes.data, max_tracks * 12)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": sample / best, "unit": "poses/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c), 1 thread, best of 3"}
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpus", type=int, default=1)
+    parser.add_argument("--steps", type=int, default=200)
+    parser.add_argument("--warmup", type=int, default=20)
+    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic"])
+    parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
+    parser.add_argument("--no-cpu-baseline", action="store_true")
+    args = parser.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world_size > 1
+    if args.gpus != world_size and distributed:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("launch N > 1 through torch.distributed.run (one process per GPU)")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from acl_amd import runtime
+
+    clips, clip_indices, times = build_workload(args.workload, rank)
+    if args.sort_by_clip:
+        order = np.argsort(clip_indices, kind="stable")
+        clip_indices, times = clip_indices[order], times[order]
+
+    context = runtime.Context(local_rank)
+    handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+    max_tracks = max(c.num_tracks for c in clips)
+    num_instances = clip_indices.size
+    pose_stride = max_tracks * 48
+
+    d_clips = torch.from_numpy(handles[clip_indices].astype(np.int32)).to(device)
+    d_times = torch.from_numpy(times).to(device)
+    d_poses = torch.empty((num_instances, max_tracks * 12), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream(device)
+    params = runtime.default_params()
+
+    def step():
+        context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride, params=params, stream=stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    if distributed:
+        elapsed_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(elapsed_tensor, op=dist.ReduceOp.MAX)
+        elapsed = float(elapsed_tensor.item())
+
+    # Roofline of the decode kernel: device time from HIP events recorded on the launch stream
+    kernel_ms = context.time_decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
+                                                     repeats=max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
+    bytes_written, bytes_read = context.batch_algorithmic_bytes(handles[clip_indices])
+    algorithmic_bytes = bytes_written + bytes_read
+    achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+
+    rejected = context.rejected_instance_count()
+    if rejected != 0:
+        raise SystemExit(f"the kernel rejected {rejected} instances")
+
+    if rank == 0:
+        total_poses = num_instances * world_size * args.steps
+        result = {
+            "metric": "poses/sec (whole node), 64k clip instances x 100 bones per GPU, seek + decompress_tracks",
+            "value": total_poses / elapsed,
+            "unit": "poses/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": {"one_clip": "64k instances of one CMU-shaped 100-bone clip, random sample times, quatf_drop_w_variable + vector3f_variable (BASELINE.json configs[1])",
+                             "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else ""),
+                             "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)"}[args.workload],
+                "instances_per_gpu": int(num_instances),
+                "bones": int(max_tracks),
+                "distinct_clips": len(clips),
+                "pose_bytes": int(pose_stride),
+                "sharding": f"instances split over {world_size} rank(s), no collective on the data path",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved_gbps,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved_gbps / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "decompress_tracks_kernel",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+            },
+        }
+        if world_size == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(clips, clip_indices, times, max_tracks)
+        print(json.dumps(result))
+
+    context.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
