@@ -1,0 +1,50 @@
+"""Multi-GPU sharding of a batch of clip instances: one process per GPU, instances are independent units.
+
+The decode needs no exchange step: rank r decodes instances [r*n/W, (r+1)*n/W) of the batch into its own pose shard with its
+own aclhip context (clip blobs are tiny and replicated on every GPU). Only when a caller wants the full pose set on
+every rank is there a collective: one all-gather of the pose shards (RCCL over xGMI with backend "nccl", gloo on CPU).
+SURVEY.md section 8(e); nothing comparable exists in the reference, which is single threaded CPU code.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_instances, rank, world_size):
+    """Contiguous, balanced partition of [0, num_instances): returns (begin, end) of `rank`'s shard."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("invalid rank / world size")
+    begin = (num_instances * rank) // world_size
+    end = (num_instances * (rank + 1)) // world_size
+    return begin, end
+
+
+def shard_sizes(num_instances, world_size):
+    return [shard_bounds(num_instances, r, world_size)[1] - shard_bounds(num_instances, r, world_size)[0] for r in range(world_size)]
+
+
+def all_gather_poses(local_poses, num_instances, group=None):
+    """Gathers the pose shards of every rank into one [num_instances, ...] tensor on every rank.
+
+    local_poses: this rank's [shard, num_tracks, 12] (or [shard, floats]) tensor. Shards may differ by one instance:
+    they are padded to the largest shard for the collective and trimmed afterwards.
+    """
+    world_size = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(num_instances, world_size)
+    if local_poses.shape[0] != sizes[rank]:
+        raise ValueError(f"rank {rank} holds {local_poses.shape[0]} poses, its shard has {sizes[rank]}")
+
+    largest = max(sizes)
+    padded = local_poses
+    if local_poses.shape[0] != largest:
+        padded = torch.zeros((largest,) + tuple(local_poses.shape[1:]), dtype=local_poses.dtype, device=local_poses.device)
+        padded[: local_poses.shape[0]] = local_poses
+    padded = padded.contiguous()
+
+    gathered = torch.empty((world_size * largest,) + tuple(local_poses.shape[1:]), dtype=local_poses.dtype, device=local_poses.device)
+    dist.all_gather_into_tensor(gathered, padded, group=group)
+
+    if all(size == largest for size in sizes):
+        return gathered
+    pieces = [gathered[r * largest: r * largest + sizes[r]] for r in range(world_size)]
+    return torch.cat(pieces, dim=0)

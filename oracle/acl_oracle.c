@@ -959,3 +959,59 @@ int aclo_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_
 	}
 	return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Restatement of the reference's exhaustive packing unit test (tests/sources/math/test_vector4_packing.cpp:385-465,
+ * unsigned half): every value of every bit width in [first_num_bits, last_num_bits] goes through
+ * pack_vector3_uXX -> memcpy_bits at bit offsets {0,1,5,31,32,33,63,64,65,93} -> unpack_vector3_uXX and must come
+ * back within 1e-6. Returns the number of mismatches (0 = pass).
+ * ---------------------------------------------------------------------------------------------- */
+uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_num_bits)
+{
+	static const uint32_t offsets[] = { 0, 1, 5, 31, 32, 33, 63, 64, 65, 93 };
+	uint32_t num_errors = 0;
+	uint32_t num_bits;
+
+	for (num_bits = first_num_bits; num_bits <= last_num_bits; ++num_bits)
+	{
+		const uint32_t max_value = (1u << num_bits) - 1;
+		const float inv_max = 1.0f / (float)max_value;
+		uint32_t value;
+
+		for (value = 0; value <= max_value; value += 3)
+		{
+			uint8_t buffer[64];
+			uint8_t shifted[64];
+			float in[3], out[3];
+			uint32_t i, c;
+			const uint32_t v1 = value + 1 < max_value ? value + 1 : max_value;
+			const uint32_t v2 = value + 2 < max_value ? value + 2 : max_value;
+
+			/* unpack_scalar_unsigned (math/scalar_packing.h:50-56) clamped to [0, 1] */
+			in[0] = (float)value * inv_max;
+			in[1] = (float)v1 * inv_max;
+			in[2] = (float)v2 * inv_max;
+			for (c = 0; c < 3; ++c)
+				in[c] = in[c] < 0.0f ? 0.0f : (in[c] > 1.0f ? 1.0f : in[c]);
+
+			memset(buffer, 0, sizeof(buffer));
+			aclo_pack_vector3_uXX(in, num_bits, buffer);
+			aclo_unpack_vector3_uXX(num_bits, buffer, 0, out);
+			for (c = 0; c < 3; ++c)
+				if (!(fabsf(in[c] - out[c]) < 1.0e-6f))
+					num_errors++;
+
+			for (i = 0; i < sizeof(offsets) / sizeof(offsets[0]); ++i)
+			{
+				memset(shifted, 0, sizeof(shifted));
+				aclo_memcpy_bits(shifted, offsets[i], buffer, 0, (uint64_t)num_bits * 3);
+				aclo_unpack_vector3_uXX(num_bits, shifted, offsets[i], out);
+				for (c = 0; c < 3; ++c)
+					if (!(fabsf(in[c] - out[c]) < 1.0e-6f))
+						num_errors++;
+			}
+		}
+	}
+
+	return num_errors;
+}

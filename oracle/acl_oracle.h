@@ -96,6 +96,9 @@ void aclo_unpack_vector3_u24(const uint8_t* data, float out[3]);												/* :
 void aclo_pack_vector3_uXX(const float in[3], uint32_t num_bits, uint8_t* out_data);
 void aclo_memcpy_bits(void* dest, uint64_t dest_bit_offset, const void* src, uint64_t src_bit_offset, uint64_t num_bits);
 
+/* The reference's exhaustive uXX packing unit test (tests/sources/math/test_vector4_packing.cpp:385-465), restated. Returns the error count. */
+uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_num_bits);
+
 /* seek_v0 (decompression.transform.h:206-563). Returns 0 ok. */
 int aclo_seek(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, aclo_seek_result* out);
 

@@ -79,6 +79,8 @@ def oracle():
         lib.aclo_unpack_vector3_u24.argtypes = [vp, vp]
         lib.aclo_pack_vector3_uXX.argtypes = [vp, u32, vp]
         lib.aclo_memcpy_bits.argtypes = [vp, u64, vp, u64, u64]
+        lib.aclo_selftest_pack_vector3_uXX.argtypes = [u32, u32]
+        lib.aclo_selftest_pack_vector3_uXX.restype = u32
         lib.aclo_seek.argtypes = [vp, f32, i32, ctypes.POINTER(Options), ctypes.POINTER(SeekResult)]
         lib.aclo_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
         lib.aclo_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]

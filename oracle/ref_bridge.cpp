@@ -196,15 +196,22 @@ extern "C"
 	}
 
 	// CPU baseline: 'count' instances {clip index, sample time}, statically partitioned over 'num_threads'
-	// std::threads, one decompression_context per thread re-initialised when the clip changes, seek +
-	// decompress_tracks per instance with the benchmark settings (benchmark.cpp:94-101,249-254).
+	// std::threads (created once), one decompression_context per thread re-initialised when the clip changes, seek +
+	// decompress_tracks per instance with the benchmark settings (benchmark.cpp:94-101,249-254). Every thread walks
+	// its partition 'repeats' times after one untimed warm-up walk; all threads start the timed part together.
 	// If 'out' is null every thread writes into its own private pose buffer (no output kept).
-	// Returns elapsed seconds of the best of 'repeats' passes (after one untimed warm-up pass).
+	// Returns the average elapsed seconds of one pass over the whole instance list.
 	double aclref_bench(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
 		uint32_t max_tracks, uint32_t num_threads, uint32_t repeats, float* out)
 	{
 		if (num_threads == 0)
 			num_threads = 1;
+		if (repeats == 0)
+			repeats = 1;
+
+		std::atomic<uint32_t> num_ready(0);
+		std::atomic<uint32_t> go(0);
+		std::atomic<uint32_t> num_done(0);
 
 		auto worker = [&](uint32_t thread_index)
 		{
@@ -215,42 +222,51 @@ extern "C"
 			acl::decompression_context<benchmark_settings> context;
 			const void* bound = nullptr;
 
-			for (uint32_t i = begin; i < end; ++i)
+			for (uint32_t pass = 0; pass <= repeats; ++pass)
 			{
-				const void* blob = blobs[clip_indices[i]];
-				if (blob != bound)
+				if (pass == 1)
 				{
-					context.initialize(*static_cast<const acl::compressed_tracks*>(blob));
-					bound = blob;
+					// warm-up walk done: rendezvous so that the timed passes of all threads overlap
+					num_ready.fetch_add(1);
+					while (go.load() == 0)
+						std::this_thread::yield();
 				}
 
-				writer_identity writer;
-				writer.out = out != nullptr ? out + size_t(i) * max_tracks * 12 : scratch.data();
-				writer.defaults = nullptr;
-				writer.per_track_policies = nullptr;
+				for (uint32_t i = begin; i < end; ++i)
+				{
+					const void* blob = blobs[clip_indices[i]];
+					if (blob != bound)
+					{
+						context.initialize(*static_cast<const acl::compressed_tracks*>(blob));
+						bound = blob;
+					}
 
-				context.seek(sample_times[i], acl::sample_rounding_policy::none);
-				context.decompress_tracks(writer);
+					writer_identity writer;
+					writer.out = out != nullptr ? out + size_t(i) * max_tracks * 12 : scratch.data();
+					writer.defaults = nullptr;
+					writer.per_track_policies = nullptr;
+
+					context.seek(sample_times[i], acl::sample_rounding_policy::none);
+					context.decompress_tracks(writer);
+				}
 			}
+
+			num_done.fetch_add(1);
 		};
 
-		double best = 1.0e30;
-		for (uint32_t pass = 0; pass <= repeats; ++pass)
-		{
-			const auto start = std::chrono::steady_clock::now();
+		std::vector<std::thread> threads;
+		for (uint32_t t = 0; t < num_threads; ++t)
+			threads.emplace_back(worker, t);
 
-			std::vector<std::thread> threads;
-			for (uint32_t t = 1; t < num_threads; ++t)
-				threads.emplace_back(worker, t);
-			worker(0);
-			for (std::thread& t : threads)
-				t.join();
+		while (num_ready.load() != num_threads)
+			std::this_thread::yield();
 
-			const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
-			if (pass != 0 && elapsed < best)
-				best = elapsed;
-		}
+		const auto start = std::chrono::steady_clock::now();
+		go.store(1);
+		for (std::thread& t : threads)
+			t.join();
+		const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
-		return best;
+		return elapsed / double(repeats);
 	}
 }

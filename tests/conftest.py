@@ -1,0 +1,58 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def native_libraries():
+    """Builds (or reuses) the in-tree native libraries: libaclhip.so, libaclsynth.so, the CPU oracle."""
+    from acl_amd import build
+    return build.build_all()
+
+
+# Clip shapes exercised by both the CPU (oracle vs reference) and the GPU (kernel vs oracle) parity tests.
+# Edge cases follow what the reference's regression validator covers (tools/acl_compressor/sources/validate_tracks.cpp):
+# single / multi segment, scale, wrap looping, stripped keyframes, old format version, one or two samples, raw and constant rates.
+CLIP_SPECS = {
+    "cmu_100": dict(),
+    "cmu_70_default": dict(seed=7, num_tracks=70),
+    "single_segment": dict(num_samples=20),
+    "scale_37": dict(has_scale=1, num_tracks=37),
+    "stripped": dict(strip_keyframes=1),
+    "wrap_77": dict(wrap=1, num_samples=77),
+    "v2_0_low_bits": dict(version=7, min_bits=3, max_bits=19),
+    "v2_1_wip": dict(version=8, min_bits=3, max_bits=19, raw_fraction=0.1),
+    "stripped_single_segment_scale": dict(strip_keyframes=1, num_samples=25, has_scale=1),
+    "stripped_wrap_scale": dict(strip_keyframes=1, wrap=1, num_samples=100, has_scale=1, num_tracks=19),
+    "one_sample": dict(num_samples=1),
+    "two_samples_three_tracks": dict(num_samples=2, num_tracks=3),
+    "raw_and_constant_rates": dict(raw_fraction=0.3, width0_fraction=0.3, num_tracks=64, has_scale=1, scale_default=0.2, scale_constant=0.2, translation_constant=0.3),
+    "cinematic_300": dict(num_tracks=300, has_scale=1, scale_default=0.5, scale_constant=0.1, rotation_constant=0.2, translation_constant=0.3, num_samples=200),
+    "all_default": dict(num_tracks=17, rotation_default=1.0, translation_default=1.0),
+    "all_animated_65": dict(num_tracks=65, rotation_default=0.0, rotation_constant=0.0, translation_default=0.0, translation_constant=0.0, num_samples=40),
+    "max_segment_31": dict(num_samples=31, num_tracks=9),
+    "two_segments_32": dict(num_samples=32, num_tracks=9),
+    "high_bits_23": dict(min_bits=20, max_bits=23, num_tracks=33, num_samples=50),
+    "default_scale_zero": dict(has_scale=1, default_scale=0, num_tracks=12, num_samples=10),
+}
+
+
+def sample_times_for(duration, count, rng):
+    """Random times slightly outside [0, duration] (clamping) plus the exact ends and the middle."""
+    times = rng.uniform(-0.1, duration + 0.1, size=count).astype(np.float32)
+    return np.concatenate([times, np.array([0.0, duration, duration * 0.5, -1.0, duration + 1.0], dtype=np.float32)])
+
+
+@pytest.fixture(scope="session")
+def clip_specs():
+    return CLIP_SPECS

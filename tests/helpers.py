@@ -1,0 +1,77 @@
+"""Shared helpers of the parity tests: maps a (settings, default mode) pair of the reference bridge onto oracle options and
+C-ABI params, loads golden fixtures."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+
+from oracle import bindings as ob
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Components compared: W lanes of translation (7) and scale (11) are unspecified in the reference
+# (animated_track_cache.transform.h:964); this framework defines them as 0.
+XYZ_LANES = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]
+
+
+def golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_golden(name):
+    data = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+    case = {key: data[key] for key in data.files}
+    from acl_amd import synth
+    blob = synth.aligned_bytes(case["blob"].size)
+    blob[:] = case["blob"]
+    case["blob"] = blob
+    case["settings"] = int(case["settings"])
+    case["default_mode"] = int(case["default_mode"])
+    case["defaults"] = case["defaults"] if case["defaults"].size else None
+    case["track_rounding"] = case["track_rounding"] if case["track_rounding"].size else None
+    return case
+
+
+def mode_triplet(default_mode):
+    """reference bridge default_mode -> (rotation, translation, scale) default_sub_track_mode"""
+    return {
+        0: (ob.DEFAULT_CONSTANT, ob.DEFAULT_CONSTANT, ob.DEFAULT_LEGACY),
+        1: (ob.DEFAULT_SKIPPED, ob.DEFAULT_SKIPPED, ob.DEFAULT_SKIPPED),
+        2: (ob.DEFAULT_CONSTANT, ob.DEFAULT_CONSTANT, ob.DEFAULT_CONSTANT),
+        3: (ob.DEFAULT_VARIABLE, ob.DEFAULT_VARIABLE, ob.DEFAULT_VARIABLE),
+    }[default_mode]
+
+
+def settings_pair(settings):
+    """reference bridge settings id -> (normalization, per_track_rounding)"""
+    return {0: (ob.NORMALIZE_LERP_ONLY, 0), 1: (ob.NORMALIZE_ALWAYS, 1), 2: (ob.NORMALIZE_LERP_ONLY, 1), 3: (ob.NORMALIZE_LERP_ONLY, 0)}[settings]
+
+
+def oracle_options(settings=0, default_mode=0, defaults=None, track_rounding=None, looping=ob.LOOP_AS_COMPRESSED):
+    normalization, per_track = settings_pair(settings)
+    rot, trans, scale = mode_triplet(default_mode)
+    options = ob.default_options(looping_policy=looping, normalization=normalization, per_track_rounding=per_track,
+                                 default_rotation_mode=rot, default_translation_mode=trans, default_scale_mode=scale)
+    if defaults is not None and default_mode in (2, 3):
+        options.default_values = defaults.ctypes.data
+    if track_rounding is not None:
+        options.track_rounding = track_rounding.ctypes.data
+    return options
+
+
+def gpu_params(runtime, rounding=0, settings=0, default_mode=0, looping=2):
+    normalization, per_track = settings_pair(settings)
+    rot, trans, scale = mode_triplet(default_mode)
+    return runtime.default_params(rounding_policy=rounding, looping_policy=looping, normalization=normalization, per_track_rounding=per_track,
+                                  default_rotation_mode=rot, default_translation_mode=trans, default_scale_mode=scale)
+
+
+def max_abs_diff(a, b):
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a[..., XYZ_LANES] - b[..., XYZ_LANES]).max())
+
+
+def bit_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a[..., XYZ_LANES]).view(np.uint32), np.ascontiguousarray(b[..., XYZ_LANES]).view(np.uint32))

@@ -1,0 +1,66 @@
+"""The C-ABI shared library loads and exports every entry point include/aclhip.h declares (no compute calls, no GPU)."""
+import ctypes
+import os
+import re
+
+from acl_amd import runtime, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    header = open(os.path.join(ROOT, "include", "aclhip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    return sorted(set(re.findall(r"\b(aclhip_[a-z_0-9]+)\s*\(", header)))
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_functions()
+    for required in ("aclhip_create", "aclhip_destroy", "aclhip_register_clip", "aclhip_unregister_clip",
+                     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch"):
+        assert required in names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = runtime.load_library()
+    missing = [name for name in declared_functions() if not hasattr(lib, name)]
+    assert not missing, missing
+    assert sorted(runtime.EXPORTED_SYMBOLS) == declared_functions()
+
+
+def test_default_params_match_the_reference_defaults():
+    params = runtime.default_params()
+    # default_transform_decompression_settings (decompression_settings.h:211-232) + track_writer defaults (track_writer.h:161-163)
+    assert params.rounding_policy == runtime.ROUND_NONE
+    assert params.looping_policy == runtime.LOOP_AS_COMPRESSED
+    assert params.normalization == runtime.NORMALIZE_LERP_ONLY
+    assert params.per_track_rounding == 0
+    assert (params.default_rotation_mode, params.default_translation_mode, params.default_scale_mode) == (runtime.DEFAULT_CONSTANT, runtime.DEFAULT_CONSTANT, runtime.DEFAULT_LEGACY)
+
+
+def test_status_strings_and_argument_checks_without_a_device():
+    lib = runtime.load_library()
+    assert lib.aclhip_status_string(0) == b"ok"
+    assert lib.aclhip_status_string(2) == b"invalid compressed_tracks"
+    # null out pointer is rejected before any HIP call
+    assert lib.aclhip_create(0, None) == 1
+
+
+def test_synth_library_loads():
+    spec = synth.default_spec()
+    assert spec.num_tracks == 100 and spec.num_samples == 301
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under acl_amd/ or include/ may reference it."""
+    offenders = []
+    for base in ("acl_amd", "include"):
+        for dirpath, _, filenames in os.walk(os.path.join(ROOT, base)):
+            for filename in filenames:
+                if filename == "build.py":
+                    continue    # building the checker (make -C oracle) is not using it
+                if filename.endswith((".py", ".h", ".hpp", ".cpp", ".hip")):
+                    text = open(os.path.join(dirpath, filename), errors="ignore").read()
+                    if re.search(r"from oracle|import oracle|acl_oracle\.h|libacloracle|libaclref|oracle/", text):
+                        offenders.append(os.path.join(dirpath, filename))
+    assert not offenders, offenders

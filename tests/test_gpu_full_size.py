@@ -1,0 +1,135 @@
+"""BASELINE.json-sized batches on the GPU through the device-pointer C ABI (torch only provides device memory and streams):
+spot checks against the oracle plus size independent properties the reference's own validator relies on
+(tools/acl_compressor/sources/validate_tracks.cpp:170-258)."""
+import numpy as np
+import pytest
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+N = 65536
+
+
+@pytest.fixture(scope="module")
+def setup():
+    import torch
+    ctx = runtime.Context(0)
+    device = torch.device("cuda:0")
+    yield ctx, torch, device
+    ctx.close()
+
+
+def _decode(ctx, torch, device, handles, which, times, max_tracks, params=None, stream=None):
+    d_clips = torch.from_numpy(np.asarray(handles, dtype=np.uint32)[which].astype(np.int32)).to(device)
+    d_times = torch.from_numpy(times).to(device)
+    d_poses = torch.zeros((times.size, max_tracks, 12), dtype=torch.float32, device=device)
+    stream = stream or torch.cuda.current_stream(device)
+    ctx.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), times.size, d_poses.data_ptr(), max_tracks * 48, params=params, stream=stream.cuda_stream)
+    stream.synchronize()
+    return d_poses
+
+
+def test_64k_instances_of_one_100_bone_clip(setup):
+    ctx, torch, device = setup
+    clip = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)      # BASELINE.json configs[1]
+    handle = ctx.register_clip(clip.blob)
+    rng = np.random.default_rng(21)
+    times = rng.uniform(0.0, clip.duration, size=N).astype(np.float32)
+    d_poses = _decode(ctx, torch, device, [handle], np.zeros(N, dtype=np.int64), times, 100)
+    poses = d_poses.cpu().numpy()
+
+    # spot check 512 instances against the oracle, bit for bit
+    for i in rng.choice(N, size=512, replace=False):
+        expected = ob.oracle_decompress_tracks(clip.blob, float(times[i]))
+        assert np.array_equal(poses[i].view(np.uint32), expected.view(np.uint32))
+
+    # every rotation is a unit quaternion with finite components, every vector finite
+    assert np.isfinite(poses).all()
+    assert np.abs(np.linalg.norm(poses[:, :, :4], axis=2) - 1.0).max() <= 1e-5
+
+    # idempotence: decoding the same batch again gives identical bits
+    again = _decode(ctx, torch, device, [handle], np.zeros(N, dtype=np.int64), times, 100).cpu().numpy()
+    assert np.array_equal(poses.view(np.uint32), again.view(np.uint32))
+
+    # a second HIP stream gives the same result (stream ordered API)
+    side_stream = torch.cuda.Stream(device)
+    other = _decode(ctx, torch, device, [handle], np.zeros(N, dtype=np.int64), times, 100, stream=side_stream).cpu().numpy()
+    assert np.array_equal(poses.view(np.uint32), other.view(np.uint32))
+
+    # clamping: seek(-0.2) == seek(0), seek(duration + 1) == seek(duration)  (validate_tracks.cpp:170-187)
+    edge_times = np.array([-0.2, 0.0, clip.duration + 1.0, clip.duration], dtype=np.float32)
+    edges = _decode(ctx, torch, device, [handle], np.zeros(4, dtype=np.int64), edge_times, 100).cpu().numpy()
+    assert np.array_equal(edges[0].view(np.uint32), edges[1].view(np.uint32))
+    assert np.array_equal(edges[2].view(np.uint32), edges[3].view(np.uint32))
+
+    # checksum of checksums: instances with equal sample times produce equal poses wherever they sit in the batch
+    repeated = np.tile(times[:1024], N // 1024)
+    tiled = _decode(ctx, torch, device, [handle], np.zeros(N, dtype=np.int64), repeated, 100).cpu().numpy().view(np.uint32)
+    assert (tiled.reshape(N // 1024, 1024, -1) == tiled[:1024].reshape(1, 1024, -1)).all()
+    ctx.unregister_clip(handle)
+
+
+def test_64k_instances_from_256_distinct_clips(setup):
+    ctx, torch, device = setup
+    spec_rng = np.random.default_rng(3)                                                       # BASELINE.json configs[2]
+    clips = []
+    for i in range(256):
+        animated = spec_rng.uniform(0.25, 0.5)
+        clips.append(synth.build_clip(seed=300 + i, num_tracks=100, num_samples=int(spec_rng.integers(31, 601)), sample_rate=30.0,
+                                      rotation_default=0.02, rotation_constant=float(0.98 - animated),
+                                      wrap=int(spec_rng.uniform() < 0.1), strip_keyframes=int(spec_rng.uniform() < 0.1),
+                                      min_bits=int(spec_rng.integers(5, 10)), max_bits=int(spec_rng.integers(12, 19))))
+    handles = [ctx.register_clip(c.blob) for c in clips]
+    rng = np.random.default_rng(22)
+    which = rng.integers(0, 256, size=N)
+    durations = np.array([c.duration for c in clips], dtype=np.float32)
+    times = (rng.uniform(0, 1, size=N).astype(np.float32) * durations[which]).astype(np.float32)
+    poses = _decode(ctx, torch, device, handles, which, times, 100).cpu().numpy()
+    for i in rng.choice(N, size=768, replace=False):
+        expected = ob.oracle_decompress_tracks(clips[which[i]].blob, float(times[i]))
+        assert np.array_equal(poses[i].view(np.uint32), expected.view(np.uint32))
+
+    # bucketing the instance list by clip only permutes the output
+    order = np.argsort(which, kind="stable")
+    sorted_poses = _decode(ctx, torch, device, handles, which[order], times[order], 100).cpu().numpy()
+    assert np.array_equal(sorted_poses.view(np.uint32), poses[order].view(np.uint32))
+    assert np.abs(np.linalg.norm(poses[:, :, :4], axis=2) - 1.0).max() <= 1e-5
+    assert ctx.rejected_instance_count() == 0
+    for h in handles:
+        ctx.unregister_clip(h)
+
+
+def test_300_bone_rig_with_scale(setup):
+    ctx, torch, device = setup
+    clip = synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,          # configs[3] shard shape
+                            scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)
+    handle = ctx.register_clip(clip.blob)
+    rng = np.random.default_rng(23)
+    n = 16384
+    times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+    poses = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300).cpu().numpy()
+    for i in rng.choice(n, size=128, replace=False):
+        expected = ob.oracle_decompress_tracks(clip.blob, float(times[i]))
+        assert np.array_equal(poses[i].view(np.uint32), expected.view(np.uint32))
+
+    # global rounding policy == per track rounding policy with the same value on every track (validate_tracks.cpp:189-211)
+    d_policies = torch.full((300,), runtime.ROUND_CEIL, dtype=torch.uint8, device=device)
+    global_params = runtime.default_params(rounding_policy=runtime.ROUND_CEIL)
+    per_track_params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+    per_track_params.track_rounding_policies = d_policies.data_ptr()
+    a = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300, params=global_params).cpu().numpy()
+    b = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300, params=per_track_params).cpu().numpy()
+    # translations/scales exactly; rotations up to the normalization the global path applies after its lerp with alpha = 1
+    assert np.array_equal(a[:, :, 4:].view(np.uint32), b[:, :, 4:].view(np.uint32))
+    assert np.abs(np.abs(a[:, :, :4]) - np.abs(b[:, :, :4])).max() <= 1e-4
+
+    # the three default modes agree on non default sub-tracks (validate_tracks.cpp:220-229)
+    skipped = runtime.default_params(default_rotation_mode=0, default_translation_mode=0, default_scale_mode=0)
+    c = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300, params=skipped).cpu().numpy()
+    reference_pose = poses
+    written = c != 0.0
+    assert np.array_equal(c[written].view(np.uint32), reference_pose[written].view(np.uint32))
+    ctx.unregister_clip(handle)

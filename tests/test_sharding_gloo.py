@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: two processes over gloo shard a batch of instances, decode their shard and all-gather the poses.
+The decode stand-in on CPU is the oracle (test infrastructure) -- the point here is the sharding / gather logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from acl_amd import sharding
+
+
+def test_shard_bounds_partition_everything():
+    for n in (0, 1, 7, 64, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            bounds = [sharding.shard_bounds(n, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            assert all(bounds[r][1] == bounds[r + 1][0] for r in range(world - 1))
+            sizes = [e - b for b, e in bounds]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sharding.shard_bounds(10, 2, 2)
+
+
+def _worker(rank, world_size, port, num_instances, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from acl_amd import synth
+        from oracle import bindings as ob
+
+        clip = synth.build_clip(seed=9, num_tracks=13, num_samples=50)
+        rng = np.random.default_rng(99)                  # same instance list on every rank
+        times = rng.uniform(0.0, clip.duration, size=num_instances).astype(np.float32)
+
+        begin, end = sharding.shard_bounds(num_instances, rank, world_size)
+        local = np.zeros((end - begin, clip.num_tracks, 12), dtype=np.float32)
+        for i in range(begin, end):
+            local[i - begin] = ob.oracle_decompress_tracks(clip.blob, float(times[i]))
+
+        gathered = sharding.all_gather_poses(torch.from_numpy(local), num_instances)
+        assert gathered.shape == (num_instances, clip.num_tracks, 12)
+
+        full = np.stack([ob.oracle_decompress_tracks(clip.blob, float(t)) for t in times]) if num_instances else np.zeros((0, clip.num_tracks, 12), np.float32)
+        assert np.array_equal(gathered.numpy(), full)
+        open(os.path.join(result_dir, f"ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_instances", [10, 11])
+def test_two_ranks_shard_and_all_gather(tmp_path, num_instances):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, num_instances, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
