@@ -941,15 +941,14 @@ namespace
 			return fail(context, ACLHIP_ERROR_DEVICE, "staging the batch on the device failed");
 		}
 
-		// skipped defaults must keep what the caller pre-filled: round trip the caller's buffer
-		const bool has_skipped = local.default_rotation_mode == ACLHIP_DEFAULT_SKIPPED || local.default_translation_mode == ACLHIP_DEFAULT_SKIPPED || local.default_scale_mode == ACLHIP_DEFAULT_SKIPPED;
-		if (has_skipped)
+		// Bytes the decode does not write (skipped defaults, tracks beyond a smaller clip's count, rejected instances) must keep
+		// what the caller had there: round trip the caller's buffer
 		{
 			const hipError_t copy_status = hipMemcpy2D(d_out, device_stride, out, out_stride_bytes, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyHostToDevice);
 			if (copy_status != hipSuccess)
 			{
 				release();
-				return fail(context, ACLHIP_ERROR_DEVICE, "uploading the pre-filled poses failed: %s", hipGetErrorString(copy_status));
+				return fail(context, ACLHIP_ERROR_DEVICE, "uploading the caller's pose buffer failed: %s", hipGetErrorString(copy_status));
 			}
 		}
 

@@ -122,9 +122,11 @@ def test_300_bone_rig_with_scale(setup):
     per_track_params.track_rounding_policies = d_policies.data_ptr()
     a = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300, params=global_params).cpu().numpy()
     b = _decode(ctx, torch, device, [handle], np.zeros(n, dtype=np.int64), times, 300, params=per_track_params).cpu().numpy()
-    # translations/scales exactly; rotations up to the normalization the global path applies after its lerp with alpha = 1
+    # translations/scales exactly; rotations up to sign and up to the normalization the global path applies after its lerp
+    # with alpha = 1 (the per track path returns the raw keyframe, whose length is off by the quantization error)
     assert np.array_equal(a[:, :, 4:].view(np.uint32), b[:, :, 4:].view(np.uint32))
-    assert np.abs(np.abs(a[:, :, :4]) - np.abs(b[:, :, :4])).max() <= 1e-4
+    b_normalized = b[:, :, :4] / np.linalg.norm(b[:, :, :4], axis=2, keepdims=True)
+    assert np.abs(np.abs(a[:, :, :4]) - np.abs(b_normalized)).max() <= 1e-6
 
     # the three default modes agree on non default sub-tracks (validate_tracks.cpp:220-229)
     skipped = runtime.default_params(default_rotation_mode=0, default_translation_mode=0, default_scale_mode=0)
