@@ -36,22 +36,10 @@ namespace aclhip
 	constexpr uint32_t k_waves_per_block = 4;
 	constexpr uint32_t k_block_size = k_wave_size * k_waves_per_block;
 
-	// Inclusive prefix sum across the 64 lanes of a wave
-	__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value, uint32_t lane)
+	// Value of a default sub-track (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310, and the
+	// "no scale" loop :1653-1680). `identity` is the track_writer default for the kind (identity / zero / legacy scale).
+	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 identity, bool& out_store)
 	{
-		#pragma unroll
-		for (uint32_t offset = 1; offset < k_wave_size; offset <<= 1)
-		{
-			const uint32_t other = __shfl_up(value, offset, k_wave_size);
-			if (lane >= offset)
-				value += other;
-		}
-		return value;
-	}
-
-	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 base_value, bool& out_store)
-	{
-		// unpack_default_*_sub_tracks (decompression.transform.h:575-675,883-985,1203-1310) and the "no scale" loop (:1653-1680)
 		const uint32_t mode = params.default_modes[kind];
 		out_store = mode != ACLHIP_DEFAULT_SKIPPED;
 
@@ -64,7 +52,44 @@ namespace aclhip
 		if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
 			return make_float4(1.0f, 1.0f, 1.0f, 0.0f);		// track_writer::get_constant_default_scale (core/track_writer.h:169)
 
-		return base_value;	// identity rotation, zero translation, the clip's legacy default scale
+		return identity;
+	}
+
+	// Turns a base pose quad into the value to store: constants pass through, animated quads come from `animated` (LDS in the
+	// pose kernel), defaults follow the default sub-track modes.
+	template<class animated_lookup_t>
+	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, const animated_lookup_t& animated, bool& out_store)
+	{
+		out_store = true;
+		const uint32_t marker = __float_as_uint(value.w);
+
+		if (params.standard_defaults)
+		{
+			// fast path: identity defaults, no constant rotation re-normalization
+			if (int32_t(marker) < 0)
+			{
+				if ((marker & k_quad_animated) != 0)
+					value = animated(marker & k_quad_ordinal_mask);
+				else
+					value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+			}
+			return value;
+		}
+
+		const uint32_t track_index = quad / 3u;
+		const uint32_t kind = quad - track_index * 3u;
+		if (int32_t(marker) < 0)
+		{
+			if ((marker & k_quad_animated) != 0)
+				return animated(marker & k_quad_ordinal_mask);
+
+			value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+			return default_quad(params, kind, track_index, value, out_store);
+		}
+
+		if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
+			value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
+		return value;
 	}
 
 	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
@@ -103,48 +128,29 @@ namespace aclhip
 
 		float4* lds_animated = reinterpret_cast<float4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
 
-		// ---- phase 1: animated sub-tracks ----
-		const uint32_t num_animated = clip.num_animated_rotations + clip.num_animated_translations + clip.num_animated_scales;
+		// ---- phase 1: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order) ----
+		const uint32_t num_animated = clip.num_animated;
 		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
-		uint32_t carry0 = 0;
-		uint32_t carry1 = 0;
 
-		for (uint32_t base = 0; base < num_animated; base += k_wave_size)
+		for (uint32_t animated_ordinal = lane; animated_ordinal < num_animated; animated_ordinal += k_wave_size)
 		{
-			const uint32_t animated_ordinal = base + lane;
-			const bool active = animated_ordinal < num_animated;
-			const animated_slot slot = make_animated_slot(clip, active ? animated_ordinal : 0);
+			const clip_range_entry clip_range = clip.clip_ranges[animated_ordinal];
+			const plan_entry plan0 = state.plan[0][animated_ordinal];
+			plan_entry plan1 = plan0;
+			if (!state.uses_single_segment)
+				plan1 = state.plan[1][animated_ordinal];
 
-			uint32_t num_bits0 = 0, num_bits1 = 0;
-			if (active)
+			uint32_t policy = k_round_none;
+			if (params.per_track_rounding != 0)
 			{
-				num_bits0 = state.format_per_track_data[0][slot.format_index];
-				num_bits1 = state.format_per_track_data[1][slot.format_index];
+				// track_writer::get_rounding_policy (core/track_writer.h:97)
+				policy = rounding_policy;
+				if (rounding_policy == k_round_per_track)
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
 			}
 
-			const uint32_t bits0 = active ? stored_bits_per_component(num_bits0, clip.raw_num_bits) * 3u : 0u;
-			const uint32_t bits1 = active ? stored_bits_per_component(num_bits1, clip.raw_num_bits) * 3u : 0u;
-			const uint32_t inclusive0 = wave_inclusive_scan(bits0, lane);
-			const uint32_t inclusive1 = wave_inclusive_scan(bits1, lane);
-			const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + carry0 + inclusive0 - bits0;
-			const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + carry1 + inclusive1 - bits1;
-			carry0 += __builtin_amdgcn_readlane(inclusive0, k_wave_size - 1);
-			carry1 += __builtin_amdgcn_readlane(inclusive1, k_wave_size - 1);
-
-			if (active)
-			{
-				uint32_t policy = k_round_none;
-				if (params.per_track_rounding != 0)
-				{
-					// track_writer::get_rounding_policy (core/track_writer.h:97)
-					policy = rounding_policy;
-					if (rounding_policy == k_round_per_track)
-						policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip.animated_tracks[animated_ordinal]] : k_round_none;
-				}
-
-				lds_animated[animated_ordinal] = decode_animated_sub_track(clip, state, slot, num_bits0, num_bits1, bit_offset0, bit_offset1,
-					policy, state.interpolation_alpha, params.normalization, normalize_samples);
-			}
+			lds_animated[animated_ordinal] = decode_animated_sub_track(state, plan0, plan1, clip_range, animated_ordinal < clip.num_animated_rotations,
+				policy, state.interpolation_alpha, params.normalization, normalize_samples);
 		}
 
 		// the wave's own LDS writes must land before its lanes read each other's results
@@ -152,31 +158,15 @@ namespace aclhip
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-		// ---- phase 2: stream the pose out, 16 bytes per lane, 1 KiB per store instruction ----
+		// ---- phase 2: lanes <-> consecutive 16 byte quads of the pose; 1 KiB of contiguous HBM per store instruction ----
 		const uint32_t num_quads = num_tracks * 3u;
 		float4* pose = reinterpret_cast<float4*>(poses + uint64_t(instance) * pose_stride_bytes);
+		const auto animated_lookup = [lds_animated](uint32_t ordinal) { return lds_animated[ordinal]; };
 
-		for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
 		{
-			const uint32_t quad = base + lane;
-			if (quad >= num_quads)
-				break;
-
-			const uint32_t entry = clip.quad_map[quad];
-			const uint32_t cls = entry & 3u;
-			float4 value = clip.base_pose[quad];
-			bool store = true;
-
-			if (cls == k_sub_track_animated)
-				value = lds_animated[entry >> 2];
-			else if (cls == k_sub_track_default)
-			{
-				const uint32_t track_index = quad / 3u;
-				value = default_quad(params, quad - track_index * 3u, track_index, value, store);
-			}
-			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && (quad % 3u) == 0)
-				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
-
+			bool store;
+			const float4 value = resolve_quad(params, clip.base_pose[quad], quad, animated_lookup, store);
 			if (store)
 				pose[quad] = value;
 		}
@@ -221,39 +211,22 @@ namespace aclhip
 			lerp_alpha = apply_rounding_policy(lerp_alpha, policy);
 		}
 
+		// The reference sums the widths of every preceding animated sub-track to find this one's bits
+		// (skip_*_groups + count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192,1664-1707): O(track index).
+		// The registration time plan already holds that prefix sum.
+		const auto animated_lookup = [&](uint32_t ordinal)
+		{
+			const plan_entry plan0 = state.plan[0][ordinal];
+			const plan_entry plan1 = state.plan[1][ordinal];
+			return decode_animated_sub_track(state, plan0, plan1, clip.clip_ranges[ordinal], ordinal < clip.num_animated_rotations,
+				k_round_none, lerp_alpha, params.normalization, false);
+		};
+
 		for (uint32_t kind = 0; kind < 3; ++kind)
 		{
 			const uint32_t quad = track_index * 3u + kind;
-			const uint32_t entry = clip.quad_map[quad];
-			const uint32_t cls = entry & 3u;
-			float4 value = clip.base_pose[quad];
-			bool store = true;
-
-			if (cls == k_sub_track_animated)
-			{
-				const uint32_t animated_ordinal = entry >> 2;
-				const animated_slot slot = make_animated_slot(clip, animated_ordinal);
-
-				// skip_*_groups + count_animated_group_bit_size (animated_track_cache.transform.h:1105-1192,1664-1707): sum the widths before us
-				uint32_t bit_offset0 = state.key_frame_bit_offsets[0];
-				uint32_t bit_offset1 = state.key_frame_bit_offsets[1];
-				for (uint32_t previous = 0; previous < animated_ordinal; ++previous)
-				{
-					const uint32_t format_index = make_animated_slot(clip, previous).format_index;
-					bit_offset0 += stored_bits_per_component(state.format_per_track_data[0][format_index], clip.raw_num_bits) * 3u;
-					bit_offset1 += stored_bits_per_component(state.format_per_track_data[1][format_index], clip.raw_num_bits) * 3u;
-				}
-
-				const uint32_t num_bits0 = state.format_per_track_data[0][slot.format_index];
-				const uint32_t num_bits1 = state.format_per_track_data[1][slot.format_index];
-				value = decode_animated_sub_track(clip, state, slot, num_bits0, num_bits1, bit_offset0, bit_offset1,
-					k_round_none, lerp_alpha, params.normalization, false);
-			}
-			else if (cls == k_sub_track_default)
-				value = default_quad(params, kind, track_index, value, store);
-			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
-				value = quat_normalize(value);
-
+			bool store;
+			const float4 value = resolve_quad(params, clip.base_pose[quad], quad, animated_lookup, store);
 			if (store)
 				transforms[size_t(instance) * 3 + kind] = value;
 		}
@@ -446,7 +419,10 @@ namespace
 		out.default_modes[0] = params->default_rotation_mode;
 		out.default_modes[1] = params->default_translation_mode;
 		out.default_modes[2] = params->default_scale_mode;
-		out.pad = 0;
+		// the common case gets a branch-light store loop: track_writer defaults (core/track_writer.h:161-163) without user values,
+		// and no re-normalization of constant rotations
+		out.standard_defaults = (params->default_rotation_mode == ACLHIP_DEFAULT_CONSTANT && params->default_translation_mode == ACLHIP_DEFAULT_CONSTANT
+			&& params->default_scale_mode == ACLHIP_DEFAULT_LEGACY && params->default_values == nullptr && params->normalization != ACLHIP_NORMALIZE_ALWAYS) ? 1 : 0;
 		return ACLHIP_OK;
 	}
 }
@@ -557,27 +533,41 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
 	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
 	const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
+	const uint8_t* tbase = blob + k_transform_header_offset;
 	const uint32_t blob_size = buffer_header.size;
 	const uint32_t num_tracks = header.num_tracks;
 	const uint32_t num_quads = num_tracks * 3;
+	const uint32_t num_samples = num_tracks != 0 ? header.num_samples : 0;
+	const uint32_t num_segments = num_tracks != 0 ? th.num_segments : 0;
 	const bool has_scale = num_tracks != 0 && header.has_scale();
+	const bool stripped = num_tracks != 0 && (header.has_stripped_keyframes() || header.has_database());
+	const bool multi_segment = num_segments > 1;
+	const uint32_t raw_num_bits = header.version >= k_version_v02_01_99_1 ? 31u : 32u;	// animated_track_cache.transform.h:523
 
 	const uint32_t num_animated_rotations = num_tracks != 0 ? th.num_animated_rotation_sub_tracks : 0;
 	const uint32_t num_animated_translations = num_tracks != 0 ? th.num_animated_translation_sub_tracks : 0;
 	const uint32_t num_animated_scales = num_tracks != 0 ? th.num_animated_scale_sub_tracks : 0;
 	const uint32_t num_animated = num_animated_rotations + num_animated_translations + num_animated_scales;
+	const uint32_t num_rotations_padded = align_to_u32(num_animated_rotations, 4);
+	if (num_animated > k_quad_ordinal_mask)
+		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "too many animated sub-tracks");
 
-	// ---- derived tables: base pose, quad map, animated ordinal -> track ----
+	// ---- derived tables ----
 	std::vector<float> base_pose(size_t(num_quads) * 4);
-	std::vector<uint32_t> quad_map(num_quads);
-	std::vector<uint32_t> animated_tracks(std::max<uint32_t>(num_animated, 1));
+	std::vector<clip_range_entry> clip_ranges(std::max<uint32_t>(num_animated, 1));
+	std::vector<segment_record> segments(std::max<uint32_t>(num_segments, 1));
+	std::vector<uint16_t> sample_to_segment(std::max<uint32_t>(num_samples, 1), 0);
+	std::vector<plan_entry> plan(std::max<size_t>(size_t(num_segments) * num_animated, 1));
+	std::memset(clip_ranges.data(), 0, clip_ranges.size() * sizeof(clip_range_entry));
+	std::memset(segments.data(), 0, segments.size() * sizeof(segment_record));
+	std::memset(plan.data(), 0, plan.size() * sizeof(plan_entry));
+	bool has_raw = false;
 
 	if (num_tracks != 0)
 	{
 		const uint32_t num_entries = (num_tracks + 15) / 16;
-		const uint32_t* types = reinterpret_cast<const uint32_t*>(blob + k_transform_header_offset + th.sub_track_types_offset);
-		const uint8_t* constant_data = blob + k_transform_header_offset + th.constant_track_data_offset;
-		const float* constant_rotations = reinterpret_cast<const float*>(constant_data);
+		const uint32_t* types = reinterpret_cast<const uint32_t*>(tbase + th.sub_track_types_offset);
+		const float* constant_rotations = reinterpret_cast<const float*>(tbase + th.constant_track_data_offset);
 		const float* constant_translations = constant_rotations + size_t(th.num_constant_rotation_samples) * 3;
 		const float* constant_scales = constant_translations + size_t(th.num_constant_translation_samples) * 3;
 		const float default_scale = float(header.default_scale());
@@ -588,18 +578,15 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 		const uint32_t animated_limits[3] = { num_animated_rotations, num_animated_translations, num_animated_scales };
 		const uint32_t constant_limits[3] = { th.num_constant_rotation_samples, th.num_constant_translation_samples, th.num_constant_scale_samples };
 
+		// base pose: constants expanded, defaults and animated sub-tracks tagged in the W lane
 		for (uint32_t track = 0; track < num_tracks; ++track)
 		{
 			for (uint32_t kind = 0; kind < 3; ++kind)
 			{
 				const uint32_t quad = track * 3 + kind;
 				float* value = &base_pose[size_t(quad) * 4];
+				uint32_t* value_bits = reinterpret_cast<uint32_t*>(value);
 				const uint32_t cls = (kind == 2 && !has_scale) ? k_sub_track_default : sub_track_class(types + size_t(kind) * num_entries, track);
-
-				// defaults: identity / zero / the clip's legacy default scale (decompression.transform.h:585,893,1548)
-				if (kind == 0) { value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f; value[3] = 1.0f; }
-				else if (kind == 1) { value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f; value[3] = 0.0f; }
-				else { value[0] = default_scale; value[1] = default_scale; value[2] = default_scale; value[3] = 0.0f; }
 
 				if (cls == k_sub_track_constant)
 				{
@@ -616,7 +603,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 						const float x = group_data[group_size * 0 + lane];
 						const float y = group_data[group_size * 1 + lane];
 						const float z = group_data[group_size * 2 + lane];
-						// quat_from_positive_w4 (math/quatf.h:135-147), same IEEE operations as the device code
+						// quat_from_positive_w4 (math/quatf.h:135-147), one IEEE operation at a time like the device code
 						volatile float w_squared = 1.0f - (x * x);
 						w_squared = w_squared - (y * y);
 						w_squared = w_squared - (z * z);
@@ -627,7 +614,8 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 						const float* src = (kind == 1 ? constant_translations : constant_scales) + size_t(index) * 3;
 						value[0] = src[0]; value[1] = src[1]; value[2] = src[2]; value[3] = 0.0f;
 					}
-					quad_map[quad] = k_sub_track_constant;
+					if (int32_t(value_bits[3]) < 0)
+						value_bits[3] &= 0x7FFFFFFFu;	// only a garbage (NaN) constant could collide with the marker bit
 				}
 				else if (cls == k_sub_track_animated)
 				{
@@ -635,11 +623,17 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 					if (index >= animated_limits[kind])
 						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more animated sub-tracks than the header declares");
 					const uint32_t ordinal = animated_bases[kind] + index;
-					animated_tracks[ordinal] = track;
-					quad_map[quad] = k_sub_track_animated | (ordinal << 2);
+					clip_ranges[ordinal].track_index = track;
+					value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f;
+					value_bits[3] = k_quad_special | k_quad_animated | ordinal;
 				}
 				else if (cls == k_sub_track_default)
-					quad_map[quad] = k_sub_track_default;
+				{
+					// identity / zero / the clip's legacy default scale (decompression.transform.h:585,893,1548)
+					const float xyz = kind == 2 ? default_scale : 0.0f;
+					value[0] = xyz; value[1] = xyz; value[2] = xyz;
+					value_bits[3] = k_quad_special | (kind == 0 ? k_quad_default_w_one : 0u);
+				}
 				else
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "invalid sub-track type");
 			}
@@ -647,24 +641,153 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 
 		if (animated_counts[0] != num_animated_rotations || animated_counts[1] != num_animated_translations || animated_counts[2] != num_animated_scales)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sub-track types disagree with the animated sub-track counts");
+
+		// clip ranges: rotations are SOA per group of 4 (last group unpadded), translations / scales AOS (write_range_data.h:79-207)
+		{
+			const float* range_data = reinterpret_cast<const float*>(tbase + th.clip_range_data_offset);
+			for (uint32_t i = 0; i < num_animated_rotations; ++i)
+			{
+				const uint32_t group = i / 4, lane = i % 4;
+				const uint32_t group_size = std::min<uint32_t>(num_animated_rotations - group * 4, 4);
+				const float* group_data = range_data + size_t(group) * 24;
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					clip_ranges[i].range_min[c] = group_data[group_size * c + lane];
+					clip_ranges[i].range_extent[c] = group_data[group_size * (3 + c) + lane];
+				}
+			}
+			const float* vector_ranges = range_data + size_t(num_animated_rotations) * 6;
+			for (uint32_t i = num_animated_rotations; i < num_animated; ++i)
+			{
+				const float* entry = vector_ranges + size_t(i - num_animated_rotations) * 6;
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					clip_ranges[i].range_min[c] = entry[c];
+					clip_ranges[i].range_extent[c] = entry[3 + c];
+				}
+			}
+		}
+
+		// segments, sample -> segment, per segment plan
+		const uint32_t segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		const uint32_t* segment_start_indices = multi_segment ? reinterpret_cast<const uint32_t*>(tbase + k_segment_start_indices_offset) : nullptr;
+		for (uint32_t si = 0; si < num_segments; ++si)
+		{
+			const segment_header& sh = *reinterpret_cast<const segment_header*>(tbase + th.segment_headers_offset + size_t(si) * segment_header_size);
+			const uint32_t start = multi_segment ? segment_start_indices[si] : 0;
+			const uint32_t end = multi_segment && si + 1 < num_segments ? segment_start_indices[si + 1] : num_samples;
+			if (start >= end || end > num_samples || end - start > 32 || (si == 0 && start != 0))
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%u, %u)", si, start, end);
+			for (uint32_t sample = start; sample < end; ++sample)
+				sample_to_segment[sample] = uint16_t(si);
+			if (num_segments > 65535)
+				return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "more than 65535 segments");
+
+			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324)
+			const uint32_t format_offset = k_transform_header_offset + sh.segment_data;
+			const uint32_t range_offset = align_to_u32(format_offset + th.num_animated_variable_sub_tracks, 2);
+			const uint32_t animated_offset = align_to_u32(range_offset + (multi_segment ? 6u * th.num_animated_variable_sub_tracks : 0u), 4);
+			const uint8_t* format_per_track = blob + format_offset;
+			const uint8_t* range_data = blob + range_offset;
+
+			segment_record& record = segments[si];
+			record.animated_offset = animated_offset;
+			record.pose_bit_size = sh.animated_pose_bit_size;
+			record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : 0xFFFFFFFFu;
+			record.start_index = start;
+			record.num_samples = end - start;
+
+			// every stored keyframe of a clip-resident segment must lie inside the blob
+			if (!header.has_database())
+			{
+				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(record.sample_indices)) : record.num_samples;
+				if (uint64_t(animated_offset) + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", si);
+			}
+
+			uint32_t bit_offset = 0;
+			for (uint32_t a = 0; a < num_animated; ++a)
+			{
+				const bool is_rotation = a < num_animated_rotations;
+				const uint32_t vector_index = a - num_animated_rotations;
+				const uint32_t format_index = is_rotation ? a : num_rotations_padded + vector_index;
+				const uint32_t stored_bits = format_per_track[format_index];
+				const bool is_raw = stored_bits == raw_num_bits;
+				if (!is_raw && stored_bits > 23)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u sub-track %u has an invalid bit width %u", si, a, stored_bits);
+				if (bit_offset > k_quad_ordinal_mask)
+					return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "keyframes larger than 2 MiB are not supported");
+
+				plan_entry& entry = plan[size_t(si) * num_animated + a];
+				const uint32_t num_bits = is_raw ? 32u : stored_bits;
+				entry.bit_offset_and_width = bit_offset | (num_bits << 24);
+				entry.inv_max_value = (num_bits == 0 || is_raw) ? 1.0f : 1.0f / float((1u << num_bits) - 1u);
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					entry.range_min[c] = 0.0f;
+					entry.range_extent[c] = 1.0f;
+				}
+				has_raw = has_raw || is_raw;
+
+				if (multi_segment && !is_raw)
+				{
+					// six bytes per sub-track: rotations SOA in padded groups of 4, translations / scales AOS (write_range_data.h:209-341)
+					uint8_t bytes[6];
+					if (is_rotation)
+					{
+						const uint8_t* group = range_data + size_t(a / 4) * 24 + (a % 4);
+						for (uint32_t i = 0; i < 6; ++i)
+							bytes[i] = group[i * 4];
+					}
+					else
+						std::memcpy(bytes, range_data + size_t(num_rotations_padded) * 6 + size_t(vector_index) * 6, 6);
+
+					if (num_bits == 0)
+					{
+						// constant in this segment: a 16 bit sample lives in the range bytes, hi/lo split across the SOA rows for rotations
+						// (animated_track_cache.transform.h:552-588), little endian u16 for vectors (math/vector4_packing.h:628-653)
+						for (uint32_t c = 0; c < 3; ++c)
+						{
+							const uint32_t sample = is_rotation ? ((uint32_t(bytes[c * 2]) << 8) | bytes[c * 2 + 1]) : ((uint32_t(bytes[c * 2 + 1]) << 8) | bytes[c * 2]);
+							entry.range_min[c] = float(sample) * (1.0f / 65535.0f);
+							entry.range_extent[c] = 0.0f;
+						}
+					}
+					else
+					{
+						for (uint32_t c = 0; c < 3; ++c)
+						{
+							entry.range_min[c] = float(bytes[c]) * (1.0f / 255.0f);
+							entry.range_extent[c] = float(bytes[3 + c]) * (1.0f / 255.0f);
+						}
+					}
+				}
+
+				bit_offset += num_bits * 3;
+			}
+
+			if (bit_offset != sh.animated_pose_bit_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: sub-track widths add up to %u bits, header says %u", si, bit_offset, sh.animated_pose_bit_size);
+		}
 	}
 
-	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | quad map | animated tracks ----
-	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// the decoder reads 8 byte windows: keep well past the reference's 15 bytes of slack
+	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
+	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
-	const uint64_t quad_map_offset = base_pose_offset + uint64_t(num_quads) * 16;
-	const uint64_t animated_tracks_offset = quad_map_offset + align_to_u32(num_quads * 4, 16);
-	const uint64_t total_bytes = animated_tracks_offset + align_to_u32(std::max<uint32_t>(num_animated, 1) * 4, 16);
+	const uint64_t segments_offset = base_pose_offset + uint64_t(num_quads) * 16;
+	const uint64_t plan_offset = segments_offset + segments.size() * sizeof(segment_record);
+	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
+	const uint64_t sample_to_segment_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
+	const uint64_t total_bytes = sample_to_segment_offset + align_to_u32(uint32_t(sample_to_segment.size() * sizeof(uint16_t)), 16);
 
 	std::vector<uint8_t> staging(total_bytes, 0);
 	std::memcpy(staging.data(), blob, blob_size);
 	if (num_quads != 0)
-	{
 		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
-		std::memcpy(staging.data() + quad_map_offset, quad_map.data(), size_t(num_quads) * 4);
-	}
-	if (num_animated != 0)
-		std::memcpy(staging.data() + animated_tracks_offset, animated_tracks.data(), size_t(num_animated) * 4);
+	std::memcpy(staging.data() + segments_offset, segments.data(), segments.size() * sizeof(segment_record));
+	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
+	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
+	std::memcpy(staging.data() + sample_to_segment_offset, sample_to_segment.data(), sample_to_segment.size() * sizeof(uint16_t));
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -701,32 +824,28 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	std::memset(&record, 0, sizeof(record));
 	record.blob = d_memory;
 	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
-	record.quad_map = reinterpret_cast<const uint32_t*>(d_memory + quad_map_offset);
-	record.animated_tracks = reinterpret_cast<const uint32_t*>(d_memory + animated_tracks_offset);
+	record.segments = reinterpret_cast<const segment_record*>(d_memory + segments_offset);
+	record.sample_to_segment = reinterpret_cast<const uint16_t*>(d_memory + sample_to_segment_offset);
+	record.plan = reinterpret_cast<const plan_entry*>(d_memory + plan_offset);
+	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + clip_ranges_offset);
 	record.num_tracks = num_tracks;
-	record.num_samples = header.num_samples;
+	record.num_samples = num_samples;
 	record.sample_rate = header.sample_rate;
-	record.duration_clamp = header.num_samples <= 1 ? 0.0f : float(header.num_samples - 1) / header.sample_rate;
-	record.duration_wrap = header.num_samples == 0 ? 0.0f : float(header.num_samples) / header.sample_rate;
+	record.duration_clamp = num_samples <= 1 ? 0.0f : float(num_samples - 1) / header.sample_rate;
+	record.duration_wrap = num_samples == 0 ? 0.0f : float(num_samples) / header.sample_rate;
 	record.flags = k_clip_valid;
 	if (num_tracks != 0)
 	{
-		const bool stripped = header.has_stripped_keyframes() || header.has_database();
 		record.flags |= has_scale ? k_clip_has_scale : 0u;
 		record.flags |= stripped ? k_clip_has_stripped_keyframes : 0u;
 		record.flags |= header.has_database() ? k_clip_has_database : 0u;
 		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
-		record.num_segments = th.num_segments;
-		record.segment_headers_offset = k_transform_header_offset + th.segment_headers_offset;
-		record.segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		record.flags |= has_raw ? k_clip_has_raw : 0u;
+		record.num_segments = num_segments;
 		record.num_animated_rotations = num_animated_rotations;
-		record.num_animated_translations = num_animated_translations;
-		record.num_animated_scales = num_animated_scales;
-		record.num_animated_variable = th.num_animated_variable_sub_tracks;
-		record.clip_range_offset = k_transform_header_offset + th.clip_range_data_offset;
-		record.raw_num_bits = header.version >= k_version_v02_01_99_1 ? 31u : 32u;
+		record.num_animated = num_animated;
 		if (header.has_database())
-			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(blob + k_transform_header_offset + th.database_header_offset)->clip_header_offset;
+			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(tbase + th.database_header_offset)->clip_header_offset;
 	}
 
 	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
@@ -744,7 +863,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	entry.info.num_samples = header.num_samples;
 	entry.info.sample_rate = header.sample_rate;
 	entry.info.duration = finite_duration(header, k_loop_as_compressed);
-	entry.info.num_segments = num_tracks != 0 ? th.num_segments : 0;
+	entry.info.num_segments = num_segments;
 	entry.info.has_scale = has_scale ? 1 : 0;
 	entry.info.looping_policy = (header.version > k_version_first && header.is_wrap_optimized()) ? ACLHIP_LOOP_WRAP : ACLHIP_LOOP_CLAMP;
 	entry.info.compressed_size = blob_size;
@@ -752,7 +871,8 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	entry.info.num_animated_sub_tracks = num_animated;
 	entry.info.has_database = num_tracks != 0 && header.has_database() ? 1 : 0;
 	entry.info.has_stripped_keyframes = num_tracks != 0 && header.has_stripped_keyframes() ? 1 : 0;
-	entry.touched_bytes = uint64_t(blob_size) + uint64_t(num_quads) * 20 + uint64_t(num_animated) * 4;
+	// bytes a batch may read from this clip: the blob itself plus the registration time tables
+	entry.touched_bytes = total_bytes - 64;
 	entry.max_lds_quads = num_animated;
 	context->max_lds_quads = std::max(context->max_lds_quads, num_animated);
 

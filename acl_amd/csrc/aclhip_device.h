@@ -2,7 +2,7 @@
 // one animated sub-track from the ACL bitstream. No host code here.
 //
 // Arithmetic follows the reference operation by operation (fp32, round to nearest, NO contraction -- this file
-// must be compiled with -ffp-contract=off) so that poses match the reference CPU decoder:
+// must be compiled with -ffp-contract=off) so that poses match the reference CPU decoder bit for bit:
 //   seek_v0                         decompression/impl/decompression.transform.h:206-563
 //   unpack_animated_quat            decompression/impl/animated_track_cache.transform.h:515-687
 //   unpack_animated_vector3         decompression/impl/animated_track_cache.transform.h:871-990
@@ -10,6 +10,12 @@
 //   quat_from_positive_w4 / quat_lerp_no_normalization4 / quat_normalize4   math/quatf.h:135-211
 //   unpack_vector3_uXX / _96 / _u48 / _u24                                   math/vector4_packing.h:479-599,628-653,781-818,921-1035
 // (paths relative to /root/reference/includes/acl)
+//
+// What differs from the reference is WHERE the per clip bookkeeping happens: everything that only depends on
+// (clip, segment) -- which segment a sample lives in, where each animated sub-track's bits start inside a keyframe,
+// its width, its segment range as floats -- is worked out once at registration and kept next to the blob in HBM
+// (segment_record / plan_entry / clip_range_entry below). The CPU walks the format bytes serially per pose
+// (count_animated_group_bit_size); a wave here looks the answers up.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -19,37 +25,81 @@
 
 namespace aclhip
 {
+	// One per segment, 32 bytes, read through the scalar cache
+	struct alignas(32) segment_record
+	{
+		uint32_t animated_offset;		// first stored keyframe of the segment, from the blob start (4 byte aligned)
+		uint32_t pose_bit_size;			// bits per stored keyframe (segment_header::animated_pose_bit_size)
+		uint32_t sample_indices;		// stored keyframes of the segment, MSB = first sample (0xFFFFFFFF when nothing is stripped)
+		uint32_t start_index;			// clip relative index of the segment's first sample
+		uint32_t num_samples;
+		uint32_t reserved[3];
+	};
+
+	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
+	// how to expand them. Widths: 1..23 = quantized, 0 = constant in the segment (the 16 bit sample is pre-converted into
+	// range_min, range_extent = 0, nothing is read), 32 = raw fp32 (ranges ignored).
+	// Segment range values are float(u8) * (1/255) exactly as the reference computes them per pose
+	// (animated_track_cache.transform.h:188-196, math/vector4_packing.h:781-818); single segment clips get min 0 / extent 1.
+	struct alignas(16) plan_entry
+	{
+		uint32_t bit_offset_and_width;	// bit offset inside the keyframe (low 24 bits) | num_bits << 24
+		float inv_max_value;			// 1 / (2^num_bits - 1) (math/vector4_packing.h:927-935), 1 for widths 0 and 32
+		float range_min[3];
+		float range_extent[3];
+	};
+
+	// One per animated sub-track, 32 bytes: clip range (AOS copy of the blob's clip range data, which is SOA per group of 4
+	// for rotations) and the track it belongs to.
+	struct alignas(16) clip_range_entry
+	{
+		float range_min[3];
+		uint32_t track_index;
+		float range_extent[3];
+		uint32_t reserved;
+	};
+
+	static_assert(sizeof(segment_record) == 32, "layout");
+	static_assert(sizeof(plan_entry) == 32, "layout");
+	static_assert(sizeof(clip_range_entry) == 32, "layout");
+
+	// Markers in the W lane of a base pose quad (a real W is never negative: sqrt(|..|) for rotations, 0 for vectors)
+	constexpr uint32_t k_quad_special = 0x80000000u;			// sign bit set: not a constant sub-track
+	constexpr uint32_t k_quad_animated = 0x20000000u;			// special + this bit: low 24 bits = animated ordinal
+	constexpr uint32_t k_quad_default_w_one = 0x00000001u;		// special, not animated: default sub-track, this bit = its identity W is 1
+	constexpr uint32_t k_quad_ordinal_mask = 0x00FFFFFFu;
+
 	// Per clip record in HBM, written once at registration; read through the scalar cache by every wave.
 	struct alignas(128) device_clip
 	{
-		const uint8_t* blob;				// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 32 bytes of tail padding
-		const float4* base_pose;			// [3 * num_tracks] rotation | translation | scale per track with default and constant sub-tracks expanded
-		const uint32_t* quad_map;			// [3 * num_tracks] (class & 3) | (animated ordinal across rot,trans,scale) << 2
-		const uint32_t* animated_tracks;	// [num animated sub-tracks] track index of every animated sub-track (rot, then trans, then scale)
-		const uint8_t* db_headers;			// database runtime clip/segment headers (device) or null
-		const uint8_t* db_bulk_data[2];		// database bulk data, medium / low importance tier (device) or null
+		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding
+		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
+		const segment_record* segments;			// [num_segments]
+		const uint16_t* sample_to_segment;		// [num_samples]
+		const plan_entry* plan;					// [num_segments][num_animated]
+		const clip_range_entry* clip_ranges;	// [num_animated]
+		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
+		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
 		uint32_t num_tracks;
 		uint32_t num_samples;
 		float sample_rate;
-		float duration_clamp;				// calculate_finite_duration(num_samples)
-		float duration_wrap;				// calculate_finite_duration(num_samples + 1)
-		uint32_t flags;						// k_clip_*
+		float duration_clamp;					// calculate_finite_duration(num_samples)
+		float duration_wrap;					// calculate_finite_duration(num_samples + 1)
+		uint32_t flags;							// k_clip_*
 		uint32_t num_segments;
-		uint32_t segment_headers_offset;	// from the blob start
-		uint32_t segment_header_size;		// 16, or 20 with stripped keyframes / database
 		uint32_t num_animated_rotations;
-		uint32_t num_animated_translations;
-		uint32_t num_animated_scales;
-		uint32_t num_animated_variable;		// rotations padded to 4 + translations + scales
-		uint32_t clip_range_offset;			// from the blob start
-		uint32_t raw_num_bits;				// 31 from v02_01_99_1 on, 32 before
-		uint32_t db_clip_header_offset;		// into db_headers
+		uint32_t num_animated;					// rotations + translations + scales
+		uint32_t db_clip_header_offset;			// into db_headers
+		uint32_t reserved[4];
 	};
 
+	static_assert(sizeof(device_clip) == 128, "layout");
+
 	constexpr uint32_t k_clip_has_scale = 1u << 0;
-	constexpr uint32_t k_clip_has_stripped_keyframes = 1u << 1;	// stripped keyframes or database: 20 byte segment headers
+	constexpr uint32_t k_clip_has_stripped_keyframes = 1u << 1;	// stripped keyframes or database: sample_indices matter
 	constexpr uint32_t k_clip_has_database = 1u << 2;
 	constexpr uint32_t k_clip_wraps = 1u << 3;					// compressed_tracks::get_looping_policy() == wrap
+	constexpr uint32_t k_clip_has_raw = 1u << 4;				// some (segment, sub-track) uses the raw bit rate
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// Launch wide settings (aclhip_decompress_params resolved to device pointers)
@@ -63,25 +113,18 @@ namespace aclhip
 		uint8_t normalization;
 		uint8_t per_track_rounding;
 		uint8_t default_modes[3];
-		uint8_t pad;
+		uint8_t standard_defaults;		// 1 when default sub-tracks take the track_writer defaults (identity / zero / legacy scale) and normalization != always
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)
 	struct seek_state
 	{
-		const uint8_t* format_per_track_data[2];
-		const uint8_t* segment_range_data[2];
-		const uint8_t* animated_track_data[2];
+		const uint8_t* animated_track_data[2];	// first stored keyframe of each key's data source
+		const plan_entry* plan[2];				// the two segments' plans
 		uint32_t key_frame_bit_offsets[2];
 		float interpolation_alpha;
 		bool uses_single_segment;
-		bool has_segments;
 	};
-
-	__device__ __forceinline__ uint32_t load_u32(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }				// 4 byte aligned
-	__device__ __forceinline__ uint64_t load_u64_aligned8(const uint8_t* p) { return *reinterpret_cast<const uint64_t*>(p); }
-	__device__ __forceinline__ float load_f32(const uint8_t* p) { return *reinterpret_cast<const float*>(p); }						// 4 byte aligned
-	__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }	// any alignment
 
 	// core/impl/interpolation_utils.impl.h:261-278
 	__device__ __forceinline__ float apply_rounding_policy(float alpha, uint32_t policy)
@@ -102,29 +145,13 @@ namespace aclhip
 		return sample_index - float(index0);
 	}
 
-	__device__ __forceinline__ void get_segment_data(const device_clip& clip, const uint8_t* segment_header,
-		const uint8_t*& out_format, const uint8_t*& out_range, const uint8_t*& out_animated)
-	{
-		// core/impl/compressed_headers.h:309-324: offsets are relative to the transform_tracks_header, alignment is absolute
-		const uint32_t segment_data = load_u32(segment_header + 12) + k_transform_header_offset;
-		const uint32_t range_offset = align_to_u32(segment_data + clip.num_animated_variable, 2);
-		const uint32_t range_size = clip.num_segments > 1 ? 6u * clip.num_animated_variable : 0u;
-		const uint32_t animated_offset = align_to_u32(range_offset + range_size, 4);
-		out_format = clip.blob + segment_data;
-		out_range = clip.blob + range_offset;
-		out_animated = clip.blob + animated_offset;
-	}
-
 	// seek_v0 (decompression/impl/decompression.transform.h:206-563). Everything here is wave uniform in the pose kernel.
+	// The reference guesses the segment and scans up to 4 start indices (:374-409); the lookup table gives the same answer.
 	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
 	{
 		const bool wrap = looping_policy == k_loop_as_compressed ? (clip.flags & k_clip_wraps) != 0 : looping_policy == k_loop_wrap;
 		const float clip_duration = wrap ? clip.duration_wrap : clip.duration_clamp;
 		const uint32_t num_samples = clip.num_samples;
-		const uint32_t num_segments = clip.num_segments;
-		const bool has_stripped_keyframes = (clip.flags & k_clip_has_stripped_keyframes) != 0;
-		const bool has_database = (clip.flags & k_clip_has_database) != 0 && clip.db_headers != nullptr;
-		const uint8_t* segment_headers = clip.blob + clip.segment_headers_offset;
 
 		// :215-216 scalar_clamp
 		sample_time = fminf(fmaxf(sample_time, 0.0f), clip_duration);
@@ -147,54 +174,24 @@ namespace aclhip
 
 		float alpha = apply_rounding_policy(sample_index - float(key_frame0), rounding_policy);
 
-		uint32_t segment_index0 = 0;
-		uint32_t segment_index1 = 0;
-		uint32_t segment_key_frame0 = key_frame0;
-		uint32_t segment_key_frame1 = key_frame1;
-		uint32_t segment_start0 = 0;
-		uint32_t segment_start1 = 0;
+		const uint32_t segment_index0 = clip.sample_to_segment[key_frame0];
+		const uint32_t segment_index1 = clip.sample_to_segment[key_frame1];
+		const segment_record& segment0 = clip.segments[segment_index0];
+		const segment_record& segment1 = clip.segments[segment_index1];
 
-		if (num_segments > 1)
-		{
-			// :372-409: guess, then scan at most 4 start indices (the list ends with a 0xFFFFFFFF sentinel)
-			const uint8_t* segment_start_indices = clip.blob + (k_transform_header_offset + k_segment_start_indices_offset);
-			const uint32_t approx_num_samples_per_segment = num_samples / num_segments;
-			const uint32_t approx_segment_index = key_frame0 / approx_num_samples_per_segment;
-			const uint32_t start_segment_index = approx_segment_index > 0 ? (approx_segment_index - 1) : 0;
+		uint32_t segment_key_frame0 = key_frame0 - segment0.start_index;
+		uint32_t segment_key_frame1 = key_frame1 - segment1.start_index;
 
-			for (uint32_t i = 0; i < 4; ++i)
-			{
-				const uint32_t segment_index = start_segment_index + i;
-				const uint32_t segment_start = load_u32(segment_start_indices + 4 * segment_index);
-				if (key_frame0 < segment_start)
-				{
-					segment_index0 = segment_index - 1;
-					if (key_frame1 == 0)
-						segment_index1 = 0;		// wrapped around: first segment
-					else
-						segment_index1 = key_frame1 < segment_start ? segment_index0 : segment_index;
-					break;
-				}
-			}
+		const uint8_t* animated_track_data0 = clip.blob + segment0.animated_offset;
+		const uint8_t* animated_track_data1 = clip.blob + segment1.animated_offset;
 
-			segment_start0 = load_u32(segment_start_indices + 4 * segment_index0);
-			segment_start1 = load_u32(segment_start_indices + 4 * segment_index1);
-			segment_key_frame0 = key_frame0 - segment_start0;
-			segment_key_frame1 = key_frame1 - segment_start1;
-		}
-
-		const uint8_t* segment_header0 = segment_headers + clip.segment_header_size * segment_index0;
-		const uint8_t* segment_header1 = segment_headers + clip.segment_header_size * segment_index1;
-
-		const uint8_t* db_animated_track_data0 = nullptr;
-		const uint8_t* db_animated_track_data1 = nullptr;
-
-		if (has_stripped_keyframes)
+		if ((clip.flags & k_clip_has_stripped_keyframes) != 0)
 		{
 			// :272-362 / :411-515: snap to the nearest keyframes that are present, in the clip or in a streamed database tier
-			uint32_t sample_indices0 = load_u32(segment_header0 + 16);
-			uint32_t sample_indices1 = load_u32(segment_header1 + 16);
+			uint32_t sample_indices0 = segment0.sample_indices;
+			uint32_t sample_indices1 = segment1.sample_indices;
 			const float clip_sample_index = alpha + float(key_frame0);
+			const bool has_database = (clip.flags & k_clip_has_database) != 0 && clip.db_headers != nullptr;
 
 			uint64_t medium0 = 0, medium1 = 0, low0 = 0, low1 = 0;
 			if (has_database)
@@ -215,19 +212,19 @@ namespace aclhip
 			const uint32_t candidate_indices1 = sample_indices1 & (0xFFFFFFFFu >> segment_key_frame1);
 			segment_key_frame1 = uint32_t(__builtin_clz(candidate_indices1));
 
-			alpha = find_linear_interpolation_alpha(clip_sample_index, segment_start0 + segment_key_frame0, segment_start1 + segment_key_frame1);
+			alpha = find_linear_interpolation_alpha(clip_sample_index, segment0.start_index + segment_key_frame0, segment1.start_index + segment_key_frame1);
 
-			sample_indices0 = load_u32(segment_header0 + 16);
-			sample_indices1 = load_u32(segment_header1 + 16);
+			sample_indices0 = segment0.sample_indices;
+			sample_indices1 = segment1.sample_indices;
 
 			if (has_database)
 			{
 				const uint64_t sample_bit0 = uint64_t(1) << (31 - segment_key_frame0);
 				const uint64_t sample_bit1 = uint64_t(1) << (31 - segment_key_frame1);
-				if ((medium0 & sample_bit0) != 0) { sample_indices0 = uint32_t(medium0); db_animated_track_data0 = clip.db_bulk_data[0] + uint32_t(medium0 >> 32); }
-				else if ((low0 & sample_bit0) != 0) { sample_indices0 = uint32_t(low0); db_animated_track_data0 = clip.db_bulk_data[1] + uint32_t(low0 >> 32); }
-				if ((medium1 & sample_bit1) != 0) { sample_indices1 = uint32_t(medium1); db_animated_track_data1 = clip.db_bulk_data[0] + uint32_t(medium1 >> 32); }
-				else if ((low1 & sample_bit1) != 0) { sample_indices1 = uint32_t(low1); db_animated_track_data1 = clip.db_bulk_data[1] + uint32_t(low1 >> 32); }
+				if ((medium0 & sample_bit0) != 0) { sample_indices0 = uint32_t(medium0); animated_track_data0 = clip.db_bulk_data[0] + uint32_t(medium0 >> 32); }
+				else if ((low0 & sample_bit0) != 0) { sample_indices0 = uint32_t(low0); animated_track_data0 = clip.db_bulk_data[1] + uint32_t(low0 >> 32); }
+				if ((medium1 & sample_bit1) != 0) { sample_indices1 = uint32_t(medium1); animated_track_data1 = clip.db_bulk_data[0] + uint32_t(medium1 >> 32); }
+				else if ((low1 & sample_bit1) != 0) { sample_indices1 = uint32_t(low1); animated_track_data1 = clip.db_bulk_data[1] + uint32_t(low1 >> 32); }
 			}
 
 			// ordinal among the keyframes stored by the chosen data source
@@ -236,192 +233,92 @@ namespace aclhip
 		}
 
 		// :530-562
-		get_segment_data(clip, segment_header0, out.format_per_track_data[0], out.segment_range_data[0], out.animated_track_data[0]);
-		get_segment_data(clip, segment_header1, out.format_per_track_data[1], out.segment_range_data[1], out.animated_track_data[1]);
-		if (db_animated_track_data0 != nullptr)
-			out.animated_track_data[0] = db_animated_track_data0;
-		if (db_animated_track_data1 != nullptr)
-			out.animated_track_data[1] = db_animated_track_data1;
-
-		out.key_frame_bit_offsets[0] = segment_key_frame0 * load_u32(segment_header0 + 0);
-		out.key_frame_bit_offsets[1] = segment_key_frame1 * load_u32(segment_header1 + 0);
+		out.animated_track_data[0] = animated_track_data0;
+		out.animated_track_data[1] = animated_track_data1;
+		out.plan[0] = clip.plan + size_t(segment_index0) * clip.num_animated;
+		out.plan[1] = clip.plan + size_t(segment_index1) * clip.num_animated;
+		out.key_frame_bit_offsets[0] = segment_key_frame0 * segment0.pose_bit_size;
+		out.key_frame_bit_offsets[1] = segment_key_frame1 * segment1.pose_bit_size;
 		out.interpolation_alpha = alpha;
 		out.uses_single_segment = segment_index0 == segment_index1;
-		out.has_segments = num_segments > 1;
 	}
 
-	// Bits a sub-track occupies per component in the animated pose (count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192)
-	__device__ __forceinline__ uint32_t stored_bits_per_component(uint32_t num_bits, uint32_t raw_num_bits) { return num_bits == raw_num_bits ? 32u : num_bits; }
-
-	// Where one animated sub-track lives: kind, ordinal within kind, index of its format byte
-	struct animated_slot
+	// 4 bytes at any alignment, as a big endian number
+	__device__ __forceinline__ uint32_t load_be32(const uint8_t* p)
 	{
-		uint32_t kind;			// 0 rotation, 1 translation, 2 scale
-		uint32_t index;			// ordinal within the kind
-		uint32_t format_index;	// into format_per_track_data (rotations are padded to a multiple of 4)
-	};
-
-	__device__ __forceinline__ animated_slot make_animated_slot(const device_clip& clip, uint32_t animated_ordinal)
-	{
-		const uint32_t num_rotations = clip.num_animated_rotations;
-		const uint32_t num_rotations_padded = (num_rotations + 3u) & ~3u;
-		animated_slot slot;
-		if (animated_ordinal < num_rotations)
-		{
-			slot.kind = 0;
-			slot.index = animated_ordinal;
-			slot.format_index = animated_ordinal;
-		}
-		else
-		{
-			const uint32_t vector_index = animated_ordinal - num_rotations;		// translations then scales share one AOS region
-			slot.kind = vector_index < clip.num_animated_translations ? 1 : 2;
-			slot.index = vector_index;
-			slot.format_index = num_rotations_padded + vector_index;
-		}
-		return slot;
+		uint32_t v;
+		__builtin_memcpy(&v, p, 4);
+		return __builtin_bswap32(v);
 	}
 
-	// The x, y, z of one sub-track at one keyframe, range expanded. `bit_offset` is relative to animated_track_data.
-	__device__ __forceinline__ void unpack_animated_sample(const device_clip& clip, const seek_state& state, uint32_t key, const animated_slot& slot,
-		uint32_t num_bits, uint32_t bit_offset, float out_xyz[3])
+	// The quantized x, y, z of one sub-track at one keyframe as floats in [0, 1] (or the raw fp32 values): the bit unpack of
+	// math/vector4_packing.h:921-1035 / :479-599. `bit_offset` is relative to `data`.
+	__device__ __forceinline__ void unpack_bits(const uint8_t* data, uint32_t bit_offset, uint32_t num_bits, float inv_max_value, float out_xyz[3])
 	{
-		const bool is_rotation = slot.kind == 0;
-		const uint32_t num_rotations = clip.num_animated_rotations;
-		const uint32_t num_rotations_padded = (num_rotations + 3u) & ~3u;
-
-		// Segment range bytes of this sub-track: rotations are SOA in groups of 4 (stride 4 between the six values),
-		// translations/scales are AOS (stride 1)
-		const uint8_t* segment_range = state.segment_range_data[key];
-		uint32_t segment_range_stride;
-		if (is_rotation)
+		if (num_bits == 32)
 		{
-			segment_range += (slot.index >> 2) * 24u + (slot.index & 3u);
-			segment_range_stride = 4;
-		}
-		else
-		{
-			segment_range += num_rotations_padded * 6u + slot.index * 6u;
-			segment_range_stride = 1;
+			// raw: three big endian floats starting at an arbitrary bit
+			const uint8_t* bytes = data + (bit_offset >> 3);
+			const uint32_t shift = bit_offset & 7u;
+			const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
+			out_xyz[0] = __uint_as_float(__funnelshift_l(w1, w0, shift));
+			out_xyz[1] = __uint_as_float(__funnelshift_l(w2, w1, shift));
+			out_xyz[2] = __uint_as_float(__funnelshift_l(w3, w2, shift));
+			return;
 		}
 
-		const bool is_constant_in_segment = num_bits == 0;
-		const bool is_raw = num_bits == clip.raw_num_bits;
-		const bool needs_segment_range = state.has_segments && !is_raw;		// width 0 reads its sample from the same bytes
+		// x and y sit inside the 64 bit window that starts at the byte holding the first bit (7 + 2 * 23 <= 64); x even inside its
+		// top 32 bits (7 + 23 <= 32). z gets its own 32 bit window. Width 0 extracts 0.
+		const uint8_t* bytes_xy = data + (bit_offset >> 3);
+		const uint32_t shift_xy = bit_offset & 7u;
+		const uint32_t hi = load_be32(bytes_xy);
+		const uint32_t lo = load_be32(bytes_xy + 4);
+		const uint32_t field_shift = 32u - num_bits;
 
-		uint32_t range_bytes[6] = { 0, 0, 0, 0, 0, 0 };
-		if (needs_segment_range)
-		{
-			#pragma unroll
-			for (uint32_t i = 0; i < 6; ++i)
-				range_bytes[i] = segment_range[i * segment_range_stride];
-		}
+		const uint32_t x = (hi << shift_xy) >> field_shift;
+		const uint32_t window_y = __funnelshift_l(lo, hi, shift_xy + num_bits);		// bits [shift + w, shift + w + 32) of hi:lo
+		const uint32_t y = window_y >> field_shift;
+
+		const uint32_t bit_offset_z = bit_offset + 2u * num_bits;
+		const uint32_t hi_z = load_be32(data + (bit_offset_z >> 3));
+		const uint32_t z = (hi_z << (bit_offset_z & 7u)) >> field_shift;
+
+		const bool has_bits = num_bits != 0;		// a shift by 32 is not a shift by 32 in hardware: width 0 extracts 0 explicitly
+		out_xyz[0] = float(has_bits ? x : 0u) * inv_max_value;
+		out_xyz[1] = float(has_bits ? y : 0u) * inv_max_value;
+		out_xyz[2] = float(has_bits ? z : 0u) * inv_max_value;
+	}
+
+	// x, y, z of one animated sub-track at one keyframe, segment and clip range expanded.
+	__device__ __forceinline__ void unpack_animated_sample(const uint8_t* animated_track_data, uint32_t key_frame_bit_offset,
+		const plan_entry& plan, const clip_range_entry& clip_range, bool is_rotation, float out_xyz[3])
+	{
+		const uint32_t num_bits = plan.bit_offset_and_width >> 24;
+		const uint32_t bit_offset = key_frame_bit_offset + (plan.bit_offset_and_width & 0x00FFFFFFu);
 
 		float xyz[3];
-		if (is_constant_in_segment)
+		unpack_bits(animated_track_data, bit_offset, num_bits, plan.inv_max_value, xyz);
+
+		if (num_bits == 32)
 		{
-			// animated_track_cache.transform.h:552-588 (rotation: hi/lo bytes split across SOA rows),
-			// math/vector4_packing.h:628-653 (vector3: little endian u16)
-			uint32_t x, y, z;
+			// raw samples skip both range expansions; in the reference's SOA rotation path the ignored lanes still see
+			// value * 1 + 0 twice (animated_track_cache.transform.h:316-349,420-465), which only matters for a -0.0
 			if (is_rotation)
 			{
-				x = (range_bytes[0] << 8) | range_bytes[1];
-				y = (range_bytes[2] << 8) | range_bytes[3];
-				z = (range_bytes[4] << 8) | range_bytes[5];
-			}
-			else
-			{
-				x = (range_bytes[1] << 8) | range_bytes[0];
-				y = (range_bytes[3] << 8) | range_bytes[2];
-				z = (range_bytes[5] << 8) | range_bytes[4];
-			}
-			xyz[0] = float(x) * (1.0f / 65535.0f);
-			xyz[1] = float(y) * (1.0f / 65535.0f);
-			xyz[2] = float(z) * (1.0f / 65535.0f);
-		}
-		else if (is_raw)
-		{
-			// math/vector4_packing.h:479-599: three big endian floats at an arbitrary bit
-			const uint8_t* data = state.animated_track_data[key] + (bit_offset >> 3);
-			const uint32_t shift = bit_offset & 7u;
-			#pragma unroll
-			for (uint32_t c = 0; c < 3; ++c)
-			{
-				uint64_t window = __builtin_bswap64(load_u64_unaligned(data + 4 * c));
-				window <<= shift;
-				xyz[c] = __uint_as_float(uint32_t(window >> 32));
+				#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c)
+					xyz[c] = ((xyz[c] * 1.0f) + 0.0f) * 1.0f + 0.0f;
 			}
 		}
 		else
 		{
-			// math/vector4_packing.h:921-1035. x and y come out of one 64 bit big endian window (7 + 2 * 23 <= 64), z out of a second one
-			const uint32_t mask = (1u << num_bits) - 1u;
-			const float inv_max_value = 1.0f / float(mask);
-			const uint8_t* data = state.animated_track_data[key];
-
-			const uint64_t window_xy = __builtin_bswap64(load_u64_unaligned(data + (bit_offset >> 3)));
-			const uint32_t shift_xy = bit_offset & 7u;
-			const uint32_t x = uint32_t(window_xy >> (64u - shift_xy - num_bits)) & mask;
-			const uint32_t y = uint32_t(window_xy >> (64u - shift_xy - 2u * num_bits)) & mask;
-
-			const uint32_t bit_offset_z = bit_offset + 2u * num_bits;
-			const uint64_t window_z = __builtin_bswap64(load_u64_unaligned(data + (bit_offset_z >> 3)));
-			const uint32_t z = uint32_t(window_z >> (64u - (bit_offset_z & 7u) - num_bits)) & mask;
-
-			xyz[0] = float(x) * inv_max_value;
-			xyz[1] = float(y) * inv_max_value;
-			xyz[2] = float(z) * inv_max_value;
-		}
-
-		const bool ignore_segment_range = is_constant_in_segment || is_raw;
-		const bool ignore_clip_range = is_raw;
-
-		if (is_rotation)
-		{
-			// Whole pose flavour: ignored lanes still see a multiply by 1 and an add of 0
-			// (remap_segment_range_data4 / remap_clip_range_data4, animated_track_cache.transform.h:316-349,420-465)
-			if (state.has_segments)
-			{
-				#pragma unroll
-				for (uint32_t c = 0; c < 3; ++c)
-				{
-					const float range_min = ignore_segment_range ? 0.0f : float(range_bytes[c]) * (1.0f / 255.0f);
-					const float range_extent = ignore_segment_range ? 1.0f : float(range_bytes[3 + c]) * (1.0f / 255.0f);
-					xyz[c] = (xyz[c] * range_extent) + range_min;
-				}
-			}
-
-			const uint32_t group = slot.index >> 2;
-			const uint32_t group_size = min(num_rotations - group * 4u, 4u);
-			const uint8_t* clip_range = clip.blob + clip.clip_range_offset + group * 96u + (slot.index & 3u) * 4u;
+			// v = v * segment_extent + segment_min, then v = v * clip_extent + clip_min (multiply, then add: never fused).
+			// Constant-in-segment sub-tracks arrive here as 0 * 0 + sample; single segment clips as v * 1 + 0: exact for v >= +0.
 			#pragma unroll
 			for (uint32_t c = 0; c < 3; ++c)
 			{
-				const float range_min = ignore_clip_range ? 0.0f : load_f32(clip_range + group_size * 4u * c);
-				const float range_extent = ignore_clip_range ? 1.0f : load_f32(clip_range + group_size * 4u * (3u + c));
-				xyz[c] = (xyz[c] * range_extent) + range_min;
-			}
-		}
-		else
-		{
-			// unpack_animated_vector3, animated_track_cache.transform.h:930-960
-			if (state.has_segments && !ignore_segment_range)
-			{
-				#pragma unroll
-				for (uint32_t c = 0; c < 3; ++c)
-				{
-					const float range_min = float(range_bytes[c]) * (1.0f / 255.0f);
-					const float range_extent = float(range_bytes[3 + c]) * (1.0f / 255.0f);
-					xyz[c] = (xyz[c] * range_extent) + range_min;
-				}
-			}
-
-			if (!ignore_clip_range)
-			{
-				const uint8_t* clip_range = clip.blob + clip.clip_range_offset + num_rotations * 24u + slot.index * 24u;
-				#pragma unroll
-				for (uint32_t c = 0; c < 3; ++c)
-					xyz[c] = (xyz[c] * load_f32(clip_range + 12u + 4u * c)) + load_f32(clip_range + 4u * c);
+				xyz[c] = (xyz[c] * plan.range_extent[c]) + plan.range_min[c];
+				xyz[c] = (xyz[c] * clip_range.range_extent[c]) + clip_range.range_min[c];
 			}
 		}
 
@@ -469,18 +366,17 @@ namespace aclhip
 	// rtm::vector_lerp in its stable form: end * alpha + (start - start * alpha)
 	__device__ __forceinline__ float lerp_stable(float start, float end, float alpha) { return (end * alpha) + (start - (start * alpha)); }
 
-	// Decodes animated sub-track `slot` of one instance: both keyframes, range expansion, W reconstruction, interpolation.
+	// Decodes one animated sub-track of one instance: both keyframes, range expansion, W reconstruction, interpolation.
 	// `policy` is the effective rounding policy of the track (none unless per track rounding is enabled);
 	// `lerp_alpha` the alpha handed to the interpolation.
-	__device__ __forceinline__ float4 decode_animated_sub_track(const device_clip& clip, const seek_state& state, const animated_slot& slot,
-		uint32_t num_bits0, uint32_t num_bits1, uint32_t bit_offset0, uint32_t bit_offset1,
-		uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
+		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
 		float v0[3], v1[3];
-		unpack_animated_sample(clip, state, 0, slot, num_bits0, bit_offset0, v0);
-		unpack_animated_sample(clip, state, 1, slot, num_bits1, bit_offset1, v1);
+		unpack_animated_sample(state.animated_track_data[0], state.key_frame_bit_offsets[0], plan0, clip_range, is_rotation, v0);
+		unpack_animated_sample(state.animated_track_data[1], state.key_frame_bit_offsets[1], plan1, clip_range, is_rotation, v1);
 
-		if (slot.kind == 0)
+		if (is_rotation)
 		{
 			float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w(v0[0], v0[1], v0[2]));
 			float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w(v1[0], v1[1], v1[2]));
