@@ -55,6 +55,38 @@ namespace aclhip
 		return identity;
 	}
 
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+	// The whole 128 byte clip record in two scalar loads (wave uniform address)
+	__device__ __forceinline__ device_clip load_clip(const device_clip* clips, uint32_t clip_id)
+	{
+		const ACLHIP_CONSTANT u32x16* source = (const ACLHIP_CONSTANT u32x16*)(clips + clip_id);
+		struct { u32x16 lo, hi; } raw = { source[0], source[1] };
+		device_clip clip;
+		__builtin_memcpy(&clip, &raw, sizeof(clip));
+		return clip;
+	}
+
+	// A 32 byte table entry (plan_entry / clip_range_entry) in two 16 byte loads
+	template<class entry_t>
+	__device__ __forceinline__ entry_t load_entry(const entry_t* table, uint32_t index)
+	{
+		static_assert(sizeof(entry_t) == 32, "two dwordx4 loads");
+		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(table + index);
+		struct { u32x4 lo, hi; } raw = { source[0], source[1] };
+		entry_t entry;
+		__builtin_memcpy(&entry, &raw, sizeof(entry));
+		return entry;
+	}
+
+	__device__ __forceinline__ float4 load_quad(const float4* table, uint32_t index)
+	{
+		const f32x4 raw = ((const ACLHIP_CONSTANT f32x4*)table)[index];
+		return make_float4(raw.x, raw.y, raw.z, raw.w);
+	}
+
 	// Turns a base pose quad into the value to store: constants pass through, animated quads come from `animated` (LDS in the
 	// pose kernel), defaults follow the default sub-track modes.
 	template<class animated_lookup_t>
@@ -92,6 +124,35 @@ namespace aclhip
 		return value;
 	}
 
+	// Phase 1 of the pose kernel: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order); every lane
+	// decodes its sub-track for both keyframes and parks the interpolated float4 in LDS at its animated ordinal.
+	template<bool kHasRaw, bool kPolicies>
+	__device__ __forceinline__ void decode_animated_sub_tracks(const device_clip& clip, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t lane, float4* lds_animated)
+	{
+		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
+
+		for (uint32_t animated_ordinal = lane; animated_ordinal < clip.num_animated; animated_ordinal += k_wave_size)
+		{
+			// three independent table reads; when both keyframes share a segment plan[1] == plan[0] and the second read hits L1
+			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
+			const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
+			const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
+
+			uint32_t policy = k_round_none;
+			if (kPolicies && params.per_track_rounding != 0)
+			{
+				// track_writer::get_rounding_policy (core/track_writer.h:97)
+				policy = rounding_policy;
+				if (rounding_policy == k_round_per_track)
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
+			}
+
+			lds_animated[animated_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, animated_ordinal < clip.num_animated_rotations,
+				policy, state.interpolation_alpha, params.normalization, normalize_samples);
+		}
+	}
+
 	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
@@ -105,20 +166,21 @@ namespace aclhip
 		if (instance >= num_instances)
 			return;
 
-		const uint32_t clip_id = __builtin_amdgcn_readfirstlane(clip_ids[instance]);
-		if (clip_id >= num_clips || (clips[clip_id].flags & k_clip_valid) == 0)
+		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
 		{
 			if (lane == 0)
 				atomicAdd(rejected_count, 1ull);
 			return;
 		}
 
-		const device_clip& clip = clips[clip_id];
 		const uint32_t num_tracks = clip.num_tracks;
 		if (num_tracks == 0)
 			return;		// empty track list (decompression.transform.h:1531-1533)
 
-		const float sample_time = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(sample_times[instance])));
 		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
 			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
 			: uint32_t(params.rounding_policy);
@@ -128,30 +190,11 @@ namespace aclhip
 
 		float4* lds_animated = reinterpret_cast<float4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
 
-		// ---- phase 1: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order) ----
-		const uint32_t num_animated = clip.num_animated;
-		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
-
-		for (uint32_t animated_ordinal = lane; animated_ordinal < num_animated; animated_ordinal += k_wave_size)
-		{
-			const clip_range_entry clip_range = clip.clip_ranges[animated_ordinal];
-			const plan_entry plan0 = state.plan[0][animated_ordinal];
-			plan_entry plan1 = plan0;
-			if (!state.uses_single_segment)
-				plan1 = state.plan[1][animated_ordinal];
-
-			uint32_t policy = k_round_none;
-			if (params.per_track_rounding != 0)
-			{
-				// track_writer::get_rounding_policy (core/track_writer.h:97)
-				policy = rounding_policy;
-				if (rounding_policy == k_round_per_track)
-					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
-			}
-
-			lds_animated[animated_ordinal] = decode_animated_sub_track(state, plan0, plan1, clip_range, animated_ordinal < clip.num_animated_rotations,
-				policy, state.interpolation_alpha, params.normalization, normalize_samples);
-		}
+		// ---- phase 1 ----
+		if ((clip.flags & k_clip_has_raw) == 0 && params.per_track_rounding == 0)
+			decode_animated_sub_tracks<false, false>(clip, state, params, rounding_policy, lane, lds_animated);
+		else
+			decode_animated_sub_tracks<true, true>(clip, state, params, rounding_policy, lane, lds_animated);
 
 		// the wave's own LDS writes must land before its lanes read each other's results
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -163,12 +206,23 @@ namespace aclhip
 		float4* pose = reinterpret_cast<float4*>(poses + uint64_t(instance) * pose_stride_bytes);
 		const auto animated_lookup = [lds_animated](uint32_t ordinal) { return lds_animated[ordinal]; };
 
-		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+		constexpr uint32_t k_unroll = 4;	// base pose reads of four store instructions in flight together
+		for (uint32_t base = 0; base < num_quads; base += k_wave_size * k_unroll)
 		{
-			bool store;
-			const float4 value = resolve_quad(params, clip.base_pose[quad], quad, animated_lookup, store);
-			if (store)
-				pose[quad] = value;
+			float4 values[k_unroll];
+			#pragma unroll
+			for (uint32_t j = 0; j < k_unroll; ++j)
+				values[j] = load_quad(clip.base_pose, min(base + j * k_wave_size + lane, num_quads - 1));
+
+			#pragma unroll
+			for (uint32_t j = 0; j < k_unroll; ++j)
+			{
+				const uint32_t quad = base + j * k_wave_size + lane;
+				bool store;
+				const float4 value = resolve_quad(params, values[j], quad, animated_lookup, store);
+				if (store && quad < num_quads)
+					pose[quad] = value;
+			}
 		}
 	}
 
@@ -216,9 +270,10 @@ namespace aclhip
 		// The registration time plan already holds that prefix sum.
 		const auto animated_lookup = [&](uint32_t ordinal)
 		{
-			const plan_entry plan0 = state.plan[0][ordinal];
-			const plan_entry plan1 = state.plan[1][ordinal];
-			return decode_animated_sub_track(state, plan0, plan1, clip.clip_ranges[ordinal], ordinal < clip.num_animated_rotations,
+			const plan_entry plan0 = load_entry(state.plan[0], ordinal);
+			const plan_entry plan1 = load_entry(state.plan[1], ordinal);
+			const clip_range_entry clip_range = load_entry(clip.clip_ranges, ordinal);
+			return decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, ordinal < clip.num_animated_rotations,
 				k_round_none, lerp_alpha, params.normalization, false);
 		};
 
@@ -226,7 +281,7 @@ namespace aclhip
 		{
 			const uint32_t quad = track_index * 3u + kind;
 			bool store;
-			const float4 value = resolve_quad(params, clip.base_pose[quad], quad, animated_lookup, store);
+			const float4 value = resolve_quad(params, load_quad(clip.base_pose, quad), quad, animated_lookup, store);
 			if (store)
 				transforms[size_t(instance) * 3 + kind] = value;
 		}
@@ -555,11 +610,10 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	// ---- derived tables ----
 	std::vector<float> base_pose(size_t(num_quads) * 4);
 	std::vector<clip_range_entry> clip_ranges(std::max<uint32_t>(num_animated, 1));
-	std::vector<segment_record> segments(std::max<uint32_t>(num_segments, 1));
-	std::vector<uint16_t> sample_to_segment(std::max<uint32_t>(num_samples, 1), 0);
+	std::vector<sample_record> samples(std::max<uint32_t>(num_samples, 1));
 	std::vector<plan_entry> plan(std::max<size_t>(size_t(num_segments) * num_animated, 1));
 	std::memset(clip_ranges.data(), 0, clip_ranges.size() * sizeof(clip_range_entry));
-	std::memset(segments.data(), 0, segments.size() * sizeof(segment_record));
+	std::memset(samples.data(), 0, samples.size() * sizeof(sample_record));
 	std::memset(plan.data(), 0, plan.size() * sizeof(plan_entry));
 	bool has_raw = false;
 
@@ -678,11 +732,6 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 			const uint32_t end = multi_segment && si + 1 < num_segments ? segment_start_indices[si + 1] : num_samples;
 			if (start >= end || end > num_samples || end - start > 32 || (si == 0 && start != 0))
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%u, %u)", si, start, end);
-			for (uint32_t sample = start; sample < end; ++sample)
-				sample_to_segment[sample] = uint16_t(si);
-			if (num_segments > 65535)
-				return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "more than 65535 segments");
-
 			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324)
 			const uint32_t format_offset = k_transform_header_offset + sh.segment_data;
 			const uint32_t range_offset = align_to_u32(format_offset + th.num_animated_variable_sub_tracks, 2);
@@ -690,17 +739,21 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 			const uint8_t* format_per_track = blob + format_offset;
 			const uint8_t* range_data = blob + range_offset;
 
-			segment_record& record = segments[si];
+			sample_record record;
+			std::memset(&record, 0, sizeof(record));
 			record.animated_offset = animated_offset;
 			record.pose_bit_size = sh.animated_pose_bit_size;
 			record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : 0xFFFFFFFFu;
 			record.start_index = start;
-			record.num_samples = end - start;
+			record.plan_row = si * num_animated;
+			record.segment_index = si;
+			for (uint32_t sample = start; sample < end; ++sample)
+				samples[sample] = record;
 
 			// every stored keyframe of a clip-resident segment must lie inside the blob
 			if (!header.has_database())
 			{
-				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(record.sample_indices)) : record.num_samples;
+				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(record.sample_indices)) : (end - start);
 				if (uint64_t(animated_offset) + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", si);
 			}
@@ -721,7 +774,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 				plan_entry& entry = plan[size_t(si) * num_animated + a];
 				const uint32_t num_bits = is_raw ? 32u : stored_bits;
 				entry.bit_offset_and_width = bit_offset | (num_bits << 24);
-				entry.inv_max_value = (num_bits == 0 || is_raw) ? 1.0f : 1.0f / float((1u << num_bits) - 1u);
+				entry.inv_max_value = num_bits == 0 ? 0.0f : (is_raw ? 1.0f : 1.0f / float((1u << num_bits) - 1u));
 				for (uint32_t c = 0; c < 3; ++c)
 				{
 					entry.range_min[c] = 0.0f;
@@ -774,20 +827,18 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
-	const uint64_t segments_offset = base_pose_offset + uint64_t(num_quads) * 16;
-	const uint64_t plan_offset = segments_offset + segments.size() * sizeof(segment_record);
+	const uint64_t samples_offset = align_to_u32(uint32_t(base_pose_offset + uint64_t(num_quads) * 16), 32);
+	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
-	const uint64_t sample_to_segment_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
-	const uint64_t total_bytes = sample_to_segment_offset + align_to_u32(uint32_t(sample_to_segment.size() * sizeof(uint16_t)), 16);
+	const uint64_t total_bytes = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
 
 	std::vector<uint8_t> staging(total_bytes, 0);
 	std::memcpy(staging.data(), blob, blob_size);
 	if (num_quads != 0)
 		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
-	std::memcpy(staging.data() + segments_offset, segments.data(), segments.size() * sizeof(segment_record));
+	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
-	std::memcpy(staging.data() + sample_to_segment_offset, sample_to_segment.data(), sample_to_segment.size() * sizeof(uint16_t));
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -824,8 +875,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	std::memset(&record, 0, sizeof(record));
 	record.blob = d_memory;
 	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
-	record.segments = reinterpret_cast<const segment_record*>(d_memory + segments_offset);
-	record.sample_to_segment = reinterpret_cast<const uint16_t*>(d_memory + sample_to_segment_offset);
+	record.samples = reinterpret_cast<const sample_record*>(d_memory + samples_offset);
 	record.plan = reinterpret_cast<const plan_entry*>(d_memory + plan_offset);
 	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + clip_ranges_offset);
 	record.num_tracks = num_tracks;

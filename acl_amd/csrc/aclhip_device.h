@@ -14,7 +14,7 @@
 // What differs from the reference is WHERE the per clip bookkeeping happens: everything that only depends on
 // (clip, segment) -- which segment a sample lives in, where each animated sub-track's bits start inside a keyframe,
 // its width, its segment range as floats -- is worked out once at registration and kept next to the blob in HBM
-// (segment_record / plan_entry / clip_range_entry below). The CPU walks the format bytes serially per pose
+// (sample_record / plan_entry / clip_range_entry below). The CPU walks the format bytes serially per pose
 // (count_animated_group_bit_size); a wave here looks the answers up.
 #pragma once
 
@@ -23,17 +23,26 @@
 
 #include "acl_format.h"
 
+// Clip tables are read-only for the lifetime of a launch: reading them through the constant address space lets wave uniform
+// accesses go through the scalar cache (s_load) and per lane accesses through global_load instead of flat_load.
+#define ACLHIP_CONSTANT __attribute__((address_space(4)))
+
 namespace aclhip
 {
-	// One per segment, 32 bytes, read through the scalar cache
-	struct alignas(32) segment_record
+	template<class T>
+	__device__ __forceinline__ const ACLHIP_CONSTANT T* as_constant(const T* pointer) { return (const ACLHIP_CONSTANT T*)pointer; }
+
+	// One per SAMPLE (a copy of its segment's facts), 32 bytes, read through the scalar cache: one load tells a wave
+	// everything seek needs about the keyframe it lands on.
+	struct alignas(32) sample_record
 	{
-		uint32_t animated_offset;		// first stored keyframe of the segment, from the blob start (4 byte aligned)
+		uint32_t animated_offset;		// first stored keyframe of the sample's segment, from the blob start (4 byte aligned)
 		uint32_t pose_bit_size;			// bits per stored keyframe (segment_header::animated_pose_bit_size)
 		uint32_t sample_indices;		// stored keyframes of the segment, MSB = first sample (0xFFFFFFFF when nothing is stripped)
 		uint32_t start_index;			// clip relative index of the segment's first sample
-		uint32_t num_samples;
-		uint32_t reserved[3];
+		uint32_t plan_row;				// index of the segment's first plan entry (= segment index * num_animated)
+		uint32_t segment_index;
+		uint32_t reserved[2];
 	};
 
 	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
@@ -44,7 +53,7 @@ namespace aclhip
 	struct alignas(16) plan_entry
 	{
 		uint32_t bit_offset_and_width;	// bit offset inside the keyframe (low 24 bits) | num_bits << 24
-		float inv_max_value;			// 1 / (2^num_bits - 1) (math/vector4_packing.h:927-935), 1 for widths 0 and 32
+		float inv_max_value;			// 1 / (2^num_bits - 1) (math/vector4_packing.h:927-935); 0 for width 0 (nothing is read), 1 for width 32
 		float range_min[3];
 		float range_extent[3];
 	};
@@ -59,7 +68,7 @@ namespace aclhip
 		uint32_t reserved;
 	};
 
-	static_assert(sizeof(segment_record) == 32, "layout");
+	static_assert(sizeof(sample_record) == 32, "layout");
 	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
 
@@ -74,8 +83,8 @@ namespace aclhip
 	{
 		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
-		const segment_record* segments;			// [num_segments]
-		const uint16_t* sample_to_segment;		// [num_samples]
+		const sample_record* samples;			// [num_samples]
+		const void* reserved_pointer;
 		const plan_entry* plan;					// [num_segments][num_animated]
 		const clip_range_entry* clip_ranges;	// [num_animated]
 		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
@@ -126,6 +135,16 @@ namespace aclhip
 		bool uses_single_segment;
 	};
 
+	// One 32 byte sample record in a single (scalar, when the index is wave uniform) load
+	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+	__device__ __forceinline__ sample_record load_sample_record(const sample_record* table, uint32_t index)
+	{
+		const u32x8 raw = ((const ACLHIP_CONSTANT u32x8*)table)[index];
+		sample_record record;
+		__builtin_memcpy(&record, &raw, sizeof(record));
+		return record;
+	}
+
 	// core/impl/interpolation_utils.impl.h:261-278
 	__device__ __forceinline__ float apply_rounding_policy(float alpha, uint32_t policy)
 	{
@@ -174,10 +193,10 @@ namespace aclhip
 
 		float alpha = apply_rounding_policy(sample_index - float(key_frame0), rounding_policy);
 
-		const uint32_t segment_index0 = clip.sample_to_segment[key_frame0];
-		const uint32_t segment_index1 = clip.sample_to_segment[key_frame1];
-		const segment_record& segment0 = clip.segments[segment_index0];
-		const segment_record& segment1 = clip.segments[segment_index1];
+		const sample_record segment0 = load_sample_record(clip.samples, key_frame0);
+		const sample_record segment1 = load_sample_record(clip.samples, key_frame1);
+		const uint32_t segment_index0 = segment0.segment_index;
+		const uint32_t segment_index1 = segment1.segment_index;
 
 		uint32_t segment_key_frame0 = key_frame0 - segment0.start_index;
 		uint32_t segment_key_frame1 = key_frame1 - segment1.start_index;
@@ -235,30 +254,38 @@ namespace aclhip
 		// :530-562
 		out.animated_track_data[0] = animated_track_data0;
 		out.animated_track_data[1] = animated_track_data1;
-		out.plan[0] = clip.plan + size_t(segment_index0) * clip.num_animated;
-		out.plan[1] = clip.plan + size_t(segment_index1) * clip.num_animated;
+		out.plan[0] = clip.plan + segment0.plan_row;
+		out.plan[1] = clip.plan + segment1.plan_row;
 		out.key_frame_bit_offsets[0] = segment_key_frame0 * segment0.pose_bit_size;
 		out.key_frame_bit_offsets[1] = segment_key_frame1 * segment1.pose_bit_size;
 		out.interpolation_alpha = alpha;
 		out.uses_single_segment = segment_index0 == segment_index1;
 	}
 
-	// 4 bytes at any alignment, as a big endian number
-	__device__ __forceinline__ uint32_t load_be32(const uint8_t* p)
+	// 4 / 8 bytes at any alignment (gfx950 global loads need no alignment)
+	__device__ __forceinline__ uint32_t load_be32(const ACLHIP_CONSTANT uint8_t* p)
 	{
 		uint32_t v;
-		__builtin_memcpy(&v, p, 4);
+		__builtin_memcpy(&v, (const ACLHIP_CONSTANT void*)p, 4);
 		return __builtin_bswap32(v);
 	}
 
-	// The quantized x, y, z of one sub-track at one keyframe as floats in [0, 1] (or the raw fp32 values): the bit unpack of
-	// math/vector4_packing.h:921-1035 / :479-599. `bit_offset` is relative to `data`.
-	__device__ __forceinline__ void unpack_bits(const uint8_t* data, uint32_t bit_offset, uint32_t num_bits, float inv_max_value, float out_xyz[3])
+	__device__ __forceinline__ uint64_t load_u64(const ACLHIP_CONSTANT uint8_t* p)
 	{
-		if (num_bits == 32)
+		uint64_t v;
+		__builtin_memcpy(&v, (const ACLHIP_CONSTANT void*)p, 8);
+		return v;
+	}
+
+	// The quantized x, y, z of one sub-track at one keyframe as floats in [0, 1] (or the raw fp32 values): the bit unpack of
+	// math/vector4_packing.h:921-1035 / :479-599. `bit_offset` is relative to `data`. kHasRaw = false compiles the raw path out.
+	template<bool kHasRaw>
+	__device__ __forceinline__ void unpack_bits(const ACLHIP_CONSTANT uint8_t* data, uint32_t bit_offset, uint32_t num_bits, float inv_max_value, float out_xyz[3])
+	{
+		if (kHasRaw && num_bits == 32)
 		{
 			// raw: three big endian floats starting at an arbitrary bit
-			const uint8_t* bytes = data + (bit_offset >> 3);
+			const ACLHIP_CONSTANT uint8_t* bytes = data + (bit_offset >> 3);
 			const uint32_t shift = bit_offset & 7u;
 			const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
 			out_xyz[0] = __uint_as_float(__funnelshift_l(w1, w0, shift));
@@ -268,38 +295,38 @@ namespace aclhip
 		}
 
 		// x and y sit inside the 64 bit window that starts at the byte holding the first bit (7 + 2 * 23 <= 64); x even inside its
-		// top 32 bits (7 + 23 <= 32). z gets its own 32 bit window. Width 0 extracts 0.
-		const uint8_t* bytes_xy = data + (bit_offset >> 3);
-		const uint32_t shift_xy = bit_offset & 7u;
-		const uint32_t hi = load_be32(bytes_xy);
-		const uint32_t lo = load_be32(bytes_xy + 4);
-		const uint32_t field_shift = 32u - num_bits;
-
-		const uint32_t x = (hi << shift_xy) >> field_shift;
-		const uint32_t window_y = __funnelshift_l(lo, hi, shift_xy + num_bits);		// bits [shift + w, shift + w + 32) of hi:lo
-		const uint32_t y = window_y >> field_shift;
-
+		// top 32 bits (7 + 23 <= 32). z gets its own 32 bit window. Two loads per keyframe, both issued before either is used.
 		const uint32_t bit_offset_z = bit_offset + 2u * num_bits;
+		const uint64_t window_xy = load_u64(data + (bit_offset >> 3));
 		const uint32_t hi_z = load_be32(data + (bit_offset_z >> 3));
-		const uint32_t z = (hi_z << (bit_offset_z & 7u)) >> field_shift;
 
-		const bool has_bits = num_bits != 0;		// a shift by 32 is not a shift by 32 in hardware: width 0 extracts 0 explicitly
-		out_xyz[0] = float(has_bits ? x : 0u) * inv_max_value;
-		out_xyz[1] = float(has_bits ? y : 0u) * inv_max_value;
-		out_xyz[2] = float(has_bits ? z : 0u) * inv_max_value;
+		const uint32_t shift_xy = bit_offset & 7u;
+		const uint32_t hi = __builtin_bswap32(uint32_t(window_xy));
+		const uint32_t lo = __builtin_bswap32(uint32_t(window_xy >> 32));
+
+		// v_bfe_u32: (source >> offset) & ((1 << width) - 1), and 0 for width 0 (a sub-track that is constant in its segment)
+		const uint32_t x = __builtin_amdgcn_ubfe(hi, 32u - shift_xy - num_bits, num_bits);
+		const uint32_t window_y = __funnelshift_l(lo, hi, shift_xy + num_bits);		// bits [shift + w, shift + w + 32) of hi:lo
+		const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
+		const uint32_t z = __builtin_amdgcn_ubfe(hi_z, 32u - (bit_offset_z & 7u) - num_bits, num_bits);
+
+		out_xyz[0] = float(x) * inv_max_value;
+		out_xyz[1] = float(y) * inv_max_value;
+		out_xyz[2] = float(z) * inv_max_value;
 	}
 
 	// x, y, z of one animated sub-track at one keyframe, segment and clip range expanded.
-	__device__ __forceinline__ void unpack_animated_sample(const uint8_t* animated_track_data, uint32_t key_frame_bit_offset,
+	template<bool kHasRaw>
+	__device__ __forceinline__ void unpack_animated_sample(const ACLHIP_CONSTANT uint8_t* animated_track_data, uint32_t key_frame_bit_offset,
 		const plan_entry& plan, const clip_range_entry& clip_range, bool is_rotation, float out_xyz[3])
 	{
 		const uint32_t num_bits = plan.bit_offset_and_width >> 24;
 		const uint32_t bit_offset = key_frame_bit_offset + (plan.bit_offset_and_width & 0x00FFFFFFu);
 
 		float xyz[3];
-		unpack_bits(animated_track_data, bit_offset, num_bits, plan.inv_max_value, xyz);
+		unpack_bits<kHasRaw>(animated_track_data, bit_offset, num_bits, plan.inv_max_value, xyz);
 
-		if (num_bits == 32)
+		if (kHasRaw && num_bits == 32)
 		{
 			// raw samples skip both range expansions; in the reference's SOA rotation path the ignored lanes still see
 			// value * 1 + 0 twice (animated_track_cache.transform.h:316-349,420-465), which only matters for a -0.0
@@ -369,12 +396,14 @@ namespace aclhip
 	// Decodes one animated sub-track of one instance: both keyframes, range expansion, W reconstruction, interpolation.
 	// `policy` is the effective rounding policy of the track (none unless per track rounding is enabled);
 	// `lerp_alpha` the alpha handed to the interpolation.
+	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
+	template<bool kHasRaw, bool kPolicies>
 	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
 		float v0[3], v1[3];
-		unpack_animated_sample(state.animated_track_data[0], state.key_frame_bit_offsets[0], plan0, clip_range, is_rotation, v0);
-		unpack_animated_sample(state.animated_track_data[1], state.key_frame_bit_offsets[1], plan1, clip_range, is_rotation, v1);
+		unpack_animated_sample<kHasRaw>(as_constant(state.animated_track_data[0]), state.key_frame_bit_offsets[0], plan0, clip_range, is_rotation, v0);
+		unpack_animated_sample<kHasRaw>(as_constant(state.animated_track_data[1]), state.key_frame_bit_offsets[1], plan1, clip_range, is_rotation, v1);
 
 		if (is_rotation)
 		{
@@ -382,18 +411,21 @@ namespace aclhip
 			float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w(v1[0], v1[1], v1[2]));
 
 			// animated_track_cache.transform.h:1463-1473
-			if (normalize_samples)
+			if (kPolicies && normalize_samples)
 			{
 				q0 = quat_normalize(q0);
 				q1 = quat_normalize(q1);
 			}
 
-			if (policy == k_round_floor)
-				return q0;
-			if (policy == k_round_ceil)
-				return q1;
-			if (policy == k_round_nearest)
-				return state.interpolation_alpha < 0.5f ? q0 : q1;
+			if (kPolicies)
+			{
+				if (policy == k_round_floor)
+					return q0;
+				if (policy == k_round_ceil)
+					return q1;
+				if (policy == k_round_nearest)
+					return state.interpolation_alpha < 0.5f ? q0 : q1;
+			}
 
 			// :1604-1616
 			float4 result = quat_lerp_no_normalization(q0, q1, lerp_alpha);
@@ -403,12 +435,15 @@ namespace aclhip
 		}
 
 		// unpack_translation_group / unpack_scale_group, animated_track_cache.transform.h:1774-1836,1896-1958
-		if (policy == k_round_floor)
-			return make_float4(v0[0], v0[1], v0[2], 0.0f);
-		if (policy == k_round_ceil)
-			return make_float4(v1[0], v1[1], v1[2], 0.0f);
-		if (policy == k_round_nearest)
-			return state.interpolation_alpha < 0.5f ? make_float4(v0[0], v0[1], v0[2], 0.0f) : make_float4(v1[0], v1[1], v1[2], 0.0f);
+		if (kPolicies)
+		{
+			if (policy == k_round_floor)
+				return make_float4(v0[0], v0[1], v0[2], 0.0f);
+			if (policy == k_round_ceil)
+				return make_float4(v1[0], v1[1], v1[2], 0.0f);
+			if (policy == k_round_nearest)
+				return state.interpolation_alpha < 0.5f ? make_float4(v0[0], v0[1], v0[2], 0.0f) : make_float4(v1[0], v1[1], v1[2], 0.0f);
+		}
 
 		return make_float4(lerp_stable(v0[0], v1[0], lerp_alpha), lerp_stable(v0[1], v1[1], lerp_alpha), lerp_stable(v0[2], v1[2], lerp_alpha), 0.0f);
 	}
