@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -226,6 +227,97 @@ namespace aclhip
 		}
 	}
 
+	// The common case as its own kernel: track_writer defaults, no per track rounding, poses small enough that a wave can hold the
+	// whole pose image in LDS (<= k_image_max_quads). One wave64 per instance:
+	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
+	//   2. while it does, the clip's resolved base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
+	//   3. lanes <-> animated sub-tracks decode straight into their quad of the LDS image;
+	//   4. the finished image streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
+	constexpr uint32_t k_image_max_quads = 320;		// 5 KiB per wave, 8 blocks of 4 waves per CU
+
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_image_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		uint32_t rounding_policy, uint32_t looping_policy, uint32_t normalization,
+		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t instance = blockIdx.x * k_waves_per_block + wave_in_block;
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
+		{
+			if (lane == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		if (num_quads == 0)
+			return;		// empty track list (decompression.transform.h:1531-1533)
+
+		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
+
+		// base pose -> LDS image, asynchronously: lane i of pass p fetches quad p * 64 + i into image[p * 64 + i]
+		{
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
+			for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+			{
+				if (base + lane < num_quads)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
+						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+			}
+		}
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
+
+		// lanes <-> animated sub-tracks
+		const bool has_raw = (clip.flags & k_clip_has_raw) != 0;
+		for (uint32_t animated_ordinal = lane; animated_ordinal < clip.num_animated; animated_ordinal += k_wave_size)
+		{
+			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
+			const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
+			const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
+			const bool is_rotation = animated_ordinal < clip.num_animated_rotations;
+
+			float4 value;
+			if (!has_raw)
+				value = decode_animated_sub_track<false, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+			else
+				value = decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+
+			const f32x4 packed = { value.x, value.y, value.z, value.w };
+			image[clip_range.quad_index] = packed;
+		}
+
+		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+			pose[quad] = image[quad];
+	}
+
+	// Measurement aid: streams `num_quads` float4 to HBM, 16 bytes per lane, to find the write bandwidth a pose-shaped store
+	// stream can reach on this device (the decode kernel is a write streamer).
+	__global__ __launch_bounds__(k_block_size) void stream_write_kernel(float4* __restrict__ destination, uint64_t num_quads, float seed)
+	{
+		const uint64_t stride = uint64_t(gridDim.x) * k_block_size;
+		const float4 value = make_float4(seed, seed + 1.0f, seed + 2.0f, seed + 3.0f);
+		for (uint64_t quad = uint64_t(blockIdx.x) * k_block_size + threadIdx.x; quad < num_quads; quad += stride)
+			destination[quad] = value;
+	}
+
 	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
 		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
@@ -315,6 +407,8 @@ struct aclhip_context
 	uint32_t d_clips_capacity = 0;
 	unsigned long long* d_rejected = nullptr;
 	uint32_t max_lds_quads = 0;				// largest animated sub-track count among registered clips
+	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
+	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): never take the LDS image fast path
 	mutable std::string last_error;
 };
 
@@ -535,6 +629,10 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	if (context == nullptr)
 		return ACLHIP_ERROR_OUT_OF_MEMORY;
 	context->device = device_index;
+	{
+		const char* force_generic = std::getenv("ACLHIP_FORCE_GENERIC_KERNEL");
+		context->force_generic_kernel = force_generic != nullptr && force_generic[0] == '1';
+	}
 
 	device_guard guard(device_index);
 	if (!guard.ok || hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
@@ -678,6 +776,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more animated sub-tracks than the header declares");
 					const uint32_t ordinal = animated_bases[kind] + index;
 					clip_ranges[ordinal].track_index = track;
+					clip_ranges[ordinal].quad_index = quad;
 					value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f;
 					value_bits[3] = k_quad_special | k_quad_animated | ordinal;
 				}
@@ -827,7 +926,17 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
-	const uint64_t samples_offset = align_to_u32(uint32_t(base_pose_offset + uint64_t(num_quads) * 16), 32);
+	// resolved pose: what a decode with the track_writer defaults stores for every non animated sub-track (animated slots: zero)
+	std::vector<float> resolved_pose(base_pose);
+	for (uint32_t quad = 0; quad < num_quads; ++quad)
+	{
+		uint32_t* value_bits = reinterpret_cast<uint32_t*>(&resolved_pose[size_t(quad) * 4]);
+		if (int32_t(value_bits[3]) < 0)
+			resolved_pose[size_t(quad) * 4 + 3] = (value_bits[3] & (k_quad_animated | k_quad_default_w_one)) == k_quad_default_w_one ? 1.0f : 0.0f;
+	}
+
+	const uint64_t resolved_pose_offset = base_pose_offset + uint64_t(num_quads) * 16;
+	const uint64_t samples_offset = align_to_u32(uint32_t(resolved_pose_offset + uint64_t(num_quads) * 16), 32);
 	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t total_bytes = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
@@ -836,6 +945,8 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	std::memcpy(staging.data(), blob, blob_size);
 	if (num_quads != 0)
 		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
+	if (num_quads != 0)
+		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
 	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
@@ -875,6 +986,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	std::memset(&record, 0, sizeof(record));
 	record.blob = d_memory;
 	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
+	record.resolved_pose = reinterpret_cast<const float4*>(d_memory + resolved_pose_offset);
 	record.samples = reinterpret_cast<const sample_record*>(d_memory + samples_offset);
 	record.plan = reinterpret_cast<const plan_entry*>(d_memory + plan_offset);
 	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + clip_ranges_offset);
@@ -925,6 +1037,7 @@ extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const voi
 	entry.touched_bytes = total_bytes - 64;
 	entry.max_lds_quads = num_animated;
 	context->max_lds_quads = std::max(context->max_lds_quads, num_animated);
+	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
 
 	*out_clip = slot;
 	return ACLHIP_OK;
@@ -980,12 +1093,28 @@ namespace
 	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
+		const uint32_t num_blocks = (num_instances + k_waves_per_block - 1) / k_waves_per_block;
+
+		// the common case: track_writer defaults, no per track / per instance rounding, poses that fit the LDS image
+		const bool image_mode = params.standard_defaults != 0 && params.per_track_rounding == 0 && params.instance_rounding_policies == nullptr
+			&& context->max_pose_quads <= k_image_max_quads && !context->force_generic_kernel;
+		if (image_mode)
+		{
+			const uint32_t lds_quads_per_wave = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64);
+			const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
+			hipLaunchKernelGGL(decompress_tracks_image_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
+				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances,
+				uint32_t(params.rounding_policy), uint32_t(params.looping_policy), uint32_t(params.normalization),
+				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+			ACLHIP_CHECK_HIP(context, hipGetLastError());
+			return ACLHIP_OK;
+		}
+
 		const uint32_t lds_quads_per_wave = std::max<uint32_t>(align_to_u32(context->max_lds_quads, 4), 4);
 		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
 		if (lds_bytes > 160 * 1024)
 			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "a registered clip has too many animated sub-tracks for the LDS staging (%u)", context->max_lds_quads);
 
-		const uint32_t num_blocks = (num_instances + k_waves_per_block - 1) / k_waves_per_block;
 		hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
@@ -1202,6 +1331,32 @@ extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* con
 	(void)hipEventDestroy(stop);
 	*out_ms_per_launch = elapsed_ms / float(repeats);
 	return status;
+}
+
+extern "C" aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second)
+{
+	if (context == nullptr || buffer == nullptr || out_gb_per_second == nullptr || repeats == 0 || size_bytes < 16 || (reinterpret_cast<uintptr_t>(buffer) & 15u) != 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	const uint64_t num_quads = size_bytes / 16;
+	const uint32_t num_blocks = uint32_t(std::min<uint64_t>((num_quads + k_block_size - 1) / k_block_size, 256ull * 32ull));
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	hipLaunchKernelGGL(stream_write_kernel, dim3(num_blocks), dim3(k_block_size), 0, hip_stream, static_cast<float4*>(buffer), num_quads, 0.0f);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats; ++i)
+		hipLaunchKernelGGL(stream_write_kernel, dim3(num_blocks), dim3(k_block_size), 0, hip_stream, static_cast<float4*>(buffer), num_quads, float(i));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_gb_per_second = float(double(num_quads) * 16.0 * repeats / (double(elapsed_ms) * 1.0e-3) / 1.0e9);
+	return ACLHIP_OK;
 }
 
 extern "C" aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,

@@ -65,7 +65,7 @@ namespace aclhip
 		float range_min[3];
 		uint32_t track_index;
 		float range_extent[3];
-		uint32_t reserved;
+		uint32_t quad_index;			// track_index * 3 + kind: where the sub-track lands in the pose
 	};
 
 	static_assert(sizeof(sample_record) == 32, "layout");
@@ -84,7 +84,7 @@ namespace aclhip
 		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
 		const sample_record* samples;			// [num_samples]
-		const void* reserved_pointer;
+		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
 		const plan_entry* plan;					// [num_segments][num_animated]
 		const clip_range_entry* clip_ranges;	// [num_animated]
 		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
@@ -306,7 +306,8 @@ namespace aclhip
 
 		// v_bfe_u32: (source >> offset) & ((1 << width) - 1), and 0 for width 0 (a sub-track that is constant in its segment)
 		const uint32_t x = __builtin_amdgcn_ubfe(hi, 32u - shift_xy - num_bits, num_bits);
-		const uint32_t window_y = __funnelshift_l(lo, hi, shift_xy + num_bits);		// bits [shift + w, shift + w + 32) of hi:lo
+		// bits [shift + w, shift + w + 32) of hi:lo; shift + w is in [1, 30] for real widths (a width 0 result is discarded by the bfe)
+		const uint32_t window_y = __builtin_amdgcn_alignbit(hi, lo, 32u - (shift_xy + num_bits));
 		const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
 		const uint32_t z = __builtin_amdgcn_ubfe(hi_z, 32u - (bit_offset_z & 7u) - num_bits, num_bits);
 

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_register_clip", "aclhip_unregister_clip", "aclhip_get_clip_info", "aclhip_clip_matches",
     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
     "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
+    "aclhip_measure_write_bandwidth",
 ]
 
 
@@ -87,6 +88,7 @@ def load_library():
     lib.aclhip_decompress_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, u32, vp]
     lib.aclhip_get_rejected_instance_count.argtypes = [vp, ctypes.POINTER(u64)]
     lib.aclhip_time_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_float)]
+    lib.aclhip_measure_write_bandwidth.argtypes = [vp, vp, u64, u32, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aclhip_batch_algorithmic_bytes.argtypes = [vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     _lib = lib
     return lib
@@ -230,6 +232,12 @@ class Context:
         count = ctypes.c_uint64(0)
         self._check(self._lib.aclhip_get_rejected_instance_count(self._handle, ctypes.byref(count)))
         return count.value
+
+    def measure_write_bandwidth(self, buffer_ptr, size_bytes, repeats=20, stream=None):
+        """GB/s of a plain 16 byte per lane store stream into the given device buffer."""
+        gbps = ctypes.c_float(0.0)
+        self._check(self._lib.aclhip_measure_write_bandwidth(self._handle, buffer_ptr, size_bytes, repeats, stream, ctypes.byref(gbps)))
+        return gbps.value
 
     def batch_algorithmic_bytes(self, clips):
         clips = np.ascontiguousarray(clips, dtype=np.uint32)

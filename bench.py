@@ -175,6 +175,8 @@ def main():
     algorithmic_bytes = bytes_written + bytes_read
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
 
+    write_ceiling_gbps = context.measure_write_bandwidth(d_poses.data_ptr(), num_instances * pose_stride, repeats=20, stream=stream.cuda_stream)
+
     rejected = context.rejected_instance_count()
     if rejected != 0:
         raise SystemExit(f"the kernel rejected {rejected} instances")
@@ -214,6 +216,7 @@ def main():
                 "kernel": "decompress_tracks_kernel",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
+                "measured_write_stream_gbps": write_ceiling_gbps,
             },
         }
         if world_size == 1 and not args.no_cpu_baseline:

@@ -15,9 +15,15 @@ pytestmark = pytest.mark.gpu
 TOLERANCE = 1.0e-5      # BASELINE.json: within 1e-5 per component of the reference CPU decompress_tracks()
 
 
-@pytest.fixture(scope="module")
-def context():
-    ctx = runtime.Context(0)
+@pytest.fixture(scope="module", params=["fast_kernels", "generic_kernel"])
+def context(request):
+    """Every test runs twice: with the launch heuristics free to pick the LDS image fast path, and pinned to the generic kernel."""
+    if request.param == "generic_kernel":
+        os.environ["ACLHIP_FORCE_GENERIC_KERNEL"] = "1"
+    try:
+        ctx = runtime.Context(0)
+    finally:
+        os.environ.pop("ACLHIP_FORCE_GENERIC_KERNEL", None)
     yield ctx
     ctx.close()
 
