@@ -279,13 +279,15 @@ namespace aclhip
 		seek(clip, sample_time, rounding_policy, looping_policy, state);
 
 		// lanes <-> animated sub-tracks
-		const bool has_raw = (clip.flags & k_clip_has_raw) != 0;
 		for (uint32_t animated_ordinal = lane; animated_ordinal < clip.num_animated; animated_ordinal += k_wave_size)
 		{
 			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
 			const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
 			const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
 			const bool is_rotation = animated_ordinal < clip.num_animated_rotations;
+
+			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
+			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
 
 			float4 value;
 			if (!has_raw)

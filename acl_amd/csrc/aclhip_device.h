@@ -277,82 +277,92 @@ namespace aclhip
 		return v;
 	}
 
-	// The quantized x, y, z of one sub-track at one keyframe as floats in [0, 1] (or the raw fp32 values): the bit unpack of
-	// math/vector4_packing.h:921-1035 / :479-599. `bit_offset` is relative to `data`. kHasRaw = false compiles the raw path out.
+	// Both keyframes of one animated sub-track, range expanded: the bit unpack of math/vector4_packing.h:921-1035 (quantized) and
+	// :479-599 (raw), then the segment and clip range expansion of animated_track_cache.transform.h:302-350,391-466,930-960.
+	// All four bitstream loads are issued before any of them is used. kHasRaw = false compiles the raw fix-up out.
 	template<bool kHasRaw>
-	__device__ __forceinline__ void unpack_bits(const ACLHIP_CONSTANT uint8_t* data, uint32_t bit_offset, uint32_t num_bits, float inv_max_value, float out_xyz[3])
+	__device__ __forceinline__ void unpack_animated_samples(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
+		const clip_range_entry& clip_range, bool is_rotation, float out_v0[3], float out_v1[3])
 	{
-		if (kHasRaw && num_bits == 32)
-		{
-			// raw: three big endian floats starting at an arbitrary bit
-			const ACLHIP_CONSTANT uint8_t* bytes = data + (bit_offset >> 3);
-			const uint32_t shift = bit_offset & 7u;
-			const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
-			out_xyz[0] = __uint_as_float(__funnelshift_l(w1, w0, shift));
-			out_xyz[1] = __uint_as_float(__funnelshift_l(w2, w1, shift));
-			out_xyz[2] = __uint_as_float(__funnelshift_l(w3, w2, shift));
-			return;
-		}
+		const ACLHIP_CONSTANT uint8_t* data0 = as_constant(state.animated_track_data[0]);
+		const ACLHIP_CONSTANT uint8_t* data1 = as_constant(state.animated_track_data[1]);
+
+		const uint32_t num_bits0 = plan0.bit_offset_and_width >> 24;
+		const uint32_t num_bits1 = plan1.bit_offset_and_width >> 24;
+		const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + (plan0.bit_offset_and_width & 0x00FFFFFFu);
+		const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + (plan1.bit_offset_and_width & 0x00FFFFFFu);
+		const uint32_t bit_offset_z0 = bit_offset0 + 2u * num_bits0;
+		const uint32_t bit_offset_z1 = bit_offset1 + 2u * num_bits1;
 
 		// x and y sit inside the 64 bit window that starts at the byte holding the first bit (7 + 2 * 23 <= 64); x even inside its
-		// top 32 bits (7 + 23 <= 32). z gets its own 32 bit window. Two loads per keyframe, both issued before either is used.
-		const uint32_t bit_offset_z = bit_offset + 2u * num_bits;
-		const uint64_t window_xy = load_u64(data + (bit_offset >> 3));
-		const uint32_t hi_z = load_be32(data + (bit_offset_z >> 3));
+		// top 32 bits (7 + 23 <= 32). z gets its own 32 bit window.
+		const uint64_t window_xy0 = load_u64(data0 + (bit_offset0 >> 3));
+		const uint32_t window_z0 = load_be32(data0 + (bit_offset_z0 >> 3));
+		const uint64_t window_xy1 = load_u64(data1 + (bit_offset1 >> 3));
+		const uint32_t window_z1 = load_be32(data1 + (bit_offset_z1 >> 3));
 
-		const uint32_t shift_xy = bit_offset & 7u;
-		const uint32_t hi = __builtin_bswap32(uint32_t(window_xy));
-		const uint32_t lo = __builtin_bswap32(uint32_t(window_xy >> 32));
-
-		// v_bfe_u32: (source >> offset) & ((1 << width) - 1), and 0 for width 0 (a sub-track that is constant in its segment)
-		const uint32_t x = __builtin_amdgcn_ubfe(hi, 32u - shift_xy - num_bits, num_bits);
-		// bits [shift + w, shift + w + 32) of hi:lo; shift + w is in [1, 30] for real widths (a width 0 result is discarded by the bfe)
-		const uint32_t window_y = __builtin_amdgcn_alignbit(hi, lo, 32u - (shift_xy + num_bits));
-		const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
-		const uint32_t z = __builtin_amdgcn_ubfe(hi_z, 32u - (bit_offset_z & 7u) - num_bits, num_bits);
-
-		out_xyz[0] = float(x) * inv_max_value;
-		out_xyz[1] = float(y) * inv_max_value;
-		out_xyz[2] = float(z) * inv_max_value;
-	}
-
-	// x, y, z of one animated sub-track at one keyframe, segment and clip range expanded.
-	template<bool kHasRaw>
-	__device__ __forceinline__ void unpack_animated_sample(const ACLHIP_CONSTANT uint8_t* animated_track_data, uint32_t key_frame_bit_offset,
-		const plan_entry& plan, const clip_range_entry& clip_range, bool is_rotation, float out_xyz[3])
-	{
-		const uint32_t num_bits = plan.bit_offset_and_width >> 24;
-		const uint32_t bit_offset = key_frame_bit_offset + (plan.bit_offset_and_width & 0x00FFFFFFu);
-
-		float xyz[3];
-		unpack_bits<kHasRaw>(animated_track_data, bit_offset, num_bits, plan.inv_max_value, xyz);
-
-		if (kHasRaw && num_bits == 32)
+		float v[2][3];
+		#pragma unroll
+		for (uint32_t key = 0; key < 2; ++key)
 		{
-			// raw samples skip both range expansions; in the reference's SOA rotation path the ignored lanes still see
-			// value * 1 + 0 twice (animated_track_cache.transform.h:316-349,420-465), which only matters for a -0.0
-			if (is_rotation)
-			{
-				#pragma unroll
-				for (uint32_t c = 0; c < 3; ++c)
-					xyz[c] = ((xyz[c] * 1.0f) + 0.0f) * 1.0f + 0.0f;
-			}
-		}
-		else
-		{
+			const uint64_t window_xy = key == 0 ? window_xy0 : window_xy1;
+			const uint32_t hi_z = key == 0 ? window_z0 : window_z1;
+			const uint32_t num_bits = key == 0 ? num_bits0 : num_bits1;
+			const uint32_t shift_xy = (key == 0 ? bit_offset0 : bit_offset1) & 7u;
+			const uint32_t shift_z = (key == 0 ? bit_offset_z0 : bit_offset_z1) & 7u;
+			const plan_entry& plan = key == 0 ? plan0 : plan1;
+
+			const uint32_t hi = __builtin_bswap32(uint32_t(window_xy));
+			const uint32_t lo = __builtin_bswap32(uint32_t(window_xy >> 32));
+
+			// v_bfe_u32: (source >> offset) & ((1 << width) - 1), and 0 for width 0 (a sub-track that is constant in its segment)
+			const uint32_t x = __builtin_amdgcn_ubfe(hi, 32u - shift_xy - num_bits, num_bits);
+			// bits [shift + w, shift + w + 32) of hi:lo; shift + w is in [1, 30] for real widths (a width 0 result is discarded by the bfe)
+			const uint32_t window_y = __builtin_amdgcn_alignbit(hi, lo, 32u - (shift_xy + num_bits));
+			const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
+			const uint32_t z = __builtin_amdgcn_ubfe(hi_z, 32u - shift_z - num_bits, num_bits);
+
+			const float quantized[3] = { float(x) * plan.inv_max_value, float(y) * plan.inv_max_value, float(z) * plan.inv_max_value };
+
 			// v = v * segment_extent + segment_min, then v = v * clip_extent + clip_min (multiply, then add: never fused).
 			// Constant-in-segment sub-tracks arrive here as 0 * 0 + sample; single segment clips as v * 1 + 0: exact for v >= +0.
 			#pragma unroll
 			for (uint32_t c = 0; c < 3; ++c)
 			{
-				xyz[c] = (xyz[c] * plan.range_extent[c]) + plan.range_min[c];
-				xyz[c] = (xyz[c] * clip_range.range_extent[c]) + clip_range.range_min[c];
+				const float segment_value = (quantized[c] * plan.range_extent[c]) + plan.range_min[c];
+				v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
 			}
 		}
 
-		out_xyz[0] = xyz[0];
-		out_xyz[1] = xyz[1];
-		out_xyz[2] = xyz[2];
+		if (kHasRaw)
+		{
+			// Raw (fp32) keyframes: three big endian floats starting at an arbitrary bit (math/vector4_packing.h:479-599). What the
+			// code above computed for them is discarded. Raw samples skip both range expansions; in the reference's SOA rotation
+			// path the ignored lanes still see value * 1 + 0 twice (animated_track_cache.transform.h:316-349,420-465), which only
+			// matters for a -0.0.
+			#pragma unroll
+			for (uint32_t key = 0; key < 2; ++key)
+			{
+				if ((key == 0 ? num_bits0 : num_bits1) == 32u)
+				{
+					const uint32_t bit_offset = key == 0 ? bit_offset0 : bit_offset1;
+					const ACLHIP_CONSTANT uint8_t* bytes = (key == 0 ? data0 : data1) + (bit_offset >> 3);
+					const uint32_t shift = bit_offset & 7u;
+					const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
+					float raw[3] = { __uint_as_float(__funnelshift_l(w1, w0, shift)), __uint_as_float(__funnelshift_l(w2, w1, shift)), __uint_as_float(__funnelshift_l(w3, w2, shift)) };
+					#pragma unroll
+					for (uint32_t c = 0; c < 3; ++c)
+						v[key][c] = is_rotation ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
+				}
+			}
+		}
+
+		#pragma unroll
+		for (uint32_t c = 0; c < 3; ++c)
+		{
+			out_v0[c] = v[0][c];
+			out_v1[c] = v[1][c];
+		}
 	}
 
 	// math/quatf.h:135-147
@@ -403,8 +413,7 @@ namespace aclhip
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
 		float v0[3], v1[3];
-		unpack_animated_sample<kHasRaw>(as_constant(state.animated_track_data[0]), state.key_frame_bit_offsets[0], plan0, clip_range, is_rotation, v0);
-		unpack_animated_sample<kHasRaw>(as_constant(state.animated_track_data[1]), state.key_frame_bit_offsets[1], plan1, clip_range, is_rotation, v1);
+		unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 
 		if (is_rotation)
 		{
