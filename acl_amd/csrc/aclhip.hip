@@ -1335,6 +1335,20 @@ extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* con
 	return status;
 }
 
+extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity)
+{
+	if (context == nullptr || out_name == nullptr || capacity == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	decode_params device_params;
+	const aclhip_status status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+	const bool image_mode = device_params.standard_defaults != 0 && device_params.per_track_rounding == 0 && device_params.instance_rounding_policies == nullptr
+		&& context->max_pose_quads <= k_image_max_quads && !context->force_generic_kernel;
+	std::snprintf(out_name, capacity, "%s", image_mode ? "decompress_tracks_image_kernel" : "decompress_tracks_kernel");
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second)
 {
 	if (context == nullptr || buffer == nullptr || out_gb_per_second == nullptr || repeats == 0 || size_bytes < 16 || (reinterpret_cast<uintptr_t>(buffer) & 15u) != 0)

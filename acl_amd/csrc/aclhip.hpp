@@ -1,0 +1,367 @@
+// aclhip.hpp -- host side C++ mirror of the reference's decompression surface on top of the C ABI (include/aclhip.h).
+//
+// The reference's boundary is a header-only template class, acl::decompression_context<settings>
+// (/root/reference/includes/acl/decompression/decompress.h:76-201), fed by a user supplied acl::track_writer
+// (core/track_writer.h:82-216). This header offers the same names, argument meaning and error behaviour:
+//
+//     aclhip::device gpu(0);
+//     aclhip::decompression_context<aclhip::default_transform_decompression_settings> context;
+//     context.initialize(gpu, compressed_tracks_bytes);      // reference: initialize(const compressed_tracks&)
+//     context.seek(sample_time, aclhip::sample_rounding_policy::none);
+//     context.decompress_tracks(writer);                      // writer.write_rotation/translation/scale, same phase order
+//     context.decompress_track(bone_index, writer);
+//
+// A context decodes a batch of ONE instance per call through aclhip_decompress_tracks_host: it exists so that code written
+// against the reference keeps compiling and can be validated; throughput comes from aclhip_decompress_tracks_batch.
+// Like the reference: initialize()/relocated() return bool, everything else returns void and silently does nothing on misuse
+// (uninitialised context, no seek yet, bad track index: impl/decompress.impl.h:213-214,226-227; impl/decompression.transform.h:1536-1537,1767-1768).
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/aclhip.h"
+
+namespace aclhip
+{
+	// acl::sample_rounding_policy (core/sample_rounding_policy.h)
+	enum class sample_rounding_policy : uint8_t { none = 0, floor = 1, ceil = 2, nearest = 3, per_track = 4 };
+	// acl::sample_looping_policy (core/sample_looping_policy.h)
+	enum class sample_looping_policy : uint8_t { clamp = 0, wrap = 1, non_looping = clamp, as_compressed = 2 };
+	// acl::rotation_normalization_policy_t (decompression/decompression_settings.h:50-62)
+	enum class rotation_normalization_policy_t : uint8_t { never = 0, lerp_only = 1, always = 2 };
+	// acl::default_sub_track_mode (core/track_writer.h:49-74)
+	enum class default_sub_track_mode { skipped, constant, variable, legacy };
+
+	struct quatf { float x, y, z, w; };
+	struct vector4f { float x, y, z, w; };
+
+	// acl::decompression_settings (decompression/decompression_settings.h:74-166): the switches that matter to the transform path
+	struct decompression_settings
+	{
+		static constexpr bool clamp_sample_time() { return true; }
+		static constexpr rotation_normalization_policy_t get_rotation_normalization_policy() { return rotation_normalization_policy_t::always; }
+		static constexpr bool skip_initialize_safety_checks() { return false; }
+		static constexpr bool is_wrapping_supported() { return true; }
+		static constexpr bool is_per_track_rounding_supported() { return true; }
+	};
+
+	// acl::debug_transform_decompression_settings (decompression_settings.h:186-191)
+	struct debug_transform_decompression_settings : public decompression_settings {};
+
+	// acl::default_transform_decompression_settings (decompression_settings.h:211-232)
+	struct default_transform_decompression_settings : public decompression_settings
+	{
+		static constexpr rotation_normalization_policy_t get_rotation_normalization_policy() { return rotation_normalization_policy_t::lerp_only; }
+		static constexpr bool is_per_track_rounding_supported() { return false; }
+	};
+
+	// acl::track_writer (core/track_writer.h:82-216), transform part. Derive and override what you need.
+	struct track_writer
+	{
+		sample_rounding_policy get_rounding_policy(sample_rounding_policy seek_policy, uint32_t /*track_index*/) const { return seek_policy; }
+
+		static constexpr default_sub_track_mode get_default_rotation_mode() { return default_sub_track_mode::constant; }
+		static constexpr default_sub_track_mode get_default_translation_mode() { return default_sub_track_mode::constant; }
+		static constexpr default_sub_track_mode get_default_scale_mode() { return default_sub_track_mode::legacy; }
+
+		quatf get_constant_default_rotation() const { return quatf{ 0.0f, 0.0f, 0.0f, 1.0f }; }
+		vector4f get_constant_default_translation() const { return vector4f{ 0.0f, 0.0f, 0.0f, 0.0f }; }
+		vector4f get_constant_default_scale() const { return vector4f{ 1.0f, 1.0f, 1.0f, 0.0f }; }
+
+		quatf get_variable_default_rotation(uint32_t /*track_index*/) const { return quatf{ 0.0f, 0.0f, 0.0f, 1.0f }; }
+		vector4f get_variable_default_translation(uint32_t /*track_index*/) const { return vector4f{ 0.0f, 0.0f, 0.0f, 0.0f }; }
+		vector4f get_variable_default_scale(uint32_t /*track_index*/) const { return vector4f{ 1.0f, 1.0f, 1.0f, 0.0f }; }
+
+		static constexpr bool skip_all_rotations() { return false; }
+		static constexpr bool skip_all_translations() { return false; }
+		static constexpr bool skip_all_scales() { return false; }
+
+		bool skip_track_rotation(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_translation(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_scale(uint32_t /*track_index*/) const { return false; }
+
+		void write_rotation(uint32_t /*track_index*/, quatf /*rotation*/) {}
+		void write_translation(uint32_t /*track_index*/, vector4f /*translation*/) {}
+		void write_scale(uint32_t /*track_index*/, vector4f /*scale*/) {}
+	};
+
+	// RAII owner of an aclhip_context (one per GPU); clips registered by contexts live in it.
+	class device
+	{
+	public:
+		explicit device(int device_index = 0) { if (aclhip_create(device_index, &m_context) != ACLHIP_OK) m_context = nullptr; }
+		~device() { aclhip_destroy(m_context); }
+		device(const device&) = delete;
+		device& operator=(const device&) = delete;
+
+		bool is_valid() const { return m_context != nullptr; }
+		aclhip_context* get() const { return m_context; }
+
+	private:
+		aclhip_context* m_context = nullptr;
+	};
+
+	namespace impl
+	{
+		inline aclhip_default_mode to_c_mode(default_sub_track_mode mode)
+		{
+			switch (mode)
+			{
+			case default_sub_track_mode::skipped: return ACLHIP_DEFAULT_SKIPPED;
+			case default_sub_track_mode::constant: return ACLHIP_DEFAULT_CONSTANT;
+			case default_sub_track_mode::variable: return ACLHIP_DEFAULT_VARIABLE;
+			default: return ACLHIP_DEFAULT_LEGACY;
+			}
+		}
+
+		// Sub-track class of a track (core/impl/compressed_headers.h:214-224): 0 default, 1 constant, 2 animated
+		inline uint32_t sub_track_class(const uint8_t* blob, uint32_t kind, uint32_t track_index)
+		{
+			uint32_t num_tracks, misc_packed, types_offset;
+			memcpy(&num_tracks, blob + 16, 4);
+			memcpy(&misc_packed, blob + 28, 4);
+			memcpy(&types_offset, blob + 32 + 40, 4);			// transform_tracks_header::sub_track_types_offset
+			if (kind == 2 && (misc_packed & 1u) == 0)
+				return 0;											// no scale: every scale sub-track is default
+			const uint32_t num_entries = (num_tracks + 15) / 16;
+			uint32_t packed;
+			memcpy(&packed, blob + 32 + types_offset + 4 * (size_t(kind) * num_entries + track_index / 16), 4);
+			return (packed >> ((15 - (track_index % 16)) * 2)) & 3u;
+		}
+	}
+
+	template<class decompression_settings_type>
+	class decompression_context
+	{
+	public:
+		using settings_type = decompression_settings_type;
+
+		decompression_context() = default;
+		~decompression_context() { reset(); }
+		decompression_context(const decompression_context&) = delete;
+		decompression_context& operator=(const decompression_context&) = delete;
+
+		// reference: bool initialize(const compressed_tracks&) (decompress.h:103). The bytes are copied to the GPU; `compressed_tracks`
+		// must stay alive while bound because default / constant / animated classes are read from it when replaying writes.
+		bool initialize(device& gpu, const void* compressed_tracks, uint64_t size)
+		{
+			reset();
+			if (!gpu.is_valid() || compressed_tracks == nullptr)
+				return false;
+
+			aclhip_clip clip = ACLHIP_INVALID_HANDLE;
+			// is_valid(false): the reference does not check the hash on initialize (impl/decompress.impl.h:70)
+			if (aclhip_register_clip(gpu.get(), compressed_tracks, size, 0, &clip) != ACLHIP_OK)
+				return false;
+
+			m_device = &gpu;
+			m_clip = clip;
+			m_tracks = static_cast<const uint8_t*>(compressed_tracks);
+			aclhip_get_clip_info(gpu.get(), clip, &m_info);
+			m_looping_policy = settings_type::is_wrapping_supported() ? static_cast<sample_looping_policy>(m_info.looping_policy) : sample_looping_policy::clamp;
+			m_sample_time = -1.0f;
+			return true;
+		}
+
+		bool is_initialized() const { return m_device != nullptr; }
+
+		void reset()
+		{
+			if (m_device != nullptr)
+				aclhip_unregister_clip(m_device->get(), m_clip);
+			m_device = nullptr;
+			m_tracks = nullptr;
+			m_clip = ACLHIP_INVALID_HANDLE;
+		}
+
+		// reference: relocated(const compressed_tracks&) (decompress.h:123): same clip, new address
+		bool relocated(const void* compressed_tracks)
+		{
+			if (!is_bound_to_hash(compressed_tracks))
+				return false;
+			m_tracks = static_cast<const uint8_t*>(compressed_tracks);
+			m_sample_time = -1.0f;		// forces a new seek, like relocated_v0 (impl/decompression.transform.h:151-154)
+			return true;
+		}
+
+		// reference: is_bound_to(const compressed_tracks&) (decompress.h:138): same pointer and same hash
+		bool is_bound_to(const void* compressed_tracks) const { return compressed_tracks == m_tracks && is_bound_to_hash(compressed_tracks); }
+
+		void set_looping_policy(sample_looping_policy policy)
+		{
+			if (!is_initialized() || !settings_type::is_wrapping_supported())
+				return;		// only clamping is supported (impl/decompression.transform.h:189-190)
+			if (policy == sample_looping_policy::as_compressed)
+				policy = static_cast<sample_looping_policy>(m_info.looping_policy);
+			m_looping_policy = policy;
+		}
+
+		sample_looping_policy get_looping_policy() const { return m_looping_policy; }
+
+		// reference: seek(float sample_time, sample_rounding_policy) (decompress.h:160). The seek itself runs on the GPU with the decode.
+		void seek(float sample_time, sample_rounding_policy rounding_policy)
+		{
+			if (!is_initialized())
+				return;
+			if (rounding_policy == sample_rounding_policy::per_track && !settings_type::is_per_track_rounding_supported())
+				return;		// the reference asserts here
+			m_sample_time = sample_time < 0.0f && settings_type::clamp_sample_time() ? 0.0f : sample_time;
+			m_rounding_policy = rounding_policy;
+		}
+
+		// reference: decompress_tracks(track_writer_type&) (decompress.h:166)
+		template<class track_writer_type>
+		void decompress_tracks(track_writer_type& writer)
+		{
+			if (!is_initialized() || m_info.num_tracks == 0 || m_sample_time < 0.0f)
+				return;
+
+			const uint32_t num_tracks = m_info.num_tracks;
+			m_pose.assign(size_t(num_tracks) * 12, 0.0f);
+			if (!run(writer, nullptr, m_pose.data(), num_tracks))
+				return;
+
+			// Replay in the reference's phase order (impl/decompression.transform.h:1605-1733): default rotations, constant rotations,
+			// default translations, constant translations, default / constant scales, animated rotations, translations, scales
+			static const uint32_t phases[8][2] = { { 0, 0 }, { 0, 1 }, { 1, 0 }, { 1, 1 }, { 2, 0 }, { 2, 1 }, { 0, 2 }, { 1, 2 } };
+			for (uint32_t phase = 0; phase < 9; ++phase)
+			{
+				const uint32_t kind = phase < 8 ? phases[phase][0] : 2;
+				const uint32_t cls = phase < 8 ? phases[phase][1] : 2;
+				for (uint32_t track = 0; track < num_tracks; ++track)
+					if (impl::sub_track_class(m_tracks, kind, track) == cls)
+						write_sub_track(writer, kind, cls, track, &m_pose[size_t(track) * 12], true);
+			}
+		}
+
+		// reference: decompress_track(uint32_t, track_writer_type&) (decompress.h:172). Like the reference it does not consult
+		// skip_track_* (impl/decompression.transform.h:1985-2046).
+		template<class track_writer_type>
+		void decompress_track(uint32_t track_index, track_writer_type& writer)
+		{
+			if (!is_initialized() || m_sample_time < 0.0f || track_index >= m_info.num_tracks)
+				return;
+
+			float transform[12] = { 0 };
+			if (!run(writer, &track_index, transform, 1))
+				return;
+
+			for (uint32_t kind = 0; kind < 3; ++kind)
+				write_sub_track(writer, kind, impl::sub_track_class(m_tracks, kind, track_index), track_index, transform, false);
+		}
+
+	private:
+		bool is_bound_to_hash(const void* compressed_tracks) const
+		{
+			if (!is_initialized() || compressed_tracks == nullptr)
+				return false;
+			int matches = 0;
+			return aclhip_clip_matches(m_device->get(), m_clip, compressed_tracks, &matches) == ACLHIP_OK && matches != 0;
+		}
+
+		template<class track_writer_type>
+		bool run(track_writer_type& writer, const uint32_t* track_index, float* out, uint32_t out_tracks)
+		{
+			aclhip_decompress_params params;
+			aclhip_default_params(&params);
+			params.rounding_policy = static_cast<uint8_t>(m_rounding_policy);
+			params.looping_policy = static_cast<uint8_t>(m_looping_policy);
+			params.normalization = static_cast<uint8_t>(settings_type::get_rotation_normalization_policy());
+			params.per_track_rounding = settings_type::is_per_track_rounding_supported() ? 1 : 0;
+			params.default_rotation_mode = impl::to_c_mode(track_writer_type::get_default_rotation_mode());
+			params.default_translation_mode = impl::to_c_mode(track_writer_type::get_default_translation_mode());
+			params.default_scale_mode = impl::to_c_mode(track_writer_type::get_default_scale_mode());
+
+			const uint32_t num_tracks = m_info.num_tracks;
+			const bool any_variable = track_writer_type::get_default_rotation_mode() == default_sub_track_mode::variable
+				|| track_writer_type::get_default_translation_mode() == default_sub_track_mode::variable
+				|| track_writer_type::get_default_scale_mode() == default_sub_track_mode::variable;
+
+			// default values the writer supplies; a variable mode needs the per track table, a constant one row
+			uint32_t default_count = any_variable ? num_tracks : 1;
+			m_defaults.assign(size_t(default_count) * 12, 0.0f);
+			for (uint32_t i = 0; i < default_count; ++i)
+			{
+				float* row = &m_defaults[size_t(i) * 12];
+				const quatf rotation = track_writer_type::get_default_rotation_mode() == default_sub_track_mode::variable ? writer.get_variable_default_rotation(i) : writer.get_constant_default_rotation();
+				const vector4f translation = track_writer_type::get_default_translation_mode() == default_sub_track_mode::variable ? writer.get_variable_default_translation(i) : writer.get_constant_default_translation();
+				vector4f scale = track_writer_type::get_default_scale_mode() == default_sub_track_mode::variable ? writer.get_variable_default_scale(i) : writer.get_constant_default_scale();
+				if (track_writer_type::get_default_scale_mode() == default_sub_track_mode::legacy)
+				{
+					const float legacy = float((m_tracks[28] >> 1) & 1u);		// tracks_header default scale bit
+					scale = vector4f{ legacy, legacy, legacy, 0.0f };
+				}
+				row[0] = rotation.x; row[1] = rotation.y; row[2] = rotation.z; row[3] = rotation.w;
+				row[4] = translation.x; row[5] = translation.y; row[6] = translation.z;
+				row[8] = scale.x; row[9] = scale.y; row[10] = scale.z;
+			}
+
+			// with one mode variable every CONSTANT-mode kind must repeat its value on each row; the loop above already did.
+			// a legacy scale mode next to user defaults is expressed as constant (the value was resolved above)
+			if (params.default_scale_mode == ACLHIP_DEFAULT_LEGACY)
+				params.default_scale_mode = any_variable ? ACLHIP_DEFAULT_VARIABLE : ACLHIP_DEFAULT_CONSTANT;
+			if (any_variable)
+			{
+				if (params.default_rotation_mode == ACLHIP_DEFAULT_CONSTANT) params.default_rotation_mode = ACLHIP_DEFAULT_VARIABLE;
+				if (params.default_translation_mode == ACLHIP_DEFAULT_CONSTANT) params.default_translation_mode = ACLHIP_DEFAULT_VARIABLE;
+				if (params.default_scale_mode == ACLHIP_DEFAULT_CONSTANT) params.default_scale_mode = ACLHIP_DEFAULT_VARIABLE;
+			}
+			params.default_values = m_defaults.data();
+
+			if (settings_type::is_per_track_rounding_supported())
+			{
+				m_track_rounding.resize(num_tracks);
+				for (uint32_t i = 0; i < num_tracks; ++i)
+					m_track_rounding[i] = static_cast<uint8_t>(writer.get_rounding_policy(m_rounding_policy, i));
+				params.track_rounding_policies = m_track_rounding.data();
+			}
+
+			const float sample_time = m_sample_time;
+			if (track_index != nullptr)
+				return aclhip_decompress_track_host(m_device->get(), &m_clip, &sample_time, track_index, 1, &params, default_count, out) == ACLHIP_OK;
+			return aclhip_decompress_tracks_host(m_device->get(), &m_clip, &sample_time, 1, &params, default_count, out, uint64_t(out_tracks) * 48) == ACLHIP_OK;
+		}
+
+		template<class track_writer_type>
+		static void write_sub_track(track_writer_type& writer, uint32_t kind, uint32_t cls, uint32_t track_index, const float* qvv, bool honour_skips)
+		{
+			const default_sub_track_mode mode = kind == 0 ? track_writer_type::get_default_rotation_mode()
+				: (kind == 1 ? track_writer_type::get_default_translation_mode() : track_writer_type::get_default_scale_mode());
+			if (cls == 0 && mode == default_sub_track_mode::skipped)
+				return;		// nothing to write
+
+			if (kind == 0)
+			{
+				if (honour_skips && (track_writer_type::skip_all_rotations() || writer.skip_track_rotation(track_index)))
+					return;
+				writer.write_rotation(track_index, quatf{ qvv[0], qvv[1], qvv[2], qvv[3] });
+			}
+			else if (kind == 1)
+			{
+				if (honour_skips && (track_writer_type::skip_all_translations() || writer.skip_track_translation(track_index)))
+					return;
+				writer.write_translation(track_index, vector4f{ qvv[4], qvv[5], qvv[6], 0.0f });
+			}
+			else
+			{
+				if (honour_skips && (track_writer_type::skip_all_scales() || writer.skip_track_scale(track_index)))
+					return;
+				writer.write_scale(track_index, vector4f{ qvv[8], qvv[9], qvv[10], 0.0f });
+			}
+		}
+
+		device* m_device = nullptr;
+		const uint8_t* m_tracks = nullptr;
+		aclhip_clip m_clip = ACLHIP_INVALID_HANDLE;
+		aclhip_clip_info m_info = {};
+		sample_looping_policy m_looping_policy = sample_looping_policy::clamp;
+		sample_rounding_policy m_rounding_policy = sample_rounding_policy::none;
+		float m_sample_time = -1.0f;
+		std::vector<float> m_pose;
+		std::vector<float> m_defaults;
+		std::vector<uint8_t> m_track_rounding;
+	};
+}

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_register_clip", "aclhip_unregister_clip", "aclhip_get_clip_info", "aclhip_clip_matches",
     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
     "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
-    "aclhip_measure_write_bandwidth",
+    "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
 ]
 
 
@@ -89,6 +89,7 @@ def load_library():
     lib.aclhip_get_rejected_instance_count.argtypes = [vp, ctypes.POINTER(u64)]
     lib.aclhip_time_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_float)]
     lib.aclhip_measure_write_bandwidth.argtypes = [vp, vp, u64, u32, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.aclhip_describe_tracks_kernel.argtypes = [vp, pparams, ctypes.c_char_p, u32]
     lib.aclhip_batch_algorithmic_bytes.argtypes = [vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     _lib = lib
     return lib
@@ -238,6 +239,12 @@ class Context:
         gbps = ctypes.c_float(0.0)
         self._check(self._lib.aclhip_measure_write_bandwidth(self._handle, buffer_ptr, size_bytes, repeats, stream, ctypes.byref(gbps)))
         return gbps.value
+
+    def tracks_kernel_name(self, params=None):
+        params = params if params is not None else default_params()
+        name = ctypes.create_string_buffer(128)
+        self._check(self._lib.aclhip_describe_tracks_kernel(self._handle, ctypes.byref(params), name, 128))
+        return name.value.decode()
 
     def batch_algorithmic_bytes(self, clips):
         clips = np.ascontiguousarray(clips, dtype=np.uint32)

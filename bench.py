@@ -97,6 +97,23 @@ def cpu_baseline(clips, clip_indices, times, max_tracks):
             "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c), 1 thread, best of 3"}
 
 
+def measured_traffic(workload, kernel_name):
+    """HBM bytes per launch of the decode kernel from rocprofv3 PMC passes of this same command, committed under profiles/
+    (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units, FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md). None when no committed measurement matches the workload and kernel."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        entries = json.load(open(path))
+    except ValueError:
+        return None
+    for entry in entries:
+        if entry.get("workload") == workload and entry.get("kernel") == kernel_name:
+            return entry.get("traffic_bytes_per_launch")
+    return None
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -212,8 +229,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": None,
-                "kernel": "decompress_tracks_kernel",
+                "traffic": measured_traffic(args.workload, context.tracks_kernel_name(params)),
+                "kernel": context.tracks_kernel_name(params),
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
                 "measured_write_stream_gbps": write_ceiling_gbps,

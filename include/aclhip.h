@@ -184,6 +184,10 @@ aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64
 aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch);
 
+/* Name of the kernel aclhip_decompress_tracks_batch would launch for `params` with the clips registered so far
+ * (to match rocprofv3 kernel traces with bench results). */
+aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity);
+
 /* Streams `size_bytes` of 16 byte per lane stores into `buffer` (DEVICE pointer, 16 byte aligned) `repeats` times and returns the
  * GB/s reached: the practical ceiling of a pose shaped write stream on this device, to read roofline fractions against. */
 aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second);

@@ -1,0 +1,55 @@
+"""The C++ mirror of acl::decompression_context (acl_amd/csrc/aclhip.hpp) built with g++ against the C-ABI library and driven
+like the reference's validator. Needs a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mirror_binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "context_mirror_test"
+    lib_dir = os.path.dirname(runtime.library_path())
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "context_mirror_test.cpp"),
+                    "-L" + lib_dir, "-laclhip", "-Wl,-rpath," + lib_dir, "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("mode", ["identity", "skipped", "variable"])
+def test_cpp_context_matches_oracle(mirror_binary, tmp_path, mode):
+    clip = synth.build_clip(seed=31, num_tracks=23, num_samples=80, has_scale=1, rotation_default=0.2, translation_default=0.3, scale_default=0.5)
+    blob_path, times_path, out_path = tmp_path / "clip.acl", tmp_path / "times.txt", tmp_path / "poses.bin"
+    clip.blob.tofile(blob_path)
+    rng = np.random.default_rng(5)
+    times = rng.uniform(0.0, clip.duration, size=20).astype(np.float32)
+    times_path.write_text("\n".join(repr(float(t)) for t in times))
+
+    result = subprocess.run([mirror_binary, str(blob_path), str(times_path), str(out_path), mode])
+    assert result.returncode == 0
+
+    poses = np.fromfile(out_path, dtype=np.float32).reshape(times.size, clip.num_tracks, 12)
+    defaults = None
+    if mode == "variable":
+        defaults = np.zeros((clip.num_tracks, 12), dtype=np.float32)
+        for i in range(clip.num_tracks):
+            defaults[i] = [0.5, -0.5, 0.5, 0.5 + i, i, 2.0, 3.0, 0.0, 2.0, i, 2.0, 0.0]
+    options = {
+        "identity": ob.default_options(),
+        "skipped": ob.default_options(default_rotation_mode=ob.DEFAULT_SKIPPED, default_translation_mode=ob.DEFAULT_SKIPPED, default_scale_mode=ob.DEFAULT_SKIPPED),
+        "variable": ob.default_options(default_rotation_mode=ob.DEFAULT_VARIABLE, default_translation_mode=ob.DEFAULT_VARIABLE, default_scale_mode=ob.DEFAULT_VARIABLE),
+    }[mode]
+    if defaults is not None:
+        options.default_values = defaults.ctypes.data
+    lanes = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]
+    for i, t in enumerate(times):
+        expected = np.full((clip.num_tracks, 12), -7.0, dtype=np.float32)
+        ob.oracle_decompress_tracks(clip.blob, float(t), 0, options, out=expected)
+        assert np.array_equal(poses[i][:, lanes].view(np.uint32), expected[:, lanes].view(np.uint32))
