@@ -431,16 +431,26 @@ namespace
 	#define ACLHIP_CHECK_HIP(context, expression) \
 		do { const hipError_t hip_status_ = (expression); if (hip_status_ != hipSuccess) return fail((context), ACLHIP_ERROR_DEVICE, "%s failed: %s", #expression, hipGetErrorString(hip_status_)); } while (0)
 
+	// Makes the context's device current for the duration of a call; a no-op (one thread-local read) when it already is,
+	// which is the one-process-per-GPU case the launch path cares about.
 	struct device_guard
 	{
 		int previous = -1;
+		bool switched = false;
 		bool ok = false;
 		explicit device_guard(int device)
 		{
-			if (hipGetDevice(&previous) == hipSuccess)
+			if (hipGetDevice(&previous) != hipSuccess)
+				return;
+			if (previous == device)
+				ok = true;
+			else
+			{
 				ok = hipSetDevice(device) == hipSuccess;
+				switched = ok;
+			}
 		}
-		~device_guard() { if (previous >= 0) (void)hipSetDevice(previous); }
+		~device_guard() { if (switched) (void)hipSetDevice(previous); }
 	};
 
 	// compressed_tracks::is_valid (core/impl/compressed_tracks.impl.h:278-301) + bounds checks so that a decode can never read outside the blob
