@@ -14,7 +14,15 @@ namespace rtm
 	using quatf = __m128;
 	using mask4f = __m128;
 
-	struct scalarf { __m128 value; };
+	// A float kept in lane 0 of an SSE register; converts to and from float like RTM's scalarf does through scalar_cast / scalar_set.
+	struct scalarf
+	{
+		__m128 value;
+		scalarf() = default;
+		scalarf(__m128 value_) noexcept : value(value_) {}
+		scalarf(float value_) noexcept : value(_mm_set_ps1(value_)) {}
+		operator float() const noexcept { return _mm_cvtss_f32(value); }
+	};
 
 	struct float2f { float x; float y; };
 	struct float3f { float x; float y; float z; };

@@ -46,6 +46,11 @@ namespace rtm
 	inline float vector_get_z(vector4f v) noexcept { return _mm_cvtss_f32(_mm_shuffle_ps(v, v, _MM_SHUFFLE(2, 2, 2, 2))); }
 	inline float vector_get_w(vector4f v) noexcept { return _mm_cvtss_f32(_mm_shuffle_ps(v, v, _MM_SHUFFLE(3, 3, 3, 3))); }
 
+	inline scalarf vector_get_x_as_scalar(vector4f v) noexcept { return scalarf(v); }
+	inline scalarf vector_get_y_as_scalar(vector4f v) noexcept { return scalarf(_mm_shuffle_ps(v, v, _MM_SHUFFLE(1, 1, 1, 1))); }
+	inline scalarf vector_get_z_as_scalar(vector4f v) noexcept { return scalarf(_mm_shuffle_ps(v, v, _MM_SHUFFLE(2, 2, 2, 2))); }
+	inline scalarf vector_get_w_as_scalar(vector4f v) noexcept { return scalarf(_mm_shuffle_ps(v, v, _MM_SHUFFLE(3, 3, 3, 3))); }
+
 	inline vector4f vector_set_x(vector4f v, float x) noexcept { return _mm_move_ss(v, _mm_set_ss(x)); }
 	inline vector4f vector_set_w(vector4f v, float w) noexcept { return _mm_set_ps(w, vector_get_z(v), vector_get_y(v), vector_get_x(v)); }
 
@@ -151,6 +156,7 @@ namespace rtm
 	inline bool vector_all_near_equal(vector4f a, vector4f b, float threshold = 0.00001F) noexcept { return vector_all_less_equal(vector_abs(_mm_sub_ps(a, b)), _mm_set_ps1(threshold)); }
 	inline bool vector_all_near_equal3(vector4f a, vector4f b, float threshold = 0.00001F) noexcept { return vector_all_less_equal3(vector_abs(_mm_sub_ps(a, b)), _mm_set_ps1(threshold)); }
 	inline bool vector_is_finite(vector4f v) noexcept { return std::isfinite(vector_get_x(v)) && std::isfinite(vector_get_y(v)) && std::isfinite(vector_get_z(v)) && std::isfinite(vector_get_w(v)); }
+	inline bool vector_is_finite2(vector4f v) noexcept { return std::isfinite(vector_get_x(v)) && std::isfinite(vector_get_y(v)); }
 	inline bool vector_is_finite3(vector4f v) noexcept { return std::isfinite(vector_get_x(v)) && std::isfinite(vector_get_y(v)) && std::isfinite(vector_get_z(v)); }
 
 	//////////////////////////////////////////////////////////////////////////

@@ -36,14 +36,37 @@ CASES = {
 }
 
 
+# Clips compressed by the REFERENCE's own compressor (oracle/_ref/libaclref_compress.so: compress_track_list with
+# get_default_compression_settings()) from synthetic raw animation: name -> (raw animation spec, compressor options)
+REAL_COMPRESSOR_CASES = {
+    "real_default_settings_70_bones": (dict(seed=41, num_tracks=70, num_samples=301), dict()),                    # BASELINE.json configs[0]
+    "real_scale_single_segment": (dict(seed=42, num_tracks=24, num_samples=25, has_scale=1, scale_default=0.3), dict()),
+    "real_keyframe_stripping": (dict(seed=43, num_tracks=30, num_samples=150), dict(strip_proportion=0.4)),
+    "real_loop_optimized": (dict(seed=44, num_tracks=20, num_samples=91), dict(optimize_loops=True, make_looping=True)),
+    "real_high_precision": (dict(seed=45, num_tracks=16, num_samples=64, translation_extent=50.0), dict(precision=0.000001)),
+}
+
+
+def real_compressor_blob(spec, options):
+    options = dict(options)
+    raw_clip = synth.build_clip(with_side_data=True, **spec)
+    raw = raw_clip.raw_keyframes.copy()
+    if options.pop("make_looping", False):
+        raw[-1] = raw[0]        # first == last sample: the compressor drops the last one and sets the wrap flag
+    return ob.ref_compress(raw, raw_clip.sample_rate, **options)
+
+
 def main():
     if not ob.have_ref():
         raise SystemExit("oracle/_ref/libaclref.so is missing: run `make -C oracle ref` where /root/reference exists")
     rng = np.random.default_rng(2024)
-    for name, (spec, settings, default_mode) in CASES.items():
-        clip = synth.build_clip(**spec)
-        blob = clip.blob
-        num_tracks = clip.num_tracks
+    cases = dict(CASES)
+    if ob.have_ref_compressor():
+        for name, (spec, options) in REAL_COMPRESSOR_CASES.items():
+            cases[name] = (real_compressor_blob(spec, options), 0, 0)
+    for name, (spec, settings, default_mode) in cases.items():
+        blob = spec if isinstance(spec, np.ndarray) else synth.build_clip(**spec).blob
+        num_tracks = ob.ref().aclref_get_num_tracks(blob.ctypes.data)
         duration = ob.ref().aclref_get_duration(blob.ctypes.data, -1)
         times = np.concatenate([rng.uniform(-0.05, duration + 0.05, size=40), [0.0, duration, duration * 0.5]]).astype(np.float32)
 
