@@ -136,6 +136,58 @@ namespace aclhip
 		uint64_t tier_metadata[2];
 	};
 
+	// ---- compressed_database (core/impl/compressed_headers.h:447-606), follows a raw_buffer_header ----
+	struct database_header
+	{
+		uint32_t tag;							// k_tag_compressed_database
+		uint16_t version;
+		uint16_t misc_packed;					// bit 0: bulk data inline
+		uint32_t num_chunks[2];					// [0] medium importance tier, [1] low importance tier
+		uint32_t max_chunk_size;
+		uint32_t num_clips;
+		uint32_t num_segments;
+		uint32_t clip_metadata_offset;			// offsets are relative to this header
+		uint32_t bulk_data_size[2];
+		uint32_t bulk_data_offset[2];			// k_invalid_offset when the bulk data isn't inline
+		uint32_t bulk_data_hash[2];
+		// chunk descriptions follow: num_chunks[0] for the medium tier, then num_chunks[1] for the low tier
+	};
+
+	struct database_chunk_description
+	{
+		uint32_t size;
+		uint32_t offset;						// of the chunk header, from the start of the tier's bulk data
+	};
+
+	struct database_clip_metadata
+	{
+		uint32_t clip_hash;
+		uint32_t clip_header_offset;			// into the runtime clip/segment header block
+	};
+
+	struct database_chunk_header
+	{
+		uint32_t index;
+		uint32_t size;
+		uint32_t num_segments;
+		// database_chunk_segment_header[num_segments] follow, then the sample data
+	};
+
+	struct database_chunk_segment_header
+	{
+		uint32_t clip_hash;
+		uint32_t sample_indices;				// samples of the segment stored in this chunk, MSB = first sample
+		uint32_t samples_offset;				// from the start of the tier's bulk data
+		uint32_t clip_header_offset;			// runtime headers to patch when the chunk streams in / out
+		uint32_t segment_header_offset;
+	};
+
+	static_assert(sizeof(database_header) == 56, "layout");
+	static_assert(sizeof(database_chunk_description) == 8, "layout");
+	static_assert(sizeof(database_clip_metadata) == 8, "layout");
+	static_assert(sizeof(database_chunk_header) == 12, "layout");
+	static_assert(sizeof(database_chunk_segment_header) == 20, "layout");
+
 	static_assert(sizeof(raw_buffer_header) == 8, "layout");
 	static_assert(sizeof(tracks_header) == 24, "layout");
 	static_assert(sizeof(segment_header) == 16, "layout");

@@ -25,6 +25,8 @@ EXPORTED_SYMBOLS = [
     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
     "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
     "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
+    "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
+    "aclhip_database_stream_in", "aclhip_database_stream_out",
 ]
 
 
@@ -44,6 +46,18 @@ class ClipInfo(ctypes.Structure):
         ("num_segments", ctypes.c_uint32), ("has_scale", ctypes.c_uint32), ("looping_policy", ctypes.c_uint32), ("compressed_size", ctypes.c_uint32),
         ("hash", ctypes.c_uint32), ("num_animated_sub_tracks", ctypes.c_uint32), ("has_database", ctypes.c_uint32), ("has_stripped_keyframes", ctypes.c_uint32),
     ]
+
+
+class DatabaseInfo(ctypes.Structure):
+    """aclhip_database_info"""
+    _fields_ = [
+        ("num_clips", ctypes.c_uint32), ("num_segments", ctypes.c_uint32), ("max_chunk_size", ctypes.c_uint32),
+        ("num_chunks", ctypes.c_uint32 * 2), ("num_loaded_chunks", ctypes.c_uint32 * 2), ("bulk_data_size", ctypes.c_uint32 * 2),
+    ]
+
+
+TIER_MEDIUM_IMPORTANCE = 1  # quality_tier::medium_importance (core/quality_tiers.h)
+TIER_LOWEST_IMPORTANCE = 2
 
 
 class AclHipError(RuntimeError):
@@ -91,6 +105,12 @@ def load_library():
     lib.aclhip_measure_write_bandwidth.argtypes = [vp, vp, u64, u32, vp, ctypes.POINTER(ctypes.c_float)]
     lib.aclhip_describe_tracks_kernel.argtypes = [vp, pparams, ctypes.c_char_p, u32]
     lib.aclhip_batch_algorithmic_bytes.argtypes = [vp, vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    lib.aclhip_register_database.argtypes = [vp, vp, u64, vp, vp, i32, ctypes.POINTER(u32)]
+    lib.aclhip_unregister_database.argtypes = [vp, u32]
+    lib.aclhip_get_database_info.argtypes = [vp, u32, ctypes.POINTER(DatabaseInfo)]
+    lib.aclhip_register_clip_with_database.argtypes = [vp, vp, u64, i32, u32, ctypes.POINTER(u32)]
+    lib.aclhip_database_stream_in.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
+    lib.aclhip_database_stream_out.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     _lib = lib
     return lib
 
@@ -163,6 +183,41 @@ class Context:
         matches = ctypes.c_int(0)
         self._check(self._lib.aclhip_clip_matches(self._handle, clip, blob.ctypes.data, ctypes.byref(matches)))
         return bool(matches.value)
+
+    # ---- databases (database_context) ----
+    def register_database(self, database, bulk_data_medium=None, bulk_data_low=None, check_hash=True):
+        """database: one compressed_database (bytes-like / uint8 array); bulk data arrays when it was split off. Returns the handle."""
+        as_array = lambda b: None if b is None else (np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b)
+        array, medium, low = as_array(database), as_array(bulk_data_medium), as_array(bulk_data_low)
+        handle = ctypes.c_uint32(INVALID_HANDLE)
+        self._check(self._lib.aclhip_register_database(self._handle, array.ctypes.data, array.size, _host_ptr(medium), _host_ptr(low),
+                                                       1 if check_hash else 0, ctypes.byref(handle)))
+        return handle.value
+
+    def unregister_database(self, database):
+        self._check(self._lib.aclhip_unregister_database(self._handle, database))
+
+    def database_info(self, database):
+        info = DatabaseInfo()
+        self._check(self._lib.aclhip_get_database_info(self._handle, database, ctypes.byref(info)))
+        return info
+
+    def register_clip_with_database(self, blob, database, check_hash=True):
+        array = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+        handle = ctypes.c_uint32(INVALID_HANDLE)
+        self._check(self._lib.aclhip_register_clip_with_database(self._handle, array.ctypes.data, array.size, 1 if check_hash else 0, database, ctypes.byref(handle)))
+        return handle.value
+
+    def database_stream_in(self, database, tier, num_chunks=0xFFFFFFFF, stream=None):
+        """database_context::stream_in(tier, num_chunks); returns how many chunks were enqueued (0 = nothing left)."""
+        moved = ctypes.c_uint32(0)
+        self._check(self._lib.aclhip_database_stream_in(self._handle, database, tier, num_chunks, stream, ctypes.byref(moved)))
+        return moved.value
+
+    def database_stream_out(self, database, tier, num_chunks=0xFFFFFFFF, stream=None):
+        moved = ctypes.c_uint32(0)
+        self._check(self._lib.aclhip_database_stream_out(self._handle, database, tier, num_chunks, stream, ctypes.byref(moved)))
+        return moved.value
 
     # ---- device pointer API (inputs and outputs resident in HBM) ----
     def decompress_tracks_batch(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, params=None, stream=None):

@@ -147,6 +147,42 @@ aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip cl
  * was registered from a blob with the same hash and size. */
 aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches);
 
+/* ---- databases (streamed keyframe tiers) ------------------------------------------------------- */
+
+typedef struct aclhip_database_info
+{
+	uint32_t num_clips;
+	uint32_t num_segments;
+	uint32_t max_chunk_size;
+	uint32_t num_chunks[2];					/* [0] medium importance tier, [1] low importance tier */
+	uint32_t num_loaded_chunks[2];
+	uint32_t bulk_data_size[2];
+} aclhip_database_info;
+
+/* Replaces database_context::initialize(allocator, database, medium_streamer, low_streamer)
+ * (decompression/database/database.h:116; impl/database.impl.h): registers a compressed_database (HOST pointer, `size` bytes).
+ * Bulk data of the two tiers is given separately (split_database_bulk_data) or may be null when it is inline in the database.
+ * The bulk data is copied once into PINNED host memory -- the streamer's backing store -- and HBM buffers of the same size are
+ * reserved; nothing is resident on the GPU until aclhip_database_stream_in. The runtime tier metadata the decoder reads
+ * (database_runtime_segment_header::tier_metadata, core/impl/compressed_headers.h:404-422) lives in HBM. */
+aclhip_status aclhip_register_database(aclhip_context* context, const void* compressed_database, uint64_t size,
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database);
+aclhip_status aclhip_unregister_database(aclhip_context* context, aclhip_database database);
+aclhip_status aclhip_get_database_info(const aclhip_context* context, aclhip_database database, aclhip_database_info* out_info);
+
+/* Replaces decompression_context::initialize(const compressed_tracks&, const database_context&) (decompress.h:108;
+ * impl/decompress.impl.h:85-113): like aclhip_register_clip for a clip that database.contains(). */
+aclhip_status aclhip_register_clip_with_database(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash,
+	aclhip_database database, aclhip_clip* out_clip);
+
+/* Replace database_context::stream_in / stream_out(tier, num_chunks) (database/database.h:160-181, impl/database.impl.h:443-640):
+ * tier 1 = medium importance, 2 = lowest importance. stream_in copies the next `num_chunks` missing chunks from pinned host
+ * memory to HBM with hipMemcpyAsync on `stream` and then publishes their segments' tier metadata (stream ordered: decodes enqueued
+ * later on the same stream see the new keyframes); stream_out retires the metadata of the first `num_chunks` resident chunks.
+ * `out_num_chunks` (optional) receives how many chunks were actually moved (0 = done, like database_stream_request_result::done). */
+aclhip_status aclhip_database_stream_in(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
+aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
+
 /* ---- decompression ---------------------------------------------------------------------------- */
 
 /* Replaces, for every instance i in [0, num_instances):

@@ -208,3 +208,102 @@ def ref_compress(raw, sample_rate, parents=None, precision=0.0001, shell_distanc
     written = _ref_compress.aclref_compress(*args, blob.ctypes.data, size, error, 256)
     assert written == size
     return blob
+
+
+REF_DB_PATH = os.path.join(_HERE, "_ref", "libaclref_db.so")
+_ref_db = None
+
+
+def have_ref_database():
+    return os.path.exists(REF_DB_PATH)
+
+
+def ref_db():
+    """The reference's database builder + database_context (oracle/_ref/libaclref_db.so)."""
+    global _ref_db
+    if _ref_db is None:
+        if not os.path.exists(REF_DB_PATH):
+            raise RuntimeError(f"{REF_DB_PATH} is missing: built from /root/reference by `make -C oracle ref`")
+        lib = ctypes.CDLL(REF_DB_PATH)
+        vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
+        lib.aclref_db_compress.argtypes = [vp, u32, u32, f32, f32, vp, u32]
+        lib.aclref_db_compress.restype = u32
+        lib.aclref_db_build.argtypes = [vp, u32, f32, f32, u32]
+        lib.aclref_db_build.restype = vp
+        for name in ("aclref_db_clip_size",):
+            getattr(lib, name).argtypes = [vp, u32]
+            getattr(lib, name).restype = u32
+        lib.aclref_db_get_clip.argtypes = [vp, u32, vp]
+        lib.aclref_db_database_size.argtypes = [vp, i32]
+        lib.aclref_db_database_size.restype = u32
+        lib.aclref_db_get_database.argtypes = [vp, i32, vp]
+        lib.aclref_db_bulk_size.argtypes = [vp, i32]
+        lib.aclref_db_bulk_size.restype = u32
+        lib.aclref_db_get_bulk.argtypes = [vp, i32, vp]
+        lib.aclref_db_num_chunks.argtypes = [vp, i32]
+        lib.aclref_db_num_chunks.restype = u32
+        lib.aclref_db_context_create.argtypes = [vp]
+        lib.aclref_db_stream.argtypes = [vp, i32, u32, i32]
+        lib.aclref_db_decompress.argtypes = [vp, u32, f32, i32, vp]
+        lib.aclref_db_destroy.argtypes = [vp]
+        _ref_db = lib
+    return _ref_db
+
+
+def ref_db_compress(raw, sample_rate, precision=0.0001):
+    """compress_track_list with enable_database_support (keeps the contributing error metadata build_database needs)."""
+    from acl_amd.synth import aligned_bytes
+    lib = ref_db()
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    size = lib.aclref_db_compress(raw.ctypes.data, raw.shape[1], raw.shape[0], ctypes.c_float(sample_rate), ctypes.c_float(precision), None, 0)
+    if size == 0:
+        raise RuntimeError("aclref_db_compress failed")
+    blob = aligned_bytes(size)
+    assert lib.aclref_db_compress(raw.ctypes.data, raw.shape[1], raw.shape[0], ctypes.c_float(sample_rate), ctypes.c_float(precision), blob.ctypes.data, size) == size
+    return blob
+
+
+class ReferenceDatabase:
+    """build_database + split_database_bulk_data + a database_context with in-memory streamers, all from the reference."""
+
+    def __init__(self, clip_blobs, medium_proportion=0.3, low_proportion=0.4, max_chunk_size=4096):
+        from acl_amd.synth import aligned_bytes
+        self._lib = ref_db()
+        self._inputs = clip_blobs
+        pointers = (ctypes.c_void_p * len(clip_blobs))(*[b.ctypes.data for b in clip_blobs])
+        self._handle = self._lib.aclref_db_build(pointers, len(clip_blobs), ctypes.c_float(medium_proportion), ctypes.c_float(low_proportion), max_chunk_size)
+        if not self._handle:
+            raise RuntimeError("build_database failed")
+        self.clips = []
+        for i in range(len(clip_blobs)):
+            blob = aligned_bytes(self._lib.aclref_db_clip_size(self._handle, i))
+            self._lib.aclref_db_get_clip(self._handle, i, blob.ctypes.data)
+            self.clips.append(blob)
+        self.database = aligned_bytes(self._lib.aclref_db_database_size(self._handle, 1))      # bulk data split out
+        self._lib.aclref_db_get_database(self._handle, 1, self.database.ctypes.data)
+        self.database_inline = aligned_bytes(self._lib.aclref_db_database_size(self._handle, 0))
+        self._lib.aclref_db_get_database(self._handle, 0, self.database_inline.ctypes.data)
+        self.bulk = {}
+        for tier in (1, 2):
+            data = aligned_bytes(max(self._lib.aclref_db_bulk_size(self._handle, tier), 1))
+            self._lib.aclref_db_get_bulk(self._handle, tier, data.ctypes.data)
+            self.bulk[tier] = data[: self._lib.aclref_db_bulk_size(self._handle, tier)]
+        self.num_chunks = {tier: self._lib.aclref_db_num_chunks(self._handle, tier) for tier in (1, 2)}
+        if self._lib.aclref_db_context_create(self._handle) != 0:
+            raise RuntimeError("database_context::initialize failed")
+
+    def stream(self, tier, num_chunks, stream_in=True):
+        return self._lib.aclref_db_stream(self._handle, tier, num_chunks, 1 if stream_in else 0)
+
+    def decompress(self, clip_index, sample_time, rounding=ROUND_NONE):
+        num_tracks = oracle().aclo_num_tracks(self.clips[clip_index].ctypes.data)
+        out = np.zeros((num_tracks, 12), dtype=np.float32)
+        result = self._lib.aclref_db_decompress(self._handle, clip_index, ctypes.c_float(sample_time), rounding, out.ctypes.data)
+        if result != 0:
+            raise RuntimeError(f"aclref_db_decompress failed: {result}")
+        return out
+
+    def close(self):
+        if self._handle:
+            self._lib.aclref_db_destroy(self._handle)
+            self._handle = None

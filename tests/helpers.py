@@ -75,3 +75,28 @@ def max_abs_diff(a, b):
 
 def bit_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a[..., XYZ_LANES]).view(np.uint32), np.ascontiguousarray(b[..., XYZ_LANES]).view(np.uint32))
+
+
+# ---- compressed_database fixtures (tests/golden/database/*.npz, see make_golden_database.py) ----
+DATABASE_GOLDEN_DIR = os.path.join(GOLDEN_DIR, "database")
+
+
+def database_golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(DATABASE_GOLDEN_DIR, "*.npz")))
+
+
+def load_database_golden(name):
+    from acl_amd import synth
+
+    def aligned(array):
+        out = synth.aligned_bytes(max(array.size, 1))
+        out[: array.size] = array
+        return out[: array.size] if array.size else out[:0]
+
+    data = np.load(os.path.join(DATABASE_GOLDEN_DIR, f"{name}.npz"))
+    case = {key: data[key] for key in data.files}
+    offsets = case["clip_offsets"]
+    case["clips"] = [aligned(case["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)]
+    for key in ("database", "database_inline", "bulk_medium", "bulk_low"):
+        case[key] = aligned(case[key])
+    return case

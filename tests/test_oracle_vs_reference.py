@@ -103,3 +103,39 @@ def test_decompress_track_close_to_reference(name):
             actual = ob.oracle_decompress_track(clip.blob, float(t), int(track))
             worst = max(worst, helpers.max_abs_diff(actual, full[track]))
     assert worst <= 1e-6
+
+
+@pytest.mark.skipif(not ob.have_ref_database(), reason="oracle/_ref/libaclref_db.so not built (needs /root/reference)")
+@pytest.mark.parametrize("max_chunk_size", [4096, 16384])
+def test_database_streaming_states_bit_exact(max_chunk_size):
+    """The restated database_context (oracle/database.py) walks the same stream_in / stream_out script as the reference's, holes
+    included, and decoding through its runtime headers gives the reference's poses after every request."""
+    from oracle.database import OracleDatabase
+    blobs = []
+    for seed, (num_tracks, num_samples) in enumerate([(30, 150), (20, 90), (25, 200), (40, 333)]):
+        raw = synth.build_clip(seed=60 + seed, num_tracks=num_tracks, num_samples=num_samples, with_side_data=True)
+        blobs.append(ob.ref_db_compress(raw.raw_keyframes, raw.sample_rate))
+    reference = ob.ReferenceDatabase(blobs, max_chunk_size=max_chunk_size)
+    database = OracleDatabase(reference.database, reference.bulk[1], reference.bulk[2])
+    assert database.num_chunks == reference.num_chunks
+    rng = np.random.default_rng(9)
+
+    def check(label):
+        for c, clip in enumerate(reference.clips):
+            assert database.contains(clip)
+            duration = ob.ref().aclref_get_duration(clip.ctypes.data, -1)
+            for t in sample_times_for(duration, 12, rng):
+                for policy in (ob.ROUND_NONE, ob.ROUND_FLOOR, ob.ROUND_CEIL, ob.ROUND_NEAREST):
+                    expected = reference.decompress(c, float(t), policy)
+                    actual = database.decompress_tracks(clip, float(t), policy)
+                    assert helpers.bit_equal(actual, expected), f"{label} clip {c} t {t} policy {policy}"
+
+    check("nothing resident")
+    script = [(1, 1, True), (2, 2, True), (1, 1, False), (1, 2, True), (1, 100, True), (2, 1, False), (2, 100, True),
+              (1, 100, False), (1, 100, True), (2, 100, False), (1, 100, False)]
+    for tier, num_chunks, stream_in in script:
+        result = reference.stream(tier, num_chunks, stream_in)
+        moved = database.stream_in(tier, num_chunks) if stream_in else database.stream_out(tier, num_chunks)
+        assert (result == 1) == (moved != 0)
+        check(f"after {(tier, num_chunks, stream_in)}")
+    reference.close()
