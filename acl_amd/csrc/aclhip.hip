@@ -34,7 +34,10 @@
 namespace aclhip
 {
 	constexpr uint32_t k_wave_size = 64;
-	constexpr uint32_t k_waves_per_block = 4;
+#if !defined(ACLHIP_WAVES_PER_BLOCK)
+	#define ACLHIP_WAVES_PER_BLOCK 4
+#endif
+	constexpr uint32_t k_waves_per_block = ACLHIP_WAVES_PER_BLOCK;
 	constexpr uint32_t k_block_size = k_wave_size * k_waves_per_block;
 
 	// Value of a default sub-track (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310, and the
@@ -149,7 +152,7 @@ namespace aclhip
 					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
 			}
 
-			lds_animated[animated_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, animated_ordinal < clip.num_animated_rotations,
+			lds_animated[animated_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
 				policy, state.interpolation_alpha, params.normalization, normalize_samples);
 		}
 	}
@@ -227,14 +230,14 @@ namespace aclhip
 		}
 	}
 
-	// The common case as its own kernel: track_writer defaults, no per track rounding, poses small enough that a wave can hold the
-	// whole pose image in LDS (<= k_image_max_quads). One wave64 per instance:
+	// The common case as its own kernel: track_writer defaults, no per track rounding. One wave64 per instance builds the pose
+	// through an LDS window of k_image_chunk_quads quads (5 KiB per wave, 8 blocks of 4 waves per CU):
 	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
-	//   2. while it does, the clip's resolved base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
-	//   3. lanes <-> animated sub-tracks decode straight into their quad of the LDS image;
-	//   4. the finished image streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
-	constexpr uint32_t k_image_max_quads = 320;		// 5 KiB per wave, 8 blocks of 4 waves per CU
-
+	//   2. meanwhile the window's slice of the clip's resolved base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
+	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are in pose
+	//      order) decode straight into their quad of the LDS image;
+	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction;
+	// and again for the next window of a pose larger than one (a 100 bone pose is a single window).
 	__global__ __launch_bounds__(k_block_size) void decompress_tracks_image_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
 		uint32_t rounding_policy, uint32_t looping_policy, uint32_t normalization,
@@ -263,51 +266,72 @@ namespace aclhip
 			return;		// empty track list (decompression.transform.h:1531-1533)
 
 		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
+		const ACLHIP_CONSTANT f32x4* resolved_pose = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
 
-		// base pose -> LDS image, asynchronously: lane i of pass p fetches quad p * 64 + i into image[p * 64 + i]
+		// base pose window -> LDS image, asynchronously: lane i of pass p fetches quad first + p * 64 + i into image[p * 64 + i]
+		const auto fetch_window = [&](uint32_t first_quad, uint32_t window_quads)
 		{
-			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
-			for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
-				if (base + lane < num_quads)
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
+				if (base + lane < window_quads)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resolved_pose + first_quad + base + lane),
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
-		}
+		};
+
+		fetch_window(0, min(num_quads, k_image_chunk_quads));
 
 		seek_state state;
 		seek(clip, sample_time, rounding_policy, looping_policy, state);
 
-		// lanes <-> animated sub-tracks
-		for (uint32_t animated_ordinal = lane; animated_ordinal < clip.num_animated; animated_ordinal += k_wave_size)
+		uint32_t first_ordinal = 0;
+		for (uint32_t first_quad = 0, chunk = 0; first_quad < num_quads; first_quad += k_image_chunk_quads, ++chunk)
 		{
-			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-			const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
-			const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
-			const bool is_rotation = animated_ordinal < clip.num_animated_rotations;
+			const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
+			const bool last_window = first_quad + k_image_chunk_quads >= num_quads;
+			const uint32_t end_ordinal = last_window ? clip.num_animated : as_constant(clip.image_chunks)[chunk + 1];
 
-			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
-			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+			// lanes <-> animated sub-tracks of this window
+			for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
+			{
+				const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
+				const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
+				const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
+				const bool is_rotation = is_rotation_entry(clip_range);
 
-			float4 value;
-			if (!has_raw)
-				value = decode_animated_sub_track<false, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
-			else
-				value = decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+				// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
+				const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
 
-			const f32x4 packed = { value.x, value.y, value.z, value.w };
-			image[clip_range.quad_index] = packed;
+				float4 value;
+				if (!has_raw)
+					value = decode_animated_sub_track<false, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+				else
+					value = decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+
+				const f32x4 packed = { value.x, value.y, value.z, value.w };
+				image[clip_range.quad_index - first_quad] = packed;
+			}
+			first_ordinal = end_ordinal;
+
+			// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+			for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
+				pose[first_quad + quad] = image[quad];
+
+			if (!last_window)
+			{
+				// every lane has read its quads of the image: the next window's base pose may now overwrite it
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				fetch_window(first_quad + k_image_chunk_quads, min(num_quads - first_quad - k_image_chunk_quads, k_image_chunk_quads));
+			}
 		}
-
-		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
-		__builtin_amdgcn_s_waitcnt(0);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
-		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
-			pose[quad] = image[quad];
 	}
 
 	// One entry per (chunk, segment) of a database tier: which runtime segment header the chunk's keyframes belong to and what
@@ -390,7 +414,7 @@ namespace aclhip
 			const plan_entry plan0 = load_entry(state.plan[0], ordinal);
 			const plan_entry plan1 = load_entry(state.plan[1], ordinal);
 			const clip_range_entry clip_range = load_entry(clip.clip_ranges, ordinal);
-			return decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, ordinal < clip.num_animated_rotations,
+			return decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
 				k_round_none, lerp_alpha, params.normalization, false);
 		};
 
@@ -993,6 +1017,43 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 	}
 
+	// ---- animated sub-tracks in POSE order ----
+	// The tables above follow the bitstream (rotations, translations, scales); lanes do not care which sub-track they get, so the
+	// tables are reordered by destination quad. The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
+	// a contiguous range of ordinals, image_chunks[c] .. image_chunks[c + 1]: the pose kernel can build a pose of any size through
+	// a fixed LDS window.
+	const uint32_t num_image_chunks = std::max<uint32_t>((num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+	std::vector<uint32_t> image_chunks(align_to_u32(num_image_chunks + 1, 4), num_animated);
+	if (num_animated != 0)
+	{
+		std::vector<uint32_t> order(num_animated);		// new ordinal -> bitstream ordinal
+		for (uint32_t a = 0; a < num_animated; ++a)
+			order[a] = a;
+		std::sort(order.begin(), order.end(), [&](uint32_t lhs, uint32_t rhs) { return clip_ranges[lhs].quad_index < clip_ranges[rhs].quad_index; });
+
+		std::vector<clip_range_entry> ordered_ranges(num_animated);
+		std::vector<plan_entry> ordered_plan(plan.size());
+		for (uint32_t a = 0; a < num_animated; ++a)
+		{
+			ordered_ranges[a] = clip_ranges[order[a]];
+			for (uint32_t si = 0; si < num_segments; ++si)
+				ordered_plan[size_t(si) * num_animated + a] = plan[size_t(si) * num_animated + order[a]];
+			reinterpret_cast<uint32_t*>(base_pose.data())[size_t(ordered_ranges[a].quad_index) * 4 + 3] = k_quad_special | k_quad_animated | a;
+		}
+		std::memcpy(clip_ranges.data(), ordered_ranges.data(), size_t(num_animated) * sizeof(clip_range_entry));
+		plan.swap(ordered_plan);
+
+		uint32_t next = 0;
+		for (uint32_t chunk = 0; chunk < num_image_chunks; ++chunk)
+		{
+			while (next < num_animated && clip_ranges[next].quad_index < chunk * k_image_chunk_quads)
+				next++;
+			image_chunks[chunk] = next;
+		}
+	}
+	else
+		std::fill(image_chunks.begin(), image_chunks.end(), 0u);
+
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
@@ -1009,7 +1070,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	const uint64_t samples_offset = align_to_u32(uint32_t(resolved_pose_offset + uint64_t(num_quads) * 16), 32);
 	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
-	const uint64_t total_bytes = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
+	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
+	const uint64_t total_bytes = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);
 
 	std::vector<uint8_t> staging(total_bytes, 0);
 	std::memcpy(staging.data(), blob, blob_size);
@@ -1020,6 +1082,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
+	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -1060,6 +1123,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	record.samples = reinterpret_cast<const sample_record*>(d_memory + samples_offset);
 	record.plan = reinterpret_cast<const plan_entry*>(d_memory + plan_offset);
 	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + clip_ranges_offset);
+	record.image_chunks = reinterpret_cast<const uint32_t*>(d_memory + image_chunks_offset);
 	record.num_tracks = num_tracks;
 	record.num_samples = num_samples;
 	record.sample_rate = header.sample_rate;
@@ -1074,7 +1138,6 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
 		record.flags |= has_raw ? k_clip_has_raw : 0u;
 		record.num_segments = num_segments;
-		record.num_animated_rotations = num_animated_rotations;
 		record.num_animated = num_animated;
 		if (header.has_database())
 			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(tbase + th.database_header_offset)->clip_header_offset;
@@ -1499,12 +1562,12 @@ namespace
 	{
 		const uint32_t num_blocks = (num_instances + k_waves_per_block - 1) / k_waves_per_block;
 
-		// the common case: track_writer defaults, no per track / per instance rounding, poses that fit the LDS image
+		// the common case: track_writer defaults, no per track / per instance rounding
 		const bool image_mode = params.standard_defaults != 0 && params.per_track_rounding == 0 && params.instance_rounding_policies == nullptr
-			&& context->max_pose_quads <= k_image_max_quads && !context->force_generic_kernel;
+			&& !context->force_generic_kernel;
 		if (image_mode)
 		{
-			const uint32_t lds_quads_per_wave = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64);
+			const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
 			const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
 			hipLaunchKernelGGL(decompress_tracks_image_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances,
@@ -1746,7 +1809,7 @@ extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, 
 	if (status != ACLHIP_OK)
 		return status;
 	const bool image_mode = device_params.standard_defaults != 0 && device_params.per_track_rounding == 0 && device_params.instance_rounding_policies == nullptr
-		&& context->max_pose_quads <= k_image_max_quads && !context->force_generic_kernel;
+		&& !context->force_generic_kernel;
 	std::snprintf(out_name, capacity, "%s", image_mode ? "decompress_tracks_image_kernel" : "decompress_tracks_kernel");
 	return ACLHIP_OK;
 }

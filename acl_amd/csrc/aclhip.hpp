@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "../../include/aclhip.h"
@@ -133,6 +134,128 @@ namespace aclhip
 		}
 	}
 
+	// core/quality_tiers.h: the highest importance tier lives in the compressed_tracks, the other two in a compressed_database
+	enum class quality_tier : uint8_t { highest_importance = 0, medium_importance = 1, lowest_importance = 2 };
+
+	// decompression/database/database.h:48-73
+	enum class database_stream_request_result { done, dispatched, streaming_in_progress, context_not_initialized, invalid_database_tier, no_free_streaming_requests };
+
+	struct database_settings {};
+	struct default_database_settings : public database_settings {};
+
+	// Mirrors acl::database_context<settings> (decompression/database/database.h:69-201) over a database registered with the GPU.
+	// The reference takes an allocator and two database_streamer objects; here the streamer is built in: bulk data is copied once
+	// to pinned host memory at initialize() and stream_in() is a hipMemcpyAsync into HBM followed by the metadata update, both on
+	// `stream`. Requests complete in stream order, so is_streaming() is always false and is_streamed_in() reflects what has been
+	// enqueued.
+	template<class database_settings_type>
+	class database_context
+	{
+	public:
+		using settings_type = database_settings_type;
+
+		database_context() = default;
+		~database_context() { reset(); }
+		database_context(const database_context&) = delete;
+		database_context& operator=(const database_context&) = delete;
+
+		// reference: initialize(allocator, database) for inline bulk data (database.h:110); `size` = database.get_size()
+		bool initialize(device& gpu, const void* compressed_database, uint64_t size) { return initialize(gpu, compressed_database, size, nullptr, nullptr); }
+
+		// reference: initialize(allocator, database, medium_tier_streamer, low_tier_streamer) (database.h:116): the streamers' bulk data
+		bool initialize(device& gpu, const void* compressed_database, uint64_t size, const void* bulk_data_medium, const void* bulk_data_low)
+		{
+			reset();
+			if (!gpu.is_valid() || compressed_database == nullptr)
+				return false;
+			aclhip_database handle = ACLHIP_INVALID_HANDLE;
+			// is_valid(false): no hash check, like database.impl.h:113
+			if (aclhip_register_database(gpu.get(), compressed_database, size, bulk_data_medium, bulk_data_low, 0, &handle) != ACLHIP_OK)
+				return false;
+			m_device = &gpu;
+			m_database = handle;
+			m_compressed_database = compressed_database;
+			return true;
+		}
+
+		const void* get_compressed_database() const { return m_compressed_database; }
+		bool is_initialized() const { return m_device != nullptr; }
+
+		// Fails (and stays bound) while decompression contexts are bound to it; the reference leaves that to the caller
+		void reset()
+		{
+			if (m_device != nullptr && aclhip_unregister_database(m_device->get(), m_database) != ACLHIP_OK)
+				return;
+			m_device = nullptr;
+			m_database = ACLHIP_INVALID_HANDLE;
+			m_compressed_database = nullptr;
+		}
+
+		bool is_bound_to(const void* compressed_database) const { return is_initialized() && compressed_database == m_compressed_database; }
+
+		// reference: contains(const compressed_tracks&) (database.h:147): the clip's hash is listed by the database
+		bool contains(const void* compressed_tracks) const
+		{
+			if (!is_initialized() || compressed_tracks == nullptr)
+				return false;
+			const uint8_t* tracks = static_cast<const uint8_t*>(compressed_tracks);
+			const uint8_t* db = static_cast<const uint8_t*>(m_compressed_database);
+			uint32_t misc_packed, clip_hash, num_clips, clip_metadata_offset;
+			memcpy(&misc_packed, tracks + 28, 4);
+			if ((misc_packed & (1u << 8)) == 0)
+				return false;		// not bound to any database
+			memcpy(&clip_hash, tracks + 4, 4);
+			memcpy(&num_clips, db + 8 + 20, 4);
+			memcpy(&clip_metadata_offset, db + 8 + 28, 4);
+			for (uint32_t i = 0; i < num_clips; ++i)
+			{
+				uint32_t hash;
+				memcpy(&hash, db + 8 + clip_metadata_offset + size_t(i) * 8, 4);
+				if (hash == clip_hash)
+					return true;
+			}
+			return false;
+		}
+
+		bool is_streamed_in(quality_tier tier) const
+		{
+			aclhip_database_info info;
+			if (!is_initialized() || tier == quality_tier::highest_importance || aclhip_get_database_info(m_device->get(), m_database, &info) != ACLHIP_OK)
+				return is_initialized() && tier == quality_tier::highest_importance;
+			const uint32_t tier_index = uint32_t(tier) - 1;
+			return info.num_loaded_chunks[tier_index] == info.num_chunks[tier_index];
+		}
+
+		bool is_streaming(quality_tier /*tier*/) const { return false; }
+
+		database_stream_request_result stream_in(quality_tier tier, uint32_t num_chunks_to_stream = ~0u, void* stream = nullptr) { return request(tier, num_chunks_to_stream, stream, true); }
+		database_stream_request_result stream_out(quality_tier tier, uint32_t num_chunks_to_stream = ~0u, void* stream = nullptr) { return request(tier, num_chunks_to_stream, stream, false); }
+
+		device* get_device() const { return m_device; }
+		aclhip_database get_handle() const { return m_database; }
+
+	private:
+		static_assert(std::is_base_of<database_settings, settings_type>::value, "database_settings_type must derive from database_settings!");
+
+		database_stream_request_result request(quality_tier tier, uint32_t num_chunks, void* stream, bool in)
+		{
+			if (!is_initialized())
+				return database_stream_request_result::context_not_initialized;
+			if (tier == quality_tier::highest_importance)
+				return database_stream_request_result::invalid_database_tier;
+			uint32_t moved = 0;
+			const aclhip_status status = in ? aclhip_database_stream_in(m_device->get(), m_database, uint32_t(tier), num_chunks, stream, &moved)
+				: aclhip_database_stream_out(m_device->get(), m_database, uint32_t(tier), num_chunks, stream, &moved);
+			if (status != ACLHIP_OK)
+				return database_stream_request_result::no_free_streaming_requests;
+			return moved != 0 ? database_stream_request_result::dispatched : database_stream_request_result::done;
+		}
+
+		device* m_device = nullptr;
+		aclhip_database m_database = ACLHIP_INVALID_HANDLE;
+		const void* m_compressed_database = nullptr;
+	};
+
 	template<class decompression_settings_type>
 	class decompression_context
 	{
@@ -155,6 +278,29 @@ namespace aclhip
 			aclhip_clip clip = ACLHIP_INVALID_HANDLE;
 			// is_valid(false): the reference does not check the hash on initialize (impl/decompress.impl.h:70)
 			if (aclhip_register_clip(gpu.get(), compressed_tracks, size, 0, &clip) != ACLHIP_OK)
+				return false;
+
+			m_device = &gpu;
+			m_clip = clip;
+			m_tracks = static_cast<const uint8_t*>(compressed_tracks);
+			aclhip_get_clip_info(gpu.get(), clip, &m_info);
+			m_looping_policy = settings_type::is_wrapping_supported() ? static_cast<sample_looping_policy>(m_info.looping_policy) : sample_looping_policy::clamp;
+			m_sample_time = -1.0f;
+			return true;
+		}
+
+		// reference: bool initialize(const compressed_tracks&, const database_context<..>&) (decompress.h:108, impl/decompress.impl.h:85-113):
+		// fails when the database context is not initialized or does not contain the clip
+		template<class database_settings_type>
+		bool initialize(const void* compressed_tracks, uint64_t size, const database_context<database_settings_type>& database)
+		{
+			reset();
+			if (compressed_tracks == nullptr || !database.is_initialized() || !database.contains(compressed_tracks))
+				return false;
+
+			device& gpu = *database.get_device();
+			aclhip_clip clip = ACLHIP_INVALID_HANDLE;
+			if (aclhip_register_clip_with_database(gpu.get(), compressed_tracks, size, 0, database.get_handle(), &clip) != ACLHIP_OK)
 				return false;
 
 			m_device = &gpu;

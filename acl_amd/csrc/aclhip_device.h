@@ -72,6 +72,12 @@ namespace aclhip
 	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
 
+	// Animated sub-tracks are numbered in POSE order (by quad_index), not in bitstream order: the ones that land in a window of
+	// k_image_chunk_quads consecutive quads form a contiguous range of ordinals.
+	constexpr uint32_t k_image_chunk_quads = 320;
+
+	__device__ __forceinline__ bool is_rotation_entry(const clip_range_entry& entry) { return entry.quad_index == entry.track_index * 3u; }
+
 	// Markers in the W lane of a base pose quad (a real W is never negative: sqrt(|..|) for rotations, 0 for vectors)
 	constexpr uint32_t k_quad_special = 0x80000000u;			// sign bit set: not a constant sub-track
 	constexpr uint32_t k_quad_animated = 0x20000000u;			// special + this bit: low 24 bits = animated ordinal
@@ -96,10 +102,10 @@ namespace aclhip
 		float duration_wrap;					// calculate_finite_duration(num_samples + 1)
 		uint32_t flags;							// k_clip_*
 		uint32_t num_segments;
-		uint32_t num_animated_rotations;
 		uint32_t num_animated;					// rotations + translations + scales
 		uint32_t db_clip_header_offset;			// into db_headers
-		uint32_t reserved[4];
+		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
+		uint32_t reserved[2];
 	};
 
 	static_assert(sizeof(device_clip) == 128, "layout");
@@ -169,7 +175,8 @@ namespace aclhip
 	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
 	{
 		const bool wrap = looping_policy == k_loop_as_compressed ? (clip.flags & k_clip_wraps) != 0 : looping_policy == k_loop_wrap;
-		const float clip_duration = wrap ? clip.duration_wrap : clip.duration_clamp;
+		const float duration_wrap = clip.duration_wrap, duration_clamp = clip.duration_clamp;	// two loads, then a select (not a select of addresses)
+		const float clip_duration = wrap ? duration_wrap : duration_clamp;
 		const uint32_t num_samples = clip.num_samples;
 
 		// :215-216 scalar_clamp

@@ -53,3 +53,51 @@ def test_cpp_context_matches_oracle(mirror_binary, tmp_path, mode):
         expected = np.full((clip.num_tracks, 12), -7.0, dtype=np.float32)
         ob.oracle_decompress_tracks(clip.blob, float(t), 0, options, out=expected)
         assert np.array_equal(poses[i][:, lanes].view(np.uint32), expected[:, lanes].view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def database_mirror_binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "database_mirror_test"
+    lib_dir = os.path.dirname(runtime.library_path())
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "database_mirror_test.cpp"),
+                    "-L" + lib_dir, "-laclhip", "-Wl,-rpath," + lib_dir, "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("name", ["three_clips_4k_chunks", "medium_tier_only"])
+def test_cpp_database_context_matches_oracle(database_mirror_binary, tmp_path, name):
+    import helpers
+    from oracle.database import OracleDatabase
+    case = helpers.load_database_golden(name)
+    paths = {key: tmp_path / f"{key}.bin" for key in ("database", "bulk_medium", "bulk_low", "clip")}
+    for key in ("database", "bulk_medium", "bulk_low"):
+        case[key].tofile(paths[key])
+    clip_index = len(case["clips"]) - 1
+    clip = case["clips"][clip_index]
+    clip.tofile(paths["clip"])
+    times = case["times"][clip_index]
+    (tmp_path / "times.txt").write_text("\n".join(repr(float(t)) for t in times))
+    out_path = tmp_path / "poses.bin"
+
+    result = subprocess.run([database_mirror_binary, str(paths["database"]), str(paths["bulk_medium"]), str(paths["bulk_low"]), str(paths["clip"]),
+                             str(tmp_path / "times.txt"), str(out_path)])
+    assert result.returncode == 0
+
+    num_tracks = ob.oracle().aclo_num_tracks(clip.ctypes.data)
+    poses = np.fromfile(out_path, dtype=np.float32).reshape(4, times.size, num_tracks, 12)
+    oracle_db = OracleDatabase(case["database"], case["bulk_medium"], case["bulk_low"])
+    lanes = [0, 1, 2, 3, 4, 5, 6]
+    for state in range(4):
+        if state == 1:
+            oracle_db.stream_in(1)
+        elif state == 2:
+            oracle_db.stream_in(2)
+        elif state == 3:
+            oracle_db.stream_out(1)
+            oracle_db.stream_out(2)
+        for i, t in enumerate(times):
+            expected = oracle_db.decompress_tracks(clip, float(t))
+            assert np.array_equal(poses[state, i][:, lanes].view(np.uint32), expected[:, lanes].view(np.uint32)), (state, i)
+    if name == "three_clips_4k_chunks":
+        assert not np.array_equal(poses[0], poses[2])     # the tiers made a difference
+    assert np.array_equal(poses[0], poses[3])

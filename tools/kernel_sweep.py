@@ -21,14 +21,24 @@ CASES = {
     "31 samples (one segment)": dict(seed=2, num_samples=31),
     "70 bones": dict(seed=2, num_tracks=70),
     "106 bones": dict(seed=2, num_tracks=106),
+    "cinematic 300 bones, 451 samples": dict(seed=4, num_tracks=300, num_samples=451, has_scale=1, scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8),
+    "cinematic, one segment": dict(seed=4, num_tracks=300, num_samples=31, has_scale=1, scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8),
+    "cinematic, 4 segments": dict(seed=4, num_tracks=300, num_samples=64, has_scale=1, scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8),
+    "300 bones CMU mix": dict(seed=4, num_tracks=300, num_samples=301),
+    "300 bones CMU mix, one segment": dict(seed=4, num_tracks=300, num_samples=31),
+    "200 bones CMU mix": dict(seed=4, num_tracks=200, num_samples=301),
+    "300 bones all constant": dict(seed=4, num_tracks=300, num_samples=31, rotation_constant=0.98, translation_constant=0.98),
 }
 
 
 def main():
+    only = sys.argv[1:] 
     device = torch.device("cuda:0")
     n = 65536
     rng = np.random.default_rng(0)
     for name, spec in CASES.items():
+        if only and not any(key in name for key in only):
+            continue
         ctx = runtime.Context(0)
         clip = synth.build_clip(**spec)
         handle = ctx.register_clip(clip.blob)
