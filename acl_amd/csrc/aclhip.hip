@@ -25,6 +25,7 @@
 #include <new>
 #include <string>
 #include <unordered_set>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/aclhip.h"
@@ -128,15 +129,15 @@ namespace aclhip
 		return value;
 	}
 
-	// Phase 1 of the pose kernel: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order); every lane
-	// decodes its sub-track for both keyframes and parks the interpolated float4 in LDS at its animated ordinal.
+	// Phase 1 of the generic pose kernel: lanes <-> the animated sub-tracks of one pose window; every lane decodes its sub-track for
+	// both keyframes and parks the interpolated float4 in LDS at (ordinal - first ordinal of the window).
 	template<bool kHasRaw, bool kPolicies>
 	__device__ __forceinline__ void decode_animated_sub_tracks(const device_clip& clip, const seek_state& state, const decode_params& params,
-		uint32_t rounding_policy, uint32_t lane, float4* lds_animated)
+		uint32_t rounding_policy, uint32_t lane, uint32_t first_ordinal, uint32_t end_ordinal, float4* lds_animated)
 	{
 		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
 
-		for (uint32_t animated_ordinal = lane; animated_ordinal < clip.num_animated; animated_ordinal += k_wave_size)
+		for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
 		{
 			// three independent table reads; when both keyframes share a segment plan[1] == plan[0] and the second read hits L1
 			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
@@ -152,13 +153,16 @@ namespace aclhip
 					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
 			}
 
-			lds_animated[animated_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
+			lds_animated[animated_ordinal - first_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
 				policy, state.interpolation_alpha, params.normalization, normalize_samples);
 		}
 	}
 
+	// Every settings combination (default sub-track modes, caller supplied defaults, always-normalize, per track / per instance
+	// rounding). One wave64 per (instance, pose window) like the image kernel; the base pose carries markers in its W lanes that
+	// phase 2 resolves: constants pass through, defaults follow the modes, animated quads come from the LDS staging of phase 1.
 	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
 		unsigned long long* __restrict__ rejected_count)
 	{
@@ -166,7 +170,14 @@ namespace aclhip
 
 		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		const uint32_t instance = blockIdx.x * k_waves_per_block + wave_in_block;
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
+		uint32_t instance = work_item;
+		uint32_t window = 0;
+		if (windows_per_instance != 1)
+		{
+			instance = work_item / windows_per_instance;
+			window = work_item - instance * windows_per_instance;
+		}
 		if (instance >= num_instances)
 			return;
 
@@ -176,14 +187,24 @@ namespace aclhip
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
 		{
-			if (lane == 0)
+			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
 			return;
 		}
 
-		const uint32_t num_tracks = clip.num_tracks;
-		if (num_tracks == 0)
-			return;		// empty track list (decompression.transform.h:1531-1533)
+		// an empty track list (decompression.transform.h:1531-1533) or a pose that ends before this window
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		const uint32_t first_quad = window * k_image_chunk_quads;
+		if (first_quad >= num_quads)
+			return;
+		const uint32_t end_quad = min(num_quads, first_quad + k_image_chunk_quads);
+
+		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
+		if (num_quads > k_image_chunk_quads)
+		{
+			first_ordinal = as_constant(clip.image_chunks)[window];
+			end_ordinal = as_constant(clip.image_chunks)[window + 1];
+		}
 
 		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
 			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
@@ -196,27 +217,26 @@ namespace aclhip
 
 		// ---- phase 1 ----
 		if ((clip.flags & k_clip_has_raw) == 0 && params.per_track_rounding == 0)
-			decode_animated_sub_tracks<false, false>(clip, state, params, rounding_policy, lane, lds_animated);
+			decode_animated_sub_tracks<false, false>(clip, state, params, rounding_policy, lane, first_ordinal, end_ordinal, lds_animated);
 		else
-			decode_animated_sub_tracks<true, true>(clip, state, params, rounding_policy, lane, lds_animated);
+			decode_animated_sub_tracks<true, true>(clip, state, params, rounding_policy, lane, first_ordinal, end_ordinal, lds_animated);
 
 		// the wave's own LDS writes must land before its lanes read each other's results
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-		// ---- phase 2: lanes <-> consecutive 16 byte quads of the pose; 1 KiB of contiguous HBM per store instruction ----
-		const uint32_t num_quads = num_tracks * 3u;
+		// ---- phase 2: lanes <-> consecutive 16 byte quads of the window; 1 KiB of contiguous HBM per store instruction ----
 		float4* pose = reinterpret_cast<float4*>(poses + uint64_t(instance) * pose_stride_bytes);
-		const auto animated_lookup = [lds_animated](uint32_t ordinal) { return lds_animated[ordinal]; };
+		const auto animated_lookup = [lds_animated, first_ordinal](uint32_t ordinal) { return lds_animated[ordinal - first_ordinal]; };
 
 		constexpr uint32_t k_unroll = 4;	// base pose reads of four store instructions in flight together
-		for (uint32_t base = 0; base < num_quads; base += k_wave_size * k_unroll)
+		for (uint32_t base = first_quad; base < end_quad; base += k_wave_size * k_unroll)
 		{
 			float4 values[k_unroll];
 			#pragma unroll
 			for (uint32_t j = 0; j < k_unroll; ++j)
-				values[j] = load_quad(clip.base_pose, min(base + j * k_wave_size + lane, num_quads - 1));
+				values[j] = load_quad(clip.base_pose, min(base + j * k_wave_size + lane, end_quad - 1));
 
 			#pragma unroll
 			for (uint32_t j = 0; j < k_unroll; ++j)
@@ -224,22 +244,23 @@ namespace aclhip
 				const uint32_t quad = base + j * k_wave_size + lane;
 				bool store;
 				const float4 value = resolve_quad(params, values[j], quad, animated_lookup, store);
-				if (store && quad < num_quads)
+				if (store && quad < end_quad)
 					pose[quad] = value;
 			}
 		}
 	}
 
-	// The common case as its own kernel: track_writer defaults, no per track rounding. One wave64 per instance builds the pose
-	// through an LDS window of k_image_chunk_quads quads (5 KiB per wave, 8 blocks of 4 waves per CU):
+	// The common case as its own kernel: track_writer defaults, no per track rounding. One wave64 per (instance, pose window): a
+	// window is k_image_chunk_quads consecutive quads of the pose (a 100 bone pose is a single window), built in 5 KiB of LDS:
 	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
 	//   2. meanwhile the window's slice of the clip's resolved base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
-	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are in pose
-	//      order) decode straight into their quad of the LDS image;
-	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction;
-	// and again for the next window of a pose larger than one (a 100 bone pose is a single window).
+	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are ordered by
+	//      window) decode straight into their quad of the LDS image;
+	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
+	// Windows of one pose go to consecutive waves: each repeats the (scalar) seek, none waits for another, and the chain of
+	// dependent memory round trips per wave stays as short as for a small pose.
 	__global__ __launch_bounds__(k_block_size) void decompress_tracks_image_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		uint32_t rounding_policy, uint32_t looping_policy, uint32_t normalization,
 		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
 	{
@@ -247,7 +268,14 @@ namespace aclhip
 
 		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		const uint32_t instance = blockIdx.x * k_waves_per_block + wave_in_block;
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
+		uint32_t instance = work_item;
+		uint32_t window = 0;
+		if (windows_per_instance != 1)
+		{
+			instance = work_item / windows_per_instance;
+			window = work_item - instance * windows_per_instance;
+		}
 		if (instance >= num_instances)
 			return;
 
@@ -256,47 +284,51 @@ namespace aclhip
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
 		{
-			if (lane == 0)
+			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
 			return;
 		}
 
+		// an empty track list (decompression.transform.h:1531-1533) or a pose that ends before this window
 		const uint32_t num_quads = clip.num_tracks * 3u;
-		if (num_quads == 0)
-			return;		// empty track list (decompression.transform.h:1531-1533)
+		const uint32_t first_quad = window * k_image_chunk_quads;
+		if (first_quad >= num_quads)
+			return;
+		const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
+
+		// the window's animated sub-tracks: image_chunks[window] .. image_chunks[window + 1]
+		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
+		if (num_quads > k_image_chunk_quads)
+		{
+			first_ordinal = as_constant(clip.image_chunks)[window];
+			end_ordinal = as_constant(clip.image_chunks)[window + 1];
+		}
 
 		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
-		const ACLHIP_CONSTANT f32x4* resolved_pose = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
-		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
 
 		// base pose window -> LDS image, asynchronously: lane i of pass p fetches quad first + p * 64 + i into image[p * 64 + i]
-		const auto fetch_window = [&](uint32_t first_quad, uint32_t window_quads)
 		{
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose + first_quad;
 			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
 				if (base + lane < window_quads)
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resolved_pose + first_quad + base + lane),
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
-		};
-
-		fetch_window(0, min(num_quads, k_image_chunk_quads));
+		}
 
 		seek_state state;
 		seek(clip, sample_time, rounding_policy, looping_policy, state);
 
-		uint32_t first_ordinal = 0;
-		for (uint32_t first_quad = 0, chunk = 0; first_quad < num_quads; first_quad += k_image_chunk_quads, ++chunk)
+		// lanes <-> animated sub-tracks of this window. Most sample times fall between two keyframes of ONE segment: both keys then
+		// share a plan row and it is fetched once (a third less table traffic through the texture unit).
+		const auto decode_window = [&](auto single_segment)
 		{
-			const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
-			const bool last_window = first_quad + k_image_chunk_quads >= num_quads;
-			const uint32_t end_ordinal = last_window ? clip.num_animated : as_constant(clip.image_chunks)[chunk + 1];
-
-			// lanes <-> animated sub-tracks of this window
 			for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
 			{
 				const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-				const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
+				const plan_entry plan1_loaded = decltype(single_segment)::value ? plan0 : load_entry(state.plan[1], animated_ordinal);
+				const plan_entry& plan1 = decltype(single_segment)::value ? plan0 : plan1_loaded;
 				const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
 				const bool is_rotation = is_rotation_entry(clip_range);
 
@@ -312,26 +344,22 @@ namespace aclhip
 				const f32x4 packed = { value.x, value.y, value.z, value.w };
 				image[clip_range.quad_index - first_quad] = packed;
 			}
-			first_ordinal = end_ordinal;
+		};
 
-			// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
-			__builtin_amdgcn_s_waitcnt(0);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (state.uses_single_segment)
+			decode_window(std::true_type());
+		else
+			decode_window(std::false_type());
 
-			for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
-				pose[first_quad + quad] = image[quad];
+		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-			if (!last_window)
-			{
-				// every lane has read its quads of the image: the next window's base pose may now overwrite it
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				fetch_window(first_quad + k_image_chunk_quads, min(num_quads - first_quad - k_image_chunk_quads, k_image_chunk_quads));
-			}
-		}
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad;
+		for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
+			pose[quad] = image[quad];
 	}
 
 	// One entry per (chunk, segment) of a database tier: which runtime segment header the chunk's keyframes belong to and what
@@ -1019,7 +1047,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 	// ---- animated sub-tracks in POSE order ----
 	// The tables above follow the bitstream (rotations, translations, scales); lanes do not care which sub-track they get, so the
-	// tables are reordered by destination quad. The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
+	// tables are reordered by destination window (and by kind inside a window). The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
 	// a contiguous range of ordinals, image_chunks[c] .. image_chunks[c + 1]: the pose kernel can build a pose of any size through
 	// a fixed LDS window.
 	const uint32_t num_image_chunks = std::max<uint32_t>((num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
@@ -1029,7 +1057,16 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::vector<uint32_t> order(num_animated);		// new ordinal -> bitstream ordinal
 		for (uint32_t a = 0; a < num_animated; ++a)
 			order[a] = a;
-		std::sort(order.begin(), order.end(), [&](uint32_t lhs, uint32_t rhs) { return clip_ranges[lhs].quad_index < clip_ranges[rhs].quad_index; });
+		// inside a window rotations come first: the rotation math (two square roots, a division) is most of a lane's work and every
+		// loop iteration that holds a rotation pays for it, so rotations are packed into as few iterations as possible
+		const auto sort_key = [&](uint32_t ordinal)
+		{
+			const uint32_t quad = clip_ranges[ordinal].quad_index;
+			const uint64_t window = quad / k_image_chunk_quads;
+			const uint64_t is_vector = quad != clip_ranges[ordinal].track_index * 3 ? 1 : 0;
+			return (window << 33) | (is_vector << 32) | quad;
+		};
+		std::sort(order.begin(), order.end(), [&](uint32_t lhs, uint32_t rhs) { return sort_key(lhs) < sort_key(rhs); });
 
 		std::vector<clip_range_entry> ordered_ranges(num_animated);
 		std::vector<plan_entry> ordered_plan(plan.size());
@@ -1046,7 +1083,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		uint32_t next = 0;
 		for (uint32_t chunk = 0; chunk < num_image_chunks; ++chunk)
 		{
-			while (next < num_animated && clip_ranges[next].quad_index < chunk * k_image_chunk_quads)
+			while (next < num_animated && clip_ranges[next].quad_index / k_image_chunk_quads < chunk)
 				next++;
 			image_chunks[chunk] = next;
 		}
@@ -1560,7 +1597,12 @@ namespace
 	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
-		const uint32_t num_blocks = (num_instances + k_waves_per_block - 1) / k_waves_per_block;
+		// one wave per (instance, pose window); instances of clips with fewer windows than the largest registered clip leave waves idle
+		const uint32_t windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+		const uint64_t num_waves = uint64_t(num_instances) * windows_per_instance;
+		if (num_waves > 0xFFFFFFFFull - k_waves_per_block)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u pose windows", num_instances, windows_per_instance);
+		const uint32_t num_blocks = uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block);
 
 		// the common case: track_writer defaults, no per track / per instance rounding
 		const bool image_mode = params.standard_defaults != 0 && params.per_track_rounding == 0 && params.instance_rounding_policies == nullptr
@@ -1570,20 +1612,19 @@ namespace
 			const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
 			const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
 			hipLaunchKernelGGL(decompress_tracks_image_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances,
+				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance,
 				uint32_t(params.rounding_policy), uint32_t(params.looping_policy), uint32_t(params.normalization),
 				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 			ACLHIP_CHECK_HIP(context, hipGetLastError());
 			return ACLHIP_OK;
 		}
 
-		const uint32_t lds_quads_per_wave = std::max<uint32_t>(align_to_u32(context->max_lds_quads, 4), 4);
+		// LDS staging: at most one window's worth of animated sub-tracks per wave
+		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_lds_quads, 4), 4), k_image_chunk_quads);
 		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
-		if (lds_bytes > 160 * 1024)
-			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "a registered clip has too many animated sub-tracks for the LDS staging (%u)", context->max_lds_quads);
 
 		hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params,
+			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;

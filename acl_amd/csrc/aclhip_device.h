@@ -72,8 +72,8 @@ namespace aclhip
 	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
 
-	// Animated sub-tracks are numbered in POSE order (by quad_index), not in bitstream order: the ones that land in a window of
-	// k_image_chunk_quads consecutive quads form a contiguous range of ordinals.
+	// Animated sub-tracks are numbered by destination, not in bitstream order: the ones that land in a window of
+	// k_image_chunk_quads consecutive quads form a contiguous range of ordinals, rotations first.
 	constexpr uint32_t k_image_chunk_quads = 320;
 
 	__device__ __forceinline__ bool is_rotation_entry(const clip_range_entry& entry) { return entry.quad_index == entry.track_index * 3u; }

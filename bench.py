@@ -175,7 +175,9 @@ def main():
             raise SystemExit(f"aclhip_decompress_tracks_batch failed: {status}")
 
     # device pre-warm (setup, not one of the W warm-up steps): an idle MI355X needs a few ms of work before its clocks settle
-    prewarm_deadline = time.perf_counter() + 0.15
+    # (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
+    profiling = os.environ.get("ACLHIP_BENCH_PROFILING", "0") == "1"
+    prewarm_deadline = time.perf_counter() + (0.0 if profiling else 0.15)
     while time.perf_counter() < prewarm_deadline:
         for _ in range(64):
             step()
@@ -215,12 +217,12 @@ def main():
     kernel_ms = float(marks[0].elapsed_time(marks[num_marks - 1])) / args.steps
     # the same launches back to back from C (no host pacing), for reference
     kernel_ms_back_to_back = context.time_decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
-                                                                  repeats=max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
+                                                                  repeats=1 if profiling else max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
     bytes_written, bytes_read = context.batch_algorithmic_bytes(handles[clip_indices])
     algorithmic_bytes = bytes_written + bytes_read
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
 
-    write_ceiling_gbps = context.measure_write_bandwidth(d_poses.data_ptr(), num_instances * pose_stride, repeats=20, stream=stream.cuda_stream)
+    write_ceiling_gbps = context.measure_write_bandwidth(d_poses.data_ptr(), num_instances * pose_stride, repeats=1 if profiling else 20, stream=stream.cuda_stream)
 
     rejected = context.rejected_instance_count()
     if rejected != 0:

@@ -40,6 +40,7 @@ CLIP_SPECS = {
     "cinematic_300": dict(num_tracks=300, has_scale=1, scale_default=0.5, scale_constant=0.1, rotation_constant=0.2, translation_constant=0.3, num_samples=200),
     "three_full_windows_320": dict(num_tracks=320, num_samples=40, has_scale=1, scale_default=0.3, scale_constant=0.3, raw_fraction=0.05),     # 960 quads = 3 x 320
     "crowd_rig_1200": dict(num_tracks=1200, num_samples=33, rotation_constant=0.3, translation_constant=0.6, wrap=1),
+    "giant_2500_all_animated": dict(num_tracks=2500, num_samples=6, rotation_default=0.0, rotation_constant=0.0, translation_default=0.0, translation_constant=0.0),
     "all_default": dict(num_tracks=17, rotation_default=1.0, translation_default=1.0),
     "all_animated_65": dict(num_tracks=65, rotation_default=0.0, rotation_constant=0.0, translation_default=0.0, translation_constant=0.0, num_samples=40),
     "max_segment_31": dict(num_samples=31, num_tracks=9),
