@@ -135,3 +135,51 @@ def test_300_bone_rig_with_scale(setup):
     written = c != 0.0
     assert np.array_equal(c[written].view(np.uint32), reference_pose[written].view(np.uint32))
     ctx.unregister_clip(handle)
+
+
+def test_database_tiers_streamed_in_while_batches_run(setup):
+    """configs[4] shape at the size the committed fixture allows: clips bound to a database, 32k instances per batch, the tiers
+    arrive chunk by chunk between batches on the decode stream; every batch is checked against the oracle in the same state."""
+    from oracle.database import OracleDatabase
+    ctx, torch, device = setup
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    database = ctx.register_database(case["database"], case["bulk_medium"], case["bulk_low"])
+    handles = [ctx.register_clip_with_database(clip, database) for clip in case["clips"]]
+    oracle_db = OracleDatabase(case["database"], case["bulk_medium"], case["bulk_low"])
+    max_tracks = max(ob.oracle().aclo_num_tracks(clip.ctypes.data) for clip in case["clips"])
+    durations = np.array([ob.oracle().aclo_finite_duration(clip.ctypes.data, ob.LOOP_AS_COMPRESSED) for clip in case["clips"]], dtype=np.float32)
+
+    rng = np.random.default_rng(31)
+    n = 32768
+    which = rng.integers(0, len(handles), size=n)
+    times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+    stream = torch.cuda.Stream(device)
+
+    schedule = [(None, 0)] + [(1, 1)] * 3 + [(2, 1)] * 3 + [(1, 0xFFFFFFFF), (2, 0xFFFFFFFF)]     # the last two find nothing left to do
+    previous = None
+    for tier, num_chunks in schedule:
+        if tier is not None:
+            moved = ctx.database_stream_in(database, tier, num_chunks, stream=stream.cuda_stream)
+            assert moved == oracle_db.stream_in(tier, num_chunks)
+        poses = _decode(ctx, torch, device, handles, which, times, max_tracks, stream=stream).cpu().numpy()
+        for i in rng.choice(n, size=96, replace=False):
+            clip = case["clips"][which[i]]
+            expected = oracle_db.decompress_tracks(clip, float(times[i]))
+            assert helpers.bit_equal(poses[i, : expected.shape[0]], expected)
+        if previous is not None and tier is not None and moved != 0:
+            assert not np.array_equal(previous, poses)          # new keyframes changed some poses
+        previous = poses
+    assert oracle_db.is_streamed_in(1) and oracle_db.is_streamed_in(2)
+
+    # everything resident: sample times that fall on a keyframe decode to the same pose whatever the rounding policy
+    sample_times = (np.floor(times * 30.0) / 30.0).astype(np.float32)
+    a = _decode(ctx, torch, device, handles, which, sample_times, max_tracks, params=runtime.default_params(rounding_policy=runtime.ROUND_FLOOR), stream=stream).cpu().numpy()
+    b = _decode(ctx, torch, device, handles, which, sample_times, max_tracks, params=runtime.default_params(rounding_policy=runtime.ROUND_NONE), stream=stream).cpu().numpy()
+    sample_indices = sample_times * np.float32(30.0)          # the kernel's own fp32 product
+    exact = sample_indices == np.round(sample_indices)
+    assert exact.sum() > n // 4
+    assert np.abs(a[exact] - b[exact]).max() <= 1e-6
+    assert ctx.rejected_instance_count() == 0
+    for handle in handles:
+        ctx.unregister_clip(handle)
+    ctx.unregister_database(database)
