@@ -34,6 +34,11 @@ namespace aclhip
 	constexpr uint16_t k_version_latest = 10;			// v02_01_00
 
 	constexpr uint8_t k_algorithm_uniformly_sampled = 0;
+	constexpr uint8_t k_track_type_float1f = 0;			// core/track_types.h:51-57: scalar track lists, 1 / 2 / 3 / 4 / 4 floats per sample
+	constexpr uint8_t k_track_type_float2f = 1;
+	constexpr uint8_t k_track_type_float3f = 2;
+	constexpr uint8_t k_track_type_float4f = 3;
+	constexpr uint8_t k_track_type_vector4f = 4;
 	constexpr uint8_t k_track_type_qvvf = 12;
 
 	constexpr uint8_t k_rotation_quatf_full = 0;
@@ -118,6 +123,27 @@ namespace aclhip
 		uint32_t clip_range_data_offset;
 	};
 
+	// Header of scalar track lists, follows the tracks_header (core/impl/compressed_headers.h:133-165). One bit rate byte per
+	// track; constant values; range values (min[C], extent[C]) of the quantized tracks; animated values frame major, MSB first.
+	struct scalar_tracks_header
+	{
+		uint32_t num_bits_per_frame;
+		uint32_t metadata_per_track;		// offsets relative to this struct
+		uint32_t track_constant_values;
+		uint32_t track_range_values;
+		uint32_t track_animated_values;
+	};
+
+	// bit rate -> bits per component (core/impl/variable_bit_rates.h:42-45); 0 = constant track, 32 = raw fp32
+	constexpr uint8_t k_bit_rate_num_bits_v0[] = { 0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 32 };		// v02_00_00
+	constexpr uint8_t k_bit_rate_num_bits[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 32 };
+
+	ACLHIP_HD uint32_t scalar_track_num_components(uint8_t track_type)
+	{
+		return track_type == k_track_type_float1f ? 1u : track_type == k_track_type_float2f ? 2u : track_type == k_track_type_float3f ? 3u
+			: (track_type == k_track_type_float4f || track_type == k_track_type_vector4f) ? 4u : 0u;
+	}
+
 	struct tracks_database_header
 	{
 		uint32_t clip_header_offset;		// into the database's runtime clip/segment header block
@@ -188,6 +214,7 @@ namespace aclhip
 	static_assert(sizeof(database_chunk_header) == 12, "layout");
 	static_assert(sizeof(database_chunk_segment_header) == 20, "layout");
 
+	static_assert(sizeof(scalar_tracks_header) == 20, "layout");
 	static_assert(sizeof(raw_buffer_header) == 8, "layout");
 	static_assert(sizeof(tracks_header) == 24, "layout");
 	static_assert(sizeof(segment_header) == 16, "layout");

@@ -185,7 +185,7 @@ namespace aclhip
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		const float sample_time = as_constant(sample_times)[instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -282,7 +282,7 @@ namespace aclhip
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		const float sample_time = as_constant(sample_times)[instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || (clip.flags & k_clip_valid) == 0)
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -395,6 +395,103 @@ namespace aclhip
 			destination[quad] = value;
 	}
 
+	// Scalar track lists (float1f .. vector4f): seek_v0 + decompress_tracks_v0 / decompress_track_v0 of
+	// decompression/impl/decompression.scalar.h:182-715. One THREAD per (instance, track): there are no segments and no sub-track
+	// classes, a track is C <= 4 components of one width at a known bit offset of each frame, so the work per value is a few loads
+	// and flops and lanes <-> consecutive tracks gives coalesced table reads and stores. `track_indices` == nullptr: every track,
+	// values at out + instance * stride + track * C * 4; otherwise one track per instance, C floats at out + instance * stride.
+	__global__ __launch_bounds__(k_block_size) void decompress_scalar_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices,
+		uint32_t num_instances, uint32_t tracks_per_instance, decode_params params, uint8_t* __restrict__ out, uint64_t out_stride_bytes,
+		unsigned long long* __restrict__ rejected_count)
+	{
+		const uint64_t item = uint64_t(blockIdx.x) * k_block_size + threadIdx.x;
+		const uint32_t instance = uint32_t(item / tracks_per_instance);
+		const uint32_t slot = uint32_t(item - uint64_t(instance) * tracks_per_instance);
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = clip_ids[instance];
+		const device_clip& clip = clips[clip_id < num_clips ? clip_id : 0];
+		const uint32_t flags = clip.flags;
+		const uint32_t track_index = track_indices != nullptr ? track_indices[instance] : slot;
+		if (clip_id >= num_clips || !is_scalar_clip(flags) || (track_indices != nullptr && track_index >= clip.num_tracks))
+		{
+			if (slot == 0)
+				atomicAdd(rejected_count, 1ull);	// the reference silently returns (decompression.scalar.h:496-498)
+			return;
+		}
+		if (track_index >= clip.num_tracks || clip.num_samples == 0)
+			return;		// past the end of this clip's track list / empty track list (:185-186,246-248)
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[instance]) : uint32_t(params.rounding_policy);
+
+		// seek_v0 (:182-240): no segments, a frame is num_bits_per_frame bits
+		uint32_t key_frame0, key_frame1;
+		float alpha;
+		find_key_frames(flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_times[instance], rounding_policy, params.looping_policy,
+			key_frame0, key_frame1, alpha);
+
+		if (params.per_track_rounding != 0)
+		{
+			// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
+			uint32_t policy = rounding_policy;
+			if (rounding_policy == k_round_per_track)
+				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
+			alpha = apply_rounding_policy(alpha, policy);
+		}
+
+		const uint32_t num_components = (flags >> k_clip_components_shift) & 7u;
+		const uint32_t num_bits_per_frame = clip.num_animated;
+		const scalar_track_entry* entries = reinterpret_cast<const scalar_track_entry*>(clip.plan);
+		const u32x4 packed = reinterpret_cast<const u32x4*>(entries + track_index)[0];
+		const f32x4 range_min = reinterpret_cast<const f32x4*>(entries + track_index)[1];
+		const f32x4 range_extent = reinterpret_cast<const f32x4*>(entries + track_index)[2];
+		const uint32_t num_bits = packed.x >> 24;
+		const float inv_max_value = __uint_as_float(packed.y);
+
+		const ACLHIP_CONSTANT uint8_t* animated_values = as_constant(clip.blob);		// entry offsets are relative to the blob start
+		const uint32_t bit_offset0 = key_frame0 * num_bits_per_frame + (packed.x & 0x00FFFFFFu);
+		const uint32_t bit_offset1 = key_frame1 * num_bits_per_frame + (packed.x & 0x00FFFFFFu);
+
+		float value[4];
+		#pragma unroll
+		for (uint32_t c = 0; c < 4; ++c)
+		{
+			value[c] = range_min[c];			// constant bit rate: the sample itself (:279-283)
+			if (c < num_components && num_bits != 0)
+			{
+				const uint32_t offset0 = bit_offset0 + c * num_bits;
+				const uint32_t offset1 = bit_offset1 + c * num_bits;
+				float value0, value1;
+				if (num_bits == 32)
+				{
+					// unpack_scalarf_32 / vector2_64 / vector3_96 / vector4_128: 32 bits at any bit offset (math/scalar_packing.h:71-110)
+					const uint64_t window0 = __builtin_bswap64(load_u64(animated_values + (offset0 >> 3))) << (offset0 & 7u);
+					const uint64_t window1 = __builtin_bswap64(load_u64(animated_values + (offset1 >> 3))) << (offset1 & 7u);
+					value0 = __uint_as_float(uint32_t(window0 >> 32));
+					value1 = __uint_as_float(uint32_t(window1 >> 32));
+				}
+				else
+				{
+					// unpack_*_uXX (math/scalar_packing.h:113-160, math/vector4_packing.h:262-330): float(field) * (1 / max), then the range
+					const uint32_t field0 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset0 >> 3)), 32u - num_bits - (offset0 & 7u), num_bits);
+					const uint32_t field1 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset1 >> 3)), 32u - num_bits - (offset1 & 7u), num_bits);
+					value0 = (float(field0) * inv_max_value) * range_extent[c] + range_min[c];
+					value1 = (float(field1) * inv_max_value) * range_extent[c] + range_min[c];
+				}
+				// rtm::scalar_lerp / vector_lerp: (end * alpha) + (start - (start * alpha))
+				value[c] = (value1 * alpha) + (value0 - (value0 * alpha));
+			}
+		}
+
+		float* destination = reinterpret_cast<float*>(out + uint64_t(instance) * out_stride_bytes) + (track_indices != nullptr ? 0u : track_index * num_components);
+		#pragma unroll
+		for (uint32_t c = 0; c < 4; ++c)
+			if (c < num_components)
+				destination[c] = value[c];
+	}
+
 	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
 		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
@@ -404,7 +501,7 @@ namespace aclhip
 			return;
 
 		const uint32_t clip_id = clip_ids[instance];
-		if (clip_id >= num_clips || (clips[clip_id].flags & k_clip_valid) == 0)
+		if (clip_id >= num_clips || !is_transform_clip(clips[clip_id].flags))
 		{
 			atomicAdd(rejected_count, 1ull);
 			return;
@@ -507,6 +604,7 @@ struct aclhip_context
 	unsigned long long* d_rejected = nullptr;
 	uint32_t max_lds_quads = 0;				// largest animated sub-track count among registered clips
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
+	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): never take the LDS image fast path
 	mutable std::string last_error;
 };
@@ -551,9 +649,54 @@ namespace
 	};
 
 	// compressed_tracks::is_valid (core/impl/compressed_tracks.impl.h:278-301) + bounds checks so that a decode can never read outside the blob
+	// Scalar track lists: every offset of the scalar_tracks_header and the whole animated stream must lie inside the buffer
+	// (compressed_tracks::is_valid only checks tag / version / hash, core/impl/compressed_tracks.impl.h:278-301; the device reads
+	// through these offsets, so they are checked here).
+	aclhip_status validate_scalar_clip(const aclhip_context* context, const uint8_t* blob)
+	{
+		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+		const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+		if (header.has_database())
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "database decompression is not supported for scalar tracks");	// decompression.scalar.h:107-108
+		if (header.num_tracks == 0 || header.num_samples == 0)
+			return ACLHIP_OK;
+		if (!(header.sample_rate > 0.0f))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid sample rate");
+		if (buffer_header.size < k_transform_header_offset + sizeof(scalar_tracks_header))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
+
+		const scalar_tracks_header& sh = *reinterpret_cast<const scalar_tracks_header*>(blob + k_transform_header_offset);
+		const uint64_t limit = buffer_header.size - k_transform_header_offset;
+		const uint32_t num_components = scalar_track_num_components(header.track_type);
+		const uint8_t* num_bits_at_bit_rate = header.version == k_version_first ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
+		const uint32_t num_bit_rates = header.version == k_version_first ? sizeof(k_bit_rate_num_bits_v0) : sizeof(k_bit_rate_num_bits);
+		if (uint64_t(sh.metadata_per_track) + header.num_tracks > limit)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Track metadata points outside of the buffer");
+
+		const uint8_t* bit_rates = reinterpret_cast<const uint8_t*>(&sh) + sh.metadata_per_track;
+		uint64_t num_constant = 0, num_ranged = 0, bits_per_frame = 0;
+		for (uint32_t track = 0; track < header.num_tracks; ++track)
+		{
+			if (bit_rates[track] >= num_bit_rates)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid bit rate: %u", uint32_t(bit_rates[track]));
+			const uint32_t num_bits = num_bits_at_bit_rate[bit_rates[track]];
+			num_constant += num_bits == 0 ? 1 : 0;
+			num_ranged += (num_bits != 0 && num_bits != 32) ? 1 : 0;
+			bits_per_frame += uint64_t(num_bits) * num_components;
+		}
+		if (bits_per_frame != sh.num_bits_per_frame || bits_per_frame > k_quad_ordinal_mask)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Track bit rates add up to %llu bits per frame, header says %u", static_cast<unsigned long long>(bits_per_frame), sh.num_bits_per_frame);
+		if (uint64_t(sh.track_constant_values) + num_constant * num_components * 4 > limit
+			|| uint64_t(sh.track_range_values) + num_ranged * num_components * 8 > limit
+			|| uint64_t(sh.track_animated_values) + (bits_per_frame * header.num_samples + 7) / 8 > limit
+			|| (bits_per_frame * header.num_samples) >> 32 != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+		return ACLHIP_OK;
+	}
+
 	aclhip_status validate_clip(const aclhip_context* context, const uint8_t* blob, uint64_t size, int check_hash)
 	{
-		if (blob == nullptr || size < k_transform_header_offset + sizeof(transform_tracks_header))
+		if (blob == nullptr || size < k_transform_header_offset)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "buffer is not a valid compressed_tracks instance (too small)");
 
 		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
@@ -564,13 +707,16 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm type");
 		if (header.version < k_version_first || header.version > k_version_latest)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm version");
-		if (buffer_header.size > size || buffer_header.size < k_transform_header_offset + sizeof(transform_tracks_header))
+		const bool is_scalar_list = scalar_track_num_components(header.track_type) != 0;
+		if (buffer_header.size > size || buffer_header.size < k_transform_header_offset + (is_scalar_list ? 0 : sizeof(transform_tracks_header)))
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
 		if (check_hash && hash32(blob + sizeof(raw_buffer_header), buffer_header.size - sizeof(raw_buffer_header)) != buffer_header.hash)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid hash");
 
+		if (scalar_track_num_components(header.track_type) != 0)
+			return validate_scalar_clip(context, blob);
 		if (header.track_type != k_track_type_qvvf)
-			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "only qvvf transform tracks are supported");
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "unsupported track type %u", uint32_t(header.track_type));
 		if (header.num_tracks == 0)
 			return ACLHIP_OK;
 		if (header.rotation_format() != k_rotation_quatf_drop_w_variable || header.translation_format() != k_vector_vector3f_variable
@@ -794,6 +940,150 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 	delete context;
 }
 
+// Scalar track lists (initialize_v0, decompression.scalar.h:100-126): the blob plus one scalar_track_entry per track (bit offset
+// inside a frame = the prefix sum the reference's decompress_track_v0 recomputes per call, :529-541; constant / range values
+// pulled next to it).
+static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t* blob, aclhip_clip* out_clip)
+{
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+	const uint32_t blob_size = buffer_header.size;
+	const uint32_t num_components = scalar_track_num_components(header.track_type);
+	const uint32_t num_samples = header.num_tracks != 0 ? header.num_samples : 0;
+	const uint32_t num_tracks = num_samples != 0 ? header.num_tracks : 0;
+
+	std::vector<scalar_track_entry> entries(std::max<uint32_t>(num_tracks, 1));
+	std::memset(entries.data(), 0, entries.size() * sizeof(scalar_track_entry));
+	uint32_t num_bits_per_frame = 0;
+	if (num_tracks != 0)
+	{
+		const scalar_tracks_header& sh = *reinterpret_cast<const scalar_tracks_header*>(blob + k_transform_header_offset);
+		const uint8_t* base = reinterpret_cast<const uint8_t*>(&sh);
+		const uint8_t* bit_rates = base + sh.metadata_per_track;
+		const float* constant_values = reinterpret_cast<const float*>(base + sh.track_constant_values);
+		const float* range_values = reinterpret_cast<const float*>(base + sh.track_range_values);
+		const uint8_t* num_bits_at_bit_rate = header.version == k_version_first ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
+		const uint32_t animated_bit_base = (k_transform_header_offset + sh.track_animated_values) * 8;	// entries address bits from the blob start
+
+		uint32_t track_bit_offset = 0;
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			scalar_track_entry& entry = entries[track];
+			const uint32_t num_bits = num_bits_at_bit_rate[bit_rates[track]];
+			entry.bit_offset_and_width = 0;
+			entry.inv_max_value = 1.0f;
+			for (uint32_t c = 0; c < 4; ++c)
+			{
+				entry.range_min[c] = 0.0f;
+				entry.range_extent[c] = 1.0f;
+			}
+
+			if (num_bits == 0)
+			{
+				for (uint32_t c = 0; c < num_components; ++c)
+					entry.range_min[c] = constant_values[c];
+				constant_values += num_components;
+				continue;
+			}
+
+			if (uint64_t(animated_bit_base) + track_bit_offset > k_quad_ordinal_mask)
+				return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "frames larger than 2 MiB are not supported");
+			entry.bit_offset_and_width = (animated_bit_base + track_bit_offset) | (num_bits << 24);
+			if (num_bits != 32)
+			{
+				entry.inv_max_value = 1.0f / float((1u << num_bits) - 1u);		// PackedTableEntry::max_value (math/scalar_packing.h:119)
+				for (uint32_t c = 0; c < num_components; ++c)
+				{
+					entry.range_min[c] = range_values[c];
+					entry.range_extent[c] = range_values[num_components + c];
+				}
+				range_values += num_components * 2;
+			}
+			track_bit_offset += num_bits * num_components;
+		}
+		num_bits_per_frame = sh.num_bits_per_frame;
+	}
+
+	// one device allocation: blob (+ zeroed tail padding: 8 byte windows are read, the writer reserves 15 bytes) | entries
+	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;
+	const uint64_t total_bytes = blob_bytes + entries.size() * sizeof(scalar_track_entry);
+	std::vector<uint8_t> staging(total_bytes, 0);
+	std::memcpy(staging.data(), blob, blob_size);
+	std::memcpy(staging.data() + blob_bytes, entries.data(), entries.size() * sizeof(scalar_track_entry));
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	if (!guard.ok)
+		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+
+	uint32_t slot;
+	if (!context->free_slots.empty())
+	{
+		slot = context->free_slots.back();
+		context->free_slots.pop_back();
+	}
+	else
+	{
+		slot = uint32_t(context->clips.size());
+		context->clips.emplace_back();
+	}
+	const aclhip_status status = grow_clip_table(context, slot + 1);
+	if (status != ACLHIP_OK)
+	{
+		context->free_slots.push_back(slot);
+		return status;
+	}
+
+	uint8_t* d_memory = nullptr;
+	if (hipMalloc(reinterpret_cast<void**>(&d_memory), total_bytes) != hipSuccess)
+	{
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
+	}
+
+	device_clip record;
+	std::memset(&record, 0, sizeof(record));
+	record.blob = d_memory;
+	record.plan = reinterpret_cast<const plan_entry*>(d_memory + blob_bytes);		// scalar_track_entry[num_tracks]
+	record.num_tracks = num_tracks;
+	record.num_samples = num_samples;
+	record.sample_rate = header.sample_rate;
+	record.duration_clamp = num_samples <= 1 ? 0.0f : float(num_samples - 1) / header.sample_rate;
+	record.duration_wrap = num_samples == 0 ? 0.0f : float(num_samples) / header.sample_rate;
+	record.num_animated = num_bits_per_frame;
+	record.flags = k_clip_valid | k_clip_is_scalar | (num_components << k_clip_components_shift);
+	record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
+
+	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		(void)hipFree(d_memory);
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
+	}
+
+	host_clip& entry = context->clips[slot];
+	entry.in_use = true;
+	entry.database = ACLHIP_INVALID_HANDLE;
+	entry.device_memory = d_memory;
+	entry.info = aclhip_clip_info();
+	entry.info.num_tracks = header.num_tracks;
+	entry.info.num_samples = header.num_samples;
+	entry.info.sample_rate = header.sample_rate;
+	entry.info.duration = finite_duration(header, k_loop_as_compressed);
+	entry.info.looping_policy = (header.version > k_version_first && header.is_wrap_optimized()) ? ACLHIP_LOOP_WRAP : ACLHIP_LOOP_CLAMP;
+	entry.info.compressed_size = blob_size;
+	entry.info.hash = buffer_header.hash;
+	entry.info.track_type = header.track_type;
+	entry.info.num_components = num_components;
+	entry.touched_bytes = total_bytes - 64;
+	entry.max_lds_quads = 0;
+	context->max_scalar_tracks = std::max(context->max_scalar_tracks, num_tracks);
+
+	*out_clip = slot;
+	return ACLHIP_OK;
+}
+
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip)
 {
 	if (context == nullptr || out_clip == nullptr)
@@ -807,6 +1097,12 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
 	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+	if (scalar_track_num_components(header.track_type) != 0)
+	{
+		if (database != ACLHIP_INVALID_HANDLE)
+			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "database decompression is not supported for scalar tracks");	// decompression.scalar.h:107-108
+		return register_scalar_clip(context, blob, out_clip);
+	}
 	const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
 	const uint8_t* tbase = blob + k_transform_header_offset;
 	const uint32_t blob_size = buffer_header.size;
@@ -1235,6 +1531,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.info.num_animated_sub_tracks = num_animated;
 	entry.info.has_database = num_tracks != 0 && header.has_database() ? 1 : 0;
 	entry.info.has_stripped_keyframes = num_tracks != 0 && header.has_stripped_keyframes() ? 1 : 0;
+	entry.info.track_type = k_track_type_qvvf;
+	entry.info.num_components = 12;
 	// bytes a batch may read from this clip: the blob itself plus the registration time tables
 	entry.touched_bytes = total_bytes - 64;
 	entry.max_lds_quads = num_animated;
@@ -1795,6 +2093,142 @@ extern "C" aclhip_status aclhip_decompress_track_host(aclhip_context* context, c
 	if (track_indices == nullptr)
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
 	return decompress_host(context, clips, sample_times, track_indices, num_instances, params, default_values_count, transforms, 48, 48);
+}
+
+// ---- scalar track lists --------------------------------------------------------------------------------------------
+
+namespace
+{
+	aclhip_status launch_scalar(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, void* out, uint64_t out_stride_bytes, void* stream)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+		if ((reinterpret_cast<uintptr_t>(out) & 3u) != 0 || (out_stride_bytes & 3u) != 0 || out_stride_bytes == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "the output buffer and its stride must be 4 byte aligned");
+
+		decode_params device_params;
+		const aclhip_status status = resolve_params(context, params, device_params);
+		if (status != ACLHIP_OK)
+			return status;
+
+		const uint32_t tracks_per_instance = track_indices != nullptr ? 1u : std::max<uint32_t>(context->max_scalar_tracks, 1);
+		const uint64_t num_items = uint64_t(num_instances) * tracks_per_instance;
+		const uint64_t num_blocks = (num_items + k_block_size - 1) / k_block_size;
+		if (num_blocks > 0x7FFFFFFFull)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u tracks", num_instances, tracks_per_instance);
+
+		device_guard guard(context->device);
+		hipLaunchKernelGGL(decompress_scalar_tracks_kernel, dim3(uint32_t(num_blocks)), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+			context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, tracks_per_instance, device_params,
+			static_cast<uint8_t*>(out), out_stride_bytes, context->d_rejected);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+
+	// Host pointer convenience for scalar track lists: uploads the instance lists and the caller's buffer (values the decode does
+	// not write keep what the caller had), runs the batch, downloads.
+	aclhip_status decompress_scalar_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, void* out, uint64_t out_stride_bytes)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr || out_stride_bytes == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+
+		aclhip_decompress_params local;
+		if (params != nullptr) local = *params; else aclhip_default_params(&local);
+		local.default_values = nullptr;
+
+		uint32_t max_tracks = 0;
+		{
+			std::lock_guard<std::mutex> lock(context->mutex);
+			for (uint32_t i = 0; i < num_instances; ++i)
+				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
+					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);
+		}
+
+		device_guard guard(context->device);
+		std::vector<void*> allocations;
+		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
+		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
+		{
+			void* d = nullptr;
+			if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess)
+				return false;
+			allocations.push_back(d);
+			if (host != nullptr && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+				return false;
+			*out_device = d;
+			return true;
+		};
+
+		const size_t out_bytes = size_t(out_stride_bytes) * num_instances;
+		void* d_clip_ids = nullptr; void* d_times = nullptr; void* d_tracks = nullptr; void* d_out = nullptr;
+		void* d_track_policies = nullptr; void* d_instance_policies = nullptr;
+		bool ok = upload(clips, sizeof(uint32_t) * num_instances, &d_clip_ids) && upload(sample_times, sizeof(float) * num_instances, &d_times)
+			&& upload(out, out_bytes, &d_out);
+		if (ok && track_indices != nullptr)
+			ok = upload(track_indices, sizeof(uint32_t) * num_instances, &d_tracks);
+		if (ok && local.track_rounding_policies != nullptr)
+			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
+		if (ok && local.instance_rounding_policies != nullptr)
+			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+		if (!ok)
+		{
+			release();
+			return fail(context, ACLHIP_ERROR_DEVICE, "staging the batch on the device failed");
+		}
+		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
+		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+
+		aclhip_status status = launch_scalar(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks),
+			num_instances, &local, d_out, out_stride_bytes, nullptr);
+		if (status == ACLHIP_OK)
+		{
+			hipError_t copy_status = hipDeviceSynchronize();
+			if (copy_status == hipSuccess)
+				copy_status = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+			if (copy_status != hipSuccess)
+				status = fail(context, ACLHIP_ERROR_DEVICE, "downloading the values failed: %s", hipGetErrorString(copy_status));
+		}
+		release();
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream)
+{
+	return launch_scalar(context, clips, sample_times, nullptr, num_instances, params, values, stride_bytes, stream);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream)
+{
+	if (track_indices == nullptr && num_instances != 0)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return launch_scalar(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes, stream);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes)
+{
+	return decompress_scalar_host(context, clips, sample_times, nullptr, num_instances, params, values, stride_bytes);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes)
+{
+	if (track_indices == nullptr && num_instances != 0)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_scalar_host(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes);
 }
 
 extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count)

@@ -68,6 +68,18 @@ namespace aclhip
 		uint32_t quad_index;			// track_index * 3 + kind: where the sub-track lands in the pose
 	};
 
+	// One per track of a SCALAR track list (float1f .. vector4f), 48 bytes: where the track's bits sit inside a frame and how to
+	// expand them. Widths: 1..23 = quantized, 0 = constant (the value is in range_min, nothing is read), 32 = raw fp32.
+	struct alignas(16) scalar_track_entry
+	{
+		uint32_t bit_offset_and_width;	// bit offset inside the frame (low 24 bits) | num_bits << 24
+		float inv_max_value;			// 1 / (2^num_bits - 1) (math/scalar_packing.h:117-123)
+		uint32_t reserved[2];
+		float range_min[4];				// per component; constant tracks: the sample
+		float range_extent[4];
+	};
+
+	static_assert(sizeof(scalar_track_entry) == 48, "layout");
 	static_assert(sizeof(sample_record) == 32, "layout");
 	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
@@ -91,7 +103,7 @@ namespace aclhip
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
 		const sample_record* samples;			// [num_samples]
 		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
-		const plan_entry* plan;					// [num_segments][num_animated]
+		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_entry[num_tracks] (scalar_tracks())
 		const clip_range_entry* clip_ranges;	// [num_animated]
 		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
 		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
@@ -102,7 +114,7 @@ namespace aclhip
 		float duration_wrap;					// calculate_finite_duration(num_samples + 1)
 		uint32_t flags;							// k_clip_*
 		uint32_t num_segments;
-		uint32_t num_animated;					// rotations + translations + scales
+		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
 		uint32_t db_clip_header_offset;			// into db_headers
 		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
 		uint32_t reserved[2];
@@ -115,7 +127,13 @@ namespace aclhip
 	constexpr uint32_t k_clip_has_database = 1u << 2;
 	constexpr uint32_t k_clip_wraps = 1u << 3;					// compressed_tracks::get_looping_policy() == wrap
 	constexpr uint32_t k_clip_has_raw = 1u << 4;				// some (segment, sub-track) uses the raw bit rate
+	constexpr uint32_t k_clip_is_scalar = 1u << 5;				// scalar track list: only the scalar kernel accepts it
+	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_valid = 1u << 31;
+
+	// The transform kernels take valid transform clips, the scalar kernel valid scalar clips
+	__device__ __forceinline__ bool is_transform_clip(uint32_t flags) { return (flags & (k_clip_valid | k_clip_is_scalar)) == k_clip_valid; }
+	__device__ __forceinline__ bool is_scalar_clip(uint32_t flags) { return (flags & (k_clip_valid | k_clip_is_scalar)) == (k_clip_valid | k_clip_is_scalar); }
 
 	// Launch wide settings (aclhip_decompress_params resolved to device pointers)
 	struct decode_params
@@ -170,21 +188,19 @@ namespace aclhip
 		return sample_index - float(index0);
 	}
 
-	// seek_v0 (decompression/impl/decompression.transform.h:206-563). Everything here is wave uniform in the pose kernel.
-	// The reference guesses the segment and scans up to 4 start indices (:374-409); the lookup table gives the same answer.
-	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
+	// Clamp + find_linear_interpolation_samples_with_sample_rate (core/impl/interpolation_utils.impl.h:143-201): the two key frames
+	// around a sample time and the (rounded) interpolation alpha. Shared by the transform and the scalar seek.
+	__device__ __forceinline__ void find_key_frames(uint32_t clip_flags, uint32_t num_samples, float sample_rate, float duration_clamp, float duration_wrap,
+		float sample_time, uint32_t rounding_policy, uint32_t looping_policy, uint32_t& out_key_frame0, uint32_t& out_key_frame1, float& out_alpha)
 	{
-		const bool wrap = looping_policy == k_loop_as_compressed ? (clip.flags & k_clip_wraps) != 0 : looping_policy == k_loop_wrap;
-		const float duration_wrap = clip.duration_wrap, duration_clamp = clip.duration_clamp;	// two loads, then a select (not a select of addresses)
-		const float clip_duration = wrap ? duration_wrap : duration_clamp;
-		const uint32_t num_samples = clip.num_samples;
+		const bool wrap = looping_policy == k_loop_as_compressed ? (clip_flags & k_clip_wraps) != 0 : looping_policy == k_loop_wrap;
+		const float clip_duration = wrap ? duration_wrap : duration_clamp;		// two values, then a select (not a select of addresses)
 
-		// :215-216 scalar_clamp
+		// scalar_clamp (decompression.transform.h:215-216, decompression.scalar.h:189-190)
 		sample_time = fminf(fmaxf(sample_time, 0.0f), clip_duration);
 
-		// find_linear_interpolation_samples_with_sample_rate (core/impl/interpolation_utils.impl.h:143-201)
 		const uint32_t last_sample_index = num_samples - 1;
-		float sample_index = sample_time * clip.sample_rate;
+		float sample_index = sample_time * sample_rate;
 		uint32_t key_frame0 = uint32_t(sample_index);
 		uint32_t key_frame1;
 		if (!wrap)
@@ -198,7 +214,19 @@ namespace aclhip
 		else
 			key_frame1 = key_frame0 + 1 >= num_samples ? 0 : key_frame0 + 1;
 
-		float alpha = apply_rounding_policy(sample_index - float(key_frame0), rounding_policy);
+		out_key_frame0 = key_frame0;
+		out_key_frame1 = key_frame1;
+		out_alpha = apply_rounding_policy(sample_index - float(key_frame0), rounding_policy);
+	}
+
+	// seek_v0 (decompression/impl/decompression.transform.h:206-563). Everything here is wave uniform in the pose kernel.
+	// The reference guesses the segment and scans up to 4 start indices (:374-409); the lookup table gives the same answer.
+	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
+	{
+		uint32_t key_frame0, key_frame1;
+		float alpha;
+		find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_time, rounding_policy, looping_policy,
+			key_frame0, key_frame1, alpha);
 
 		const sample_record segment0 = load_sample_record(clip.samples, key_frame0);
 		const sample_record segment1 = load_sample_record(clip.samples, key_frame1);

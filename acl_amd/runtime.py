@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
     "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
     "aclhip_database_stream_in", "aclhip_database_stream_out",
+    "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
 ]
 
 
@@ -45,6 +46,7 @@ class ClipInfo(ctypes.Structure):
         ("num_tracks", ctypes.c_uint32), ("num_samples", ctypes.c_uint32), ("sample_rate", ctypes.c_float), ("duration", ctypes.c_float),
         ("num_segments", ctypes.c_uint32), ("has_scale", ctypes.c_uint32), ("looping_policy", ctypes.c_uint32), ("compressed_size", ctypes.c_uint32),
         ("hash", ctypes.c_uint32), ("num_animated_sub_tracks", ctypes.c_uint32), ("has_database", ctypes.c_uint32), ("has_stripped_keyframes", ctypes.c_uint32),
+        ("track_type", ctypes.c_uint32), ("num_components", ctypes.c_uint32),
     ]
 
 
@@ -111,6 +113,10 @@ def load_library():
     lib.aclhip_register_clip_with_database.argtypes = [vp, vp, u64, i32, u32, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_in.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_out.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
+    lib.aclhip_decompress_scalar_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp]
+    lib.aclhip_decompress_scalar_track_batch.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
+    lib.aclhip_decompress_scalar_tracks_host.argtypes = [vp, vp, vp, u32, pparams, vp, u64]
+    lib.aclhip_decompress_scalar_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64]
     _lib = lib
     return lib
 
@@ -282,6 +288,52 @@ class Context:
             instance_rounding = np.ascontiguousarray(instance_rounding, dtype=np.uint8)
             params.instance_rounding_policies = instance_rounding.ctypes.data
         self._check(self._lib.aclhip_decompress_track_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, track_indices.ctypes.data, n, ctypes.byref(params), count, out.ctypes.data))
+        return out
+
+    # ---- scalar track lists (float1f .. vector4f) ----
+    def decompress_scalar_tracks_batch(self, clips_ptr, times_ptr, num_instances, values_ptr, stride_bytes, params=None, stream=None):
+        """seek + decompress_tracks of scalar track lists. All pointers are device addresses (ints)."""
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_scalar_tracks_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), values_ptr, stride_bytes, stream))
+
+    def decompress_scalar_track_batch(self, clips_ptr, times_ptr, tracks_ptr, num_instances, values_ptr, stride_bytes, params=None, stream=None):
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_scalar_track_batch(self._handle, clips_ptr, times_ptr, tracks_ptr, num_instances, ctypes.byref(params), values_ptr, stride_bytes, stream))
+
+    def _scalar_shape(self, clips):
+        infos = [self.clip_info(int(c)) for c in np.unique(clips)]
+        return max((i.num_tracks for i in infos), default=0), max((i.num_components for i in infos), default=1)
+
+    def decompress_scalar_tracks(self, clips, sample_times, params=None, out=None, track_rounding=None, instance_rounding=None):
+        """Host arrays in, host values out: float32 [n, max num_tracks, max num_components] (rows of clips with fewer components are packed tighter)."""
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
+        if out is None:
+            num_tracks, num_components = self._scalar_shape(clips)
+            out = np.zeros((clips.size, num_tracks, num_components), dtype=np.float32)
+        params = params if params is not None else default_params()
+        if track_rounding is not None:
+            track_rounding = np.ascontiguousarray(track_rounding, dtype=np.uint8)
+            params.track_rounding_policies = track_rounding.ctypes.data
+        if instance_rounding is not None:
+            instance_rounding = np.ascontiguousarray(instance_rounding, dtype=np.uint8)
+            params.instance_rounding_policies = instance_rounding.ctypes.data
+        stride = out.strides[0] if clips.size else 4
+        self._check(self._lib.aclhip_decompress_scalar_tracks_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, clips.size, ctypes.byref(params), out.ctypes.data, max(stride, 4)))
+        return out
+
+    def decompress_scalar_track(self, clips, sample_times, track_indices, params=None, out=None, track_rounding=None):
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
+        track_indices = np.ascontiguousarray(track_indices, dtype=np.uint32)
+        if out is None:
+            out = np.zeros((clips.size, self._scalar_shape(clips)[1]), dtype=np.float32)
+        params = params if params is not None else default_params()
+        if track_rounding is not None:
+            track_rounding = np.ascontiguousarray(track_rounding, dtype=np.uint8)
+            params.track_rounding_policies = track_rounding.ctypes.data
+        self._check(self._lib.aclhip_decompress_scalar_track_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, track_indices.ctypes.data, clips.size,
+                                                                 ctypes.byref(params), out.ctypes.data, max(out.strides[0], 4) if clips.size else 4))
         return out
 
     def rejected_instance_count(self):

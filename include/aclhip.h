@@ -114,6 +114,8 @@ typedef struct aclhip_clip_info
 	uint32_t num_animated_sub_tracks;		/* rotations + translations + scales */
 	uint32_t has_database;
 	uint32_t has_stripped_keyframes;
+	uint32_t track_type;					/* acl::track_type8 (core/track_types.h:51-68): 12 qvvf; 0..4 float1f, float2f, float3f, float4f, vector4f */
+	uint32_t num_components;				/* floats per sample of a track: 12 for qvvf (one qvv record), 1..4 for scalar track lists */
 } aclhip_clip_info;
 
 /* ---- library / context ------------------------------------------------------------------------ */
@@ -208,6 +210,30 @@ aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhi
 	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes);
 aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms);
+
+/* ---- scalar track lists (float1f / float2f / float3f / float4f / vector4f) ------------------------
+ * aclhip_register_clip accepts them like transform clips (decompression_context::initialize dispatches on the track type,
+ * impl/decompress.impl.h:66-83 -> initialize_v0 impl/decompression.scalar.h:100-126; databases are not supported for them).
+ *
+ * Replace seek() + decompress_tracks(writer) for scalar track lists (seek_v0 / decompress_tracks_v0,
+ * impl/decompression.scalar.h:182-480): instance i = (clips[i], sample_times[i]); track t of instance i is written as
+ * num_components floats at (char*)values + i * stride_bytes + t * num_components * 4 -- what track_writer::write_float1 /
+ * write_float2 / write_float3 / write_float4 / write_vector4 (core/track_writer.h:101-158) receive. Only the rounding / looping /
+ * per track rounding members of `params` apply. Transform clips in the list are rejected (and counted), as scalar clips are by the
+ * transform entry points. All pointers are DEVICE pointers; asynchronous on `stream`. */
+aclhip_status aclhip_decompress_scalar_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream);
+
+/* Replaces seek() + decompress_track(track_indices[i], writer) for scalar track lists (decompress_track_v0,
+ * impl/decompression.scalar.h:482-715): num_components floats per instance at (char*)values + i * stride_bytes. */
+aclhip_status aclhip_decompress_scalar_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream);
+
+/* The same with HOST pointers, synchronous (the C++ mirror of decompression_context uses them with a batch of one). */
+aclhip_status aclhip_decompress_scalar_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes);
+aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes);
 
 /* Number of instances the kernels refused since the context was created (unknown clip handle, track index out of range):
  * the reference silently returns in those cases (impl/decompression.transform.h:1532-1537,1766-1768). */

@@ -966,6 +966,157 @@ int aclo_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_
  * pack_vector3_uXX -> memcpy_bits at bit offsets {0,1,5,31,32,33,63,64,65,93} -> unpack_vector3_uXX and must come
  * back within 1e-6. Returns the number of mismatches (0 = pass).
  * ---------------------------------------------------------------------------------------------- */
+/* ---- scalar tracks (float1f .. float4f, vector4f) ---------------------------------------------------------------------
+ * scalar_tracks_header (core/impl/compressed_headers.h:140-165) follows the tracks_header; per track one bit rate byte, then
+ * constant values, range values (min[C] extent[C] per quantized track) and the animated bitstream, frame major. */
+typedef struct
+{
+	uint32_t num_bits_per_frame;
+	uint32_t metadata_per_track, track_constant_values, track_range_values, track_animated_values;		/* offsets from this header */
+} scalar_tracks_header_t;
+
+/* core/impl/variable_bit_rates.h:42-45 */
+static const uint8_t k_bit_rate_num_bits_v0[] = { 0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 32 };
+static const uint8_t k_bit_rate_num_bits[] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 32 };
+
+/* get_track_num_sample_elements (core/track_types.h) */
+uint32_t aclo_scalar_num_components(const void* blob)
+{
+	switch (get_tracks_header(blob)->track_type)
+	{
+	case 0: return 1;
+	case 1: return 2;
+	case 2: return 3;
+	case 3: case 4: return 4;
+	default: return 0;		/* qvvf and anything else: not a scalar track list */
+	}
+}
+
+/* One component of unpack_scalarf_uXX / vector2_uXX / vector3_uXX / vector4_uXX (math/scalar_packing.h:113-160, math/vector4_packing.h:262-330,
+ * 921-1035,1061-1130): 32 bits loaded at the byte holding the first bit, big endian, shifted, masked, converted, scaled. */
+static float unpack_component_uXX(uint32_t num_bits, const uint8_t* data, uint32_t bit_offset)
+{
+	const uint32_t mask = (1u << num_bits) - 1u;
+	const float inv_max_value = 1.0f / (float)mask;
+	const uint32_t window = bswap32(load_u32(data + (bit_offset / 8)));
+	const uint32_t value = (window >> ((32 - num_bits) - (bit_offset % 8))) & mask;
+	return (float)(int32_t)value * inv_max_value;
+}
+
+/* One component of unpack_scalarf_32 / vector2_64 / vector3_96 / vector4_128 (math/scalar_packing.h:71-110, vector4_packing.h:59-164,400-470,479-599) */
+static float unpack_component_32(const uint8_t* data, uint32_t bit_offset)
+{
+	uint64_t window = bswap64(load_u64(data + (bit_offset / 8)));
+	window <<= bit_offset % 8;
+	return bits_to_float((uint32_t)(window >> 32));
+}
+
+/* seek_v0 + decompress_tracks_v0 / decompress_track_v0 of decompression/impl/decompression.scalar.h:182-240,242-480,482-715.
+ * track_filter < 0: every track. out: [num_tracks][num_components] floats (only the filtered track's slot is written otherwise). */
+static int decode_scalar_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, int track_filter, float* out)
+{
+	const tracks_header_t* header = get_tracks_header(blob);
+	const uint32_t num_components = aclo_scalar_num_components(blob);
+	if (num_components == 0)
+		return 1;
+	if (header->num_tracks == 0 || header->num_samples == 0)
+		return 0;		/* empty track list */
+	if (track_filter >= 0 && (uint32_t)track_filter >= header->num_tracks)
+		return 0;		/* invalid track index: silently ignored (:496-498) */
+
+	{
+		const scalar_tracks_header_t* sh = (const scalar_tracks_header_t*)((const uint8_t*)blob + 32);
+		const uint8_t* base = (const uint8_t*)sh;
+		const uint8_t* metadata = base + sh->metadata_per_track;
+		const uint8_t* constant_values = base + sh->track_constant_values;
+		const uint8_t* range_values = base + sh->track_range_values;
+		const uint8_t* animated_values = base + sh->track_animated_values;
+		const uint8_t* num_bits_at_bit_rate = header->version == 7 ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
+
+		const int looping_policy = resolve_looping_policy(header, options->looping_policy);
+		const float duration = aclo_finite_duration(blob, looping_policy);
+		uint32_t key_frame0, key_frame1, track_index, c;
+		uint32_t track_bit_offset = 0;
+		float interpolation_alpha;
+
+		/* :189-190 scalar_clamp */
+		sample_time = sample_time < 0.0f ? 0.0f : (sample_time > duration ? duration : sample_time);
+		find_samples_with_rate(header->num_samples, header->sample_rate, sample_time, rounding_policy, looping_policy, &key_frame0, &key_frame1, &interpolation_alpha);
+
+		for (track_index = 0; track_index < header->num_tracks; ++track_index)
+		{
+			const uint32_t num_bits = num_bits_at_bit_rate[metadata[track_index]];
+			const int wanted = track_filter < 0 || (uint32_t)track_filter == track_index;
+			float* value = out + (size_t)track_index * num_components;
+
+			if (num_bits == 0)
+			{
+				/* constant bit rate: the sample lives in the constant values (:279-283) */
+				if (wanted)
+					for (c = 0; c < num_components; ++c)
+						value[c] = load_f32(constant_values + 4 * c);
+				constant_values += 4 * num_components;
+				continue;
+			}
+
+			if (wanted)
+			{
+				float alpha = interpolation_alpha;
+				if (options->per_track_rounding)
+				{
+					/* track_writer::get_rounding_policy, then apply_rounding_policy on the alpha the seek left behind (:246-258,273-279) */
+					int policy = rounding_policy;
+					if (rounding_policy == ACLO_ROUND_PER_TRACK)
+						policy = options->track_rounding != NULL ? options->track_rounding[track_index] : ACLO_ROUND_NONE;
+					alpha = aclo_apply_rounding_policy(interpolation_alpha, policy);
+				}
+
+				for (c = 0; c < num_components; ++c)
+				{
+					const uint32_t bit_offset0 = key_frame0 * sh->num_bits_per_frame + track_bit_offset + c * num_bits;
+					const uint32_t bit_offset1 = key_frame1 * sh->num_bits_per_frame + track_bit_offset + c * num_bits;
+					float value0, value1;
+					if (num_bits == 32)
+					{
+						value0 = unpack_component_32(animated_values, bit_offset0);
+						value1 = unpack_component_32(animated_values, bit_offset1);
+					}
+					else
+					{
+						const float range_min = load_f32(range_values + 4 * c);
+						const float range_extent = load_f32(range_values + 4 * (num_components + c));
+						value0 = unpack_component_uXX(num_bits, animated_values, bit_offset0);
+						value1 = unpack_component_uXX(num_bits, animated_values, bit_offset1);
+						value0 = (value0 * range_extent) + range_min;		/* scalar/vector_mul_add: multiply, then add */
+						value1 = (value1 * range_extent) + range_min;
+					}
+					/* rtm::scalar_lerp / vector_lerp: (end * alpha) + (start - (start * alpha)) */
+					value[c] = (value1 * alpha) + (value0 - (value0 * alpha));
+				}
+			}
+
+			if (num_bits < 32)
+				range_values += 8 * num_components;
+			track_bit_offset += num_bits * num_components;
+		}
+	}
+	return 0;
+}
+
+int aclo_scalar_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out)
+{
+	return decode_scalar_tracks(blob, sample_time, rounding_policy, options, -1, out);
+}
+
+int aclo_scalar_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_value)
+{
+	/* decode into the track's own slot of a virtual array: shift the base so that slot 'track_index' is out_value */
+	const uint32_t num_components = aclo_scalar_num_components(blob);
+	if (num_components == 0)
+		return 1;
+	return decode_scalar_tracks(blob, sample_time, rounding_policy, options, (int)track_index, out_value - (size_t)track_index * num_components);
+}
+
 uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_num_bits)
 {
 	static const uint32_t offsets[] = { 0, 1, 5, 31, 32, 33, 63, 64, 65, 93 };

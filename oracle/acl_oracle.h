@@ -113,6 +113,14 @@ int aclo_decompress_track(const void* blob, float sample_time, int rounding_poli
 int aclo_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
 	int rounding_policy, const aclo_options* options, float* out, uint64_t pose_stride_floats);
 
+/* Scalar track lists (track_type float1f / float2f / float3f / float4f / vector4f): seek_v0 + decompress_tracks_v0 /
+ * decompress_track_v0 of decompression/impl/decompression.scalar.h:182-715. Components per track: 1, 2, 3, 4, 4.
+ * out: num_tracks * num_components floats, tightly packed; out_value: num_components floats. options: looping_policy,
+ * per_track_rounding and track_rounding are used, the rest is transform specific. Returns 1 for a transform clip. */
+uint32_t aclo_scalar_num_components(const void* blob);
+int aclo_scalar_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out);
+int aclo_scalar_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,10 @@ def oracle():
         lib.aclo_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
         lib.aclo_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]
         lib.aclo_decompress_tracks_batch.argtypes = [vp, vp, vp, u32, i32, ctypes.POINTER(Options), vp, u64]
+        lib.aclo_scalar_num_components.argtypes = [vp]
+        lib.aclo_scalar_num_components.restype = u32
+        lib.aclo_scalar_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
+        lib.aclo_scalar_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]
         _oracle = lib
     return _oracle
 
@@ -212,6 +216,84 @@ def ref_compress(raw, sample_rate, parents=None, precision=0.0001, shell_distanc
 
 REF_DB_PATH = os.path.join(_HERE, "_ref", "libaclref_db.so")
 _ref_db = None
+
+
+# ---- scalar track lists (float1f .. vector4f) ----
+REF_SCALAR_PATH = os.path.join(_HERE, "_ref", "libaclref_scalar.so")
+TRACK_FLOAT1F, TRACK_FLOAT2F, TRACK_FLOAT3F, TRACK_FLOAT4F, TRACK_VECTOR4F, TRACK_QVVF = 0, 1, 2, 3, 4, 12
+_ref_scalar = None
+
+
+def oracle_scalar_decompress_tracks(blob, sample_time, rounding=ROUND_NONE, options=None, out=None):
+    """seek + decompress_tracks of a scalar track list through the C restatement. Returns [num_tracks, num_components] float32."""
+    lib = oracle()
+    if out is None:
+        out = np.zeros((lib.aclo_num_tracks(blob.ctypes.data), lib.aclo_scalar_num_components(blob.ctypes.data)), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    result = lib.aclo_scalar_decompress_tracks(blob.ctypes.data, ctypes.c_float(sample_time), rounding, ctypes.byref(options), out.ctypes.data)
+    if result != 0:
+        raise RuntimeError(f"aclo_scalar_decompress_tracks failed: {result}")
+    return out
+
+
+def oracle_scalar_decompress_track(blob, sample_time, track_index, rounding=ROUND_NONE, options=None):
+    lib = oracle()
+    out = np.zeros(lib.aclo_scalar_num_components(blob.ctypes.data), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    result = lib.aclo_scalar_decompress_track(blob.ctypes.data, ctypes.c_float(sample_time), rounding, ctypes.byref(options), track_index, out.ctypes.data)
+    if result != 0:
+        raise RuntimeError(f"aclo_scalar_decompress_track failed: {result}")
+    return out
+
+
+def have_ref_scalar():
+    return os.path.exists(REF_SCALAR_PATH)
+
+
+def ref_scalar():
+    """The reference's scalar track compressor + decoder (oracle/_ref/libaclref_scalar.so)."""
+    global _ref_scalar
+    if _ref_scalar is None:
+        if not os.path.exists(REF_SCALAR_PATH):
+            raise RuntimeError(f"{REF_SCALAR_PATH} is missing: built from /root/reference by `make -C oracle ref`")
+        lib = ctypes.CDLL(REF_SCALAR_PATH)
+        vp, u32, i32, f32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_float
+        lib.aclref_scalar_decompress.argtypes = [vp, f32, i32, i32, i32, i32, vp, vp]
+        lib.aclref_scalar_compress.argtypes = [vp, u32, u32, u32, f32, f32, u32, vp, u32, ctypes.c_char_p, u32]
+        lib.aclref_scalar_compress.restype = u32
+        _ref_scalar = lib
+    return _ref_scalar
+
+
+def ref_scalar_compress(raw, track_type, sample_rate, precision=0.0001, optimize_loops=False):
+    """compress_track_list on raw scalar samples [num_samples, num_tracks, num_components]. Returns the 16 byte aligned blob."""
+    from acl_amd.synth import aligned_bytes
+    lib = ref_scalar()
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    if raw.ndim == 2:
+        raw = raw[:, :, None]
+    num_samples, num_tracks = raw.shape[0], raw.shape[1]
+    error = ctypes.create_string_buffer(256)
+    args = (raw.ctypes.data, track_type, num_tracks, num_samples, ctypes.c_float(sample_rate), ctypes.c_float(precision), 1 if optimize_loops else 0)
+    size = lib.aclref_scalar_compress(*args, None, 0, error, 256)
+    if size == 0:
+        raise RuntimeError(f"aclref_scalar_compress failed: {error.value.decode()}")
+    blob = aligned_bytes(size)
+    assert lib.aclref_scalar_compress(*args, blob.ctypes.data, size, error, 256) == size
+    return blob
+
+
+def ref_scalar_decompress(blob, sample_time, rounding=ROUND_NONE, looping=-1, settings=0, track_index=-1, track_rounding=None, out=None):
+    """The reference's decompression_context on a scalar track list. settings 0 = default, 1 = debug (per track rounding)."""
+    lib = oracle()
+    if out is None:
+        out = np.zeros((lib.aclo_num_tracks(blob.ctypes.data), lib.aclo_scalar_num_components(blob.ctypes.data)), dtype=np.float32)
+    result = ref_scalar().aclref_scalar_decompress(blob.ctypes.data, ctypes.c_float(sample_time), rounding, looping, settings, track_index, out.ctypes.data, _ptr(track_rounding))
+    if result != 0:
+        raise RuntimeError(f"aclref_scalar_decompress failed: {result}")
+    return out
 
 
 def have_ref_database():

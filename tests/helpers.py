@@ -100,3 +100,37 @@ def load_database_golden(name):
     for key in ("database", "database_inline", "bulk_medium", "bulk_low"):
         case[key] = aligned(case[key])
     return case
+
+
+# ---- scalar track list fixtures (tests/golden/scalar/*.npz, see make_golden_scalar.py) ----
+SCALAR_GOLDEN_DIR = os.path.join(GOLDEN_DIR, "scalar")
+
+SCALAR_CLIP_SPECS = {
+    "float1f_all_rates": dict(seed=101, track_type=0, num_tracks=48, num_samples=40),
+    "float2f_v2_0_rates": dict(seed=102, track_type=1, num_tracks=19, num_samples=25, version=7),
+    "float3f_wrap": dict(seed=103, track_type=2, num_tracks=33, num_samples=61, wrap=1),
+    "float4f_mostly_raw": dict(seed=104, track_type=3, num_tracks=12, num_samples=17, raw_fraction=0.6, constant_fraction=0.1),
+    "vector4f_low_bits": dict(seed=105, track_type=4, num_tracks=27, num_samples=33, min_bits=1, max_bits=6, raw_fraction=0.0),
+    "float1f_one_sample": dict(seed=106, track_type=0, num_tracks=5, num_samples=1),
+    "float3f_all_constant": dict(seed=107, track_type=2, num_tracks=9, num_samples=12, constant_fraction=1.0),
+    "float1f_many_tracks": dict(seed=108, track_type=0, num_tracks=700, num_samples=9, version=8),
+    "vector4f_two_samples_v2_0_wrap_flag_ignored": dict(seed=109, track_type=4, num_tracks=3, num_samples=2, version=7, wrap=1),
+}
+
+
+def scalar_golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(SCALAR_GOLDEN_DIR, "*.npz")))
+
+
+def load_scalar_golden(name):
+    from acl_amd import synth
+    data = np.load(os.path.join(SCALAR_GOLDEN_DIR, f"{name}.npz"))
+    case = {key: data[key] for key in data.files}
+    blob = synth.aligned_bytes(case["blob"].size)
+    blob[:] = case["blob"]
+    case["blob"] = blob
+    return case
+
+
+def exact(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
