@@ -80,6 +80,18 @@ namespace aclhip
 		static constexpr bool skip_all_translations() { return false; }
 		static constexpr bool skip_all_scales() { return false; }
 
+		// scalar track lists (core/track_writer.h:101-158): value.x .. value.w hold the track's 1 / 2 / 3 / 4 components
+		bool skip_track_float1(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_float2(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_float3(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_float4(uint32_t /*track_index*/) const { return false; }
+		bool skip_track_vector4(uint32_t /*track_index*/) const { return false; }
+		void write_float1(uint32_t /*track_index*/, float /*value*/) {}
+		void write_float2(uint32_t /*track_index*/, vector4f /*value*/) {}
+		void write_float3(uint32_t /*track_index*/, vector4f /*value*/) {}
+		void write_float4(uint32_t /*track_index*/, vector4f /*value*/) {}
+		void write_vector4(uint32_t /*track_index*/, vector4f /*value*/) {}
+
 		bool skip_track_rotation(uint32_t /*track_index*/) const { return false; }
 		bool skip_track_translation(uint32_t /*track_index*/) const { return false; }
 		bool skip_track_scale(uint32_t /*track_index*/) const { return false; }
@@ -133,6 +145,13 @@ namespace aclhip
 			return (packed >> ((15 - (track_index % 16)) * 2)) & 3u;
 		}
 	}
+
+	// decompression_settings.h:172-204: scalar track lists; the context dispatches on the bound clip's track type either way
+	struct debug_scalar_decompression_settings : public decompression_settings {};
+	struct default_scalar_decompression_settings : public decompression_settings
+	{
+		static constexpr bool is_per_track_rounding_supported() { return false; }
+	};
 
 	// core/quality_tiers.h: the highest importance tier lives in the compressed_tracks, the other two in a compressed_database
 	enum class quality_tier : uint8_t { highest_importance = 0, medium_importance = 1, lowest_importance = 2 };
@@ -365,6 +384,18 @@ namespace aclhip
 			if (!is_initialized() || m_info.num_tracks == 0 || m_sample_time < 0.0f)
 				return;
 
+			if (m_info.track_type != 12)
+			{
+				// scalar track lists: decompress_tracks_v0 writes the tracks in order (impl/decompression.scalar.h:266-475)
+				const uint32_t num_components = m_info.num_components;
+				m_pose.assign(size_t(m_info.num_tracks) * num_components, 0.0f);
+				if (!run_scalar(writer, nullptr, m_pose.data(), uint64_t(m_info.num_tracks) * num_components * 4))
+					return;
+				for (uint32_t track = 0; track < m_info.num_tracks; ++track)
+					write_scalar_track(writer, track, &m_pose[size_t(track) * num_components], true);
+				return;
+			}
+
 			const uint32_t num_tracks = m_info.num_tracks;
 			m_pose.assign(size_t(num_tracks) * 12, 0.0f);
 			if (!run(writer, nullptr, m_pose.data(), num_tracks))
@@ -391,6 +422,15 @@ namespace aclhip
 			if (!is_initialized() || m_sample_time < 0.0f || track_index >= m_info.num_tracks)
 				return;
 
+			if (m_info.track_type != 12)
+			{
+				// decompress_track_v0 (impl/decompression.scalar.h:482-715): no skip_track_* consultation
+				float value[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+				if (run_scalar(writer, &track_index, value, 16))
+					write_scalar_track(writer, track_index, value, false);
+				return;
+			}
+
 			float transform[12] = { 0 };
 			if (!run(writer, &track_index, transform, 1))
 				return;
@@ -406,6 +446,42 @@ namespace aclhip
 				return false;
 			int matches = 0;
 			return aclhip_clip_matches(m_device->get(), m_clip, compressed_tracks, &matches) == ACLHIP_OK && matches != 0;
+		}
+
+		template<class track_writer_type>
+		bool run_scalar(track_writer_type& writer, const uint32_t* track_index, float* out, uint64_t stride_bytes)
+		{
+			aclhip_decompress_params params;
+			aclhip_default_params(&params);
+			params.rounding_policy = static_cast<uint8_t>(m_rounding_policy);
+			params.looping_policy = static_cast<uint8_t>(m_looping_policy);
+			params.per_track_rounding = settings_type::is_per_track_rounding_supported() ? 1 : 0;
+			if (settings_type::is_per_track_rounding_supported())
+			{
+				m_track_rounding.resize(m_info.num_tracks);
+				for (uint32_t i = 0; i < m_info.num_tracks; ++i)
+					m_track_rounding[i] = static_cast<uint8_t>(writer.get_rounding_policy(m_rounding_policy, i));
+				params.track_rounding_policies = m_track_rounding.data();
+			}
+			const aclhip_status status = track_index != nullptr
+				? aclhip_decompress_scalar_track_host(m_device->get(), &m_clip, &m_sample_time, track_index, 1, &params, out, stride_bytes)
+				: aclhip_decompress_scalar_tracks_host(m_device->get(), &m_clip, &m_sample_time, 1, &params, out, stride_bytes);
+			return status == ACLHIP_OK;
+		}
+
+		template<class track_writer_type>
+		void write_scalar_track(track_writer_type& writer, uint32_t track_index, const float* value, bool honour_skips)
+		{
+			const vector4f packed = { value[0], m_info.num_components > 1 ? value[1] : 0.0f, m_info.num_components > 2 ? value[2] : 0.0f, m_info.num_components > 3 ? value[3] : 0.0f };
+			switch (m_info.track_type)
+			{
+			case 0: if (!honour_skips || !writer.skip_track_float1(track_index)) writer.write_float1(track_index, value[0]); break;
+			case 1: if (!honour_skips || !writer.skip_track_float2(track_index)) writer.write_float2(track_index, packed); break;
+			case 2: if (!honour_skips || !writer.skip_track_float3(track_index)) writer.write_float3(track_index, packed); break;
+			case 3: if (!honour_skips || !writer.skip_track_float4(track_index)) writer.write_float4(track_index, packed); break;
+			case 4: if (!honour_skips || !writer.skip_track_vector4(track_index)) writer.write_vector4(track_index, packed); break;
+			default: break;
+			}
 		}
 
 		template<class track_writer_type>

@@ -101,3 +101,29 @@ def test_cpp_database_context_matches_oracle(database_mirror_binary, tmp_path, n
     if name == "three_clips_4k_chunks":
         assert not np.array_equal(poses[0], poses[2])     # the tiers made a difference
     assert np.array_equal(poses[0], poses[3])
+
+
+@pytest.fixture(scope="module")
+def scalar_mirror_binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "scalar_mirror_test"
+    lib_dir = os.path.dirname(runtime.library_path())
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "scalar_mirror_test.cpp"),
+                    "-L" + lib_dir, "-laclhip", "-Wl,-rpath," + lib_dir, "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("track_type", [0, 1, 2, 3, 4])
+def test_cpp_context_on_scalar_track_lists(scalar_mirror_binary, tmp_path, track_type):
+    clip = synth.build_scalar_clip(seed=40 + track_type, track_type=track_type, num_tracks=14, num_samples=30)
+    blob_path, times_path, out_path = tmp_path / "clip.acl", tmp_path / "times.txt", tmp_path / "values.bin"
+    clip.blob.tofile(blob_path)
+    rng = np.random.default_rng(6)
+    times = rng.uniform(0.0, clip.duration, size=12).astype(np.float32)
+    times_path.write_text("\n".join(repr(float(t)) for t in times))
+    result = subprocess.run([scalar_mirror_binary, str(blob_path), str(times_path), str(out_path)])
+    assert result.returncode == 0
+    values = np.fromfile(out_path, dtype=np.float32).reshape(times.size, 2, clip.num_tracks, clip.num_components)
+    for i, t in enumerate(times):
+        expected = ob.oracle_scalar_decompress_tracks(clip.blob, float(t))
+        assert np.array_equal(values[i, 0].view(np.uint32), expected.view(np.uint32))
+        assert np.array_equal(values[i, 1].view(np.uint32), expected.view(np.uint32))     # decompress_track == decompress_tracks
