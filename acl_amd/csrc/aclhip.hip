@@ -395,101 +395,205 @@ namespace aclhip
 			destination[quad] = value;
 	}
 
-	// Scalar track lists (float1f .. vector4f): seek_v0 + decompress_tracks_v0 / decompress_track_v0 of
-	// decompression/impl/decompression.scalar.h:182-715. One THREAD per (instance, track): there are no segments and no sub-track
-	// classes, a track is C <= 4 components of one width at a known bit offset of each frame, so the work per value is a few loads
-	// and flops and lanes <-> consecutive tracks gives coalesced table reads and stores. `track_indices` == nullptr: every track,
-	// values at out + instance * stride + track * C * 4; otherwise one track per instance, C floats at out + instance * stride.
-	__global__ __launch_bounds__(k_block_size) void decompress_scalar_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices,
-		uint32_t num_instances, uint32_t tracks_per_instance, decode_params params, uint8_t* __restrict__ out, uint64_t out_stride_bytes,
-		unsigned long long* __restrict__ rejected_count)
+	// One track of a scalar track list, C components: unpack both key frames, expand, lerp, store C packed floats.
+	template<uint32_t C>
+	__device__ __forceinline__ void decode_scalar_track(const uint8_t* blob, const scalar_track_header* headers, const float* ranges, uint32_t track_index,
+		uint32_t frame_bit_offset0, uint32_t frame_bit_offset1, float alpha, float* destination)
 	{
-		const uint64_t item = uint64_t(blockIdx.x) * k_block_size + threadIdx.x;
-		const uint32_t instance = uint32_t(item / tracks_per_instance);
-		const uint32_t slot = uint32_t(item - uint64_t(instance) * tracks_per_instance);
+		// rows are only as aligned as their size allows (8 / 16 / 24 / 32 bytes from a 16 byte aligned base): dword aligned vector loads
+		typedef float range_row __attribute__((ext_vector_type(2 * C == 6 ? 8 : 2 * C), aligned(4)));
+		typedef float range_quad __attribute__((ext_vector_type(4), aligned(4)));
+		// read only tables: constant address space loads may be hoisted above the stores of a previous track
+		typedef uint32_t header_words __attribute__((ext_vector_type(2)));
+		const header_words header_raw = *(const ACLHIP_CONSTANT header_words*)(headers + track_index);
+		scalar_track_header header;
+		header.bit_offset_and_width = header_raw.x;
+		header.inv_max_value = __uint_as_float(header_raw.y);
+		const ACLHIP_CONSTANT float* row_address = as_constant(ranges) + size_t(track_index) * 2 * C;
+		float range[2 * C];
+		if (C == 3)
+		{
+			const range_quad lo = *(const ACLHIP_CONSTANT range_quad*)row_address;		// no 6 wide vector type: 4 + 1 + 1
+			const float hi0 = row_address[4], hi1 = row_address[5];
+			range[0] = lo.x; range[1] = lo.y; range[2] = lo.z; range[3] = lo.w; range[4] = hi0; range[5] = hi1;
+		}
+		else
+		{
+			const range_row row = *(const ACLHIP_CONSTANT range_row*)row_address;
+			#pragma unroll
+			for (uint32_t c = 0; c < 2 * C; ++c)
+				range[c] = row[c];
+		}
+
+		const uint32_t num_bits = header.bit_offset_and_width >> 24;
+		const uint32_t track_bit_offset = header.bit_offset_and_width & 0x00FFFFFFu;
+		const ACLHIP_CONSTANT uint8_t* animated_values = as_constant(blob);
+
+		// Straight line code for the common case, every lane whatever its width: a constant track (width 0) reads a harmless window
+		// at bit 0 of the blob, extracts a zero wide field and is put right by the final select; the raw width (32) is rare and only
+		// a wave that meets one pays for its 64 bit windows.
+		const bool is_constant = num_bits == 0;
+		const bool is_raw = num_bits == 32;
+		const uint32_t field_bits = is_raw ? 0u : num_bits;
+		const bool wave_has_raw = __any(int(is_raw)) != 0;
+
+		float value[C];
+		#pragma unroll
+		for (uint32_t c = 0; c < C; ++c)
+		{
+			const uint32_t offset0 = frame_bit_offset0 + track_bit_offset + c * num_bits;
+			const uint32_t offset1 = frame_bit_offset1 + track_bit_offset + c * num_bits;
+
+			// unpack_*_uXX (math/scalar_packing.h:113-160, math/vector4_packing.h:262-330): float(field) * (1 / max), then the range
+			const uint32_t field0 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset0 >> 3)), 32u - field_bits - (offset0 & 7u), field_bits);
+			const uint32_t field1 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset1 >> 3)), 32u - field_bits - (offset1 & 7u), field_bits);
+			float value0 = (float(field0) * header.inv_max_value) * range[C + c] + range[c];
+			float value1 = (float(field1) * header.inv_max_value) * range[C + c] + range[c];
+
+			if (wave_has_raw)
+			{
+				// unpack_scalarf_32 / vector2_64 / vector3_96 / vector4_128: 32 bits at any bit offset (math/scalar_packing.h:71-110)
+				const uint64_t window0 = __builtin_bswap64(load_u64(animated_values + (offset0 >> 3))) << (offset0 & 7u);
+				const uint64_t window1 = __builtin_bswap64(load_u64(animated_values + (offset1 >> 3))) << (offset1 & 7u);
+				value0 = is_raw ? __uint_as_float(uint32_t(window0 >> 32)) : value0;
+				value1 = is_raw ? __uint_as_float(uint32_t(window1 >> 32)) : value1;
+			}
+
+			// rtm::scalar_lerp / vector_lerp: (end * alpha) + (start - (start * alpha)); constant bit rate: the sample itself (:279-283)
+			const float lerped = (value1 * alpha) + (value0 - (value0 * alpha));
+			value[c] = is_constant ? range[c] : lerped;
+		}
+
+		#pragma unroll
+		for (uint32_t c = 0; c < C; ++c)
+			destination[c] = value[c];
+	}
+
+	__device__ __forceinline__ void decode_scalar_track_any(uint32_t num_components, const uint8_t* blob, const scalar_track_header* headers, const float* ranges,
+		uint32_t track_index, uint32_t frame_bit_offset0, uint32_t frame_bit_offset1, float alpha, float* destination)
+	{
+		switch (num_components)
+		{
+		case 1: decode_scalar_track<1>(blob, headers, ranges, track_index, frame_bit_offset0, frame_bit_offset1, alpha, destination); break;
+		case 2: decode_scalar_track<2>(blob, headers, ranges, track_index, frame_bit_offset0, frame_bit_offset1, alpha, destination); break;
+		case 3: decode_scalar_track<3>(blob, headers, ranges, track_index, frame_bit_offset0, frame_bit_offset1, alpha, destination); break;
+		default: decode_scalar_track<4>(blob, headers, ranges, track_index, frame_bit_offset0, frame_bit_offset1, alpha, destination); break;
+		}
+	}
+
+	// Scalar track lists (float1f .. vector4f): seek_v0 + decompress_tracks_v0 of decompression/impl/decompression.scalar.h:182-480.
+	// One wave64 per (instance, 256 consecutive tracks): the seek is wave uniform (scalar unit, like the pose kernels), lanes <->
+	// tracks give coalesced table reads and value stores. There are no segments and no sub-track classes: a track is C <= 4
+	// components of one width at a known bit offset of each frame.
+	constexpr uint32_t k_scalar_tracks_per_wave = 256;
+
+	__global__ __launch_bounds__(k_block_size) void decompress_scalar_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t chunks_per_instance,
+		decode_params params, uint8_t* __restrict__ out, uint64_t out_stride_bytes, unsigned long long* __restrict__ rejected_count)
+	{
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
+		uint32_t instance = work_item;
+		uint32_t chunk = 0;
+		if (chunks_per_instance != 1)
+		{
+			instance = work_item / chunks_per_instance;
+			chunk = work_item - instance * chunks_per_instance;
+		}
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		if (clip_id >= num_clips || !is_scalar_clip(clip.flags))
+		{
+			if (lane == 0 && chunk == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const uint32_t first_track = chunk * k_scalar_tracks_per_wave;
+		if (first_track >= clip.num_tracks || clip.num_samples == 0)
+			return;		// past the end of this clip's track list / empty track list (:185-186,246-248)
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+
+		// seek_v0 (:182-240): a frame is num_bits_per_frame bits
+		uint32_t key_frame0, key_frame1;
+		float seek_alpha;
+		find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_time, rounding_policy, params.looping_policy,
+			key_frame0, key_frame1, seek_alpha);
+
+		const uint32_t num_components = (clip.flags >> k_clip_components_shift) & 7u;
+		const uint32_t num_bits_per_frame = clip.num_animated;
+		float* row = reinterpret_cast<float*>(out + uint64_t(instance) * out_stride_bytes);
+
+		// every lane takes k_scalar_tracks_per_wave / 64 tracks, 64 apart: their table and bitstream reads are independent and overlap
+		#pragma unroll
+		for (uint32_t j = 0; j < k_scalar_tracks_per_wave / k_wave_size; ++j)
+		{
+			const uint32_t track_index = first_track + j * k_wave_size + lane;
+			if (track_index >= clip.num_tracks)
+				continue;
+
+			float alpha = seek_alpha;
+			if (params.per_track_rounding != 0)
+			{
+				// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
+				uint32_t policy = rounding_policy;
+				if (rounding_policy == k_round_per_track)
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
+				alpha = apply_rounding_policy(alpha, policy);
+			}
+
+			decode_scalar_track_any(num_components, clip.blob, reinterpret_cast<const scalar_track_header*>(clip.plan), reinterpret_cast<const float*>(clip.clip_ranges),
+				track_index, key_frame0 * num_bits_per_frame, key_frame1 * num_bits_per_frame, alpha, row + track_index * num_components);
+		}
+	}
+
+	// seek_v0 + decompress_track_v0 (decompression.scalar.h:482-715) for scalar track lists: one THREAD per request (every lane has its
+	// own instance and track); C floats at out + request * stride.
+	__global__ __launch_bounds__(k_block_size) void decompress_scalar_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices,
+		uint32_t num_instances, decode_params params, uint8_t* __restrict__ out, uint64_t out_stride_bytes, unsigned long long* __restrict__ rejected_count)
+	{
+		const uint32_t instance = blockIdx.x * k_block_size + threadIdx.x;
 		if (instance >= num_instances)
 			return;
 
 		const uint32_t clip_id = clip_ids[instance];
 		const device_clip& clip = clips[clip_id < num_clips ? clip_id : 0];
 		const uint32_t flags = clip.flags;
-		const uint32_t track_index = track_indices != nullptr ? track_indices[instance] : slot;
-		if (clip_id >= num_clips || !is_scalar_clip(flags) || (track_indices != nullptr && track_index >= clip.num_tracks))
+		const uint32_t track_index = track_indices[instance];
+		if (clip_id >= num_clips || !is_scalar_clip(flags) || track_index >= clip.num_tracks)
 		{
-			if (slot == 0)
-				atomicAdd(rejected_count, 1ull);	// the reference silently returns (decompression.scalar.h:496-498)
+			atomicAdd(rejected_count, 1ull);	// the reference silently returns (:496-498)
 			return;
 		}
-		if (track_index >= clip.num_tracks || clip.num_samples == 0)
-			return;		// past the end of this clip's track list / empty track list (:185-186,246-248)
+		if (clip.num_samples == 0)
+			return;
 
 		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[instance]) : uint32_t(params.rounding_policy);
-
-		// seek_v0 (:182-240): no segments, a frame is num_bits_per_frame bits
 		uint32_t key_frame0, key_frame1;
 		float alpha;
 		find_key_frames(flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_times[instance], rounding_policy, params.looping_policy,
 			key_frame0, key_frame1, alpha);
-
 		if (params.per_track_rounding != 0)
 		{
-			// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
 			uint32_t policy = rounding_policy;
 			if (rounding_policy == k_round_per_track)
 				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
 			alpha = apply_rounding_policy(alpha, policy);
 		}
 
-		const uint32_t num_components = (flags >> k_clip_components_shift) & 7u;
 		const uint32_t num_bits_per_frame = clip.num_animated;
-		const scalar_track_entry* entries = reinterpret_cast<const scalar_track_entry*>(clip.plan);
-		const u32x4 packed = reinterpret_cast<const u32x4*>(entries + track_index)[0];
-		const f32x4 range_min = reinterpret_cast<const f32x4*>(entries + track_index)[1];
-		const f32x4 range_extent = reinterpret_cast<const f32x4*>(entries + track_index)[2];
-		const uint32_t num_bits = packed.x >> 24;
-		const float inv_max_value = __uint_as_float(packed.y);
-
-		const ACLHIP_CONSTANT uint8_t* animated_values = as_constant(clip.blob);		// entry offsets are relative to the blob start
-		const uint32_t bit_offset0 = key_frame0 * num_bits_per_frame + (packed.x & 0x00FFFFFFu);
-		const uint32_t bit_offset1 = key_frame1 * num_bits_per_frame + (packed.x & 0x00FFFFFFu);
-
-		float value[4];
-		#pragma unroll
-		for (uint32_t c = 0; c < 4; ++c)
-		{
-			value[c] = range_min[c];			// constant bit rate: the sample itself (:279-283)
-			if (c < num_components && num_bits != 0)
-			{
-				const uint32_t offset0 = bit_offset0 + c * num_bits;
-				const uint32_t offset1 = bit_offset1 + c * num_bits;
-				float value0, value1;
-				if (num_bits == 32)
-				{
-					// unpack_scalarf_32 / vector2_64 / vector3_96 / vector4_128: 32 bits at any bit offset (math/scalar_packing.h:71-110)
-					const uint64_t window0 = __builtin_bswap64(load_u64(animated_values + (offset0 >> 3))) << (offset0 & 7u);
-					const uint64_t window1 = __builtin_bswap64(load_u64(animated_values + (offset1 >> 3))) << (offset1 & 7u);
-					value0 = __uint_as_float(uint32_t(window0 >> 32));
-					value1 = __uint_as_float(uint32_t(window1 >> 32));
-				}
-				else
-				{
-					// unpack_*_uXX (math/scalar_packing.h:113-160, math/vector4_packing.h:262-330): float(field) * (1 / max), then the range
-					const uint32_t field0 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset0 >> 3)), 32u - num_bits - (offset0 & 7u), num_bits);
-					const uint32_t field1 = __builtin_amdgcn_ubfe(load_be32(animated_values + (offset1 >> 3)), 32u - num_bits - (offset1 & 7u), num_bits);
-					value0 = (float(field0) * inv_max_value) * range_extent[c] + range_min[c];
-					value1 = (float(field1) * inv_max_value) * range_extent[c] + range_min[c];
-				}
-				// rtm::scalar_lerp / vector_lerp: (end * alpha) + (start - (start * alpha))
-				value[c] = (value1 * alpha) + (value0 - (value0 * alpha));
-			}
-		}
-
-		float* destination = reinterpret_cast<float*>(out + uint64_t(instance) * out_stride_bytes) + (track_indices != nullptr ? 0u : track_index * num_components);
-		#pragma unroll
-		for (uint32_t c = 0; c < 4; ++c)
-			if (c < num_components)
-				destination[c] = value[c];
+		decode_scalar_track_any((flags >> k_clip_components_shift) & 7u, clip.blob, reinterpret_cast<const scalar_track_header*>(clip.plan),
+			reinterpret_cast<const float*>(clip.clip_ranges), track_index, key_frame0 * num_bits_per_frame, key_frame1 * num_bits_per_frame, alpha,
+			reinterpret_cast<float*>(out + uint64_t(instance) * out_stride_bytes));
 	}
 
 	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
@@ -940,7 +1044,7 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 	delete context;
 }
 
-// Scalar track lists (initialize_v0, decompression.scalar.h:100-126): the blob plus one scalar_track_entry per track (bit offset
+// Scalar track lists (initialize_v0, decompression.scalar.h:100-126): the blob plus one header and one range row per track (bit offset
 // inside a frame = the prefix sum the reference's decompress_track_v0 recomputes per call, :529-541; constant / range values
 // pulled next to it).
 static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t* blob, aclhip_clip* out_clip)
@@ -952,8 +1056,9 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	const uint32_t num_samples = header.num_tracks != 0 ? header.num_samples : 0;
 	const uint32_t num_tracks = num_samples != 0 ? header.num_tracks : 0;
 
-	std::vector<scalar_track_entry> entries(std::max<uint32_t>(num_tracks, 1));
-	std::memset(entries.data(), 0, entries.size() * sizeof(scalar_track_entry));
+	std::vector<scalar_track_header> track_headers(std::max<uint32_t>(num_tracks, 1));
+	std::vector<float> range_rows(std::max<size_t>(size_t(num_tracks) * 2 * num_components, 8), 0.0f);
+	std::memset(track_headers.data(), 0, track_headers.size() * sizeof(scalar_track_header));
 	uint32_t num_bits_per_frame = 0;
 	if (num_tracks != 0)
 	{
@@ -963,39 +1068,44 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 		const float* constant_values = reinterpret_cast<const float*>(base + sh.track_constant_values);
 		const float* range_values = reinterpret_cast<const float*>(base + sh.track_range_values);
 		const uint8_t* num_bits_at_bit_rate = header.version == k_version_first ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
-		const uint32_t animated_bit_base = (k_transform_header_offset + sh.track_animated_values) * 8;	// entries address bits from the blob start
+		const uint32_t animated_bit_base = (k_transform_header_offset + sh.track_animated_values) * 8;	// headers address bits from the blob start
 
 		uint32_t track_bit_offset = 0;
 		for (uint32_t track = 0; track < num_tracks; ++track)
 		{
-			scalar_track_entry& entry = entries[track];
+			scalar_track_header& track_header = track_headers[track];
+			float* range_min = &range_rows[size_t(track) * 2 * num_components];
+			float* range_extent = range_min + num_components;
 			const uint32_t num_bits = num_bits_at_bit_rate[bit_rates[track]];
-			entry.bit_offset_and_width = 0;
-			entry.inv_max_value = 1.0f;
-			for (uint32_t c = 0; c < 4; ++c)
+			track_header.bit_offset_and_width = 0;
+			track_header.inv_max_value = 1.0f;
+			for (uint32_t c = 0; c < num_components; ++c)
 			{
-				entry.range_min[c] = 0.0f;
-				entry.range_extent[c] = 1.0f;
+				range_min[c] = 0.0f;
+				range_extent[c] = 1.0f;
 			}
 
 			if (num_bits == 0)
 			{
 				for (uint32_t c = 0; c < num_components; ++c)
-					entry.range_min[c] = constant_values[c];
+				{
+					range_min[c] = constant_values[c];
+					range_extent[c] = 0.0f;
+				}
 				constant_values += num_components;
 				continue;
 			}
 
 			if (uint64_t(animated_bit_base) + track_bit_offset > k_quad_ordinal_mask)
 				return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "frames larger than 2 MiB are not supported");
-			entry.bit_offset_and_width = (animated_bit_base + track_bit_offset) | (num_bits << 24);
+			track_header.bit_offset_and_width = (animated_bit_base + track_bit_offset) | (num_bits << 24);
 			if (num_bits != 32)
 			{
-				entry.inv_max_value = 1.0f / float((1u << num_bits) - 1u);		// PackedTableEntry::max_value (math/scalar_packing.h:119)
+				track_header.inv_max_value = 1.0f / float((1u << num_bits) - 1u);		// PackedTableEntry::max_value (math/scalar_packing.h:119)
 				for (uint32_t c = 0; c < num_components; ++c)
 				{
-					entry.range_min[c] = range_values[c];
-					entry.range_extent[c] = range_values[num_components + c];
+					range_min[c] = range_values[c];
+					range_extent[c] = range_values[num_components + c];
 				}
 				range_values += num_components * 2;
 			}
@@ -1004,12 +1114,15 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 		num_bits_per_frame = sh.num_bits_per_frame;
 	}
 
-	// one device allocation: blob (+ zeroed tail padding: 8 byte windows are read, the writer reserves 15 bytes) | entries
+	// one device allocation: blob (+ zeroed tail padding: 8 byte windows are read, the writer reserves 15 bytes) | track headers | range rows
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;
-	const uint64_t total_bytes = blob_bytes + entries.size() * sizeof(scalar_track_entry);
+	const uint64_t headers_offset = blob_bytes;
+	const uint64_t ranges_offset = align_to_u32(uint32_t(headers_offset + track_headers.size() * sizeof(scalar_track_header)), 16);
+	const uint64_t total_bytes = ranges_offset + range_rows.size() * sizeof(float) + 16;		// a 3 component row is read as 16 + 8 bytes
 	std::vector<uint8_t> staging(total_bytes, 0);
 	std::memcpy(staging.data(), blob, blob_size);
-	std::memcpy(staging.data() + blob_bytes, entries.data(), entries.size() * sizeof(scalar_track_entry));
+	std::memcpy(staging.data() + headers_offset, track_headers.data(), track_headers.size() * sizeof(scalar_track_header));
+	std::memcpy(staging.data() + ranges_offset, range_rows.data(), range_rows.size() * sizeof(float));
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -1044,7 +1157,8 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	device_clip record;
 	std::memset(&record, 0, sizeof(record));
 	record.blob = d_memory;
-	record.plan = reinterpret_cast<const plan_entry*>(d_memory + blob_bytes);		// scalar_track_entry[num_tracks]
+	record.plan = reinterpret_cast<const plan_entry*>(d_memory + headers_offset);				// scalar_track_header[num_tracks]
+	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + ranges_offset);	// float[num_tracks][2 * C]
 	record.num_tracks = num_tracks;
 	record.num_samples = num_samples;
 	record.sample_rate = header.sample_rate;
@@ -2116,16 +2230,25 @@ namespace
 		if (status != ACLHIP_OK)
 			return status;
 
-		const uint32_t tracks_per_instance = track_indices != nullptr ? 1u : std::max<uint32_t>(context->max_scalar_tracks, 1);
-		const uint64_t num_items = uint64_t(num_instances) * tracks_per_instance;
-		const uint64_t num_blocks = (num_items + k_block_size - 1) / k_block_size;
-		if (num_blocks > 0x7FFFFFFFull)
-			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u tracks", num_instances, tracks_per_instance);
-
 		device_guard guard(context->device);
-		hipLaunchKernelGGL(decompress_scalar_tracks_kernel, dim3(uint32_t(num_blocks)), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
-			context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, tracks_per_instance, device_params,
-			static_cast<uint8_t*>(out), out_stride_bytes, context->d_rejected);
+		if (track_indices != nullptr)
+		{
+			const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
+			hipLaunchKernelGGL(decompress_scalar_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+				context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,
+				static_cast<uint8_t*>(out), out_stride_bytes, context->d_rejected);
+		}
+		else
+		{
+			// one wave per (instance, 256 tracks); instances of shorter lists than the longest registered one leave waves idle
+			const uint32_t chunks_per_instance = std::max<uint32_t>((context->max_scalar_tracks + k_scalar_tracks_per_wave - 1) / k_scalar_tracks_per_wave, 1);
+			const uint64_t num_waves = uint64_t(num_instances) * chunks_per_instance;
+			if (num_waves > 0xFFFFFFFFull - k_waves_per_block)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u track chunks", num_instances, chunks_per_instance);
+			hipLaunchKernelGGL(decompress_scalar_tracks_kernel, dim3(uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block)), dim3(k_block_size), 0,
+				static_cast<hipStream_t>(stream), context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, chunks_per_instance, device_params,
+				static_cast<uint8_t*>(out), out_stride_bytes, context->d_rejected);
+		}
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}
@@ -2329,7 +2452,7 @@ extern "C" aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* co
 		const uint32_t clip = clips[i];
 		if (clip >= context->clips.size() || !context->clips[clip].in_use)
 			continue;
-		written += uint64_t(context->clips[clip].info.num_tracks) * 48;
+		written += uint64_t(context->clips[clip].info.num_tracks) * context->clips[clip].info.num_components * 4;		// 48 bytes per transform track
 		if (distinct.insert(clip).second)
 			read += context->clips[clip].touched_bytes;
 	}

@@ -68,18 +68,17 @@ namespace aclhip
 		uint32_t quad_index;			// track_index * 3 + kind: where the sub-track lands in the pose
 	};
 
-	// One per track of a SCALAR track list (float1f .. vector4f), 48 bytes: where the track's bits sit inside a frame and how to
-	// expand them. Widths: 1..23 = quantized, 0 = constant (the value is in range_min, nothing is read), 32 = raw fp32.
-	struct alignas(16) scalar_track_entry
+	// Scalar track lists (float1f .. vector4f) get two tables, [num_tracks] each:
+	//   scalar_track_header: where the track's bits sit inside a frame and their width (1..23 = quantized, 0 = constant: the value is
+	//                        in the range row and nothing is read, 32 = raw fp32), and 1 / (2^num_bits - 1);
+	//   a range row of 2 * C floats: min[C], extent[C] (constant tracks: the sample, 0; raw tracks: 0, 1).
+	struct alignas(8) scalar_track_header
 	{
-		uint32_t bit_offset_and_width;	// bit offset inside the frame (low 24 bits) | num_bits << 24
-		float inv_max_value;			// 1 / (2^num_bits - 1) (math/scalar_packing.h:117-123)
-		uint32_t reserved[2];
-		float range_min[4];				// per component; constant tracks: the sample
-		float range_extent[4];
+		uint32_t bit_offset_and_width;	// bit offset from the blob start inside frame 0 (low 24 bits) | num_bits << 24
+		float inv_max_value;			// math/scalar_packing.h:117-123
 	};
 
-	static_assert(sizeof(scalar_track_entry) == 48, "layout");
+	static_assert(sizeof(scalar_track_header) == 8, "layout");
 	static_assert(sizeof(sample_record) == 32, "layout");
 	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
@@ -103,8 +102,8 @@ namespace aclhip
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
 		const sample_record* samples;			// [num_samples]
 		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
-		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_entry[num_tracks] (scalar_tracks())
-		const clip_range_entry* clip_ranges;	// [num_animated]
+		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
+		const clip_range_entry* clip_ranges;	// [num_animated]; scalar clips: float[num_tracks][2 * C] range rows
 		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
 		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
 		uint32_t num_tracks;

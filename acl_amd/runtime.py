@@ -76,7 +76,10 @@ def library_path():
 
 
 def load_library():
-    """Loads libaclhip.so (raises when it was not built -- there is no fallback)."""
+    """Loads libaclhip.so (raises when it was not built -- there is no fallback).
+
+    A process that also uses PyTorch on the GPU must `import torch` before this call: torch bundles its own HIP runtime and does not
+    find the device once the system one is loaded."""
     global _lib
     if _lib is not None:
         return _lib

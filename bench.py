@@ -9,6 +9,9 @@ Workloads (BASELINE.json configs):
     one_clip   64k instances of one CMU-shaped 100-bone clip, random sample times       (configs[1], the default)
     256_clips  64k instances drawn from 256 distinct 100-bone clips                      (configs[2])
     cinematic  64k instances per GPU of a 300-bone rig with scale, multi-segment         (configs[3], per GPU shard)
+    database   64k instances over 16 database-bound 100-bone clips; the low importance tier is streamed in chunk by chunk
+               on the decode stream while the batches run                                   (configs[4] shape, committed fixture)
+    scalar     64k instances of one 256-curve float1f track list (blend shape weights)      
 With N > 1 every rank decodes its own shard of instances (weak scaling, no data-path collective); rank 0 prints ONE
 JSON line with the whole-job poses/sec, the roofline of the decode kernel and, at N = 1, the CPU baseline.
 """
@@ -51,12 +54,77 @@ def build_workload(name, rank):
         clips = [synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,
                                   scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)]
         clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+    elif name == "scalar":
+        # 1 % of the curves at the raw bit rate: what the reference's compressor leaves for tracks it cannot quantize within precision
+        clips = [synth.build_scalar_clip(seed=9, track_type=0, num_tracks=256, num_samples=120, sample_rate=60.0, raw_fraction=0.01)]
+        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+    elif name == "database":
+        clips = load_database_fixture()["clips"]
+        clip_indices = rng.integers(0, len(clips), size=INSTANCES_PER_GPU).astype(np.uint32)
     else:
         raise ValueError(f"unknown workload {name}")
 
     durations = np.array([c.duration for c in clips], dtype=np.float32)
     times = (rng.uniform(0.0, 1.0, size=clip_indices.size).astype(np.float32) * durations[clip_indices]).astype(np.float32)
     return clips, clip_indices, times
+
+
+class FixtureClip:
+    """A clip that comes from a committed fixture instead of the synthetic writer."""
+
+    def __init__(self, blob):
+        from acl_amd import synth
+        self.blob = synth.aligned_bytes(blob.size)
+        self.blob[:] = blob
+        header = np.frombuffer(bytes(self.blob[8:32]), dtype=np.uint32)
+        self.num_tracks, self.num_samples = int(header[2]), int(header[3])
+        self.sample_rate = float(np.frombuffer(bytes(self.blob[24:28]), dtype=np.float32)[0])
+        self.duration = float(np.float32(self.num_samples - 1) / np.float32(self.sample_rate)) if self.num_samples > 1 else 0.0
+
+
+def load_database_fixture():
+    """tests/golden/bench/database_16_clips_100_bones.npz: clips + database + bulk data written by the reference's build_database
+    (tests/golden/make_bench_database.py); the reference itself does not exist on the GPU box."""
+    from acl_amd import synth
+    data = np.load(os.path.join(ROOT, "tests", "golden", "bench", "database_16_clips_100_bones.npz"))
+    offsets = data["clip_offsets"]
+
+    def aligned(array):
+        out = synth.aligned_bytes(max(array.size, 1))
+        out[: array.size] = array
+        return out[: array.size]
+
+    return {"clips": [FixtureClip(data["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)],
+            "database": aligned(data["database"]), "bulk_medium": aligned(data["bulk_medium"]), "bulk_low": aligned(data["bulk_low"])}
+
+
+def cpu_baseline_scalar(clips, clip_indices, times, row_floats):
+    """cpu_baseline for scalar track lists: the reference's decoder on all host cores (kind "reference") or the C restatement."""
+    import ctypes
+    from oracle import bindings as ob  # cpu_baseline leg only
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sample = min(clip_indices.size, 65536)
+    indices = np.ascontiguousarray(clip_indices[:sample], dtype=np.uint32)
+    sample_times = np.ascontiguousarray(times[:sample], dtype=np.float32)
+    blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
+    if ob.have_ref_scalar():
+        lib = ob.ref_scalar()
+        probe = lib.aclref_scalar_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, min(sample, 8192), row_floats, cores, 1)
+        repeats = int(max(1, min(400, 1.0 / max(probe / min(sample, 8192) * sample, 1e-9))))
+        seconds = min(lib.aclref_scalar_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, row_floats, cores, repeats) for _ in range(3))
+        return {"value": sample / seconds, "unit": "poses/s", "cores": cores, "kind": "reference",
+                "sample": f"{sample} instances of the same list, seek+decompress_tracks, reference headers (default_scalar_decompression_settings), "
+                          f"{cores} threads, warm cache, best of 3 rounds of {repeats} passes"}
+    sample = min(sample, 4096)
+    options = ob.default_options()
+    out = np.zeros(row_floats, dtype=np.float32)
+    t0 = time.perf_counter()
+    for i in range(sample):
+        ob.oracle().aclo_scalar_decompress_tracks(clips[indices[i]].blob.ctypes.data, ctypes.c_float(sample_times[i]), 0, ctypes.byref(options), out.ctypes.data)
+    seconds = time.perf_counter() - t0
+    return {"value": sample / seconds, "unit": "poses/s", "cores": 1, "kind": "port",
+            "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c) called from Python, 1 thread"}
 
 
 def cpu_baseline(clips, clip_indices, times, max_tracks):
@@ -120,7 +188,7 @@ def main():
     # the clocks of an idle MI355X take a few ms to ramp: the defaults warm up for ~30 ms and time ~0.1 s
     parser.add_argument("--steps", type=int, default=2000)
     parser.add_argument("--warmup", type=int, default=500)
-    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic"])
+    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar"])
     parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     args = parser.parse_args()
@@ -153,14 +221,23 @@ def main():
         clip_indices, times = clip_indices[order], times[order]
 
     context = runtime.Context(local_rank)
-    handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+    is_scalar = args.workload == "scalar"
+    database = None
+    if args.workload == "database":
+        fixture = load_database_fixture()
+        database = context.register_database(fixture["database"], fixture["bulk_medium"] if fixture["bulk_medium"].size else None,
+                                             fixture["bulk_low"] if fixture["bulk_low"].size else None)
+        handles = np.array([context.register_clip_with_database(c.blob, database) for c in clips], dtype=np.uint32)
+    else:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
     max_tracks = max(c.num_tracks for c in clips)
     num_instances = clip_indices.size
-    pose_stride = max_tracks * 48
+    # bytes of one instance's output row: 48 per transform track (rtm::qvvf), 4 per component of a scalar track
+    pose_stride = max_tracks * (4 * clips[0].num_components if is_scalar else 48)
 
     d_clips = torch.from_numpy(handles[clip_indices].astype(np.int32)).to(device)
     d_times = torch.from_numpy(times).to(device)
-    d_poses = torch.empty((num_instances, max_tracks * 12), dtype=torch.float32, device=device)
+    d_poses = torch.empty((num_instances, pose_stride // 4), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream(device)
     params = runtime.default_params()
 
@@ -168,11 +245,12 @@ def main():
     import ctypes
     lib = runtime.load_library()
     launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
+    launch = lib.aclhip_decompress_scalar_tracks_batch if is_scalar else lib.aclhip_decompress_tracks_batch
 
     def step():
-        status = lib.aclhip_decompress_tracks_batch(*launch_args)
+        status = launch(*launch_args)
         if status != 0:
-            raise SystemExit(f"aclhip_decompress_tracks_batch failed: {status}")
+            raise SystemExit(f"the batch launch failed: {status}")
 
     # device pre-warm (setup, not one of the W warm-up steps): an idle MI355X needs a few ms of work before its clocks settle
     # (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
@@ -196,10 +274,19 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     num_marks = 0
+    # database workload: the tiers arrive one chunk at a time, evenly spread over the timed steps, on the decode stream
+    stream_schedule = {}
+    if database is not None:
+        info = context.database_info(database)
+        pending = [(tier, 1) for tier in (runtime.TIER_MEDIUM_IMPORTANCE, runtime.TIER_LOWEST_IMPORTANCE) for _ in range(info.num_chunks[tier - 1])]
+        for k, request in enumerate(pending):
+            stream_schedule[(k + 1) * args.steps // (len(pending) + 1)] = request
     for i in range(args.steps):
         if i % chunk == 0:
             marks[num_marks].record(stream)
             num_marks += 1
+        if i in stream_schedule:
+            context.database_stream_in(database, stream_schedule[i][0], stream_schedule[i][1], stream=stream.cuda_stream)
         step()
     marks[num_marks].record(stream)
     num_marks += 1
@@ -216,8 +303,9 @@ def main():
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
     kernel_ms = float(marks[0].elapsed_time(marks[num_marks - 1])) / args.steps
     # the same launches back to back from C (no host pacing), for reference
-    kernel_ms_back_to_back = context.time_decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
-                                                                  repeats=1 if profiling else max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
+    kernel_ms_back_to_back = None if is_scalar else context.time_decompress_tracks_batch(
+        d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
+        repeats=1 if profiling else max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
     bytes_written, bytes_read = context.batch_algorithmic_bytes(handles[clip_indices])
     algorithmic_bytes = bytes_written + bytes_read
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
@@ -228,6 +316,7 @@ def main():
     if rejected != 0:
         raise SystemExit(f"the kernel rejected {rejected} instances")
 
+    kernel_name = "decompress_scalar_tracks_kernel" if is_scalar else context.tracks_kernel_name(params)
     if rank == 0:
         total_poses = num_instances * world_size * args.steps
         result = {
@@ -246,7 +335,9 @@ def main():
             "config": {
                 "workload": {"one_clip": "64k instances of one CMU-shaped 100-bone clip, random sample times, quatf_drop_w_variable + vector3f_variable (BASELINE.json configs[1])",
                              "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else ""),
-                             "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)"}[args.workload],
+                             "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)",
+                             "database": "64k instances per GPU over 16 database-bound 100-bone clips, low importance tier streamed in chunk by chunk on the decode stream during the timed steps (BASELINE.json configs[4] shape, committed fixture)",
+                             "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)"}[args.workload],
                 "instances_per_gpu": int(num_instances),
                 "bones": int(max_tracks),
                 "distinct_clips": len(clips),
@@ -259,8 +350,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, context.tracks_kernel_name(params)),
-                "kernel": context.tracks_kernel_name(params),
+                "traffic": measured_traffic(args.workload, kernel_name),
+                "kernel": kernel_name,
                 "kernel_ms": kernel_ms,
                 "kernel_ms_back_to_back": kernel_ms_back_to_back,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
@@ -268,9 +359,19 @@ def main():
             },
         }
         if world_size == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(clips, clip_indices, times, max_tracks)
+            if is_scalar:
+                result["cpu_baseline"] = cpu_baseline_scalar(clips, clip_indices, times, pose_stride // 4)
+            else:
+                result["cpu_baseline"] = cpu_baseline(clips, clip_indices, times, max_tracks)
+                if database is not None:
+                    # the reference's database_context is not part of the CPU bridge that travels to the GPU box
+                    result["cpu_baseline"]["sample"] += "; clips bound WITHOUT their database (highest importance tier only)"
         print(json.dumps(result))
 
+    for handle in handles:
+        context.unregister_clip(int(handle))
+    if database is not None:
+        context.unregister_database(database)
     context.close()
     if distributed:
         dist.destroy_process_group()

@@ -263,6 +263,8 @@ def ref_scalar():
         lib.aclref_scalar_decompress.argtypes = [vp, f32, i32, i32, i32, i32, vp, vp]
         lib.aclref_scalar_compress.argtypes = [vp, u32, u32, u32, f32, f32, u32, vp, u32, ctypes.c_char_p, u32]
         lib.aclref_scalar_compress.restype = u32
+        lib.aclref_scalar_bench.argtypes = [vp, vp, vp, u32, u32, u32, u32]
+        lib.aclref_scalar_bench.restype = ctypes.c_double
         _ref_scalar = lib
     return _ref_scalar
 

@@ -12,9 +12,13 @@
 #include <acl/decompression/decompress.h>
 #include <acl/decompression/decompression_settings.h>
 
+#include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <utility>
+#include <vector>
 
 namespace
 {
@@ -143,5 +147,59 @@ extern "C"
 		default:
 			return 0;
 		}
+	}
+
+	// CPU baseline for scalar track lists, same protocol as aclref_bench (ref_bridge.cpp): 'count' instances statically partitioned
+	// over 'num_threads' threads created once, one context per thread, seek + decompress_tracks with the default scalar settings;
+	// one untimed warm-up walk, then all threads start the 'repeats' timed walks together. Returns seconds per pass over the list.
+	double aclref_scalar_bench(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+		uint32_t max_row_floats, uint32_t num_threads, uint32_t repeats)
+	{
+		if (num_threads == 0) num_threads = 1;
+		if (repeats == 0) repeats = 1;
+		std::atomic<uint32_t> num_ready(0);
+		std::atomic<uint32_t> go(0);
+
+		auto worker = [&](uint32_t thread_index)
+		{
+			const uint32_t begin = uint32_t((uint64_t(count) * thread_index) / num_threads);
+			const uint32_t end = uint32_t((uint64_t(count) * (thread_index + 1)) / num_threads);
+			std::vector<float> scratch(max_row_floats + 4);
+			acl::decompression_context<default_settings> context;
+			const void* bound = nullptr;
+			for (uint32_t pass = 0; pass <= repeats; ++pass)
+			{
+				if (pass == 1)
+				{
+					num_ready.fetch_add(1);
+					while (go.load() == 0)
+						std::this_thread::yield();
+				}
+				for (uint32_t i = begin; i < end; ++i)
+				{
+					const void* blob = blobs[clip_indices[i]];
+					if (blob != bound)
+					{
+						context.initialize(*static_cast<const acl::compressed_tracks*>(blob));
+						bound = blob;
+					}
+					scalar_writer writer;
+					writer.out = scratch.data();
+					context.seek(sample_times[i], acl::sample_rounding_policy::none);
+					context.decompress_tracks(writer);
+				}
+			}
+		};
+
+		std::vector<std::thread> threads;
+		for (uint32_t t = 0; t < num_threads; ++t)
+			threads.emplace_back(worker, t);
+		while (num_ready.load() != num_threads)
+			std::this_thread::yield();
+		const auto start = std::chrono::steady_clock::now();
+		go.store(1);
+		for (std::thread& t : threads)
+			t.join();
+		return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() / double(repeats);
 	}
 }

@@ -17,7 +17,16 @@ def pytest_configure(config):
 def native_libraries():
     """Builds (or reuses) the in-tree native libraries: libaclhip.so, libaclsynth.so, the CPU oracle."""
     from acl_amd import build
-    return build.build_all()
+    paths = build.build_all()
+    # PyTorch bundles its own HIP runtime; when a process uses both torch and libaclhip.so (GPU tests allocate device memory with
+    # torch), torch has to be imported FIRST or it finds "no HIP GPUs" -- bench.py and __graft_entry__.smoke() do the same.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    return paths
 
 
 # Clip shapes exercised by both the CPU (oracle vs reference) and the GPU (kernel vs oracle) parity tests.
