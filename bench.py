@@ -207,11 +207,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ACLHIP_BENCH_BACKEND=gloo is a dry run of the N > 1 control flow on a box with fewer GPUs than ranks (ranks then share GPUs);
+    # the real thing is one rank per GPU over RCCL (backend "nccl")
+    backend = os.environ.get("ACLHIP_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
     if distributed:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from acl_amd import runtime
 
@@ -220,7 +227,7 @@ def main():
         order = np.argsort(clip_indices, kind="stable")
         clip_indices, times = clip_indices[order], times[order]
 
-    context = runtime.Context(local_rank)
+    context = runtime.Context(device_index)
     is_scalar = args.workload == "scalar"
     database = None
     if args.workload == "database":
