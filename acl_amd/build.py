@@ -11,7 +11,7 @@ ORACLE = os.path.join(ROOT, "oracle")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the decode must not fuse multiply-add (parity with the reference's unfused SSE arithmetic)
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra", "-ldl"]
 
 
 def _newer(target, sources):

@@ -14,6 +14,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared aclhip.hip -o ../lib/libaclhip.so
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -2352,6 +2353,44 @@ extern "C" aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* con
 	if (track_indices == nullptr && num_instances != 0)
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
 	return decompress_scalar_host(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes);
+}
+
+// ---- multi-GPU gather ------------------------------------------------------------------------------------------------
+
+extern "C" aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (rccl_comm == nullptr || shard_poses == nullptr || all_poses == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null communicator or buffer");
+	if (shard_bytes == 0)
+		return ACLHIP_OK;
+
+	// ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
+	// (rccl.h:678); the library is only loaded by callers that gather, decoding never touches it
+	typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+	static all_gather_fn all_gather = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (all_gather == nullptr)
+		{
+			void* library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+			if (library == nullptr)
+				library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+			if (library == nullptr)
+				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 could not be loaded: %s", dlerror());
+			all_gather = reinterpret_cast<all_gather_fn>(dlsym(library, "ncclAllGather"));
+			if (all_gather == nullptr)
+				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 has no ncclAllGather");
+		}
+	}
+
+	device_guard guard(context->device);
+	constexpr int k_nccl_uint8 = 1;		// ncclUint8 (rccl.h:460)
+	const int result = all_gather(shard_poses, all_poses, size_t(shard_bytes), k_nccl_uint8, rccl_comm, static_cast<hipStream_t>(stream));
+	if (result != 0)
+		return fail(context, ACLHIP_ERROR_DEVICE, "ncclAllGather failed: ncclResult_t %d", result);
+	return ACLHIP_OK;
 }
 
 extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count)

@@ -235,6 +235,15 @@ aclhip_status aclhip_decompress_scalar_tracks_host(aclhip_context* context, cons
 aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes);
 
+/* ---- multi-GPU ---------------------------------------------------------------------------------- */
+
+/* Decoding never needs a collective: every GPU decodes its own contiguous shard of the instance list. Only a
+ * caller that wants every rank to see every pose gathers the shards afterwards: one RCCL all-gather over xGMI.
+ * `rccl_comm` is the caller's ncclComm_t (one process per GPU); `shard_poses` are this rank's `shard_bytes` bytes, `all_poses`
+ * receives world_size * shard_bytes bytes in rank order (in place when shard_poses == all_poses + rank * shard_bytes).
+ * DEVICE pointers; asynchronous on `stream`. librccl.so.1 is loaded on first use: ACLHIP_ERROR_DEVICE when it is absent. */
+aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream);
+
 /* Number of instances the kernels refused since the context was created (unknown clip handle, track index out of range):
  * the reference silently returns in those cases (impl/decompression.transform.h:1532-1537,1766-1768). */
 aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count);
