@@ -358,9 +358,24 @@ namespace aclhip
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad;
-		for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
-			pose[quad] = image[quad];
+		// LDS -> registers -> HBM: the whole window is read first, then the stores go out back to back from one base address with
+		// immediate offsets; full 1 KiB rows take no per lane predicate, only the last (partial) row does
+		constexpr uint32_t k_rows = k_image_chunk_quads / k_wave_size;
+		const uint32_t full_rows = window_quads / k_wave_size;			// wave uniform
+		f32x4 staged[k_rows];
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+			staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
+
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad + lane;
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+		{
+			if (r < full_rows)
+				pose[r * k_wave_size] = staged[r];
+			else if (r == full_rows && r * k_wave_size + lane < window_quads)
+				pose[r * k_wave_size] = staged[r];
+		}
 	}
 
 	// One entry per (chunk, segment) of a database tier: which runtime segment header the chunk's keyframes belong to and what
