@@ -183,3 +183,39 @@ def test_database_tiers_streamed_in_while_batches_run(setup):
     for handle in handles:
         ctx.unregister_clip(handle)
     ctx.unregister_database(database)
+
+
+def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
+    """A frame of decodes (transform poses + scalar curves) captured once into a hipGraph and replayed: the batch entry points only
+    enqueue kernels on the caller's stream, so stream capture sees all of the work."""
+    ctx, torch, device = setup
+    clip = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)
+    curves = synth.build_scalar_clip(seed=9, track_type=0, num_tracks=64, num_samples=90)
+    handle, curve_handle = ctx.register_clip(clip.blob), ctx.register_clip(curves.blob)
+    n = 4096
+    rng = np.random.default_rng(41)
+    d_clips = torch.full((n,), handle, dtype=torch.int32, device=device)
+    d_curve_clips = torch.full((n,), curve_handle, dtype=torch.int32, device=device)
+    d_times = torch.zeros(n, dtype=torch.float32, device=device)
+    d_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+    d_values = torch.zeros((n, 64), dtype=torch.float32, device=device)
+
+    graph = torch.cuda.CUDAGraph()
+    capture_stream = torch.cuda.Stream(device)
+    with torch.cuda.graph(graph, stream=capture_stream):
+        stream_handle = torch.cuda.current_stream(device).cuda_stream
+        ctx.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, stream=stream_handle)
+        ctx.decompress_scalar_tracks_batch(d_curve_clips.data_ptr(), d_times.data_ptr(), n, d_values.data_ptr(), 256, stream=stream_handle)
+
+    for frame in range(3):
+        times = rng.uniform(0.0, min(clip.duration, curves.duration), size=n).astype(np.float32)
+        d_times.copy_(torch.from_numpy(times))          # same buffers, new sample times: what an engine does every frame
+        graph.replay()
+        torch.cuda.synchronize(device)
+        poses, values = d_poses.cpu().numpy(), d_values.cpu().numpy()
+        for i in rng.choice(n, size=32, replace=False):
+            assert helpers.bit_equal(poses[i], ob.oracle_decompress_tracks(clip.blob, float(times[i])))
+            assert helpers.exact(values[i], ob.oracle_scalar_decompress_tracks(curves.blob, float(times[i]))[:, 0])
+    assert ctx.rejected_instance_count() == 0
+    ctx.unregister_clip(handle)
+    ctx.unregister_clip(curve_handle)
