@@ -79,13 +79,18 @@ def library_path():
 def load_library():
     """Loads libaclhip.so (raises when it was not built -- there is no fallback).
 
-    A process that also uses PyTorch on the GPU must `import torch` before this call: torch bundles its own HIP runtime and does not
-    find the device once the system one is loaded."""
+    PyTorch is imported first when it is installed: it bundles its own HIP runtime and the two cannot be loaded in the other order."""
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError(f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback")
+    # Load order: this Python layer hands torch tensors' device pointers to the library, and the PyTorch wheel bundles its own HIP
+    # runtime. Whichever of the two runtimes is loaded second finds "no HIP device", so torch (when present) always goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(_LIB_PATH)
     vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
     pparams = ctypes.POINTER(DecompressParams)
