@@ -896,7 +896,8 @@ namespace
 		if (needed <= context->d_clips_capacity)
 			return ACLHIP_OK;
 
-		uint32_t capacity = std::max<uint32_t>(context->d_clips_capacity * 2, 256);
+		// 16384 records = 2 MiB: the table only moves (and captured hipGraphs that hold its address only go stale) past that many clips
+		uint32_t capacity = std::max<uint32_t>(context->d_clips_capacity * 2, 16384);
 		while (capacity < needed)
 			capacity *= 2;
 
