@@ -93,78 +93,39 @@ namespace aclhip
 		return make_float4(raw.x, raw.y, raw.z, raw.w);
 	}
 
-	// Turns a base pose quad into the value to store: constants pass through, animated quads come from `animated` (LDS in the
-	// pose kernel), defaults follow the default sub-track modes.
-	template<class animated_lookup_t>
-	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, const animated_lookup_t& animated, bool& out_store)
+	// What the any-settings pose kernel stores for a quad of the LDS image: default sub-tracks -- still tagged in their W lane, every
+	// other quad holds a real W >= +0 by now -- follow the default sub-track modes, the rest passes through.
+	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, bool& out_store)
 	{
 		out_store = true;
 		const uint32_t marker = __float_as_uint(value.w);
-
-		if (params.standard_defaults)
-		{
-			// fast path: identity defaults, no constant rotation re-normalization
-			if (int32_t(marker) < 0)
-			{
-				if ((marker & k_quad_animated) != 0)
-					value = animated(marker & k_quad_ordinal_mask);
-				else
-					value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
-			}
+		if (int32_t(marker) >= 0)
 			return value;
-		}
 
 		const uint32_t track_index = quad / 3u;
 		const uint32_t kind = quad - track_index * 3u;
-		if (int32_t(marker) < 0)
-		{
-			if ((marker & k_quad_animated) != 0)
-				return animated(marker & k_quad_ordinal_mask);
-
-			value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
-			return default_quad(params, kind, track_index, value, out_store);
-		}
-
-		if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
-			value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
-		return value;
+		value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+		return default_quad(params, kind, track_index, value, out_store);
 	}
 
-	// Phase 1 of the generic pose kernel: lanes <-> the animated sub-tracks of one pose window; every lane decodes its sub-track for
-	// both keyframes and parks the interpolated float4 in LDS at (ordinal - first ordinal of the window).
-	template<bool kHasRaw, bool kPolicies>
-	__device__ __forceinline__ void decode_animated_sub_tracks(const device_clip& clip, const seek_state& state, const decode_params& params,
-		uint32_t rounding_policy, uint32_t lane, uint32_t first_ordinal, uint32_t end_ordinal, float4* lds_animated)
-	{
-		const bool normalize_samples = params.normalization == ACLHIP_NORMALIZE_ALWAYS && params.per_track_rounding != 0;
-
-		for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
-		{
-			// three independent table reads; when both keyframes share a segment plan[1] == plan[0] and the second read hits L1
-			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-			const plan_entry plan1 = load_entry(state.plan[1], animated_ordinal);
-			const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
-
-			uint32_t policy = k_round_none;
-			if (kPolicies && params.per_track_rounding != 0)
-			{
-				// track_writer::get_rounding_policy (core/track_writer.h:97)
-				policy = rounding_policy;
-				if (rounding_policy == k_round_per_track)
-					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
-			}
-
-			lds_animated[animated_ordinal - first_ordinal] = decode_animated_sub_track<kHasRaw, kPolicies>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
-				policy, state.interpolation_alpha, params.normalization, normalize_samples);
-		}
-	}
-
-	// Every settings combination (default sub-track modes, caller supplied defaults, always-normalize, per track / per instance
-	// rounding). One wave64 per (instance, pose window) like the image kernel; the base pose carries markers in its W lanes that
-	// phase 2 resolves: constants pass through, defaults follow the modes, animated quads come from the LDS staging of phase 1.
-	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
+	// 100 bone pose is a single window), built in 5 KiB of LDS:
+	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
+	//   2. meanwhile the window's slice of the clip's base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
+	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are ordered by
+	//      window) decode straight into their quad of the LDS image;
+	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
+	// Windows of one pose go to consecutive waves: each repeats the (scalar) seek, none waits for another, and the chain of
+	// dependent memory round trips per wave stays as short as for a small pose.
+	//
+	// kAnySettings = false is the common case -- track_writer defaults, no per track rounding, normalization != always: the DMA source
+	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
+	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
+	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
+	template<bool kAnySettings>
+	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
-		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
+		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
 		unsigned long long* __restrict__ rejected_count)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
@@ -198,103 +159,6 @@ namespace aclhip
 		const uint32_t first_quad = window * k_image_chunk_quads;
 		if (first_quad >= num_quads)
 			return;
-		const uint32_t end_quad = min(num_quads, first_quad + k_image_chunk_quads);
-
-		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
-		if (num_quads > k_image_chunk_quads)
-		{
-			first_ordinal = as_constant(clip.image_chunks)[window];
-			end_ordinal = as_constant(clip.image_chunks)[window + 1];
-		}
-
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
-
-		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
-
-		float4* lds_animated = reinterpret_cast<float4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
-
-		// ---- phase 1 ----
-		if ((clip.flags & k_clip_has_raw) == 0 && params.per_track_rounding == 0)
-			decode_animated_sub_tracks<false, false>(clip, state, params, rounding_policy, lane, first_ordinal, end_ordinal, lds_animated);
-		else
-			decode_animated_sub_tracks<true, true>(clip, state, params, rounding_policy, lane, first_ordinal, end_ordinal, lds_animated);
-
-		// the wave's own LDS writes must land before its lanes read each other's results
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-		// ---- phase 2: lanes <-> consecutive 16 byte quads of the window; 1 KiB of contiguous HBM per store instruction ----
-		float4* pose = reinterpret_cast<float4*>(poses + uint64_t(instance) * pose_stride_bytes);
-		const auto animated_lookup = [lds_animated, first_ordinal](uint32_t ordinal) { return lds_animated[ordinal - first_ordinal]; };
-
-		constexpr uint32_t k_unroll = 4;	// base pose reads of four store instructions in flight together
-		for (uint32_t base = first_quad; base < end_quad; base += k_wave_size * k_unroll)
-		{
-			float4 values[k_unroll];
-			#pragma unroll
-			for (uint32_t j = 0; j < k_unroll; ++j)
-				values[j] = load_quad(clip.base_pose, min(base + j * k_wave_size + lane, end_quad - 1));
-
-			#pragma unroll
-			for (uint32_t j = 0; j < k_unroll; ++j)
-			{
-				const uint32_t quad = base + j * k_wave_size + lane;
-				bool store;
-				const float4 value = resolve_quad(params, values[j], quad, animated_lookup, store);
-				if (store && quad < end_quad)
-					pose[quad] = value;
-			}
-		}
-	}
-
-	// The common case as its own kernel: track_writer defaults, no per track rounding. One wave64 per (instance, pose window): a
-	// window is k_image_chunk_quads consecutive quads of the pose (a 100 bone pose is a single window), built in 5 KiB of LDS:
-	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
-	//   2. meanwhile the window's slice of the clip's resolved base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
-	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are ordered by
-	//      window) decode straight into their quad of the LDS image;
-	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
-	// Windows of one pose go to consecutive waves: each repeats the (scalar) seek, none waits for another, and the chain of
-	// dependent memory round trips per wave stays as short as for a small pose.
-	__global__ __launch_bounds__(k_block_size) void decompress_tracks_image_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
-		uint32_t rounding_policy, uint32_t looping_policy, uint32_t normalization,
-		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
-	{
-		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-
-		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
-		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
-		uint32_t instance = work_item;
-		uint32_t window = 0;
-		if (windows_per_instance != 1)
-		{
-			instance = work_item / windows_per_instance;
-			window = work_item - instance * windows_per_instance;
-		}
-		if (instance >= num_instances)
-			return;
-
-		const uint32_t clip_id = as_constant(clip_ids)[instance];
-		const float sample_time = as_constant(sample_times)[instance];
-		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
-		{
-			if (lane == 0 && window == 0)
-				atomicAdd(rejected_count, 1ull);
-			return;
-		}
-
-		// an empty track list (decompression.transform.h:1531-1533) or a pose that ends before this window
-		const uint32_t num_quads = clip.num_tracks * 3u;
-		const uint32_t first_quad = window * k_image_chunk_quads;
-		if (first_quad >= num_quads)
-			return;
 		const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
 
 		// the window's animated sub-tracks: image_chunks[window] .. image_chunks[window + 1]
@@ -307,9 +171,13 @@ namespace aclhip
 
 		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
 
+		// With the track_writer's own default sub-track modes the resolved pose already holds what default sub-tracks decode to; any
+		// other mode starts from the tagged base pose and resolves the tags when the window is stored
+		const bool resolve_defaults = kAnySettings && params.standard_default_modes == 0;
+
 		// base pose window -> LDS image, asynchronously: lane i of pass p fetches quad first + p * 64 + i into image[p * 64 + i]
 		{
-			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose + first_quad;
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
 			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
 				if (base + lane < window_quads)
@@ -318,39 +186,86 @@ namespace aclhip
 			}
 		}
 
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+		const uint32_t normalization = params.normalization;
+
 		seek_state state;
-		seek(clip, sample_time, rounding_policy, looping_policy, state);
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		if (kAnySettings && normalization == ACLHIP_NORMALIZE_ALWAYS)
+		{
+			// rotation_normalization_policy_t::always also normalizes CONSTANT rotations (constant_track_cache.transform.h:163-175):
+			// done in the image before the animated sub-tracks (normalized by their decode) replace their markers. Rare (debug
+			// settings): this path waits for the base pose instead of overlapping it with the decode.
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
+			{
+				// (slots of animated rotations hold a tag, or zeros in the resolved pose: whatever this makes of them is overwritten)
+				const f32x4 value = image[quad];
+				if ((first_quad + quad) % 3u == 0 && int32_t(__float_as_uint(value.w)) >= 0)
+				{
+					const float4 normalized = quat_normalize(make_float4(value.x, value.y, value.z, value.w));
+					image[quad] = f32x4{ normalized.x, normalized.y, normalized.z, normalized.w };
+				}
+			}
+		}
 
 		// lanes <-> animated sub-tracks of this window. Most sample times fall between two keyframes of ONE segment: both keys then
 		// share a plan row and it is fetched once (a third less table traffic through the texture unit).
-		const auto decode_window = [&](auto single_segment)
+		const auto decode_window = [&](auto single_segment, auto with_policies)
 		{
+			constexpr bool k_single_segment = decltype(single_segment)::value;
+			constexpr bool k_policies = decltype(with_policies)::value;		// per track rounding (and the sample normalization it implies)
+			const bool normalize_samples = k_policies && normalization == ACLHIP_NORMALIZE_ALWAYS;
+
 			for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
 			{
 				const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-				const plan_entry plan1_loaded = decltype(single_segment)::value ? plan0 : load_entry(state.plan[1], animated_ordinal);
-				const plan_entry& plan1 = decltype(single_segment)::value ? plan0 : plan1_loaded;
+				const plan_entry plan1_loaded = k_single_segment ? plan0 : load_entry(state.plan[1], animated_ordinal);
+				const plan_entry& plan1 = k_single_segment ? plan0 : plan1_loaded;
 				const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
 				const bool is_rotation = is_rotation_entry(clip_range);
+
+				uint32_t policy = k_round_none;
+				if (k_policies)
+				{
+					// track_writer::get_rounding_policy (core/track_writer.h:97)
+					policy = rounding_policy;
+					if (rounding_policy == k_round_per_track)
+						policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
+				}
 
 				// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
 				const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
 
 				float4 value;
 				if (!has_raw)
-					value = decode_animated_sub_track<false, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+					value = decode_animated_sub_track<false, k_policies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 				else
-					value = decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+					value = decode_animated_sub_track<true, k_policies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 
+				// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 				const f32x4 packed = { value.x, value.y, value.z, value.w };
 				image[clip_range.quad_index - first_quad] = packed;
 			}
 		};
 
-		if (state.uses_single_segment)
-			decode_window(std::true_type());
+		if (kAnySettings && params.per_track_rounding != 0)
+		{
+			if (state.uses_single_segment)
+				decode_window(std::true_type(), std::true_type());
+			else
+				decode_window(std::false_type(), std::true_type());
+		}
+		else if (state.uses_single_segment)
+			decode_window(std::true_type(), std::false_type());
 		else
-			decode_window(std::false_type());
+			decode_window(std::false_type(), std::false_type());
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -368,14 +283,59 @@ namespace aclhip
 			staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
 
 		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad + lane;
+
+		// any-settings: rows are 64 quads apart and 64 % 3 == 1, so a lane's sub-track kind advances by one per row
+		const uint32_t lane_quad = first_quad + lane;
+		const uint32_t lane_track = lane_quad / 3u;
+		uint32_t kind = lane_quad - lane_track * 3u;
+		const bool user_defaults = kAnySettings && params.default_values != nullptr;		// wave uniform
+
 		#pragma unroll
 		for (uint32_t r = 0; r < k_rows; ++r)
 		{
-			if (r < full_rows)
-				pose[r * k_wave_size] = staged[r];
-			else if (r == full_rows && r * k_wave_size + lane < window_quads)
-				pose[r * k_wave_size] = staged[r];
+			bool store = r < full_rows || (r == full_rows && r * k_wave_size + lane < window_quads);
+			f32x4 value = staged[r];
+			if (kAnySettings && resolve_defaults)
+			{
+				// default sub-tracks still carry their tag in the W lane (every other quad holds a real W >= +0 by now) and follow the
+				// default sub-track modes (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310,1653-1680)
+				const uint32_t marker = __float_as_uint(value.w);
+				const bool is_default = int32_t(marker) < 0;
+				const uint32_t mode = kind == 0 ? params.default_modes[0] : (kind == 1 ? params.default_modes[1] : params.default_modes[2]);
+				store = store && !(is_default && mode == ACLHIP_DEFAULT_SKIPPED);
+				if (is_default)
+				{
+					// the image holds the track_writer default's xyz (identity / zero / the clip's legacy default scale)
+					value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+					if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
+						value = f32x4{ 1.0f, 1.0f, 1.0f, 0.0f };		// track_writer::get_constant_default_scale (core/track_writer.h:169)
+				}
+				if (user_defaults && is_default && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
+				{
+					const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
+					const float* source = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+					value = f32x4{ source[0], source[1], source[2], kind == 0 ? source[3] : 0.0f };
+				}
+				kind = kind == 2 ? 0u : kind + 1u;
+			}
+			if (store)
+				pose[r * k_wave_size] = value;
 		}
+	}
+
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_tracks_window<false>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+	}
+
+	// 8 waves per SIMD (64 VGPRs) matter more to this variant than the few instructions the allocator saves with 65
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_tracks_window<true>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
 	}
 
 	// One entry per (chunk, segment) of a database tier: which runtime segment header the chunk's keyframes belong to and what
@@ -427,7 +387,7 @@ namespace aclhip
 		header.inv_max_value = __uint_as_float(header_raw.y);
 		const ACLHIP_CONSTANT float* row_address = as_constant(ranges) + size_t(track_index) * 2 * C;
 		float range[2 * C];
-		if (C == 3)
+		if constexpr (C == 3)
 		{
 			const range_quad lo = *(const ACLHIP_CONSTANT range_quad*)row_address;		// no 6 wide vector type: 4 + 1 + 1
 			const float hi0 = row_address[4], hi1 = row_address[5];
@@ -666,8 +626,16 @@ namespace aclhip
 		for (uint32_t kind = 0; kind < 3; ++kind)
 		{
 			const uint32_t quad = track_index * 3u + kind;
-			bool store;
-			const float4 value = resolve_quad(params, load_quad(clip.base_pose, quad), quad, animated_lookup, store);
+			// base pose quad: constant (real W), animated (marker + ordinal) or default (marker)
+			float4 value = load_quad(clip.base_pose, quad);
+			const uint32_t marker = __float_as_uint(value.w);
+			bool store = true;
+			if (int32_t(marker) < 0 && (marker & k_quad_animated) != 0)
+				value = animated_lookup(marker & k_quad_ordinal_mask);
+			else if (int32_t(marker) < 0)
+				value = resolve_quad(params, value, quad, store);
+			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
+				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
 			if (store)
 				transforms[size_t(instance) * 3 + kind] = value;
 		}
@@ -725,7 +693,7 @@ struct aclhip_context
 	uint32_t max_lds_quads = 0;				// largest animated sub-track count among registered clips
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
-	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): never take the LDS image fast path
+	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
 	mutable std::string last_error;
 };
 
@@ -946,8 +914,9 @@ namespace
 		out.default_modes[2] = params->default_scale_mode;
 		// the common case gets a branch-light store loop: track_writer defaults (core/track_writer.h:161-163) without user values,
 		// and no re-normalization of constant rotations
-		out.standard_defaults = (params->default_rotation_mode == ACLHIP_DEFAULT_CONSTANT && params->default_translation_mode == ACLHIP_DEFAULT_CONSTANT
-			&& params->default_scale_mode == ACLHIP_DEFAULT_LEGACY && params->default_values == nullptr && params->normalization != ACLHIP_NORMALIZE_ALWAYS) ? 1 : 0;
+		out.standard_default_modes = (params->default_rotation_mode == ACLHIP_DEFAULT_CONSTANT && params->default_translation_mode == ACLHIP_DEFAULT_CONSTANT
+			&& params->default_scale_mode == ACLHIP_DEFAULT_LEGACY && params->default_values == nullptr) ? 1 : 0;
+		out.standard_defaults = (out.standard_default_modes != 0 && params->normalization != ACLHIP_NORMALIZE_ALWAYS) ? 1 : 0;
 		return ACLHIP_OK;
 	}
 }
@@ -2033,28 +2002,18 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u pose windows", num_instances, windows_per_instance);
 		const uint32_t num_blocks = uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block);
 
-		// the common case: track_writer defaults, no per track / per instance rounding
-		const bool image_mode = params.standard_defaults != 0 && params.per_track_rounding == 0 && params.instance_rounding_policies == nullptr
-			&& !context->force_generic_kernel;
-		if (image_mode)
-		{
-			const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
-			const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
-			hipLaunchKernelGGL(decompress_tracks_image_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance,
-				uint32_t(params.rounding_policy), uint32_t(params.looping_policy), uint32_t(params.normalization),
-				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
-			ACLHIP_CHECK_HIP(context, hipGetLastError());
-			return ACLHIP_OK;
-		}
-
-		// LDS staging: at most one window's worth of animated sub-tracks per wave
-		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_lds_quads, 4), 4), k_image_chunk_quads);
+		// the common case (track_writer defaults, no per track rounding, normalization != always) copies a resolved pose image
+		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
+		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
 		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
-
-		hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
-			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+		if (any_settings)
+			hipLaunchKernelGGL(decompress_tracks_any_settings_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
+				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
+				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+		else
+			hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
+				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
+				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}
@@ -2461,9 +2420,8 @@ extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, 
 	const aclhip_status status = resolve_params(context, params, device_params);
 	if (status != ACLHIP_OK)
 		return status;
-	const bool image_mode = device_params.standard_defaults != 0 && device_params.per_track_rounding == 0 && device_params.instance_rounding_policies == nullptr
-		&& !context->force_generic_kernel;
-	std::snprintf(out_name, capacity, "%s", image_mode ? "decompress_tracks_image_kernel" : "decompress_tracks_kernel");
+	const bool any_settings = device_params.standard_defaults == 0 || device_params.per_track_rounding != 0 || context->force_generic_kernel;
+	std::snprintf(out_name, capacity, "%s", any_settings ? "decompress_tracks_any_settings_kernel" : "decompress_tracks_kernel");
 	return ACLHIP_OK;
 }
 

@@ -146,6 +146,7 @@ namespace aclhip
 		uint8_t per_track_rounding;
 		uint8_t default_modes[3];
 		uint8_t standard_defaults;		// 1 when default sub-tracks take the track_writer defaults (identity / zero / legacy scale) and normalization != always
+		uint8_t standard_default_modes;	// 1 when default sub-tracks take the track_writer defaults, whatever the normalization policy
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)

@@ -13,9 +13,9 @@ import helpers
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["fast_kernels", "generic_kernel"])
+@pytest.fixture(scope="module", params=["common_case_kernel", "any_settings_kernel"])
 def context(request):
-    if request.param == "generic_kernel":
+    if request.param == "any_settings_kernel":
         os.environ["ACLHIP_FORCE_GENERIC_KERNEL"] = "1"
     try:
         ctx = runtime.Context(0)

@@ -15,10 +15,10 @@ pytestmark = pytest.mark.gpu
 TOLERANCE = 1.0e-5      # BASELINE.json: within 1e-5 per component of the reference CPU decompress_tracks()
 
 
-@pytest.fixture(scope="module", params=["fast_kernels", "generic_kernel"])
+@pytest.fixture(scope="module", params=["common_case_kernel", "any_settings_kernel"])
 def context(request):
-    """Every test runs twice: with the launch heuristics free to pick the LDS image fast path, and pinned to the generic kernel."""
-    if request.param == "generic_kernel":
+    """Every test runs twice: with the launch free to pick the common case kernel, and pinned to the any-settings kernel."""
+    if request.param == "any_settings_kernel":
         os.environ["ACLHIP_FORCE_GENERIC_KERNEL"] = "1"
     try:
         ctx = runtime.Context(0)
