@@ -68,3 +68,40 @@ def sample_times_for(duration, count, rng):
 @pytest.fixture(scope="session")
 def clip_specs():
     return CLIP_SPECS
+
+
+def random_clip_specs(count, seed):
+    """Seeded random clip shapes for the sweep tests: track counts around the 16-track type word and 4-rotation group boundaries,
+    sample counts around the 16/17/32-sample segment boundaries, every class mix, both format generations."""
+    rng = np.random.default_rng(seed)
+    specs = []
+    for index in range(count):
+        has_scale = int(rng.uniform() < 0.4)
+        rotation_default = float(rng.choice([0.0, 0.05, 0.3]))
+        translation_default = float(rng.choice([0.0, 0.05, 0.5]))
+        spec = dict(
+            seed=int(1000 + seed * 100 + index),
+            num_tracks=int(rng.choice([1, 2, 3, 4, 5, 15, 16, 17, 31, 32, 33, 47, 63, 64, 65, 100, 107, 130])),
+            num_samples=int(rng.choice([1, 2, 3, 15, 16, 17, 18, 31, 32, 33, 34, 47, 48, 49, 64, 65, 100, 129])),
+            sample_rate=float(rng.choice([24.0, 30.0, 60.0, 120.0])),
+            version=int(rng.choice([7, 8, 9, 10])),
+            has_scale=has_scale,
+            default_scale=int(rng.integers(0, 2)),
+            wrap=int(rng.uniform() < 0.3),
+            strip_keyframes=int(rng.uniform() < 0.3),
+            strip_fraction=float(rng.uniform(0.1, 0.6)),
+            rotation_default=rotation_default,
+            rotation_constant=float(rng.uniform(0.0, 1.0 - rotation_default)),
+            translation_default=translation_default,
+            translation_constant=float(rng.uniform(0.0, 1.0 - translation_default)),
+            scale_default=0.3 if has_scale else 0.0,
+            scale_constant=0.3 if has_scale else 0.0,
+            min_bits=int(rng.integers(1, 9)),
+            max_bits=int(rng.integers(9, 24)),
+            width0_fraction=float(rng.choice([0.0, 0.05, 0.3])),
+            raw_fraction=float(rng.choice([0.0, 0.02, 0.2])),
+        )
+        if spec["version"] == 7:
+            spec["strip_keyframes"] = 0       # keyframe stripping appeared with v02_01_99
+        specs.append(spec)
+    return specs
