@@ -60,3 +60,27 @@ def test_kernels_match_oracle_on_random_shapes():
             assert helpers.bit_equal(single[i], whole[i, tracks[i]])
         assert context.rejected_instance_count() == 0
         context.close()
+
+
+@pytest.mark.skipif(not ob.have_ref_compressor(), reason="oracle/_ref/libaclref_compress.so not built (needs /root/reference)")
+@pytest.mark.parametrize("index", range(8))
+def test_oracle_matches_reference_on_clips_from_the_reference_compressor(index):
+    """Raw animation -> the reference's compress_track_list (default settings, some with keyframe stripping or loop optimisation)
+    -> reference decoder vs oracle, bit for bit."""
+    rng = np.random.default_rng(900 + index)
+    num_tracks = int(rng.choice([5, 16, 33, 48]))
+    num_samples = int(rng.choice([2, 17, 40, 95]))
+    raw_clip = synth.build_clip(seed=900 + index, num_tracks=num_tracks, num_samples=num_samples, has_scale=int(index % 2), scale_default=0.5,
+                                with_side_data=True)
+    raw = raw_clip.raw_keyframes.copy()
+    options = [dict(), dict(strip_proportion=0.3), dict(optimize_loops=True), dict(precision=0.001)][index % 4]
+    if options.get("optimize_loops"):
+        raw[-1] = raw[0]
+    blob = ob.ref_compress(raw, raw_clip.sample_rate, **options)
+    assert ob.ref().aclref_is_valid(blob.ctypes.data, 1) == 0
+    duration = ob.ref().aclref_get_duration(blob.ctypes.data, -1)
+    for t in sample_times_for(duration, 10, rng):
+        for policy in (ob.ROUND_NONE, ob.ROUND_FLOOR, ob.ROUND_CEIL, ob.ROUND_NEAREST):
+            expected = ob.ref_decompress(blob, float(t), policy)
+            actual = ob.oracle_decompress_tracks(blob, float(t), policy)
+            assert helpers.bit_equal(actual, expected), f"clip {index} policy {policy} t {t}"
