@@ -228,6 +228,7 @@ def main():
         clip_indices, times = clip_indices[order], times[order]
 
     context = runtime.Context(device_index)
+    registration_t0 = time.perf_counter()
     is_scalar = args.workload == "scalar"
     database = None
     if args.workload == "database":
@@ -237,6 +238,7 @@ def main():
         handles = np.array([context.register_clip_with_database(c.blob, database) for c in clips], dtype=np.uint32)
     else:
         handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+    registration_ms = (time.perf_counter() - registration_t0) * 1e3
     max_tracks = max(c.num_tracks for c in clips)
     num_instances = clip_indices.size
     # bytes of one instance's output row: 48 per transform track (rtm::qvvf), 4 per component of a scalar track
@@ -348,6 +350,7 @@ def main():
                 "instances_per_gpu": int(num_instances),
                 "bones": int(max_tracks),
                 "distinct_clips": len(clips),
+                "registration_ms_total": round(registration_ms, 3),      # validate + derive tables + upload, all clips (setup, not timed)
                 "pose_bytes": int(pose_stride),
                 "sharding": f"instances split over {world_size} rank(s), no collective on the data path",
             },
