@@ -1,18 +1,20 @@
-// aclhip.hip -- gfx950 decode kernels and the C ABI of libaclhip.so (include/aclhip.h).
+// aclhip.hip -- gfx950 decode kernels and the host side of the C ABI of libaclhip.so (include/aclhip.h).
 //
-// Kernel design:
-//   decompress_tracks_kernel   one wave64 per clip instance. The wave seeks (wave uniform, scalar loads), then
-//     phase 1: lanes <-> animated sub-tracks (rotations, translations, scales in bitstream order). A wave scan over
-//              3 * bit-width turns the per-track widths into bit offsets, every lane pulls its x/y/z for both keyframes
-//              out of the big-endian bitstream, expands segment + clip ranges, rebuilds W, lerps, normalizes and
-//              parks the float4 in LDS at its animated ordinal;
-//     phase 2: lanes <-> consecutive 16 byte quads of the output pose (rotation | translation | scale per track).
-//              Default/constant quads come from the clip's pre-expanded base pose, animated quads from LDS, and every
-//              store instruction of the wave writes 1 KiB of contiguous, 16 byte per lane, HBM.
-//   decompress_track_kernel    one thread per (instance, track) request, serial skip over the preceding widths like
-//     the reference's decompress_track (O(track index)).
+// Kernels (device helpers in aclhip_device.h):
+//   decompress_tracks_kernel / decompress_tracks_any_settings_kernel
+//       one wave64 per (clip instance, window of 320 pose quads): scalar seek, base pose DMA'd global -> LDS, lanes <-> animated
+//       sub-tracks decode in place into the LDS image (bit unpack, segment + clip range, W, lerp, normalize), the window streams
+//       out 1 KiB per store instruction. The second entry point is the same body with per track rounding, the non default
+//       default sub-track modes and always-normalize compiled in.
+//   decompress_track_kernel            one thread per (instance, bone) request; the registration time plan replaces the
+//                                      reference's O(track index) skip over preceding widths.
+//   decompress_scalar_tracks_kernel    scalar track lists: one wave64 per (instance, 256 tracks), lanes <-> tracks.
+//   decompress_scalar_track_kernel     scalar track lists: one thread per (instance, track) request.
+//   apply_tier_metadata_kernel         publishes / retires database tier metadata behind a stream ordered bulk copy.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared aclhip.hip -o ../lib/libaclhip.so
+// Host side: context and clip / database registries, blob validation, registration time tables, launches.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared aclhip.hip -ldl -o ../lib/libaclhip.so
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
@@ -656,7 +658,6 @@ namespace
 		void* device_memory = nullptr;		// one allocation: blob | base pose | quad map | animated tracks
 		aclhip_clip_info info = {};
 		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
-		uint32_t max_lds_quads = 0;
 	};
 }
 
@@ -690,7 +691,6 @@ struct aclhip_context
 	device_clip* d_clips = nullptr;
 	uint32_t d_clips_capacity = 0;
 	unsigned long long* d_rejected = nullptr;
-	uint32_t max_lds_quads = 0;				// largest animated sub-track count among registered clips
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
@@ -1177,7 +1177,6 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	entry.info.track_type = header.track_type;
 	entry.info.num_components = num_components;
 	entry.touched_bytes = total_bytes - 64;
-	entry.max_lds_quads = 0;
 	context->max_scalar_tracks = std::max(context->max_scalar_tracks, num_tracks);
 
 	*out_clip = slot;
@@ -1635,8 +1634,6 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.info.num_components = 12;
 	// bytes a batch may read from this clip: the blob itself plus the registration time tables
 	entry.touched_bytes = total_bytes - 64;
-	entry.max_lds_quads = num_animated;
-	context->max_lds_quads = std::max(context->max_lds_quads, num_animated);
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
 
 	*out_clip = slot;
