@@ -11,7 +11,9 @@ ORACLE = os.path.join(ROOT, "oracle")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the decode must not fuse multiply-add (parity with the reference's unfused SSE arithmetic)
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra", "-ldl"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wextra", "-ldl",
+             # kernel arguments arrive in SGPRs instead of behind a first scalar load (gfx940+)
+             "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _newer(target, sources):

@@ -14,7 +14,7 @@
 //
 // Host side: context and clip / database registries, blob validation, registration time tables, launches.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared aclhip.hip -ldl -o ../lib/libaclhip.so
+// Build (acl_amd/build.py): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-kernarg-preload-count=16 aclhip.hip -ldl -o ../lib/libaclhip.so
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
