@@ -340,6 +340,17 @@ namespace aclhip
 		decompress_tracks_window<true>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
 	}
 
+	// The instance list of convert_track_list's sampling loop (compression/impl/convert.impl.h:161-166): one instance per sample at
+	// min(float(i) / sample_rate, duration), with the correctly rounded fp32 division the host code performs.
+	__global__ void fill_sample_instances_kernel(uint32_t clip_id, uint32_t num_samples, float sample_rate, float duration, uint32_t* __restrict__ clip_ids, float* __restrict__ sample_times)
+	{
+		const uint32_t sample_index = blockIdx.x * blockDim.x + threadIdx.x;
+		if (sample_index >= num_samples)
+			return;
+		clip_ids[sample_index] = clip_id;
+		sample_times[sample_index] = fminf(float(sample_index) / sample_rate, duration);
+	}
+
 	// One entry per (chunk, segment) of a database tier: which runtime segment header the chunk's keyframes belong to and what
 	// its tier metadata is while the chunk is resident ((samples_offset << 32) | sample_indices, database.impl.h:195-197).
 	struct tier_patch
@@ -2325,6 +2336,52 @@ extern "C" aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* con
 	if (track_indices == nullptr && num_instances != 0)
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
 	return decompress_scalar_host(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes);
+}
+
+// ---- every sample of a clip -------------------------------------------------------------------------------------------
+
+extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, aclhip_clip clip, const aclhip_decompress_params* params,
+	void* scratch, void* out, uint64_t stride_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_clip_info info;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+		info = context->clips[clip].info;
+	}
+	if (info.num_tracks == 0 || info.num_samples == 0)
+		return ACLHIP_OK;
+	if (scratch == nullptr || out == nullptr || (reinterpret_cast<uintptr_t>(scratch) & 3u) != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null or misaligned scratch / output buffer");
+
+	aclhip_decompress_params local;
+	if (params != nullptr) local = *params; else aclhip_default_params(&local);
+	local.rounding_policy = ACLHIP_ROUND_NEAREST;		// convert.impl.h:166
+	local.instance_rounding_policies = nullptr;
+
+	// the duration the reference's loop clamps to is the one of the looping policy in effect (convert.impl.h:139)
+	float duration = info.duration;
+	if (local.looping_policy != ACLHIP_LOOP_AS_COMPRESSED)
+	{
+		const uint32_t samples = info.num_samples + (local.looping_policy == ACLHIP_LOOP_WRAP ? 1u : 0u);
+		duration = samples <= 1 ? 0.0f : float(samples - 1) / info.sample_rate;
+	}
+
+	uint32_t* clip_ids = static_cast<uint32_t*>(scratch);
+	float* sample_times = reinterpret_cast<float*>(clip_ids + info.num_samples);
+	{
+		device_guard guard(context->device);
+		hipLaunchKernelGGL(fill_sample_instances_kernel, dim3((info.num_samples + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+			clip, info.num_samples, info.sample_rate, duration, clip_ids, sample_times);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+	}
+
+	if (info.track_type == k_track_type_qvvf)
+		return aclhip_decompress_tracks_batch(context, clip_ids, sample_times, info.num_samples, &local, out, stride_bytes, stream);
+	return aclhip_decompress_scalar_tracks_batch(context, clip_ids, sample_times, info.num_samples, &local, out, stride_bytes, stream);
 }
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------------------------

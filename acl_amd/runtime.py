@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
     "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
     "aclhip_database_stream_in", "aclhip_database_stream_out",
-    "aclhip_all_gather_poses",
+    "aclhip_all_gather_poses", "aclhip_decompress_all_samples",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
 ]
 
@@ -122,6 +122,7 @@ def load_library():
     lib.aclhip_register_clip_with_database.argtypes = [vp, vp, u64, i32, u32, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_in.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_out.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
+    lib.aclhip_decompress_all_samples.argtypes = [vp, u32, pparams, vp, vp, u64, vp]
     lib.aclhip_all_gather_poses.argtypes = [vp, vp, vp, vp, u64, vp]
     lib.aclhip_decompress_scalar_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_decompress_scalar_track_batch.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
@@ -345,6 +346,10 @@ class Context:
         self._check(self._lib.aclhip_decompress_scalar_track_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, track_indices.ctypes.data, clips.size,
                                                                  ctypes.byref(params), out.ctypes.data, max(out.strides[0], 4) if clips.size else 4))
         return out
+
+    def decompress_all_samples(self, clip, scratch_ptr, out_ptr, stride_bytes, params=None, stream=None):
+        """convert_track_list's sampling loop: every sample of `clip`, nearest rounding. Device pointers; scratch = 8 * num_samples bytes."""
+        self._check(self._lib.aclhip_decompress_all_samples(self._handle, clip, ctypes.byref(params) if params is not None else None, scratch_ptr, out_ptr, stride_bytes, stream))
 
     def all_gather_poses(self, rccl_comm, shard_ptr, all_ptr, shard_bytes, stream=None):
         """One RCCL all-gather of pose shards (rank order); `rccl_comm` is an ncclComm_t handle (int / c_void_p)."""

@@ -235,6 +235,17 @@ aclhip_status aclhip_decompress_scalar_tracks_host(aclhip_context* context, cons
 aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes);
 
+/* ---- every sample of a clip --------------------------------------------------------------------- */
+
+/* The sampling loop of convert_track_list(allocator, compressed_tracks, track_array&) (compression/convert.h:52;
+ * impl/convert.impl.h:150-260): for every sample i of the clip, seek(min(float(i) / sample_rate, duration), nearest) +
+ * decompress_tracks, i.e. the clip's keyframes as the decoder sees them. Row i of `out` (DEVICE, `stride_bytes` apart) receives
+ * what aclhip_decompress_tracks_batch / aclhip_decompress_scalar_tracks_batch write for one instance. `scratch` is a DEVICE
+ * buffer of 8 * num_samples bytes (the generated instance list). `params` may be NULL; its rounding policy is ignored
+ * (nearest, like the reference), the rest applies. Asynchronous on `stream`. */
+aclhip_status aclhip_decompress_all_samples(aclhip_context* context, aclhip_clip clip, const aclhip_decompress_params* params,
+	void* scratch, void* out, uint64_t stride_bytes, void* stream);
+
 /* ---- multi-GPU ---------------------------------------------------------------------------------- */
 
 /* Decoding never needs a collective: every GPU decodes its own contiguous shard of the instance list. Only a
