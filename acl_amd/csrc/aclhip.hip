@@ -834,6 +834,8 @@ namespace
 
 		if (th.num_segments == 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
+		if (uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
 		if (th.num_animated_variable_sub_tracks != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
 		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
@@ -1044,7 +1046,7 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 // Scalar track lists (initialize_v0, decompression.scalar.h:100-126): the blob plus one header and one range row per track (bit offset
 // inside a frame = the prefix sum the reference's decompress_track_v0 recomputes per call, :529-541; constant / range values
 // pulled next to it).
-static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t* blob, aclhip_clip* out_clip)
+static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t* blob, aclhip_clip* out_clip, bool validate_only)
 {
 	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
 	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
@@ -1120,6 +1122,8 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	std::memcpy(staging.data(), blob, blob_size);
 	std::memcpy(staging.data() + headers_offset, track_headers.data(), track_headers.size() * sizeof(scalar_track_header));
 	std::memcpy(staging.data() + ranges_offset, range_rows.data(), range_rows.size() * sizeof(float));
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -1194,7 +1198,8 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	return ACLHIP_OK;
 }
 
-static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip)
+static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
+	bool validate_only = false)
 {
 	if (context == nullptr || out_clip == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -1211,7 +1216,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	{
 		if (database != ACLHIP_INVALID_HANDLE)
 			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "database decompression is not supported for scalar tracks");	// decompression.scalar.h:107-108
-		return register_scalar_clip(context, blob, out_clip);
+		return register_scalar_clip(context, blob, out_clip, validate_only);
 	}
 	const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
 	const uint8_t* tbase = blob + k_transform_header_offset;
@@ -1526,6 +1531,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
 	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -1651,9 +1658,23 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	return ACLHIP_OK;
 }
 
+// No exception crosses the C ABI: a buffer whose counts pass validation but ask for more host memory than there is ends here
+template<class callable>
+static aclhip_status guarded(aclhip_context* context, callable&& call)
+{
+	try
+	{
+		return call();
+	}
+	catch (const std::bad_alloc&)
+	{
+		return context != nullptr ? fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "out of host memory") : ACLHIP_ERROR_OUT_OF_MEMORY;
+	}
+}
+
 extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip)
 {
-	return register_clip_impl(context, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, out_clip);
+	return guarded(context, [&]() { return register_clip_impl(context, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, out_clip); });
 }
 
 extern "C" aclhip_status aclhip_register_clip_with_database(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash,
@@ -1661,7 +1682,7 @@ extern "C" aclhip_status aclhip_register_clip_with_database(aclhip_context* cont
 {
 	if (database == ACLHIP_INVALID_HANDLE)
 		return context != nullptr ? fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "invalid database handle") : ACLHIP_ERROR_INVALID_ARGUMENT;
-	return register_clip_impl(context, compressed_tracks, size, check_hash, database, out_clip);
+	return guarded(context, [&]() { return register_clip_impl(context, compressed_tracks, size, check_hash, database, out_clip); });
 }
 
 extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip)
@@ -1712,8 +1733,8 @@ namespace
 	}
 }
 
-extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const void* compressed_database, uint64_t size,
-	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database)
+static aclhip_status register_database_impl(aclhip_context* context, const void* compressed_database, uint64_t size,
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database, bool validate_only)
 {
 	if (context == nullptr || out_database == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -1767,6 +1788,8 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 	db.clip_metadata.assign(clip_metadata, clip_metadata + header.num_clips);
 
 	const uint64_t runtime_size = uint64_t(header.num_clips) * sizeof(database_runtime_clip_header) + uint64_t(header.num_segments) * sizeof(database_runtime_segment_header);
+	if (runtime_size > (256ull << 20))
+		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "%u clips / %u segments: runtime headers beyond 256 MiB are not supported", header.num_clips, header.num_segments);
 	std::vector<uint8_t> runtime(std::max<uint64_t>(runtime_size, 16), 0);
 	db.runtime_headers_size = runtime_size;
 	for (const database_clip_metadata& metadata : db.clip_metadata)
@@ -1797,7 +1820,8 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d lies outside of the bulk data", chunk_index, tier + 1);
 
 			const database_chunk_header& chunk = *reinterpret_cast<const database_chunk_header*>(bulk_sources[tier] + description.offset);
-			if (chunk.index != chunk_index || uint64_t(sizeof(database_chunk_header)) + uint64_t(chunk.num_segments) * sizeof(database_chunk_segment_header) > description.size)
+			if (chunk.index != chunk_index || chunk.size != description.size
+				|| uint64_t(sizeof(database_chunk_header)) + uint64_t(chunk.num_segments) * sizeof(database_chunk_segment_header) > description.size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d has an invalid header", chunk_index, tier + 1);
 
 			const database_chunk_segment_header* segments = reinterpret_cast<const database_chunk_segment_header*>(&chunk + 1);
@@ -1810,6 +1834,8 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 		}
 		db.chunk_first_patch[tier][num_chunks] = uint32_t(patches[tier].size());
 	}
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_database: everything above is host work
 
 	std::lock_guard<std::mutex> lock(context->mutex);
 	device_guard guard(context->device);
@@ -1849,6 +1875,39 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 	context->databases[slot] = std::move(db);
 	*out_database = slot;
 	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const void* compressed_database, uint64_t size,
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database)
+{
+	return guarded(context, [&]() { return register_database_impl(context, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, out_database, false); });
+}
+
+// ---- host only validation (no device needed) ---------------------------------------------------------------------------
+
+namespace
+{
+	aclhip_status report(const aclhip_context& scratch, aclhip_status status, char* out_message, uint32_t capacity)
+	{
+		if (out_message != nullptr && capacity != 0)
+			std::snprintf(out_message, capacity, "%s", status == ACLHIP_OK ? "" : scratch.last_error.c_str());
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, int check_hash, char* out_message, uint32_t capacity)
+{
+	aclhip_context scratch;		// collects the error message; no device is touched
+	aclhip_clip unused = ACLHIP_INVALID_HANDLE;
+	return report(scratch, guarded(&scratch, [&]() { return register_clip_impl(&scratch, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, &unused, true); }), out_message, capacity);
+}
+
+extern "C" aclhip_status aclhip_check_database(const void* compressed_database, uint64_t size, const void* bulk_data_medium, const void* bulk_data_low,
+	int check_hash, char* out_message, uint32_t capacity)
+{
+	aclhip_context scratch;
+	aclhip_database unused = ACLHIP_INVALID_HANDLE;
+	return report(scratch, guarded(&scratch, [&]() { return register_database_impl(&scratch, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, &unused, true); }), out_message, capacity);
 }
 
 extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, aclhip_database database)

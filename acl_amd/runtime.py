@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
     "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
     "aclhip_database_stream_in", "aclhip_database_stream_out",
-    "aclhip_all_gather_poses", "aclhip_decompress_all_samples",
+    "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
 ]
 
@@ -122,6 +122,8 @@ def load_library():
     lib.aclhip_register_clip_with_database.argtypes = [vp, vp, u64, i32, u32, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_in.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_out.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
+    lib.aclhip_check_clip.argtypes = [vp, u64, i32, ctypes.c_char_p, u32]
+    lib.aclhip_check_database.argtypes = [vp, u64, vp, vp, i32, ctypes.c_char_p, u32]
     lib.aclhip_decompress_all_samples.argtypes = [vp, u32, pparams, vp, vp, u64, vp]
     lib.aclhip_all_gather_poses.argtypes = [vp, vp, vp, vp, u64, vp]
     lib.aclhip_decompress_scalar_tracks_batch.argtypes = [vp, vp, vp, u32, pparams, vp, u64, vp]
@@ -130,6 +132,23 @@ def load_library():
     lib.aclhip_decompress_scalar_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64]
     _lib = lib
     return lib
+
+
+def check_clip(blob, check_hash=True):
+    """Host only validation of a compressed_tracks blob (no GPU needed). Returns (status, message); status 0 = valid."""
+    array = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+    message = ctypes.create_string_buffer(512)
+    status = load_library().aclhip_check_clip(array.ctypes.data, array.size, 1 if check_hash else 0, message, 512)
+    return status, message.value.decode()
+
+
+def check_database(database, bulk_data_medium=None, bulk_data_low=None, check_hash=True):
+    """Host only validation of a compressed_database (+ split bulk data). Returns (status, message)."""
+    as_array = lambda b: None if b is None else (np.frombuffer(b, dtype=np.uint8) if not isinstance(b, np.ndarray) else b)
+    array, medium, low = as_array(database), as_array(bulk_data_medium), as_array(bulk_data_low)
+    message = ctypes.create_string_buffer(512)
+    status = load_library().aclhip_check_database(array.ctypes.data, array.size, _host_ptr(medium), _host_ptr(low), 1 if check_hash else 0, message, 512)
+    return status, message.value.decode()
 
 
 def default_params(**overrides):

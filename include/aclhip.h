@@ -145,6 +145,13 @@ aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip);
 
 aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info);
 
+/* Replaces compressed_tracks::is_valid(check_hash) (core/impl/compressed_tracks.impl.h:278-301) as a host only call (no context,
+ * no device): everything aclhip_register_clip checks before it uploads -- tag, version, hash, every header offset, sub-track
+ * classes against counts, bit widths against the per segment pose size, stored keyframes inside the buffer. `out_message`
+ * (optional) receives the reason, like error_result::c_str(). The reference only checks alignment, tag, version and hash; the
+ * rest is here because the device reads through these offsets. */
+aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, int check_hash, char* out_message, uint32_t capacity);
+
 /* Replaces decompression_context::is_bound_to(const compressed_tracks&) (decompress.h:138): true when `clip`
  * was registered from a blob with the same hash and size. */
 aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches);
@@ -170,6 +177,11 @@ typedef struct aclhip_database_info
 aclhip_status aclhip_register_database(aclhip_context* context, const void* compressed_database, uint64_t size,
 	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database);
 aclhip_status aclhip_unregister_database(aclhip_context* context, aclhip_database database);
+
+/* Replaces compressed_database::is_valid(check_hash) (core/impl/compressed_database.impl.h:142-163) as a host only call, with the
+ * checks of aclhip_register_database (chunk and segment headers inside the bulk data, bulk data hashes). */
+aclhip_status aclhip_check_database(const void* compressed_database, uint64_t size, const void* bulk_data_medium, const void* bulk_data_low,
+	int check_hash, char* out_message, uint32_t capacity);
 aclhip_status aclhip_get_database_info(const aclhip_context* context, aclhip_database database, aclhip_database_info* out_info);
 
 /* Replaces decompression_context::initialize(const compressed_tracks&, const database_context&) (decompress.h:108;

@@ -1,0 +1,126 @@
+"""aclhip_check_clip / aclhip_check_database: the host side of registration (validation + table derivation) without a device.
+What the reference's is_valid() accepts here must be accepted, broken buffers must be refused -- never crash. No GPU."""
+import struct
+
+import numpy as np
+import pytest
+
+from acl_amd import runtime, synth
+import helpers
+from conftest import CLIP_SPECS, random_clip_specs
+
+
+@pytest.mark.parametrize("name", sorted(CLIP_SPECS))
+def test_synthetic_transform_clips_are_valid(name):
+    clip = synth.build_clip(**CLIP_SPECS[name])
+    assert runtime.check_clip(clip.blob) == (0, "")
+
+
+@pytest.mark.parametrize("name", sorted(helpers.SCALAR_CLIP_SPECS))
+def test_synthetic_scalar_clips_are_valid(name):
+    clip = synth.build_scalar_clip(**helpers.SCALAR_CLIP_SPECS[name])
+    assert runtime.check_clip(clip.blob) == (0, "")
+
+
+def test_reference_written_blobs_are_valid():
+    for name in helpers.golden_cases():
+        assert runtime.check_clip(helpers.load_golden(name)["blob"]) == (0, ""), name
+    for name in helpers.scalar_golden_cases():
+        assert runtime.check_clip(helpers.load_scalar_golden(name)["blob"]) == (0, ""), name
+    for name in helpers.database_golden_cases():
+        case = helpers.load_database_golden(name)
+        for clip in case["clips"]:
+            assert runtime.check_clip(clip) == (0, ""), name
+        assert runtime.check_database(case["database"], case["bulk_medium"], case["bulk_low"]) == (0, "")
+        assert runtime.check_database(case["database_inline"]) == (0, "")
+
+
+def _patched(blob, offset, fmt, value):
+    out = synth.aligned_bytes(blob.size)
+    out[:] = blob
+    struct.pack_into(fmt, out, offset, value)
+    return out
+
+
+def test_targeted_corruptions_are_refused_with_a_reason():
+    clip = synth.build_clip(seed=3, num_tracks=37, num_samples=80, has_scale=1)
+    blob = clip.blob
+    assert runtime.check_clip(_patched(blob, 8, "<I", 0xDEADBEEF), check_hash=False) == (2, "Invalid tag")
+    assert runtime.check_clip(_patched(blob, 12, "<H", 3), check_hash=False)[1] == "Invalid algorithm version"
+    assert runtime.check_clip(_patched(blob, 14, "<B", 9), check_hash=False)[1] == "Invalid algorithm type"
+    assert runtime.check_clip(_patched(blob, 0, "<I", blob.size + 1000), check_hash=False)[1] == "Invalid size"
+    assert runtime.check_clip(_patched(blob, 40, "<I", 1))[1] == "Invalid hash"
+    status, message = runtime.check_clip(_patched(blob, 15, "<B", 7), check_hash=False)         # track type: not qvvf, not scalar
+    assert status == 3 and "track type" in message
+    status, message = runtime.check_clip(_patched(blob, 28, "<I", 0), check_hash=False)         # formats: quatf_full + vector3f_full
+    assert status == 3
+    assert runtime.check_clip(_patched(blob, 32, "<I", 0), check_hash=False)[0] != 0            # no segments
+    assert runtime.check_clip(_patched(blob, 32 + 36, "<I", 0x7FFFFFF0), check_hash=False)[0] != 0      # segment headers offset
+    assert runtime.check_clip(_patched(blob, 32 + 4, "<I", 9999), check_hash=False)[0] != 0     # animated sub-track count
+    assert runtime.check_clip(blob[: blob.size // 2].copy(), check_hash=False)[0] != 0          # truncated
+
+    curves = synth.build_scalar_clip(seed=5, track_type=1, num_tracks=10, num_samples=12)
+    assert runtime.check_clip(_patched(curves.blob, 32, "<I", 5), check_hash=False)[0] != 0     # bits per frame
+    assert runtime.check_clip(_patched(curves.blob, 32 + 16, "<I", 0x0FFFFFFF), check_hash=False)[0] != 0   # animated values offset
+    assert runtime.check_clip(_patched(curves.blob, 52, "<B", 99), check_hash=False)[0] != 0    # first bit rate
+
+
+def test_database_corruptions_are_refused():
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    database, medium, low = case["database"], case["bulk_medium"], case["bulk_low"]
+    assert runtime.check_database(database)[0] != 0                                             # bulk data missing
+    assert runtime.check_database(_patched(database, 8, "<I", 1), medium, low, check_hash=False)[0] != 0       # tag
+    bad = medium.copy()
+    bad[5] ^= 0xFF
+    assert runtime.check_database(database, bad, low)[0] != 0                                   # bulk hash
+    assert runtime.check_database(database, bad, low, check_hash=False)[0] != 0                 # chunk header now inconsistent (index / size)
+    assert runtime.check_database(_patched(database, 8 + 8, "<I", 4000), medium, low, check_hash=False)[0] != 0     # number of chunks
+    assert runtime.check_database(database[:30].copy(), medium, low, check_hash=False)[0] != 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_corruptions_never_crash_the_host_side(seed):
+    rng = np.random.default_rng(seed)
+    specs = random_clip_specs(6, seed=50 + seed)
+    blobs = [synth.build_clip(**spec).blob for spec in specs]
+    blobs += [synth.build_scalar_clip(**spec).blob for spec in list(helpers.SCALAR_CLIP_SPECS.values())[seed: seed + 2]]
+    accepted = 0
+    for blob in blobs:
+        header_bytes = min(blob.size, 32 + 52 + 4 * 40 + 64)
+        for _ in range(250):
+            corrupt = synth.aligned_bytes(blob.size)
+            corrupt[:] = blob
+            for _ in range(int(rng.integers(1, 4))):
+                # mostly in the headers, where every field steers an offset or a count
+                at = int(rng.integers(0, header_bytes)) if rng.uniform() < 0.8 else int(rng.integers(0, blob.size))
+                corrupt[at] = int(rng.integers(0, 256))
+            size = blob.size if rng.uniform() < 0.9 else int(rng.integers(0, blob.size))
+            status, _ = runtime.check_clip(corrupt[:size] if size else corrupt[:1], check_hash=False)
+            accepted += int(status == 0)
+    assert accepted < len(blobs) * 250          # (some corruptions only touch values, those are fine)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_random_database_corruptions_never_crash_the_host_side(seed):
+    rng = np.random.default_rng(100 + seed)
+    for name in helpers.database_golden_cases():
+        case = helpers.load_database_golden(name)
+        for inline in (False, True):
+            original = case["database_inline"] if inline else case["database"]
+            for _ in range(150):
+                database = synth.aligned_bytes(original.size)
+                database[:] = original
+                medium, low = case["bulk_medium"].copy(), case["bulk_low"].copy()
+                for _ in range(int(rng.integers(1, 4))):
+                    target = int(rng.integers(0, 3))
+                    if target == 0 or inline:
+                        at = int(rng.integers(0, min(database.size, 200))) if rng.uniform() < 0.7 else int(rng.integers(0, database.size))
+                        database[at] = int(rng.integers(0, 256))
+                    elif target == 1 and medium.size:
+                        medium[int(rng.integers(0, min(medium.size, 400)))] = int(rng.integers(0, 256))
+                    elif low.size:
+                        low[int(rng.integers(0, min(low.size, 400)))] = int(rng.integers(0, 256))
+                if inline:
+                    runtime.check_database(database, check_hash=False)
+                else:
+                    runtime.check_database(database, medium if medium.size else None, low if low.size else None, check_hash=False)
