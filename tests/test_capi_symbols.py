@@ -64,3 +64,23 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"from oracle|import oracle|acl_oracle\.h|libacloracle|libaclref|oracle/", text):
                         offenders.append(os.path.join(dirpath, filename))
     assert not offenders, offenders
+
+
+def test_header_is_plain_c_and_host_entry_points_work_without_a_gpu(tmp_path):
+    """include/aclhip.h from a C99 translation unit (gcc -std=c99 -pedantic -Werror), linked against libaclhip.so, run on this CPU box."""
+    import subprocess
+    import numpy as np
+    from acl_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(runtime.library_path())
+    binary = tmp_path / "abi_smoke"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    "-L" + lib_dir, "-laclhip", "-Wl,-rpath," + lib_dir, "-o", str(binary)], check=True)
+    clip = synth.build_clip(seed=8, num_tracks=12, num_samples=40)
+    valid, broken = tmp_path / "valid.acl", tmp_path / "broken.acl"
+    clip.blob.tofile(valid)
+    corrupt = clip.blob.copy()
+    corrupt[50] ^= 0x5A
+    corrupt.tofile(broken)
+    assert subprocess.run([str(binary), str(valid), "valid"]).returncode == 0
+    assert subprocess.run([str(binary), str(broken), "invalid"]).returncode == 0
