@@ -521,26 +521,54 @@ namespace aclhip
 		const uint32_t num_bits_per_frame = clip.num_animated;
 		float* row = reinterpret_cast<float*>(out + uint64_t(instance) * out_stride_bytes);
 
-		// every lane takes k_scalar_tracks_per_wave / 64 tracks, 64 apart: their table and bitstream reads are independent and overlap
-		#pragma unroll
-		for (uint32_t j = 0; j < k_scalar_tracks_per_wave / k_wave_size; ++j)
+		// every lane takes k_scalar_tracks_per_wave / 64 tracks, 64 apart: their table and bitstream reads are independent and overlap.
+		// The component count and the per track rounding switch are wave uniform: one specialised, branch free loop runs.
+		// (plain locals, captured by value: a lambda that captures the clip record by reference keeps the whole record in scratch)
+		const uint8_t* const blob = clip.blob;
+		const scalar_track_header* const headers = reinterpret_cast<const scalar_track_header*>(clip.plan);
+		const float* const ranges = reinterpret_cast<const float*>(clip.clip_ranges);
+		const uint32_t num_tracks = clip.num_tracks;
+		const uint32_t frame_bit_offset0 = key_frame0 * num_bits_per_frame;
+		const uint32_t frame_bit_offset1 = key_frame1 * num_bits_per_frame;
+		const uint8_t* const track_rounding_policies = params.track_rounding_policies;
+		const bool per_track_rounding = params.per_track_rounding != 0;
+
+		const auto decode_tracks = [=](auto components, auto with_policies)
 		{
-			const uint32_t track_index = first_track + j * k_wave_size + lane;
-			if (track_index >= clip.num_tracks)
-				continue;
-
-			float alpha = seek_alpha;
-			if (params.per_track_rounding != 0)
+			constexpr uint32_t C = decltype(components)::value;
+			constexpr bool k_policies = decltype(with_policies)::value;
+			#pragma unroll
+			for (uint32_t j = 0; j < k_scalar_tracks_per_wave / k_wave_size; ++j)
 			{
-				// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
-				uint32_t policy = rounding_policy;
-				if (rounding_policy == k_round_per_track)
-					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
-				alpha = apply_rounding_policy(alpha, policy);
+				const uint32_t track_index = first_track + j * k_wave_size + lane;
+				if (track_index < num_tracks)
+				{
+					float alpha = seek_alpha;
+					if (k_policies)
+					{
+						// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
+						uint32_t policy = rounding_policy;
+						if (rounding_policy == k_round_per_track)
+							policy = track_rounding_policies != nullptr ? track_rounding_policies[track_index] : k_round_none;
+						alpha = apply_rounding_policy(alpha, policy);
+					}
+					decode_scalar_track<C>(blob, headers, ranges, track_index, frame_bit_offset0, frame_bit_offset1, alpha, row + track_index * C);
+				}
 			}
-
-			decode_scalar_track_any(num_components, clip.blob, reinterpret_cast<const scalar_track_header*>(clip.plan), reinterpret_cast<const float*>(clip.clip_ranges),
-				track_index, key_frame0 * num_bits_per_frame, key_frame1 * num_bits_per_frame, alpha, row + track_index * num_components);
+		};
+		const auto decode_components = [=](auto components)
+		{
+			if (per_track_rounding)
+				decode_tracks(components, std::true_type());
+			else
+				decode_tracks(components, std::false_type());
+		};
+		switch (num_components)
+		{
+		case 1: decode_components(std::integral_constant<uint32_t, 1>()); break;
+		case 2: decode_components(std::integral_constant<uint32_t, 2>()); break;
+		case 3: decode_components(std::integral_constant<uint32_t, 3>()); break;
+		default: decode_components(std::integral_constant<uint32_t, 4>()); break;
 		}
 	}
 
