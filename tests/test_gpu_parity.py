@@ -208,3 +208,17 @@ def test_empty_batch_and_empty_clip(context):
     context.decompress_tracks(np.array([handle], dtype=np.uint32), np.zeros(1, dtype=np.float32), num_tracks=4, out=out)
     assert np.all(out == 5.0)       # empty track list: nothing is written (decompression.transform.h:1531-1533)
     context.unregister_clip(handle)
+
+
+def test_non_finite_sample_times_clamp_like_the_reference(context):
+    """scalar_clamp(sample_time, 0, duration) (decompression.transform.h:215-216) with NaN / infinite / huge times: the oracle agrees
+    with the reference on these (tests/test_oracle_vs_reference.py), the kernels must agree with the oracle."""
+    clip = synth.build_clip(**CLIP_SPECS["cmu_70_default"])
+    handle = context.register_clip(clip.blob)
+    times = np.array([np.nan, np.inf, -np.inf, 1e30, -1e30, -0.0], dtype=np.float32)
+    for policy in (0, 1, 2, 3):
+        poses = context.decompress_tracks(np.full(times.size, handle), times, params=runtime.default_params(rounding_policy=policy))
+        for i, t in enumerate(times):
+            expected = ob.oracle_decompress_tracks(clip.blob, float(t), policy)
+            assert helpers.bit_equal(poses[i], expected), f"time {t} policy {policy}"
+    context.unregister_clip(handle)

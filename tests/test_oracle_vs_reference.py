@@ -139,3 +139,11 @@ def test_database_streaming_states_bit_exact(max_chunk_size):
         assert (result == 1) == (moved != 0)
         check(f"after {(tier, num_chunks, stream_in)}")
     reference.close()
+
+
+def test_non_finite_sample_times():
+    clip = synth.build_clip(**CLIP_SPECS["cmu_70_default"])
+    for t in (float("nan"), float("inf"), float("-inf"), 1e30, -1e30, -0.0):
+        for policy in (ob.ROUND_NONE, ob.ROUND_FLOOR, ob.ROUND_CEIL, ob.ROUND_NEAREST):
+            expected = ob.ref_decompress(clip.blob, t, policy)
+            assert helpers.bit_equal(ob.oracle_decompress_tracks(clip.blob, t, policy), expected), f"time {t} policy {policy}"
