@@ -222,3 +222,33 @@ def test_non_finite_sample_times_clamp_like_the_reference(context):
             expected = ob.oracle_decompress_tracks(clip.blob, float(t), policy)
             assert helpers.bit_equal(poses[i], expected), f"time {t} policy {policy}"
     context.unregister_clip(handle)
+
+
+def test_context_is_usable_from_several_host_threads(context):
+    """Registration, host-pointer decodes and unregistration from four threads at once on one context (ctypes releases the GIL):
+    every thread must get its own clips' poses, bit for bit."""
+    import threading
+    errors = []
+
+    def worker(thread_index):
+        try:
+            rng = np.random.default_rng(1000 + thread_index)
+            for iteration in range(12):
+                clip = synth.build_clip(seed=5000 + thread_index * 100 + iteration, num_tracks=int(rng.integers(3, 40)), num_samples=int(rng.integers(2, 70)))
+                handle = context.register_clip(clip.blob)
+                times = rng.uniform(0.0, clip.duration, size=16).astype(np.float32)
+                poses = context.decompress_tracks(np.full(16, handle, dtype=np.uint32), times)
+                for i in range(16):
+                    if not helpers.bit_equal(poses[i], ob.oracle_decompress_tracks(clip.blob, float(times[i]))):
+                        errors.append((thread_index, iteration, i))
+                context.unregister_clip(handle)
+        except Exception as error:      # noqa: BLE001 -- reported below
+            errors.append((thread_index, repr(error)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for thread in threads:
+        thread.start()
+    for thread in threads:
+        thread.join(timeout=120)
+    assert not any(thread.is_alive() for thread in threads)
+    assert errors == []
