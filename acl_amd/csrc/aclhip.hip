@@ -824,11 +824,12 @@ struct aclhip_context
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
-	mutable std::string last_error;
 };
 
 namespace
 {
+	thread_local std::string t_last_error;
+
 	aclhip_status fail(const aclhip_context* context, aclhip_status status, const char* format, ...)
 	{
 		char buffer[512];
@@ -836,8 +837,8 @@ namespace
 		va_start(args, format);
 		std::vsnprintf(buffer, sizeof(buffer), format, args);
 		va_end(args);
-		if (context != nullptr)
-			context->last_error = buffer;
+		(void)context;
+		t_last_error = buffer;		// per thread: contexts are shared between threads, messages are not
 		return status;
 	}
 
@@ -1073,7 +1074,8 @@ extern "C" const char* aclhip_status_string(aclhip_status status)
 
 extern "C" const char* aclhip_last_error_message(const aclhip_context* context)
 {
-	return context != nullptr ? context->last_error.c_str() : "";
+	(void)context;
+	return t_last_error.c_str();
 }
 
 extern "C" void aclhip_default_params(aclhip_decompress_params* out_params)
@@ -2008,10 +2010,10 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 
 namespace
 {
-	aclhip_status report(const aclhip_context& scratch, aclhip_status status, char* out_message, uint32_t capacity)
+	aclhip_status report(const aclhip_context&, aclhip_status status, char* out_message, uint32_t capacity)
 	{
 		if (out_message != nullptr && capacity != 0)
-			std::snprintf(out_message, capacity, "%s", status == ACLHIP_OK ? "" : scratch.last_error.c_str());
+			std::snprintf(out_message, capacity, "%s", status == ACLHIP_OK ? "" : t_last_error.c_str());
 		return status;
 	}
 }

@@ -122,7 +122,7 @@ typedef struct aclhip_clip_info
 
 const char* aclhip_status_string(aclhip_status status);
 
-/* Message of the last failing call made through this context on any thread (empty string when none). */
+/* Message of the last failing call made on the CALLING thread (empty string when none); `context` is not used to find it. */
 const char* aclhip_last_error_message(const aclhip_context* context);
 
 /* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are
