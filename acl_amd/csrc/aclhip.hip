@@ -2185,6 +2185,10 @@ namespace
 	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
+		// launches read the clip table's address and the registry's maxima: enqueue under the registry lock, so that a registration
+		// that moves the table (it synchronizes the device first) never frees it under a launch that is being prepared
+		std::lock_guard<std::mutex> lock(context->mutex);
+
 		// one wave per (instance, pose window); instances of clips with fewer windows than the largest registered clip leave waves idle
 		const uint32_t windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
 		const uint64_t num_waves = uint64_t(num_instances) * windows_per_instance;
@@ -2254,6 +2258,7 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 	if (status != ACLHIP_OK)
 		return status;
 
+	std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
 	device_guard guard(context->device);
 	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
 	hipLaunchKernelGGL(decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
@@ -2396,6 +2401,7 @@ namespace
 		if (status != ACLHIP_OK)
 			return status;
 
+		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
 		device_guard guard(context->device);
 		if (track_indices != nullptr)
 		{
