@@ -2,7 +2,8 @@
 // acl_gpu::decompression_context<settings> with the interface of acl::decompression_context<settings>
 // (/root/reference/includes/acl/decompression/decompress.h:76-201), taking acl::compressed_tracks and acl::track_writer types and
 // running on the GPU through aclhip.hpp / libaclhip.so. This header needs the reference's headers (and RTM) on the include path; the
-// product itself does not include it. oracle/adapter_parity_test.cpp drives it next to the reference's own context.
+// product itself does not include it. The in-process parity program described in INTEGRATION.md section 2 drives it next to the
+// reference's own context.
 #pragma once
 
 #include <acl/core/compressed_tracks.h>
