@@ -48,6 +48,28 @@ namespace
 		void RTM_SIMD_CALL write_scale(uint32_t i, rtm::vector4f_arg0 v) { rtm::vector_store3(v, pose + size_t(i) * 12 + 8); }
 	};
 
+	// scalar track lists: value[track][component], what write_float1 .. write_vector4 receive
+	struct value_writer final : public acl::track_writer
+	{
+		float* values = nullptr;
+		float* pose = nullptr;		// (alias used by compare())
+		const uint8_t* per_track_policies = nullptr;
+		uint32_t num_components = 1;
+
+		acl::sample_rounding_policy get_rounding_policy(acl::sample_rounding_policy policy, uint32_t i) const
+		{
+			if (policy == acl::sample_rounding_policy::per_track)
+				return per_track_policies != nullptr ? static_cast<acl::sample_rounding_policy>(per_track_policies[i]) : acl::sample_rounding_policy::none;
+			return policy;
+		}
+
+		void RTM_SIMD_CALL write_float1(uint32_t i, rtm::scalarf_arg0 v) { pose[i] = rtm::scalar_cast(v); }
+		void RTM_SIMD_CALL write_float2(uint32_t i, rtm::vector4f_arg0 v) { rtm::vector_store2(v, pose + size_t(i) * 2); }
+		void RTM_SIMD_CALL write_float3(uint32_t i, rtm::vector4f_arg0 v) { rtm::vector_store3(v, pose + size_t(i) * 3); }
+		void RTM_SIMD_CALL write_float4(uint32_t i, rtm::vector4f_arg0 v) { rtm::vector_store(v, pose + size_t(i) * 4); }
+		void RTM_SIMD_CALL write_vector4(uint32_t i, rtm::vector4f_arg0 v) { rtm::vector_store(v, pose + size_t(i) * 4); }
+	};
+
 	template<class settings_type, class writer_type>
 	int compare(const acl::compressed_tracks& tracks, bool per_track)
 	{
@@ -64,7 +86,8 @@ namespace
 		for (uint32_t i = 0; i < num_tracks; ++i)
 			policies[i] = uint8_t((i * 7 + 1) % 4);
 
-		std::vector<float> cpu_pose(size_t(num_tracks) * 12), gpu_pose(size_t(num_tracks) * 12);
+		// 12 floats per track hold a qvv as well as any scalar sample
+		std::vector<float> cpu_pose(size_t(num_tracks) * 12 + 4), gpu_pose(size_t(num_tracks) * 12 + 4);
 		writer_type cpu_writer, gpu_writer;
 		cpu_writer.per_track_policies = gpu_writer.per_track_policies = policies.data();
 
@@ -120,6 +143,16 @@ int main(int argc, char** argv)
 		const acl::compressed_tracks& tracks = *reinterpret_cast<const acl::compressed_tracks*>(blob);
 		if (tracks.is_valid(true).any())
 			return 102;
+
+		if (tracks.get_track_type() != acl::track_type8::qvvf)
+		{
+			int result = compare<acl::default_scalar_decompression_settings, value_writer>(tracks, false);
+			if (result != 0) return 50 + result;
+			result = compare<acl::debug_scalar_decompression_settings, value_writer>(tracks, true);
+			if (result != 0) return 60 + result;
+			std::printf("%s: bit identical\n", argv[arg]);
+			continue;
+		}
 
 		using identity_writer = pose_writer<acl::default_sub_track_mode::constant, acl::default_sub_track_mode::legacy>;
 		using skipped_writer = pose_writer<acl::default_sub_track_mode::skipped, acl::default_sub_track_mode::skipped>;

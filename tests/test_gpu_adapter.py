@@ -28,6 +28,14 @@ def test_reference_context_and_gpu_adapter_agree_bit_for_bit(tmp_path):
             path = tmp_path / f"{name}.acl"
             helpers.load_golden(name)["blob"].tofile(path)
             paths.append(str(path))
+    for name in ("float1f_all_rates", "float3f_wrap", "vector4f_low_bits", "float2f_v2_0_rates"):
+        path = tmp_path / f"{name}.acl"
+        synth.build_scalar_clip(**helpers.SCALAR_CLIP_SPECS[name]).blob.tofile(path)
+        paths.append(str(path))
+    for name in helpers.scalar_golden_cases():      # scalar lists written by the reference's own compressor
+        path = tmp_path / f"scalar_{name}.acl"
+        helpers.load_scalar_golden(name)["blob"].tofile(path)
+        paths.append(str(path))
     result = subprocess.run([BINARY] + paths, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0, f"exit code {result.returncode}\n{result.stdout}\n{result.stderr}"
     assert result.stdout.count("bit identical") == len(paths)
