@@ -32,7 +32,7 @@ typedef enum aclhip_status
 	ACLHIP_OK = 0,
 	ACLHIP_ERROR_INVALID_ARGUMENT = 1,
 	ACLHIP_ERROR_INVALID_CLIP = 2,			/* compressed_tracks::is_valid() would fail (core/impl/compressed_tracks.impl.h:278-301) */
-	ACLHIP_ERROR_UNSUPPORTED_FORMAT = 3,	/* not qvvf / not quatf_drop_w_variable + vector3f_variable */
+	ACLHIP_ERROR_UNSUPPORTED_FORMAT = 3,	/* a transform clip that is not quatf_drop_w_variable + vector3f_variable, an unknown track type */
 	ACLHIP_ERROR_UNKNOWN_CLIP = 4,
 	ACLHIP_ERROR_OUT_OF_MEMORY = 5,
 	ACLHIP_ERROR_DEVICE = 6,				/* a HIP call failed, see aclhip_last_error_message */
@@ -205,7 +205,7 @@ aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_databas
  * with writer.write_rotation/translation/scale storing into
  *     (char*)poses + i * pose_stride_bytes + track_index * 48.
  * clips / sample_times / poses are DEVICE pointers; pose_stride_bytes must be a multiple of 16 and at least
- * 48 * num_tracks of the largest clip referenced. One wavefront decodes one instance. */
+ * 48 * num_tracks of the largest clip referenced. One wavefront decodes one window of 320 pose quads (106 tracks) of one instance. */
 aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream);
 
