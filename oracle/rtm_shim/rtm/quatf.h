@@ -19,16 +19,29 @@ namespace rtm
 
 	inline quatf quat_conjugate(quatf q) noexcept { return _mm_xor_ps(q, _mm_set_ps(0.0F, -0.0F, -0.0F, -0.0F)); }
 
-	// Hamilton product in RTM's convention: quat_mul(lhs, rhs) applies lhs first, then rhs.
+	// Hamilton product in RTM's convention: quat_mul(lhs, rhs) applies lhs first, then rhs. The four products of every lane are
+	// summed pairwise, (a*rw + b*rx) + (c*ry + d*rz), with the signs applied to the products before the additions: the
+	// association of RTM's SSE2 form (whole-register multiplies by rhs.wwww / xxxx / yyyy / zzzz, sign flips, two adds, one add).
 	inline quatf quat_mul(quatf lhs, quatf rhs) noexcept
 	{
-		const float lx = vector_get_x(lhs), ly = vector_get_y(lhs), lz = vector_get_z(lhs), lw = vector_get_w(lhs);
-		const float rx = vector_get_x(rhs), ry = vector_get_y(rhs), rz = vector_get_z(rhs), rw = vector_get_w(rhs);
-		const float x = (rw * lx) + (rx * lw) + (ry * lz) - (rz * ly);
-		const float y = (rw * ly) - (rx * lz) + (ry * lw) + (rz * lx);
-		const float z = (rw * lz) + (rx * ly) - (ry * lx) + (rz * lw);
-		const float w = (rw * lw) - (rx * lx) - (ry * ly) - (rz * lz);
-		return quat_set(x, y, z, w);
+		const __m128 sign_wzyx = _mm_set_ps(-0.0F, 0.0F, -0.0F, 0.0F);		// lanes x, y, z, w = +, -, +, -
+		const __m128 sign_zwxy = _mm_set_ps(-0.0F, -0.0F, 0.0F, 0.0F);		// +, +, -, -
+		const __m128 sign_yxwz = _mm_set_ps(-0.0F, 0.0F, 0.0F, -0.0F);		// -, +, +, -
+
+		const __m128 r_xxxx = _mm_shuffle_ps(rhs, rhs, _MM_SHUFFLE(0, 0, 0, 0));
+		const __m128 r_yyyy = _mm_shuffle_ps(rhs, rhs, _MM_SHUFFLE(1, 1, 1, 1));
+		const __m128 r_zzzz = _mm_shuffle_ps(rhs, rhs, _MM_SHUFFLE(2, 2, 2, 2));
+		const __m128 r_wwww = _mm_shuffle_ps(rhs, rhs, _MM_SHUFFLE(3, 3, 3, 3));
+
+		const __m128 l_wzyx = _mm_shuffle_ps(lhs, lhs, _MM_SHUFFLE(0, 1, 2, 3));
+		const __m128 l_zwxy = _mm_shuffle_ps(lhs, lhs, _MM_SHUFFLE(1, 0, 3, 2));
+		const __m128 l_yxwz = _mm_shuffle_ps(lhs, lhs, _MM_SHUFFLE(2, 3, 0, 1));
+
+		const __m128 by_w = _mm_mul_ps(r_wwww, lhs);
+		const __m128 by_x = _mm_xor_ps(_mm_mul_ps(r_xxxx, l_wzyx), sign_wzyx);
+		const __m128 by_y = _mm_xor_ps(_mm_mul_ps(r_yyyy, l_zwxy), sign_zwxy);
+		const __m128 by_z = _mm_xor_ps(_mm_mul_ps(r_zzzz, l_yxwz), sign_yxwz);
+		return _mm_add_ps(_mm_add_ps(by_w, by_x), _mm_add_ps(by_y, by_z));
 	}
 
 	// Rotates a vector3: q^-1 * v * q in RTM's multiplication convention.
