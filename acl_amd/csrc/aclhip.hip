@@ -110,6 +110,65 @@ namespace aclhip
 		return default_quad(params, kind, track_index, value, out_store);
 	}
 
+	// Lanes <-> the animated sub-tracks [first_ordinal, end_ordinal) of one pose window, decoded into their quads of the window's LDS
+	// image (image[0] = quad first_quad of the pose). Most sample times fall between two keyframes of ONE segment: both keys then
+	// share a plan row and it is fetched once (a third less table traffic through the texture unit).
+	template<bool kSingleSegment, bool kPolicies>
+	__device__ __forceinline__ void decode_window_sub_tracks_with(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+	{
+		// kPolicies: per track rounding (and the sample normalization it implies)
+		const bool normalize_samples = kPolicies && normalization == ACLHIP_NORMALIZE_ALWAYS;
+
+		for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
+		{
+			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
+			const plan_entry plan1_loaded = kSingleSegment ? plan0 : load_entry(state.plan[1], animated_ordinal);
+			const plan_entry& plan1 = kSingleSegment ? plan0 : plan1_loaded;
+			const clip_range_entry clip_range = load_entry(clip_ranges, animated_ordinal);
+			const bool is_rotation = is_rotation_entry(clip_range);
+
+			uint32_t policy = k_round_none;
+			if (kPolicies)
+			{
+				// track_writer::get_rounding_policy (core/track_writer.h:97)
+				policy = rounding_policy;
+				if (rounding_policy == k_round_per_track)
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
+			}
+
+			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
+			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+
+			float4 value;
+			if (!has_raw)
+				value = decode_animated_sub_track<false, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+			else
+				value = decode_animated_sub_track<true, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+
+			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
+			const f32x4 packed = { value.x, value.y, value.z, value.w };
+			image[clip_range.quad_index - first_quad] = packed;
+		}
+	}
+
+	template<bool kAnySettings>
+	__device__ __forceinline__ void decode_window_sub_tracks(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+	{
+		if (kAnySettings && params.per_track_rounding != 0)
+		{
+			if (state.uses_single_segment)
+				decode_window_sub_tracks_with<true, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			else
+				decode_window_sub_tracks_with<false, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		}
+		else if (state.uses_single_segment)
+			decode_window_sub_tracks_with<true, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		else
+			decode_window_sub_tracks_with<false, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+	}
+
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
 	// 100 bone pose is a single window), built in 5 KiB of LDS:
 	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
@@ -217,57 +276,8 @@ namespace aclhip
 			}
 		}
 
-		// lanes <-> animated sub-tracks of this window. Most sample times fall between two keyframes of ONE segment: both keys then
-		// share a plan row and it is fetched once (a third less table traffic through the texture unit).
-		const auto decode_window = [&](auto single_segment, auto with_policies)
-		{
-			constexpr bool k_single_segment = decltype(single_segment)::value;
-			constexpr bool k_policies = decltype(with_policies)::value;		// per track rounding (and the sample normalization it implies)
-			const bool normalize_samples = k_policies && normalization == ACLHIP_NORMALIZE_ALWAYS;
-
-			for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
-			{
-				const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-				const plan_entry plan1_loaded = k_single_segment ? plan0 : load_entry(state.plan[1], animated_ordinal);
-				const plan_entry& plan1 = k_single_segment ? plan0 : plan1_loaded;
-				const clip_range_entry clip_range = load_entry(clip.clip_ranges, animated_ordinal);
-				const bool is_rotation = is_rotation_entry(clip_range);
-
-				uint32_t policy = k_round_none;
-				if (k_policies)
-				{
-					// track_writer::get_rounding_policy (core/track_writer.h:97)
-					policy = rounding_policy;
-					if (rounding_policy == k_round_per_track)
-						policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
-				}
-
-				// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
-				const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
-
-				float4 value;
-				if (!has_raw)
-					value = decode_animated_sub_track<false, k_policies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
-				else
-					value = decode_animated_sub_track<true, k_policies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
-
-				// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
-				const f32x4 packed = { value.x, value.y, value.z, value.w };
-				image[clip_range.quad_index - first_quad] = packed;
-			}
-		};
-
-		if (kAnySettings && params.per_track_rounding != 0)
-		{
-			if (state.uses_single_segment)
-				decode_window(std::true_type(), std::true_type());
-			else
-				decode_window(std::false_type(), std::true_type());
-		}
-		else if (state.uses_single_segment)
-			decode_window(std::true_type(), std::false_type());
-		else
-			decode_window(std::false_type(), std::false_type());
+		// lanes <-> animated sub-tracks of this window
+		decode_window_sub_tracks<kAnySettings>(clip.clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -338,6 +348,173 @@ namespace aclhip
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
 	{
 		decompress_tracks_window<true>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+	}
+
+	// ---- pose consumers -----------------------------------------------------------------------------------------------
+	// Decodes the whole local pose of one clip instance into an LDS image (image[0] = quad 0), window by window like the pose kernels
+	// but in ONE wave, because what follows needs every transform of the pose. Common-case settings only (see launch_consumers).
+	__device__ __forceinline__ void decode_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		uint32_t lane, f32x4* image)
+	{
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		{
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
+			for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+			{
+				if (base + lane < num_quads)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
+						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+			}
+		}
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		if (num_quads <= k_image_chunk_quads)
+			decode_window_sub_tracks<false>(clip.clip_ranges, state, params, rounding_policy, params.normalization, 0, clip.num_animated, 0, lane, image);
+		else
+		{
+			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
+			for (uint32_t window = 0; window < num_windows; ++window)
+			{
+				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
+				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
+				decode_window_sub_tracks<false>(clip.clip_ranges, state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, 0, lane, image);
+			}
+		}
+	}
+
+	__device__ __forceinline__ void wave_lds_barrier()
+	{
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+
+	__device__ __forceinline__ qvv load_qvv(const f32x4* image, uint32_t transform_index)
+	{
+		const f32x4 r = image[transform_index * 3u + 0], t = image[transform_index * 3u + 1], s = image[transform_index * 3u + 2];
+		qvv value;
+		value.rotation = make_float4(r.x, r.y, r.z, r.w);
+		value.translation = make_float4(t.x, t.y, t.z, 0.0f);
+		value.scale = make_float4(s.x, s.y, s.z, 0.0f);
+		return value;
+	}
+
+	__device__ __forceinline__ void store_qvv(f32x4* image, uint32_t transform_index, const qvv& value)
+	{
+		image[transform_index * 3u + 0] = f32x4{ value.rotation.x, value.rotation.y, value.rotation.z, value.rotation.w };
+		image[transform_index * 3u + 1] = f32x4{ value.translation.x, value.translation.y, value.translation.z, 0.0f };
+		image[transform_index * 3u + 2] = f32x4{ value.scale.x, value.scale.y, value.scale.z, 0.0f };
+	}
+
+	// One wave64 per instance: decode the (additive) clip instance -- and its base clip instance, when the base is a clip -- into LDS,
+	// combine them per transform (apply_additive_to_base, core/additive_utils.h:150), walk the hierarchy level by level
+	// (local_to_object_space, compression/transform_pose_utils.h:35: lanes <-> the transforms of one depth, whose parents are final),
+	// then stream the finished pose out. What a caller would otherwise do in further passes over the pose buffer in HBM happens on
+	// the 5 KiB image the decode already holds.
+	__global__ __launch_bounds__(k_block_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
+		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t images_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t instance = blockIdx.x * (blockDim.x / k_wave_size) + wave_in_block;
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		const bool has_base = consumers.additive_format != 0;
+		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
+
+		// rejected: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images
+		bool rejected = clip_id >= num_clips || !is_transform_clip(clip.flags) || (consumers.object_space != 0 && clip.hierarchy == nullptr)
+			|| clip.num_tracks * 3u > lds_quads_per_image;
+
+		uint32_t base_clip_id = 0;
+		float base_sample_time = 0.0f;
+		if (base_is_clip)
+		{
+			base_clip_id = as_constant(consumers.base_clip_ids)[instance];
+			base_sample_time = as_constant(consumers.base_sample_times)[instance];
+			rejected = rejected || base_clip_id >= num_clips;
+		}
+		if (rejected)
+		{
+			if (lane == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const uint32_t num_tracks = clip.num_tracks;
+		if (num_tracks == 0)
+			return;
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+
+		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * images_per_wave * lds_quads_per_image;
+		f32x4* base_image = image + lds_quads_per_image;
+
+		if (base_is_clip)
+		{
+			// the base must describe the same transforms (the reference asserts matching track counts where it combines them)
+			const device_clip base_clip = load_clip(clips, base_clip_id);
+			if (!is_transform_clip(base_clip.flags) || base_clip.num_tracks != num_tracks)
+			{
+				if (lane == 0)
+					atomicAdd(rejected_count, 1ull);
+				return;
+			}
+			decode_pose_into_image(base_clip, base_sample_time, rounding_policy, params, lane, base_image);
+		}
+
+		decode_pose_into_image(clip, sample_time, rounding_policy, params, lane, image);
+		wave_lds_barrier();
+
+		if (has_base)
+		{
+			const f32x4* base_source = base_is_clip ? base_image : reinterpret_cast<const f32x4*>(consumers.base_poses + uint64_t(instance) * consumers.base_pose_stride_bytes);
+			for (uint32_t transform_index = lane; transform_index < num_tracks; transform_index += k_wave_size)
+			{
+				const qvv additive = load_qvv(image, transform_index);
+				const qvv base = load_qvv(base_source, transform_index);
+				store_qvv(image, transform_index, apply_additive_to_base(consumers.additive_format, base, additive));
+			}
+			wave_lds_barrier();
+		}
+
+		if (consumers.object_space != 0)
+		{
+			const ACLHIP_CONSTANT uint32_t* hierarchy = as_constant(clip.hierarchy);
+			const uint32_t num_levels = hierarchy[0];
+			const uint2* pairs = reinterpret_cast<const uint2*>(clip.hierarchy + 1 + num_levels + ((num_levels & 1u) == 0 ? 1 : 0));
+			uint32_t level_start = 0;
+			for (uint32_t level = 0; level < num_levels; ++level)
+			{
+				const uint32_t level_end = hierarchy[1 + level];
+				for (uint32_t pair_index = level_start + lane; pair_index < level_end; pair_index += k_wave_size)
+				{
+					const uint2 pair = pairs[pair_index];		// x: transform, y: its parent (one level up or higher: final by now)
+					qvv object = qvv_mul(load_qvv(image, pair.x), load_qvv(image, pair.y));
+					object.rotation = quat_normalize(object.rotation);
+					store_qvv(image, pair.x, object);
+				}
+				wave_lds_barrier();
+				level_start = level_end;
+			}
+		}
+
+		const uint32_t num_quads = num_tracks * 3u;
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+			pose[quad] = image[quad];
 	}
 
 	// The instance list of convert_track_list's sampling loop (compression/impl/convert.impl.h:161-166): one instance per sample at
@@ -785,6 +962,7 @@ namespace
 		bool in_use = false;
 		uint32_t database = ACLHIP_INVALID_HANDLE;
 		void* device_memory = nullptr;		// one allocation: blob | base pose | quad map | animated tracks
+		uint32_t* d_hierarchy = nullptr;	// aclhip_set_clip_hierarchy
 		aclhip_clip_info info = {};
 		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
 	};
@@ -1143,6 +1321,9 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 		for (host_clip& clip : context->clips)
 			if (clip.in_use && clip.device_memory != nullptr)
 				(void)hipFree(clip.device_memory);
+		for (host_clip& clip : context->clips)
+			if (clip.in_use && clip.d_hierarchy != nullptr)
+				(void)hipFree(clip.d_hierarchy);
 		for (host_database& db : context->databases)
 		{
 			if (!db.in_use)
@@ -1823,6 +2004,8 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
 	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
 	ACLHIP_CHECK_HIP(context, hipFree(context->clips[clip].device_memory));
+	if (context->clips[clip].d_hierarchy != nullptr)
+		(void)hipFree(context->clips[clip].d_hierarchy);
 	const uint32_t bound_database = context->clips[clip].database;
 	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
 		context->databases[bound_database].num_bound_clips--;
@@ -2268,11 +2451,161 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 	return ACLHIP_OK;
 }
 
+// ---- pose consumers ------------------------------------------------------------------------------------------------
+
+extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (parent_indices == nullptr && num_tracks != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null parent index list");
+
+	return guarded(context, [&]() -> aclhip_status
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+		host_clip& entry = context->clips[clip];
+		if (entry.info.track_type != k_track_type_qvvf)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "clip %u is a scalar track list: no hierarchy", clip);
+		if (entry.info.num_tracks != num_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u parent indices for a clip of %u tracks", num_tracks, entry.info.num_tracks);
+
+		// depth of every transform; local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order
+		// and needs parents first, which makes the result independent of the order INSIDE a depth: lanes take one depth at a time
+		std::vector<uint32_t> depth(num_tracks, 0);
+		uint32_t num_levels = 0;
+		for (uint32_t i = 1; i < num_tracks; ++i)
+		{
+			const uint32_t parent = parent_indices[i];
+			if (parent == ACLHIP_NO_PARENT)
+				continue;
+			if (parent >= i)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", i, parent);
+			depth[i] = depth[parent] + 1;
+			num_levels = std::max(num_levels, depth[i]);
+		}
+
+		// num_levels | level_end[num_levels] | pad to 8 bytes | {transform, parent} of depth 1, depth 2, ...
+		const uint32_t header_words = (1 + num_levels + 1) & ~1u;
+		std::vector<uint32_t> level_end(num_levels, 0);
+		for (uint32_t i = 1; i < num_tracks; ++i)
+			if (depth[i] != 0)
+				level_end[depth[i] - 1]++;
+		for (uint32_t level = 1; level < num_levels; ++level)
+			level_end[level] += level_end[level - 1];
+		const uint32_t num_pairs = num_levels != 0 ? level_end[num_levels - 1] : 0;
+		std::vector<uint32_t> image(size_t(header_words) + size_t(num_pairs) * 2, 0);
+		image[0] = num_levels;
+		std::vector<uint32_t> cursor(num_levels, 0);
+		for (uint32_t level = 1; level < num_levels; ++level)
+			cursor[level] = level_end[level - 1];
+		for (uint32_t i = 1; i < num_tracks; ++i)
+		{
+			if (depth[i] == 0)
+				continue;
+			const uint32_t slot = cursor[depth[i] - 1]++;
+			image[header_words + size_t(slot) * 2 + 0] = i;
+			image[header_words + size_t(slot) * 2 + 1] = parent_indices[i];
+		}
+		std::copy(level_end.begin(), level_end.end(), image.begin() + 1);
+
+		device_guard guard(context->device);
+		uint32_t* d_hierarchy = nullptr;
+		if (hipMalloc(reinterpret_cast<void**>(&d_hierarchy), image.size() * sizeof(uint32_t)) != hipSuccess)
+			return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed", image.size() * sizeof(uint32_t));
+		hipError_t hip_status = hipMemcpy(d_hierarchy, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+		// launches in flight may still walk the hierarchy that is being replaced
+		if (hip_status == hipSuccess)
+			hip_status = hipDeviceSynchronize();
+		if (hip_status == hipSuccess)
+			hip_status = hipMemcpy(reinterpret_cast<uint8_t*>(context->d_clips + clip) + offsetof(device_clip, hierarchy), &d_hierarchy, sizeof(d_hierarchy), hipMemcpyHostToDevice);
+		if (hip_status != hipSuccess)
+		{
+			(void)hipFree(d_hierarchy);
+			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the hierarchy failed: %s", hipGetErrorString(hip_status));
+		}
+		if (entry.d_hierarchy != nullptr)
+			(void)hipFree(entry.d_hierarchy);
+		entry.d_hierarchy = d_hierarchy;
+		return ACLHIP_OK;
+	});
+}
+
+namespace
+{
+	aclhip_status launch_consumers(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+		const decode_params& params, const aclhip_pose_consumers& consumers, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
+	{
+		if (consumers.additive_format > ACLHIP_ADDITIVE_ADDITIVE1)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown additive format %u", consumers.additive_format);
+		const bool has_base = consumers.additive_format != ACLHIP_ADDITIVE_NONE;
+		const bool base_is_clip = has_base && consumers.base_clips != nullptr;
+		if (base_is_clip && consumers.base_sample_times == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "base clips without base sample times");
+		if (has_base && !base_is_clip && (consumers.base_poses == nullptr || (consumers.base_pose_stride_bytes & 15u) != 0 || (reinterpret_cast<uintptr_t>(consumers.base_poses) & 15u) != 0))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an additive format needs base clips or a 16 byte aligned base pose buffer");
+		// a consumer needs every sub-track of the pose: the track_writer's own defaults (what the resolved pose image holds)
+		if (params.standard_defaults == 0 || params.per_track_rounding != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding, normalization != always");
+
+		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+
+		// one wave per instance, the whole pose (and its base) in LDS
+		const uint32_t images_per_wave = base_is_clip ? 2 : 1;
+		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64);
+		const size_t lds_bytes_per_wave = size_t(lds_quads_per_image) * 16 * images_per_wave;
+		constexpr size_t k_lds_bytes = 160 * 1024;
+		if (lds_bytes_per_wave > k_lds_bytes)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per wave)", context->max_pose_quads / 3, lds_bytes_per_wave);
+		const uint32_t waves_per_block = uint32_t(std::min<size_t>(k_waves_per_block, k_lds_bytes / lds_bytes_per_wave));
+		const uint32_t num_blocks = (num_instances + waves_per_block - 1) / waves_per_block;
+		const size_t lds_bytes = lds_bytes_per_wave * waves_per_block;
+		if (lds_bytes > 64 * 1024)
+			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(decompress_poses_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
+
+		consumer_params device_consumers;
+		device_consumers.base_clip_ids = base_is_clip ? consumers.base_clips : nullptr;
+		device_consumers.base_sample_times = base_is_clip ? consumers.base_sample_times : nullptr;
+		device_consumers.base_poses = has_base && !base_is_clip ? static_cast<const uint8_t*>(consumers.base_poses) : nullptr;
+		device_consumers.base_pose_stride_bytes = consumers.base_pose_stride_bytes;
+		device_consumers.additive_format = consumers.additive_format;
+		device_consumers.object_space = consumers.object_space != 0 ? 1 : 0;
+
+		hipLaunchKernelGGL(decompress_poses_consumer_kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
+			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, images_per_wave, context->d_rejected);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (consumers == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null consumers");
+	if (num_instances == 0)
+		return ACLHIP_OK;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	return launch_consumers(context, clips, sample_times, num_instances, device_params, *consumers, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
 namespace
 {
 	// Host pointer convenience path: upload, launch, download, synchronously
 	aclhip_status decompress_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
-		const aclhip_decompress_params* params, uint32_t default_values_count, void* out, uint64_t out_stride_bytes, uint64_t out_row_bytes)
+		const aclhip_decompress_params* params, uint32_t default_values_count, void* out, uint64_t out_stride_bytes, uint64_t out_row_bytes,
+		const aclhip_pose_consumers* consumers = nullptr)
 	{
 		if (context == nullptr)
 			return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -2325,6 +2658,29 @@ namespace
 			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
 		if (ok && local.instance_rounding_policies != nullptr)
 			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+
+		aclhip_pose_consumers local_consumers = {};
+		if (consumers != nullptr)
+		{
+			local_consumers = *consumers;
+			void* d_base_clips = nullptr; void* d_base_times = nullptr; void* d_base_poses = nullptr;
+			if (ok && consumers->base_clips != nullptr)
+				ok = upload(consumers->base_clips, sizeof(uint32_t) * num_instances, &d_base_clips);
+			if (ok && consumers->base_sample_times != nullptr)
+				ok = upload(consumers->base_sample_times, sizeof(float) * num_instances, &d_base_times);
+			if (ok && consumers->base_poses != nullptr && consumers->base_clips == nullptr && consumers->additive_format != ACLHIP_ADDITIVE_NONE)
+			{
+				if (consumers->base_pose_stride_bytes < uint64_t(max_tracks) * 48)
+				{
+					release();
+					return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "base pose stride %llu is smaller than a pose of %u transforms", (unsigned long long)consumers->base_pose_stride_bytes, max_tracks);
+				}
+				ok = upload(consumers->base_poses, size_t(consumers->base_pose_stride_bytes) * num_instances, &d_base_poses);
+			}
+			local_consumers.base_clips = static_cast<const aclhip_clip*>(d_base_clips);
+			local_consumers.base_sample_times = static_cast<const float*>(d_base_times);
+			local_consumers.base_poses = d_base_poses;
+		}
 		if (!ok)
 		{
 			release();
@@ -2349,6 +2705,8 @@ namespace
 		aclhip_status status;
 		if (single_track)
 			status = aclhip_decompress_track_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks), num_instances, &local, d_out, nullptr);
+		else if (consumers != nullptr)
+			status = aclhip_decompress_poses_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, &local_consumers, d_out, device_stride, nullptr);
 		else
 			status = aclhip_decompress_tracks_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, d_out, device_stride, nullptr);
 
@@ -2370,6 +2728,16 @@ extern "C" aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, 
 	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes)
 {
 	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, default_values_count, poses, pose_stride_bytes, 0);
+}
+
+extern "C" aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes)
+{
+	if (consumers == nullptr)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null consumers") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (params != nullptr && (params->default_values != nullptr || params->track_rounding_policies != nullptr))
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, 0, poses, pose_stride_bytes, 0, consumers);
 }
 
 extern "C" aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
@@ -2500,6 +2868,7 @@ namespace
 			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
 		if (ok && local.instance_rounding_policies != nullptr)
 			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+
 		if (!ok)
 		{
 			release();
@@ -2669,6 +3038,38 @@ extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* con
 	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
 	for (uint32_t i = 0; i < repeats && status == ACLHIP_OK; ++i)
 		status = launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, hip_stream);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_ms_per_launch = elapsed_ms / float(repeats);
+	return status;
+}
+
+extern "C" aclhip_status aclhip_time_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch)
+{
+	if (out_ms_per_launch == nullptr || repeats == 0 || consumers == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats && status == ACLHIP_OK; ++i)
+		status = launch_consumers(context, clips, sample_times, num_instances, device_params, *consumers, poses, pose_stride_bytes, hip_stream);
 	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
 	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
 	float elapsed_ms = 0.0f;

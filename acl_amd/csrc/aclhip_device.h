@@ -116,7 +116,7 @@ namespace aclhip
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
 		uint32_t db_clip_header_offset;			// into db_headers
 		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
-		uint32_t reserved[2];
+		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: num_levels | level_end[num_levels] | {child, parent} pairs by level; or null
 	};
 
 	static_assert(sizeof(device_clip) == 128, "layout");
@@ -147,6 +147,17 @@ namespace aclhip
 		uint8_t default_modes[3];
 		uint8_t standard_defaults;		// 1 when default sub-tracks take the track_writer defaults (identity / zero / legacy scale) and normalization != always
 		uint8_t standard_default_modes;	// 1 when default sub-tracks take the track_writer defaults, whatever the normalization policy
+	};
+
+	// What happens to a decoded (local space) pose before it is stored (aclhip_pose_consumers resolved to device pointers)
+	struct consumer_params
+	{
+		const uint32_t* base_clip_ids;		// [num_instances] the base clip instance each (additive) instance applies onto, or null
+		const float* base_sample_times;
+		const uint8_t* base_poses;			// precomputed base poses when base_clip_ids is null
+		uint64_t base_pose_stride_bytes;
+		uint32_t additive_format;			// acl::additive_clip_format8; 0 = no base
+		uint32_t object_space;				// 1: local -> object space with the clip's hierarchy
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)
@@ -491,5 +502,68 @@ namespace aclhip
 		}
 
 		return make_float4(lerp_stable(v0[0], v1[0], lerp_alpha), lerp_stable(v0[1], v1[1], lerp_alpha), lerp_stable(v0[2], v1[2], lerp_alpha), 0.0f);
+	}
+
+	// ---- pose consumers (core/additive_utils.h:128-160, compression/transform_pose_utils.h:35-50) ----------------------------------
+	// The reference writes these in Realtime Math (rtm::quat_mul / qvv_mul / qvv_normalize), a submodule that is absent from its
+	// checkout: restated from RTM's x86 forms -- every lane of quat_mul sums its four products pairwise, (a + b) + (c + d), signs
+	// folded into the products -- with two documented differences: the rotation is normalized with the decoder's
+	// own correctly rounded sqrt + division (RTM starts from the hardware rsqrt ESTIMATE, which is not reproducible between CPUs),
+	// and negative scales do not take RTM's detour through a matrix.
+	struct qvv
+	{
+		float4 rotation;
+		float4 translation;		// w = 0
+		float4 scale;			// w = 0
+	};
+
+	__device__ __forceinline__ float4 quat_mul(float4 lhs, float4 rhs)
+	{
+		const float x = ((rhs.w * lhs.x) + (rhs.x * lhs.w)) + ((rhs.y * lhs.z) + -(rhs.z * lhs.y));
+		const float y = ((rhs.w * lhs.y) + -(rhs.x * lhs.z)) + ((rhs.y * lhs.w) + (rhs.z * lhs.x));
+		const float z = ((rhs.w * lhs.z) + (rhs.x * lhs.y)) + (-(rhs.y * lhs.x) + (rhs.z * lhs.w));
+		const float w = ((rhs.w * lhs.w) + -(rhs.x * lhs.x)) + (-(rhs.y * lhs.y) + -(rhs.z * lhs.z));
+		return make_float4(x, y, z, w);
+	}
+
+	// quat_mul(quat_mul(conjugate(rotation), (vector.xyz, 0)), rotation); the W lane of the result is numeric residue and dropped
+	__device__ __forceinline__ float4 quat_mul_vector3(float4 vector, float4 rotation)
+	{
+		const float4 vector_quat = make_float4(vector.x, vector.y, vector.z, 0.0f);
+		const float4 inv_rotation = make_float4(-rotation.x, -rotation.y, -rotation.z, rotation.w);
+		const float4 result = quat_mul(quat_mul(inv_rotation, vector_quat), rotation);
+		return make_float4(result.x, result.y, result.z, 0.0f);
+	}
+
+	// lhs first, then rhs (child, then parent)
+	__device__ __forceinline__ qvv qvv_mul(const qvv& lhs, const qvv& rhs)
+	{
+		qvv result;
+		result.rotation = quat_mul(lhs.rotation, rhs.rotation);
+		const float4 scaled = make_float4(lhs.translation.x * rhs.scale.x, lhs.translation.y * rhs.scale.y, lhs.translation.z * rhs.scale.z, 0.0f);
+		const float4 rotated = quat_mul_vector3(scaled, rhs.rotation);
+		result.translation = make_float4(rotated.x + rhs.translation.x, rotated.y + rhs.translation.y, rotated.z + rhs.translation.z, 0.0f);
+		result.scale = make_float4(lhs.scale.x * rhs.scale.x, lhs.scale.y * rhs.scale.y, lhs.scale.z * rhs.scale.z, 0.0f);
+		return result;
+	}
+
+	// apply_additive_to_base (core/additive_utils.h:150-160); format: acl::additive_clip_format8
+	__device__ __forceinline__ qvv apply_additive_to_base(uint32_t additive_format, const qvv& base, const qvv& additive)
+	{
+		if (additive_format == 1)
+			return qvv_mul(additive, base);
+		if (additive_format == 2 || additive_format == 3)
+		{
+			// transform_add0 / transform_add1 (:128-142)
+			qvv result;
+			result.rotation = quat_mul(additive.rotation, base.rotation);
+			result.translation = make_float4(additive.translation.x + base.translation.x, additive.translation.y + base.translation.y, additive.translation.z + base.translation.z, 0.0f);
+			if (additive_format == 2)
+				result.scale = make_float4(additive.scale.x * base.scale.x, additive.scale.y * base.scale.y, additive.scale.z * base.scale.z, 0.0f);
+			else
+				result.scale = make_float4((1.0f + additive.scale.x) * base.scale.x, (1.0f + additive.scale.y) * base.scale.y, (1.0f + additive.scale.z) * base.scale.z, 0.0f);
+			return result;
+		}
+		return additive;
 	}
 }

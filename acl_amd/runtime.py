@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_database_stream_in", "aclhip_database_stream_out",
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
+    "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
 
@@ -39,6 +40,18 @@ class DecompressParams(ctypes.Structure):
         ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("default_values", ctypes.c_void_p), ("track_rounding_policies", ctypes.c_void_p), ("instance_rounding_policies", ctypes.c_void_p),
     ]
+
+
+class PoseConsumers(ctypes.Structure):
+    """aclhip_pose_consumers"""
+    _fields_ = [
+        ("additive_format", ctypes.c_uint32), ("object_space", ctypes.c_uint32),
+        ("base_clips", ctypes.c_void_p), ("base_sample_times", ctypes.c_void_p), ("base_poses", ctypes.c_void_p), ("base_pose_stride_bytes", ctypes.c_uint64),
+    ]
+
+
+ADDITIVE_NONE, ADDITIVE_RELATIVE, ADDITIVE_ADDITIVE0, ADDITIVE_ADDITIVE1 = 0, 1, 2, 3  # aclhip_additive_format
+NO_PARENT = 0xFFFFFFFF
 
 
 class ClipInfo(ctypes.Structure):
@@ -130,6 +143,11 @@ def load_library():
     lib.aclhip_decompress_scalar_track_batch.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_decompress_scalar_tracks_host.argtypes = [vp, vp, vp, u32, pparams, vp, u64]
     lib.aclhip_decompress_scalar_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64]
+    pconsumers = ctypes.POINTER(PoseConsumers)
+    lib.aclhip_set_clip_hierarchy.argtypes = [vp, u32, vp, u32]
+    lib.aclhip_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp]
+    lib.aclhip_decompress_poses_host.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64]
+    lib.aclhip_time_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_float)]
     _lib = lib
     return lib
 
@@ -271,6 +289,52 @@ class Context:
         ms = ctypes.c_float(0.0)
         self._check(self._lib.aclhip_time_decompress_tracks_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream, repeats, ctypes.byref(ms)))
         return ms.value
+
+    # ---- pose consumers: additive apply and local -> object space fused into the decode ----
+    def set_clip_hierarchy(self, clip, parent_indices):
+        parents = np.ascontiguousarray(parent_indices, dtype=np.uint32)
+        self._check(self._lib.aclhip_set_clip_hierarchy(self._handle, clip, parents.ctypes.data, parents.size))
+
+    def decompress_poses_batch(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, consumers, params=None, stream=None):
+        """aclhip_decompress_poses_batch; `consumers` is a PoseConsumers holding device addresses."""
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_poses_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), ctypes.byref(consumers), poses_ptr, pose_stride_bytes, stream))
+
+    def time_decompress_poses_batch(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, consumers, repeats, params=None, stream=None):
+        params = params if params is not None else default_params()
+        ms = ctypes.c_float(0.0)
+        self._check(self._lib.aclhip_time_decompress_poses_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), ctypes.byref(consumers), poses_ptr, pose_stride_bytes, stream, repeats, ctypes.byref(ms)))
+        return ms.value
+
+    def decompress_poses(self, clips, sample_times, additive_format=ADDITIVE_NONE, object_space=False, base_clips=None, base_sample_times=None, base_poses=None,
+                         params=None, num_tracks=None, out=None, instance_rounding=None):
+        """Host arrays in, host poses out: float32 [n, num_tracks, 12] after the consumers. The base of an additive instance is either
+        (base_clips[i], base_sample_times[i]) or base_poses[i] ([n, num_tracks, 12])."""
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
+        n = clips.size
+        if num_tracks is None:
+            num_tracks = max((self.clip_info(int(c)).num_tracks for c in np.unique(clips)), default=0)
+        if out is None:
+            out = np.zeros((n, num_tracks, 12), dtype=np.float32)
+        params = params if params is not None else default_params()
+        if instance_rounding is not None:
+            instance_rounding = np.ascontiguousarray(instance_rounding, dtype=np.uint8)
+            params.instance_rounding_policies = instance_rounding.ctypes.data
+        consumers = PoseConsumers()
+        consumers.additive_format = int(additive_format)
+        consumers.object_space = 1 if object_space else 0
+        if base_clips is not None:
+            base_clips = np.ascontiguousarray(base_clips, dtype=np.uint32)
+            base_sample_times = np.ascontiguousarray(base_sample_times, dtype=np.float32)
+            consumers.base_clips = base_clips.ctypes.data
+            consumers.base_sample_times = base_sample_times.ctypes.data
+        if base_poses is not None:
+            base_poses = np.ascontiguousarray(base_poses, dtype=np.float32)
+            consumers.base_poses = base_poses.ctypes.data
+            consumers.base_pose_stride_bytes = base_poses.strides[0] if base_poses.ndim == 3 else num_tracks * 48
+        self._check(self._lib.aclhip_decompress_poses_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, n, ctypes.byref(params), ctypes.byref(consumers), out.ctypes.data, num_tracks * 48))
+        return out
 
     # ---- host pointer convenience API ----
     def decompress_tracks(self, clips, sample_times, params=None, num_tracks=None, out=None, default_values=None, track_rounding=None, instance_rounding=None):

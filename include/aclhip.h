@@ -258,6 +258,54 @@ aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const
 aclhip_status aclhip_decompress_all_samples(aclhip_context* context, aclhip_clip clip, const aclhip_decompress_params* params,
 	void* scratch, void* out, uint64_t stride_bytes, void* stream);
 
+/* ---- pose consumers ---------------------------------------------------------------
+ * What callers of decompress_tracks do next with the local space pose, fused into the decode so that the pose buffer makes
+ * one trip to HBM instead of two or three: combining an additive clip with its base (acl::apply_additive_to_base,
+ * core/additive_utils.h:150-160) and local -> object space (acl::local_to_object_space,
+ * compression/transform_pose_utils.h:35-50). The reference writes both in Realtime Math; DESIGN.md 4.7 says what is restated
+ * and how far an x86 build of the reference can be matched (rtm::quat_normalize starts from a hardware estimate). */
+
+/* acl::additive_clip_format8 (core/additive_utils.h:43-68) */
+typedef enum aclhip_additive_format
+{
+	ACLHIP_ADDITIVE_NONE = 0,		/* no base: the decoded pose passes through */
+	ACLHIP_ADDITIVE_RELATIVE = 1,	/* qvv_mul(additive, base) */
+	ACLHIP_ADDITIVE_ADDITIVE0 = 2,	/* transform_add0: scale = additive.scale * base.scale */
+	ACLHIP_ADDITIVE_ADDITIVE1 = 3	/* transform_add1: scale = (1 + additive.scale) * base.scale */
+} aclhip_additive_format;
+
+#define ACLHIP_NO_PARENT 0xFFFFFFFFu
+
+/* Parent of every transform of a registered transform clip (track_desc_transformf::parent_index, core/track_desc.h), copied.
+ * parent_indices[i] < i for every transform but the roots (sorted parent first, as local_to_object_space assumes); transform 0
+ * is a root whatever parent_indices[0] says (the reference never reads it), ACLHIP_NO_PARENT marks further roots.
+ * num_tracks must be the clip's. Replaces a previous hierarchy of the clip; synchronizes the device. */
+aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks);
+
+typedef struct aclhip_pose_consumers
+{
+	uint32_t additive_format;			/* aclhip_additive_format: how each decoded instance combines with its base pose */
+	uint32_t object_space;				/* 1: convert the (combined) local pose to object space with the clip's hierarchy */
+	const aclhip_clip* base_clips;		/* DEVICE [num_instances] or NULL: the base of instance i is clip base_clips[i] sampled at ... */
+	const float* base_sample_times;		/* DEVICE [num_instances] ... base_sample_times[i], decoded by the same wave (same params) */
+	const void* base_poses;				/* DEVICE or NULL; used when base_clips is NULL: base pose i at base_poses + i * base_pose_stride_bytes, */
+	uint64_t base_pose_stride_bytes;	/* 48 bytes per transform like the output; must not alias `poses` */
+} aclhip_pose_consumers;
+
+/* aclhip_decompress_tracks_batch followed by the consumers, in one kernel. `params` as for aclhip_decompress_tracks_batch but
+ * restricted to what a consumer can work with -- the track_writer's own default sub-track modes, no per track rounding,
+ * normalization != always -- else ACLHIP_ERROR_INVALID_ARGUMENT. Instances the kernel refuses (and counts, see
+ * aclhip_get_rejected_instance_count) leave their pose untouched: unknown or scalar clips, object_space for a clip without
+ * hierarchy, a base clip with another number of tracks. Poses are limited by the 160 KiB of LDS a wave can use: 3413
+ * transforms, 1706 when the base is a clip (ACLHIP_ERROR_INVALID_ARGUMENT when a registered clip is larger).
+ * Asynchronous on `stream`. */
+aclhip_status aclhip_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream);
+
+/* Same with host arrays (clips, times, base clips / times / poses, output): staged through temporary device buffers, synchronous. */
+aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes);
+
 /* ---- multi-GPU ---------------------------------------------------------------------------------- */
 
 /* Decoding never needs a collective: every GPU decodes its own contiguous shard of the instance list. Only a
@@ -277,6 +325,10 @@ aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64
  * stream and returns the average milliseconds per launch (device time of the decode kernel, no host overhead). */
 aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch);
+
+/* Same for aclhip_decompress_poses_batch. */
+aclhip_status aclhip_time_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch);
 
 /* Name of the kernel aclhip_decompress_tracks_batch would launch for `params` with the clips registered so far
  * (to match rocprofv3 kernel traces with bench results). */

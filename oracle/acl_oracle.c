@@ -1166,3 +1166,116 @@ uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_n
 
 	return num_errors;
 }
+
+/* ---- pose consumers: what callers do with a decompressed local pose -------------------------------------------
+ * core/additive_utils.h:128-160 (apply_additive_to_base, transform_add0 / transform_add1) and
+ * compression/transform_pose_utils.h:35-50 (local_to_object_space), on poses of 12 floats per transform
+ * (rotation xyzw | translation xyz0 | scale xyz0).
+ *
+ * Both are written in Realtime Math (rtm::quat_mul, rtm::qvv_mul, rtm::qvv_normalize), an un-vendored git submodule
+ * (external/rtm, absent from the checkout). Restated from RTM 2.x's published x86 (SSE2) forms:
+ *   - quat_mul: per lane (a*rw + b*rx) + (c*ry + d*rz), signs folded into the products;
+ *   - quat_mul_vector3(v, q) = quat_mul(quat_mul(conjugate(q), (v.xyz, 0)), q);
+ *   - qvv_mul(lhs, rhs): rotation = quat_mul(lhs.r, rhs.r); translation = quat_mul_vector3(lhs.t * rhs.s, rhs.r) + rhs.t;
+ *     scale = lhs.s * rhs.s. RTM routes NEGATIVE scales through a matrix decomposition instead: not restated;
+ *   - qvv_normalize normalizes the rotation. RTM's x86 quat_normalize starts from the hardware reciprocal square root ESTIMATE
+ *     (not reproducible between CPU vendors); restated with the reference's own deterministic normalize (quat_normalize above,
+ *     acl/math/quatf.h:200-222 arithmetic). Agreement with an x86 build of the reference is therefore to a few ulp per level of
+ *     the hierarchy, not bit for bit; tests/test_pose_consumers_oracle.py states the tolerance.
+ * The W lanes of translation and scale are unspecified in the reference (numeric residue of the rotation); 0 here. */
+void aclo_quat_mul(const float lhs[4], const float rhs[4], float out[4])
+{
+	const float lx = lhs[0], ly = lhs[1], lz = lhs[2], lw = lhs[3];
+	const float rx = rhs[0], ry = rhs[1], rz = rhs[2], rw = rhs[3];
+	const float x = ((rw * lx) + (rx * lw)) + ((ry * lz) + -(rz * ly));
+	const float y = ((rw * ly) + -(rx * lz)) + ((ry * lw) + (rz * lx));
+	const float z = ((rw * lz) + (rx * ly)) + (-(ry * lx) + (rz * lw));
+	const float w = ((rw * lw) + -(rx * lx)) + (-(ry * ly) + -(rz * lz));
+	out[0] = x; out[1] = y; out[2] = z; out[3] = w;
+}
+
+static void quat_mul_vector3(const float vector[3], const float rotation[4], float out[3])
+{
+	const float vector_quat[4] = { vector[0], vector[1], vector[2], 0.0f };
+	const float inv_rotation[4] = { -rotation[0], -rotation[1], -rotation[2], rotation[3] };
+	float tmp[4], result[4];
+	aclo_quat_mul(inv_rotation, vector_quat, tmp);
+	aclo_quat_mul(tmp, rotation, result);
+	out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
+}
+
+void aclo_qvv_mul(const float lhs[12], const float rhs[12], float out[12])
+{
+	float rotation[4], scaled[3], rotated[3];
+	uint32_t c;
+	aclo_quat_mul(lhs + 0, rhs + 0, rotation);
+	for (c = 0; c < 3; ++c)
+		scaled[c] = lhs[4 + c] * rhs[8 + c];
+	quat_mul_vector3(scaled, rhs + 0, rotated);
+	for (c = 0; c < 3; ++c)
+	{
+		const float translation = rotated[c] + rhs[4 + c];
+		const float scale = lhs[8 + c] * rhs[8 + c];
+		out[4 + c] = translation;
+		out[8 + c] = scale;
+	}
+	out[0] = rotation[0]; out[1] = rotation[1]; out[2] = rotation[2]; out[3] = rotation[3];
+	out[7] = 0.0f;
+	out[11] = 0.0f;
+}
+
+/* apply_additive_to_base (core/additive_utils.h:150-160): format 0 none (the additive pose passes through), 1 relative
+ * (qvv_mul(additive, base)), 2 additive0, 3 additive1. Poses may alias. */
+void aclo_apply_additive_to_base(int additive_format, const float* base_pose, const float* additive_pose, uint32_t num_transforms, float* out_pose)
+{
+	uint32_t i, c;
+	for (i = 0; i < num_transforms; ++i)
+	{
+		const float* base = base_pose + (uint64_t)i * 12;
+		const float* additive = additive_pose + (uint64_t)i * 12;
+		float result[12];
+		if (additive_format == 1)
+			aclo_qvv_mul(additive, base, result);
+		else if (additive_format == 2 || additive_format == 3)
+		{
+			/* transform_add0 / transform_add1 (:128-142) */
+			aclo_quat_mul(additive + 0, base + 0, result + 0);
+			for (c = 0; c < 3; ++c)
+			{
+				result[4 + c] = additive[4 + c] + base[4 + c];
+				result[8 + c] = additive_format == 2 ? additive[8 + c] * base[8 + c] : (1.0f + additive[8 + c]) * base[8 + c];
+			}
+			result[7] = 0.0f;
+			result[11] = 0.0f;
+		}
+		else
+		{
+			memcpy(result, additive, sizeof(result));
+			result[7] = 0.0f;
+			result[11] = 0.0f;
+		}
+		memcpy(out_pose + (uint64_t)i * 12, result, sizeof(result));
+	}
+}
+
+/* local_to_object_space (compression/transform_pose_utils.h:35-50): transform 0 is the root, every other transform follows
+ * its parent (parent_indices[i] < i; parent_indices[0] is not read). Extension used by the GPU path and mirrored here: a
+ * parent of 0xFFFFFFFF marks a further root. Poses may alias. */
+void aclo_local_to_object_space(const uint32_t* parent_indices, const float* local_pose, uint32_t num_transforms, float* out_object_pose)
+{
+	uint32_t i;
+	for (i = 0; i < num_transforms; ++i)
+	{
+		float result[12];
+		if (i == 0 || parent_indices[i] == 0xFFFFFFFFu)
+			memcpy(result, local_pose + (uint64_t)i * 12, sizeof(result));
+		else
+		{
+			aclo_qvv_mul(local_pose + (uint64_t)i * 12, out_object_pose + (uint64_t)parent_indices[i] * 12, result);
+			quat_normalize(result);
+		}
+		result[7] = 0.0f;
+		result[11] = 0.0f;
+		memcpy(out_object_pose + (uint64_t)i * 12, result, sizeof(result));
+	}
+}

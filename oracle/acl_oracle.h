@@ -121,6 +121,13 @@ uint32_t aclo_scalar_num_components(const void* blob);
 int aclo_scalar_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out);
 int aclo_scalar_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_value);
 
+/* Pose consumers: core/additive_utils.h:128-160 and compression/transform_pose_utils.h:35-50 over poses of
+ * 12 floats per transform. See acl_oracle.c for what is restated from Realtime Math and how it is pinned. */
+void aclo_quat_mul(const float lhs[4], const float rhs[4], float out[4]);
+void aclo_qvv_mul(const float lhs[12], const float rhs[12], float out[12]);
+void aclo_apply_additive_to_base(int additive_format, const float* base_pose, const float* additive_pose, uint32_t num_transforms, float* out_pose);
+void aclo_local_to_object_space(const uint32_t* parent_indices, const float* local_pose, uint32_t num_transforms, float* out_object_pose);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,14 @@ def oracle():
         lib.aclo_scalar_num_components.restype = u32
         lib.aclo_scalar_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
         lib.aclo_scalar_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]
+        lib.aclo_quat_mul.argtypes = [vp, vp, vp]
+        lib.aclo_quat_mul.restype = None
+        lib.aclo_qvv_mul.argtypes = [vp, vp, vp]
+        lib.aclo_qvv_mul.restype = None
+        lib.aclo_apply_additive_to_base.argtypes = [i32, vp, vp, u32, vp]
+        lib.aclo_apply_additive_to_base.restype = None
+        lib.aclo_local_to_object_space.argtypes = [vp, vp, u32, vp]
+        lib.aclo_local_to_object_space.restype = None
         _oracle = lib
     return _oracle
 
@@ -391,3 +399,79 @@ class ReferenceDatabase:
         if self._handle:
             self._lib.aclref_db_destroy(self._handle)
             self._handle = None
+
+
+# ---- pose consumers: additive apply and local -> object space ------------------------------------------
+REF_POSE_PATH = os.path.join(_HERE, "_ref", "libaclref_pose.so")
+
+ADDITIVE_NONE, ADDITIVE_RELATIVE, ADDITIVE_ADDITIVE0, ADDITIVE_ADDITIVE1 = 0, 1, 2, 3
+INVALID_PARENT = 0xFFFFFFFF
+
+
+def _pose_args(*poses):
+    out = []
+    for pose in poses:
+        pose = np.ascontiguousarray(pose, dtype=np.float32)
+        assert pose.ndim == 2 and pose.shape[1] == 12
+        out.append(pose)
+    return out
+
+
+def oracle_apply_additive_to_base(additive_format, base_pose, additive_pose):
+    """apply_additive_to_base (core/additive_utils.h:150) per transform; poses [num_transforms, 12]"""
+    base_pose, additive_pose = _pose_args(base_pose, additive_pose)
+    assert base_pose.shape == additive_pose.shape
+    out = np.empty_like(base_pose)
+    oracle().aclo_apply_additive_to_base(int(additive_format), _ptr(base_pose), _ptr(additive_pose), base_pose.shape[0], _ptr(out))
+    return out
+
+
+def oracle_local_to_object_space(parent_indices, local_pose):
+    """local_to_object_space (compression/transform_pose_utils.h:35); pose [num_transforms, 12]"""
+    (local_pose,) = _pose_args(local_pose)
+    parents = np.ascontiguousarray(parent_indices, dtype=np.uint32)
+    assert parents.size == local_pose.shape[0]
+    out = np.empty_like(local_pose)
+    oracle().aclo_local_to_object_space(_ptr(parents), _ptr(local_pose), local_pose.shape[0], _ptr(out))
+    return out
+
+
+def oracle_quat_mul(lhs, rhs):
+    lhs = np.ascontiguousarray(lhs, dtype=np.float32)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float32)
+    out = np.empty(4, dtype=np.float32)
+    oracle().aclo_quat_mul(_ptr(lhs), _ptr(rhs), _ptr(out))
+    return out
+
+
+def have_ref_pose():
+    return os.path.exists(REF_POSE_PATH)
+
+
+def ref_pose():
+    """The reference's pose consumers (oracle/_ref/libaclref_pose.so)."""
+    if "pose" not in _ref:
+        if not have_ref_pose():
+            raise RuntimeError(f"{REF_POSE_PATH} missing: run `make -C oracle` where /root/reference exists")
+        lib = ctypes.CDLL(REF_POSE_PATH)
+        lib.aclref_apply_additive_to_base.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        lib.aclref_apply_additive_to_base.restype = None
+        lib.aclref_local_to_object_space.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        lib.aclref_local_to_object_space.restype = None
+        _ref["pose"] = lib
+    return _ref["pose"]
+
+
+def ref_apply_additive_to_base(additive_format, base_pose, additive_pose):
+    base_pose, additive_pose = _pose_args(base_pose, additive_pose)
+    out = np.empty_like(base_pose)
+    ref_pose().aclref_apply_additive_to_base(int(additive_format), _ptr(base_pose), _ptr(additive_pose), base_pose.shape[0], _ptr(out))
+    return out
+
+
+def ref_local_to_object_space(parent_indices, local_pose):
+    (local_pose,) = _pose_args(local_pose)
+    parents = np.ascontiguousarray(parent_indices, dtype=np.uint32)
+    out = np.empty_like(local_pose)
+    ref_pose().aclref_local_to_object_space(_ptr(parents), _ptr(local_pose), local_pose.shape[0], _ptr(out))
+    return out

@@ -134,3 +134,22 @@ def load_scalar_golden(name):
 
 def exact(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+# ---- pose consumer fixtures (tests/golden/consumers/*.npz, see make_golden_consumers.py) ----
+CONSUMER_GOLDEN_DIR = os.path.join(GOLDEN_DIR, "consumers")
+
+
+def consumer_golden_cases():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(CONSUMER_GOLDEN_DIR, "*.npz")))
+
+
+def load_consumer_golden(name):
+    from acl_amd import synth
+    data = np.load(os.path.join(CONSUMER_GOLDEN_DIR, f"{name}.npz"))
+    case = {key: data[key] for key in data.files}
+    for key in ("additive_blob", "base_blob"):
+        blob = synth.aligned_bytes(case[key].size)
+        blob[:] = case[key]
+        case[key] = blob
+    return case
