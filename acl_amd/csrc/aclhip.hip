@@ -409,111 +409,155 @@ namespace aclhip
 		image[transform_index * 3u + 2] = f32x4{ value.scale.x, value.scale.y, value.scale.z, 0.0f };
 	}
 
-	// One wave64 per instance: decode the (additive) clip instance -- and its base clip instance, when the base is a clip -- into LDS,
-	// combine them per transform (apply_additive_to_base, core/additive_utils.h:150), walk the hierarchy level by level
-	// (local_to_object_space, compression/transform_pose_utils.h:35: lanes <-> the transforms of one depth, whose parents are final),
-	// then stream the finished pose out. What a caller would otherwise do in further passes over the pose buffer in HBM happens on
-	// the 5 KiB image the decode already holds.
-	__global__ __launch_bounds__(k_block_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+	// Up to 8 instances per workgroup, one wave64 per clip instance to decode: the (additive) clip instance and, when the base is a clip,
+	// its base clip instance in a second wave, each into its own LDS image; the two are combined per transform
+	// (apply_additive_to_base, core/additive_utils.h:150). local_to_object_space (compression/transform_pose_utils.h:35) is a walk
+	// down the hierarchy, one depth after the other, and a depth of a 100 bone skeleton is 4-18 transforms wide: done per wave it
+	// would leave most lanes idle for some 130 instructions per depth. So the workgroup's FIRST wave walks all its instances at
+	// once, lanes <-> (instance, transform of the current depth), from copies of the hierarchies the waves left in LDS next to
+	// their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
+	// HBM happens on the image the decode already holds.
+	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
+	constexpr uint32_t k_consumer_max_instances = 8;
+	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
+
+	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
-		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t images_per_wave, unsigned long long* __restrict__ rejected_count)
+		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t log2_instances_per_block,
+		unsigned long long* __restrict__ rejected_count)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+		__shared__ uint32_t walk_levels[k_consumer_max_instances];		// depths to walk per instance of the workgroup; 0: nothing to do
 
-		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
-		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		const uint32_t instance = blockIdx.x * (blockDim.x / k_wave_size) + wave_in_block;
-		if (instance >= num_instances)
-			return;
-
-		const uint32_t clip_id = as_constant(clip_ids)[instance];
-		const float sample_time = as_constant(sample_times)[instance];
-		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		const bool has_base = consumers.additive_format != 0;
 		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
+		const bool object_space = consumers.object_space != 0;
 
-		// rejected: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images
-		bool rejected = clip_id >= num_clips || !is_transform_clip(clip.flags) || (consumers.object_space != 0 && clip.hierarchy == nullptr)
-			|| clip.num_tracks * 3u > lds_quads_per_image;
+		// wave -> (instance slot of the workgroup, role): role 1 waves (base clips only) decode the slot's base
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t slot = wave_in_block & ((1u << log2_instances_per_block) - 1u);
+		const uint32_t role = wave_in_block >> log2_instances_per_block;
+		const uint32_t waves_per_instance = base_is_clip ? 2u : 1u;
+		const uint32_t instance = (blockIdx.x << log2_instances_per_block) + slot;
 
-		uint32_t base_clip_id = 0;
-		float base_sample_time = 0.0f;
-		if (base_is_clip)
-		{
-			base_clip_id = as_constant(consumers.base_clip_ids)[instance];
-			base_sample_time = as_constant(consumers.base_sample_times)[instance];
-			rejected = rejected || base_clip_id >= num_clips;
-		}
-		if (rejected)
-		{
-			if (lane == 0)
-				atomicAdd(rejected_count, 1ull);
-			return;
-		}
-
-		const uint32_t num_tracks = clip.num_tracks;
-		if (num_tracks == 0)
-			return;
-
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
-
-		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * images_per_wave * lds_quads_per_image;
+		uint8_t* instance_lds = dynamic_lds + size_t(slot) * lds_bytes_per_instance;
+		f32x4* image = reinterpret_cast<f32x4*>(instance_lds);
 		f32x4* base_image = image + lds_quads_per_image;
+		uint32_t* hierarchy_copy = reinterpret_cast<uint32_t*>(base_is_clip ? base_image + lds_quads_per_image : base_image);
 
-		if (base_is_clip)
+		uint32_t num_tracks = 0;		// stays 0 for a wave without work: past the batch, refused instance, empty track list
+		uint32_t num_levels = 0;
+		if (instance < num_instances)
 		{
-			// the base must describe the same transforms (the reference asserts matching track counts where it combines them)
-			const device_clip base_clip = load_clip(clips, base_clip_id);
-			if (!is_transform_clip(base_clip.flags) || base_clip.num_tracks != num_tracks)
+			const uint32_t clip_id = as_constant(clip_ids)[instance];
+			const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+
+			// refused: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images, bases that
+			// are unknown or describe another number of transforms (the reference asserts matching track counts where it combines them).
+			// Both waves of an instance come to the same verdict; the first one reports it.
+			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr) || clip.num_tracks * 3u > lds_quads_per_image;
+
+			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+				: uint32_t(params.rounding_policy);
+
+			if (base_is_clip)
 			{
-				if (lane == 0)
-					atomicAdd(rejected_count, 1ull);
-				return;
+				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
+				const device_clip base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
+				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks;
+				if (!refused && role == 1 && clip.num_tracks != 0)
+					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}
-			decode_pose_into_image(base_clip, base_sample_time, rounding_policy, params, lane, base_image);
+
+			if (refused)
+			{
+				if (lane == 0 && role == 0)
+					atomicAdd(rejected_count, 1ull);
+			}
+			else if (clip.num_tracks != 0)
+			{
+				num_tracks = clip.num_tracks;
+				if (role == 0)
+				{
+					decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+					if (object_space)
+					{
+						// num_levels | total words | level_end[num_levels] | pad | {transform, parent} pairs by depth
+						const ACLHIP_CONSTANT uint32_t* hierarchy = as_constant(clip.hierarchy);
+						num_levels = hierarchy[0];
+						const uint32_t num_words = hierarchy[1];
+						for (uint32_t word = lane; word < num_words; word += k_wave_size)
+							hierarchy_copy[word] = clip.hierarchy[word];
+					}
+				}
+			}
 		}
 
-		decode_pose_into_image(clip, sample_time, rounding_policy, params, lane, image);
-		wave_lds_barrier();
+		// both images of every instance are complete
+		if (base_is_clip)
+			__syncthreads();
+		else
+			wave_lds_barrier();
 
 		if (has_base)
 		{
 			const f32x4* base_source = base_is_clip ? base_image : reinterpret_cast<const f32x4*>(consumers.base_poses + uint64_t(instance) * consumers.base_pose_stride_bytes);
-			for (uint32_t transform_index = lane; transform_index < num_tracks; transform_index += k_wave_size)
+			for (uint32_t transform_index = role * k_wave_size + lane; transform_index < num_tracks; transform_index += waves_per_instance * k_wave_size)
 			{
 				const qvv additive = load_qvv(image, transform_index);
 				const qvv base = load_qvv(base_source, transform_index);
 				store_qvv(image, transform_index, apply_additive_to_base(consumers.additive_format, base, additive));
 			}
-			wave_lds_barrier();
 		}
 
-		if (consumers.object_space != 0)
+		if (object_space)
 		{
-			const ACLHIP_CONSTANT uint32_t* hierarchy = as_constant(clip.hierarchy);
-			const uint32_t num_levels = hierarchy[0];
-			const uint2* pairs = reinterpret_cast<const uint2*>(clip.hierarchy + 1 + num_levels + ((num_levels & 1u) == 0 ? 1 : 0));
-			uint32_t level_start = 0;
-			for (uint32_t level = 0; level < num_levels; ++level)
+			if (lane == 0 && role == 0)
+				walk_levels[slot] = num_levels;
+			__syncthreads();
+
+			if (wave_in_block == 0)
 			{
-				const uint32_t level_end = hierarchy[1 + level];
-				for (uint32_t pair_index = level_start + lane; pair_index < level_end; pair_index += k_wave_size)
+				// lanes <-> (instance slot, transform of the current depth): slot = lane % instances, the lanes of a slot stride over its
+				// depth. A transform's parent sits at a lower depth: final by the time it is read.
+				const uint32_t walk_slot = lane & ((1u << log2_instances_per_block) - 1u);
+				const uint32_t first = lane >> log2_instances_per_block;
+				const uint32_t stride = k_wave_size >> log2_instances_per_block;
+				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
+				const uint32_t* slot_hierarchy = reinterpret_cast<const uint32_t*>(slot_image + lds_quads_per_image * (base_is_clip ? 2u : 1u));
+				const uint32_t slot_levels = walk_levels[walk_slot];
+				const uint2* pairs = reinterpret_cast<const uint2*>(slot_hierarchy + ((2u + slot_levels + 1u) & ~1u));
+
+				uint32_t level_start = 0;
+				for (uint32_t level = 0; __any(int(level < slot_levels)) != 0; ++level)
 				{
-					const uint2 pair = pairs[pair_index];		// x: transform, y: its parent (one level up or higher: final by now)
-					qvv object = qvv_mul(load_qvv(image, pair.x), load_qvv(image, pair.y));
-					object.rotation = quat_normalize(object.rotation);
-					store_qvv(image, pair.x, object);
+					if (level < slot_levels)
+					{
+						const uint32_t level_end = slot_hierarchy[2 + level];
+						for (uint32_t pair_index = level_start + first; pair_index < level_end; pair_index += stride)
+						{
+							const uint2 pair = pairs[pair_index];		// x: transform, y: its parent
+							qvv object = qvv_mul(load_qvv(slot_image, pair.x), load_qvv(slot_image, pair.y));
+							object.rotation = quat_normalize(object.rotation);
+							store_qvv(slot_image, pair.x, object);
+						}
+						level_start = level_end;
+					}
+					wave_lds_barrier();
 				}
-				wave_lds_barrier();
-				level_start = level_end;
 			}
+			__syncthreads();
 		}
+		else if (base_is_clip)
+			__syncthreads();
+		else
+			wave_lds_barrier();
 
 		const uint32_t num_quads = num_tracks * 3u;
 		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
-		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+		for (uint32_t quad = role * k_wave_size + lane; quad < num_quads; quad += waves_per_instance * k_wave_size)
 			pose[quad] = image[quad];
 	}
 
@@ -999,6 +1043,7 @@ struct aclhip_context
 	uint32_t d_clips_capacity = 0;
 	unsigned long long* d_rejected = nullptr;
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
+	uint32_t max_hierarchy_words = 0;		// largest hierarchy image (aclhip_set_clip_hierarchy) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
@@ -2486,8 +2531,8 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			num_levels = std::max(num_levels, depth[i]);
 		}
 
-		// num_levels | level_end[num_levels] | pad to 8 bytes | {transform, parent} of depth 1, depth 2, ...
-		const uint32_t header_words = (1 + num_levels + 1) & ~1u;
+		// num_levels | total words | level_end[num_levels] | pad to 8 bytes | {transform, parent} of depth 1, depth 2, ...
+		const uint32_t header_words = (2 + num_levels + 1) & ~1u;
 		std::vector<uint32_t> level_end(num_levels, 0);
 		for (uint32_t i = 1; i < num_tracks; ++i)
 			if (depth[i] != 0)
@@ -2508,7 +2553,8 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			image[header_words + size_t(slot) * 2 + 0] = i;
 			image[header_words + size_t(slot) * 2 + 1] = parent_indices[i];
 		}
-		std::copy(level_end.begin(), level_end.end(), image.begin() + 1);
+		image[1] = uint32_t(image.size());
+		std::copy(level_end.begin(), level_end.end(), image.begin() + 2);
 
 		device_guard guard(context->device);
 		uint32_t* d_hierarchy = nullptr;
@@ -2528,6 +2574,7 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (entry.d_hierarchy != nullptr)
 			(void)hipFree(entry.d_hierarchy);
 		entry.d_hierarchy = d_hierarchy;
+		context->max_hierarchy_words = std::max(context->max_hierarchy_words, uint32_t(image.size()));
 		return ACLHIP_OK;
 	});
 }
@@ -2551,17 +2598,24 @@ namespace
 
 		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
 
-		// one wave per instance, the whole pose (and its base) in LDS
-		const uint32_t images_per_wave = base_is_clip ? 2 : 1;
+		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
+		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
 		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64);
-		const size_t lds_bytes_per_wave = size_t(lds_quads_per_image) * 16 * images_per_wave;
-		constexpr size_t k_lds_bytes = 160 * 1024;
-		if (lds_bytes_per_wave > k_lds_bytes)
-			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per wave)", context->max_pose_quads / 3, lds_bytes_per_wave);
-		const uint32_t waves_per_block = uint32_t(std::min<size_t>(k_waves_per_block, k_lds_bytes / lds_bytes_per_wave));
-		const uint32_t num_blocks = (num_instances + waves_per_block - 1) / waves_per_block;
-		const size_t lds_bytes = lds_bytes_per_wave * waves_per_block;
-		if (lds_bytes > 64 * 1024)
+		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (base_is_clip ? 2 : 1)
+			+ (consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0);
+		constexpr size_t k_lds_bytes = 160 * 1024 - 64;		// the kernel's few static words
+		if (lds_bytes_per_instance > k_lds_bytes)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per instance)", context->max_pose_quads / 3, lds_bytes_per_instance);
+		uint32_t log2_instances_per_block = 2;
+		if (const char* forced = std::getenv("ACLHIP_CONSUMER_LOG2_INSTANCES"))
+			log2_instances_per_block = std::min<uint32_t>(uint32_t(forced[0] - '0'), 3);
+		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) > k_lds_bytes / 3)
+			log2_instances_per_block--;
+		const uint32_t instances_per_block = 1u << log2_instances_per_block;
+		const uint32_t waves_per_block = instances_per_block * (base_is_clip ? 2 : 1);
+		const uint32_t num_blocks = (num_instances + instances_per_block - 1) / instances_per_block;
+		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block;
+		if (lds_bytes > 64 * 1024 - 64)		// above the default limit
 			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(decompress_poses_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
 
 		consumer_params device_consumers;
@@ -2574,7 +2628,7 @@ namespace
 
 		hipLaunchKernelGGL(decompress_poses_consumer_kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
-			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, images_per_wave, context->d_rejected);
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, uint32_t(lds_bytes_per_instance), log2_instances_per_block, context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}

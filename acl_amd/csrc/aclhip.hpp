@@ -35,9 +35,12 @@ namespace aclhip
 	enum class rotation_normalization_policy_t : uint8_t { never = 0, lerp_only = 1, always = 2 };
 	// acl::default_sub_track_mode (core/track_writer.h:49-74)
 	enum class default_sub_track_mode { skipped, constant, variable, legacy };
+	// reference: core/additive_utils.h:43-68
+	enum class additive_clip_format8 : uint8_t { none = 0, relative = 1, additive0 = 2, additive1 = 3 };
 
 	struct quatf { float x, y, z, w; };
 	struct vector4f { float x, y, z, w; };
+	struct qvvf { quatf rotation; vector4f translation; vector4f scale; };		// 48 bytes, the layout of a pose row
 
 	// acl::decompression_settings (decompression/decompression_settings.h:74-166): the switches that matter to the transform path
 	struct decompression_settings
@@ -377,6 +380,51 @@ namespace aclhip
 			m_rounding_policy = rounding_policy;
 		}
 
+		// ---- pose consumers: what reference callers do next with the pose decompress_tracks wrote, fused into the decode ----
+		// Parent of every transform (track_desc_transformf::parent_index), sorted parent first; k_no_parent marks roots.
+		static constexpr uint32_t k_no_parent = ACLHIP_NO_PARENT;
+		bool set_parent_indices(const uint32_t* parent_indices, uint32_t num_transforms)
+		{
+			return is_initialized() && aclhip_set_clip_hierarchy(m_device->get(), m_clip, parent_indices, num_transforms) == ACLHIP_OK;
+		}
+
+		// The pose at the last seek() as a caller of the reference would have it after
+		//     decompress_tracks(writer into local_pose);
+		//     local_pose[i] = acl::apply_additive_to_base(additive_format, base_pose[i], local_pose[i]);   (core/additive_utils.h:150)
+		//     acl::local_to_object_space(parent_indices, local_pose, num_transforms, out_pose);            (compression/transform_pose_utils.h:35)
+		// with the track_writer's default sub-track modes. `base` is another context of the same device, sought to the base's sample
+		// time (null with additive_clip_format8::none). out_pose: one qvvf per track of the clip. False when nothing was written.
+		bool decompress_pose(qvvf* out_pose, bool object_space, additive_clip_format8 additive_format = additive_clip_format8::none,
+			const decompression_context* base = nullptr)
+		{
+			if (!is_initialized() || m_info.track_type != 12 || m_info.num_tracks == 0 || m_sample_time < 0.0f || out_pose == nullptr)
+				return false;
+			if (additive_format != additive_clip_format8::none && (base == nullptr || !base->is_initialized() || base->m_device != m_device || base->m_sample_time < 0.0f))
+				return false;
+
+			aclhip_decompress_params params;
+			aclhip_default_params(&params);
+			params.rounding_policy = static_cast<uint8_t>(m_rounding_policy);
+			params.looping_policy = static_cast<uint8_t>(m_looping_policy);
+			params.normalization = static_cast<uint8_t>(settings_type::get_rotation_normalization_policy());
+
+			aclhip_pose_consumers consumers = {};
+			consumers.additive_format = static_cast<uint32_t>(additive_format);
+			consumers.object_space = object_space ? 1 : 0;
+			float base_time = 0.0f;
+			if (additive_format != additive_clip_format8::none)
+			{
+				base_time = base->m_sample_time;
+				consumers.base_clips = &base->m_clip;
+				consumers.base_sample_times = &base_time;
+			}
+			const float sample_time = m_sample_time;
+			const uint64_t before = rejected_count();
+			if (aclhip_decompress_poses_host(m_device->get(), &m_clip, &sample_time, 1, &params, &consumers, out_pose, uint64_t(m_info.num_tracks) * sizeof(qvvf)) != ACLHIP_OK)
+				return false;
+			return rejected_count() == before;
+		}
+
 		// reference: decompress_tracks(track_writer_type&) (decompress.h:166)
 		template<class track_writer_type>
 		void decompress_tracks(track_writer_type& writer)
@@ -440,6 +488,13 @@ namespace aclhip
 		}
 
 	private:
+		uint64_t rejected_count() const
+		{
+			uint64_t count = 0;
+			(void)aclhip_get_rejected_instance_count(m_device->get(), &count);
+			return count;
+		}
+
 		bool is_bound_to_hash(const void* compressed_tracks) const
 		{
 			if (!is_initialized() || compressed_tracks == nullptr)

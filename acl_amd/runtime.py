@@ -17,6 +17,9 @@ ROUND_NONE, ROUND_FLOOR, ROUND_CEIL, ROUND_NEAREST, ROUND_PER_TRACK = 0, 1, 2, 3
 LOOP_CLAMP, LOOP_WRAP, LOOP_AS_COMPRESSED = 0, 1, 2
 NORMALIZE_NEVER, NORMALIZE_LERP_ONLY, NORMALIZE_ALWAYS = 0, 1, 2
 DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY = 0, 1, 2, 3
+# aclhip_status
+(OK, ERROR_INVALID_ARGUMENT, ERROR_INVALID_CLIP, ERROR_UNSUPPORTED_FORMAT, ERROR_UNKNOWN_CLIP, ERROR_OUT_OF_MEMORY, ERROR_DEVICE, ERROR_NO_DEVICE,
+ ERROR_UNKNOWN_DATABASE, ERROR_NOT_IN_DATABASE) = range(10)
 INVALID_HANDLE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [

@@ -214,3 +214,42 @@ def build_scalar_clip(seed=1, track_type=0, num_tracks=16, num_samples=40, sampl
     struct.pack_into("<II", blob, 0, size, _hash32(blob[8:size]))
     # the wrap flag is only honoured from v02_01_99 on (compressed_tracks::get_looping_policy, core/impl/compressed_tracks.impl.h:102-110)
     return SyntheticScalarClip(blob, keyframes, track_type, sample_rate, bit_rates, bool(wrap) and version > 7)
+
+
+def humanoid_hierarchy(num_tracks=100):
+    """Parent index per transform of a game-character-like skeleton, sorted parent first (NO_PARENT = 0xFFFFFFFF for the root):
+    root > pelvis > 4 spine bones > neck > head with 12 face bones; two arms (clavicle > upper arm > lower arm > hand, 5 fingers of
+    3 joints, 2 twist bones); two legs (thigh > calf > foot > ball, 2 twist bones); the rest are 2-bone accessory chains hanging off
+    the trunk. 100 transforms: 13 depths, 4 to 12 transforms wide. Smaller / larger counts truncate / add accessory chains."""
+    parents = [0xFFFFFFFF, 0]                       # root, pelvis
+    spine = []
+    for _ in range(4):
+        parents.append(spine[-1] if spine else 1)
+        spine.append(len(parents) - 1)
+    parents.append(spine[-1]); neck = len(parents) - 1
+    parents.append(neck); head = len(parents) - 1
+    parents += [head] * 12
+    for _ in range(2):                              # arms
+        parents.append(spine[-1]); clavicle = len(parents) - 1
+        parents.append(clavicle); upper = len(parents) - 1
+        parents.append(upper); lower = len(parents) - 1
+        parents.append(lower); hand = len(parents) - 1
+        parents += [upper, lower]                   # twist bones
+        for _ in range(5):
+            parents.append(hand)
+            parents.append(len(parents) - 1)
+            parents.append(len(parents) - 1)
+    for _ in range(2):                              # legs
+        parents.append(1); thigh = len(parents) - 1
+        parents.append(thigh); calf = len(parents) - 1
+        parents.append(calf); foot = len(parents) - 1
+        parents.append(foot)
+        parents += [thigh, calf]
+    anchors = [1] + spine + [head]
+    k = 0
+    while len(parents) < num_tracks:
+        parents.append(anchors[k % len(anchors)])
+        if len(parents) < num_tracks:
+            parents.append(len(parents) - 1)
+        k += 1
+    return np.array(parents[:num_tracks], dtype=np.uint32)

@@ -36,9 +36,14 @@ def build_workload(name, rank):
     from acl_amd import synth
 
     rng = np.random.default_rng(1000 + rank)
-    if name == "one_clip":
+    if name in ("one_clip", "object_space"):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
         clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+    elif name == "additive_object_space":
+        # instance = additive clip 1 applied onto base clip 0 (instance i's base time is drawn in main), then local -> object space
+        clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0),
+                 synth.build_clip(seed=12, num_tracks=100, num_samples=121, sample_rate=30.0, rotation_constant=0.5, translation_constant=0.8)]
+        clip_indices = np.ones(INSTANCES_PER_GPU, dtype=np.uint32)
     elif name == "256_clips":
         clips = []
         spec_rng = np.random.default_rng(3)
@@ -188,7 +193,7 @@ def main():
     # the clocks of an idle MI355X take a few ms to ramp: the defaults warm up for ~30 ms and time ~0.1 s
     parser.add_argument("--steps", type=int, default=2000)
     parser.add_argument("--warmup", type=int, default=500)
-    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar"])
+    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar", "object_space", "additive_object_space"])
     parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     args = parser.parse_args()
@@ -256,6 +261,25 @@ def main():
     launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
     launch = lib.aclhip_decompress_scalar_tracks_batch if is_scalar else lib.aclhip_decompress_tracks_batch
 
+    # pose consumers: the same decode with the additive apply / local -> object space fused in
+    consumers = None
+    if args.workload in ("object_space", "additive_object_space"):
+        from acl_amd import synth
+        parents = synth.humanoid_hierarchy(max_tracks)     # 13 depths, 4-18 transforms wide
+        for handle in handles:
+            context.set_clip_hierarchy(int(handle), parents)
+        consumers = runtime.PoseConsumers()
+        consumers.object_space = 1
+        if args.workload == "additive_object_space":
+            base_rng = np.random.default_rng(2000 + rank)
+            d_base_clips = torch.full((num_instances,), int(handles[0]), dtype=torch.int32, device=device)
+            d_base_times = torch.from_numpy(base_rng.uniform(0.0, clips[0].duration, size=num_instances).astype(np.float32)).to(device)
+            consumers.additive_format = runtime.ADDITIVE_ADDITIVE1
+            consumers.base_clips = d_base_clips.data_ptr()
+            consumers.base_sample_times = d_base_times.data_ptr()
+        launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), ctypes.byref(consumers), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
+        launch = lib.aclhip_decompress_poses_batch
+
     def step():
         status = launch(*launch_args)
         if status != 0:
@@ -312,10 +336,18 @@ def main():
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
     kernel_ms = float(marks[0].elapsed_time(marks[num_marks - 1])) / args.steps
     # the same launches back to back from C (no host pacing), for reference
-    kernel_ms_back_to_back = None if is_scalar else context.time_decompress_tracks_batch(
-        d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
-        repeats=1 if profiling else max(10, min(args.steps, 100)), params=params, stream=stream.cuda_stream)
+    repeats = 1 if profiling else max(10, min(args.steps, 100))
+    if is_scalar:
+        kernel_ms_back_to_back = None
+    elif consumers is not None:
+        kernel_ms_back_to_back = context.time_decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
+                                                                     consumers, repeats=repeats, params=params, stream=stream.cuda_stream)
+    else:
+        kernel_ms_back_to_back = context.time_decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
+                                                                      repeats=repeats, params=params, stream=stream.cuda_stream)
     bytes_written, bytes_read = context.batch_algorithmic_bytes(handles[clip_indices])
+    if args.workload == "additive_object_space":
+        bytes_read += context.batch_algorithmic_bytes(handles[:1])[1]        # the base clip is read too; one pose per instance is written
     algorithmic_bytes = bytes_written + bytes_read
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
 
@@ -325,7 +357,7 @@ def main():
     if rejected != 0:
         raise SystemExit(f"the kernel rejected {rejected} instances")
 
-    kernel_name = "decompress_scalar_tracks_kernel" if is_scalar else context.tracks_kernel_name(params)
+    kernel_name = "decompress_scalar_tracks_kernel" if is_scalar else ("decompress_poses_consumer_kernel" if consumers is not None else context.tracks_kernel_name(params))
     if rank == 0:
         total_poses = num_instances * world_size * args.steps
         result = {
@@ -346,7 +378,9 @@ def main():
                              "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else ""),
                              "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)",
                              "database": "64k instances per GPU over 16 database-bound 100-bone clips, low importance tier streamed in chunk by chunk on the decode stream during the timed steps (BASELINE.json configs[4] shape, committed fixture)",
-                             "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)"}[args.workload],
+                             "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
+                             "object_space": "the one_clip batch with local -> object space fused into the decode (pose consumers, SURVEY 8 f3)",
+                             "additive_object_space": "64k instances per GPU: an additive clip applied (additive1) onto a base clip instance decoded by the same wave, then local -> object space (SURVEY 8 f3)"}[args.workload],
                 "instances_per_gpu": int(num_instances),
                 "bones": int(max_tracks),
                 "distinct_clips": len(clips),
@@ -376,6 +410,8 @@ def main():
                 if database is not None:
                     # the reference's database_context is not part of the CPU bridge that travels to the GPU box
                     result["cpu_baseline"]["sample"] += "; clips bound WITHOUT their database (highest importance tier only)"
+                if consumers is not None:
+                    result["cpu_baseline"]["sample"] += "; decode of the (additive) clip only, the consumers are not part of the CPU timing"
         print(json.dumps(result))
 
     for handle in handles:

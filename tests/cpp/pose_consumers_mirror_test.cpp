@@ -1,0 +1,101 @@
+// Exercises the pose consumer methods of aclhip::decompression_context (acl_amd/csrc/aclhip.hpp): set_parent_indices and
+// decompress_pose, i.e. what a caller of the reference does with decompress_tracks + acl::apply_additive_to_base
+// (core/additive_utils.h:150) + acl::local_to_object_space (compression/transform_pose_utils.h:35).
+// argv: additive_clip base_clip parents(raw u32) times(text: "additive_time base_time" per line) output(raw floats)
+// output per time: for additive format 0..3: local pose [num_tracks x 12] then object space pose [num_tracks x 12]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../acl_amd/csrc/aclhip.hpp"
+
+namespace
+{
+	struct aligned_file
+	{
+		std::vector<uint8_t> storage;
+		const uint8_t* data = nullptr;
+		size_t size = 0;
+
+		bool read(const char* path)
+		{
+			FILE* file = std::fopen(path, "rb");
+			if (file == nullptr)
+				return false;
+			std::fseek(file, 0, SEEK_END);
+			size = size_t(std::ftell(file));
+			std::fseek(file, 0, SEEK_SET);
+			storage.resize(size + 32);
+			uint8_t* aligned = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(storage.data()) + 15) & ~uintptr_t(15));
+			const bool ok = std::fread(aligned, 1, size, file) == size;
+			std::fclose(file);
+			data = aligned;
+			return ok;
+		}
+	};
+}
+
+int main(int argc, char** argv)
+{
+	if (argc != 6)
+		return 1;
+	aligned_file additive_clip, base_clip, parents_file;
+	if (!additive_clip.read(argv[1]) || !base_clip.read(argv[2]) || !parents_file.read(argv[3]))
+		return 2;
+	const uint32_t* parents = reinterpret_cast<const uint32_t*>(parents_file.data);
+	const uint32_t num_tracks = uint32_t(parents_file.size / 4);
+
+	std::vector<float> times;
+	{
+		FILE* file = std::fopen(argv[4], "r");
+		if (file == nullptr)
+			return 2;
+		float a, b;
+		while (std::fscanf(file, "%f %f", &a, &b) == 2) { times.push_back(a); times.push_back(b); }
+		std::fclose(file);
+	}
+
+	aclhip::device gpu(0);
+	if (!gpu.is_valid())
+		return 3;
+
+	using context_type = aclhip::decompression_context<aclhip::default_transform_decompression_settings>;
+	context_type additive, base;
+	std::vector<aclhip::qvvf> pose(num_tracks);
+	// not initialized: nothing is written
+	if (additive.set_parent_indices(parents, num_tracks) || additive.decompress_pose(pose.data(), false))
+		return 4;
+	if (!additive.initialize(gpu, additive_clip.data, additive_clip.size) || !base.initialize(gpu, base_clip.data, base_clip.size))
+		return 5;
+	// before a seek, object space before a hierarchy, a hierarchy of the wrong size, an additive format without a base
+	if (additive.decompress_pose(pose.data(), false))
+		return 7;
+	additive.seek(0.0f, aclhip::sample_rounding_policy::none);
+	if (additive.decompress_pose(pose.data(), true) || additive.set_parent_indices(parents, num_tracks - 1)
+		|| additive.decompress_pose(pose.data(), false, aclhip::additive_clip_format8::relative, nullptr))
+		return 8;
+	if (!additive.set_parent_indices(parents, num_tracks))
+		return 9;
+
+	FILE* out = std::fopen(argv[5], "wb");
+	if (out == nullptr)
+		return 2;
+	for (size_t i = 0; i < times.size(); i += 2)
+	{
+		additive.seek(times[i], aclhip::sample_rounding_policy::none);
+		base.seek(times[i + 1], aclhip::sample_rounding_policy::none);
+		for (int format = 0; format < 4; ++format)
+		{
+			for (int object_space = 0; object_space < 2; ++object_space)
+			{
+				std::memset(pose.data(), 0xCD, pose.size() * sizeof(aclhip::qvvf));
+				if (!additive.decompress_pose(pose.data(), object_space != 0, static_cast<aclhip::additive_clip_format8>(format), format != 0 ? &base : nullptr))
+					return 10;
+				std::fwrite(pose.data(), sizeof(aclhip::qvvf), pose.size(), out);
+			}
+		}
+	}
+	std::fclose(out);
+	return 0;
+}

@@ -1,0 +1,233 @@
+"""Pose consumers fused into the decode (aclhip_decompress_poses_batch) through the C ABI: bit exact against the CPU
+oracle's decode -> apply_additive_to_base -> local_to_object_space pipeline, and against the reference's own functions through
+the committed fixtures (bit exact for the additive formats; within the tolerance test_pose_consumers_oracle.py explains for object
+space, where the reference's x86 arithmetic starts from a hardware estimate). Needs a GPU."""
+import numpy as np
+import pytest
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+import helpers
+from test_pose_consumers_oracle import assert_object_space_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def context():
+    ctx = runtime.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def random_hierarchy(rng, num_tracks, parent_span, extra_roots=0):
+    parents = np.zeros(num_tracks, dtype=np.uint32)
+    parents[0] = runtime.NO_PARENT
+    for i in range(1, num_tracks):
+        parents[i] = rng.integers(max(0, i - parent_span), i)
+    if extra_roots and num_tracks > 1:
+        parents[rng.choice(np.arange(1, num_tracks), size=min(extra_roots, num_tracks - 1), replace=False)] = runtime.NO_PARENT
+    return parents
+
+
+def oracle_poses(blobs, clip_indices, times, rounding=0, options=None):
+    return np.stack([ob.oracle_decompress_tracks(blobs[c], float(t), rounding, options) for c, t in zip(clip_indices, times)])
+
+
+@pytest.mark.parametrize("name", helpers.consumer_golden_cases())
+def test_matches_reference_fixtures(context, name):
+    case = helpers.load_consumer_golden(name)
+    additive, base = context.register_clip(case["additive_blob"]), context.register_clip(case["base_blob"])
+    context.set_clip_hierarchy(additive, case["parents"])
+    n = case["times"].shape[0]
+    additive_handles, base_handles = np.full(n, additive, dtype=np.uint32), np.full(n, base, dtype=np.uint32)
+    additive_times, base_times = case["times"][:, 0].copy(), case["times"][:, 1].copy()
+    base_poses = context.decompress_tracks(base_handles, base_times)
+    for additive_format in range(4):
+        kwargs = dict(additive_format=additive_format)
+        if additive_format != runtime.ADDITIVE_NONE:
+            kwargs.update(base_clips=base_handles, base_sample_times=base_times)
+        local = context.decompress_poses(additive_handles, additive_times, **kwargs)
+        assert helpers.bit_equal(local, case["local"][additive_format]), (name, additive_format)
+        object_space = context.decompress_poses(additive_handles, additive_times, object_space=True, **kwargs)
+        assert_object_space_close(object_space, case["object_space"][additive_format])
+        # the base as a pose buffer in HBM instead of a clip instance decoded by the same wave: same bits
+        if additive_format != runtime.ADDITIVE_NONE:
+            from_buffer = context.decompress_poses(additive_handles, additive_times, additive_format=additive_format, base_poses=base_poses, object_space=True)
+            assert helpers.exact(from_buffer, object_space)
+        # and bit exact against the oracle pipeline
+        for index in range(n):
+            additive_pose = ob.oracle_decompress_tracks(case["additive_blob"], float(additive_times[index]))
+            base_pose = ob.oracle_decompress_tracks(case["base_blob"], float(base_times[index]))
+            expected_local = ob.oracle_apply_additive_to_base(additive_format, base_pose, additive_pose)
+            assert helpers.exact(local[index], expected_local)
+            assert helpers.exact(object_space[index], ob.oracle_local_to_object_space(case["parents"], expected_local))
+    context.unregister_clip(additive)
+    context.unregister_clip(base)
+    assert context.rejected_instance_count() == 0
+
+
+CLIP_SHAPES = {
+    "one_bone": dict(seed=301, num_tracks=1, num_samples=9),
+    "small_scale": dict(seed=302, num_tracks=17, num_samples=33, has_scale=1, scale_default=0.3),
+    "window_boundary_106": dict(seed=303, num_tracks=106, num_samples=40, has_scale=1),
+    "window_boundary_107": dict(seed=304, num_tracks=107, num_samples=40, has_scale=1),
+    "crowd_rig_1200": dict(seed=305, num_tracks=1200, num_samples=12, has_scale=1, scale_default=0.5),
+    "stripped_wrap": dict(seed=306, num_tracks=50, num_samples=100, strip_keyframes=1, wrap=1, has_scale=1),
+    "mostly_default": dict(seed=307, num_tracks=64, num_samples=20, rotation_default=0.6, translation_default=0.6, has_scale=1, scale_default=0.8),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CLIP_SHAPES))
+def test_matches_oracle_on_synthetic_clips(name):
+    """Every rounding policy and looping policy, mixed clips in one batch, per instance rounding; a context of its own because
+    the LDS image size follows the largest registered clip."""
+    rng = np.random.default_rng(CLIP_SHAPES[name]["seed"])
+    spec = CLIP_SHAPES[name]
+    clips = [synth.build_clip(**spec), synth.build_clip(**dict(spec, seed=spec["seed"] + 1000, num_samples=spec["num_samples"] + 7))]
+    blobs = [c.blob for c in clips]
+    num_tracks = spec["num_tracks"]
+    parents = random_hierarchy(rng, num_tracks, parent_span=max(1, num_tracks // 8), extra_roots=2 if num_tracks > 8 else 0)
+    with runtime.Context(0) as context:
+        handles = [context.register_clip(b) for b in blobs]
+        for handle in handles:
+            context.set_clip_hierarchy(handle, parents)
+        n = 24 if num_tracks < 500 else 6
+        which = rng.integers(0, 2, size=n)
+        base_which = rng.integers(0, 2, size=n)
+        times = np.array([rng.uniform(-0.05, clips[c].duration + 0.05) for c in which], dtype=np.float32)
+        base_times = np.array([rng.uniform(-0.05, clips[c].duration + 0.05) for c in base_which], dtype=np.float32)
+        clip_handles = np.array([handles[c] for c in which], dtype=np.uint32)
+        base_handles = np.array([handles[c] for c in base_which], dtype=np.uint32)
+        for rounding, looping, additive_format in ((0, 2, 1), (1, 0, 2), (2, 1, 3), (3, 2, 0), (0, 1, 1)):
+            params = runtime.default_params(rounding_policy=rounding, looping_policy=looping)
+            options = ob.default_options(looping_policy=looping)
+            kwargs = dict(additive_format=additive_format, params=params, object_space=True)
+            if additive_format != 0:
+                kwargs.update(base_clips=base_handles, base_sample_times=base_times)
+            got = context.decompress_poses(clip_handles, times, **kwargs)
+            additive_poses = oracle_poses(blobs, which, times, rounding, options)
+            base_poses = oracle_poses(blobs, base_which, base_times, rounding, options)
+            for i in range(n):
+                local = ob.oracle_apply_additive_to_base(additive_format, base_poses[i], additive_poses[i])
+                assert helpers.exact(got[i], ob.oracle_local_to_object_space(parents, local)), (name, rounding, looping, additive_format, i)
+        # per instance rounding policies reach both the instance and its base
+        instance_rounding = rng.integers(0, 4, size=n).astype(np.uint8)
+        got = context.decompress_poses(clip_handles, times, additive_format=2, base_clips=base_handles, base_sample_times=base_times, instance_rounding=instance_rounding)
+        for i in range(n):
+            a = ob.oracle_decompress_tracks(blobs[which[i]], float(times[i]), int(instance_rounding[i]))
+            b = ob.oracle_decompress_tracks(blobs[base_which[i]], float(base_times[i]), int(instance_rounding[i]))
+            assert helpers.exact(got[i], ob.oracle_apply_additive_to_base(2, b, a))
+        assert context.rejected_instance_count() == 0
+
+
+def test_no_consumers_equals_decompress_tracks(context):
+    clip = synth.build_clip(seed=77, num_tracks=90, num_samples=50, has_scale=1)
+    handle = context.register_clip(clip.blob)
+    times = np.linspace(0.0, clip.duration, 40, dtype=np.float32)
+    handles = np.full(times.size, handle, dtype=np.uint32)
+    assert helpers.exact(context.decompress_poses(handles, times), context.decompress_tracks(handles, times))
+    context.unregister_clip(handle)
+
+
+def test_refused_instances_and_arguments(context):
+    rng = np.random.default_rng(3)
+    with_hierarchy = synth.build_clip(seed=81, num_tracks=20, num_samples=20)
+    without = synth.build_clip(seed=82, num_tracks=20, num_samples=20)
+    other_size = synth.build_clip(seed=83, num_tracks=21, num_samples=20)
+    scalar = synth.build_scalar_clip(seed=84, track_type=0, num_tracks=20, num_samples=10)
+    h_with, h_without, h_other, h_scalar = (context.register_clip(c.blob) for c in (with_hierarchy, without, other_size, scalar))
+    parents = random_hierarchy(rng, 20, 4)
+    context.set_clip_hierarchy(h_with, parents)
+    before = context.rejected_instance_count()
+
+    # object space without a hierarchy, unknown handle, scalar clip: refused, counted, output untouched
+    handles = np.array([h_with, h_without, 12345, h_scalar], dtype=np.uint32)
+    times = np.zeros(4, dtype=np.float32)
+    out = np.full((4, 20, 12), 7.0, dtype=np.float32)
+    context.decompress_poses(handles, times, object_space=True, out=out, num_tracks=20)
+    assert context.rejected_instance_count() == before + 3
+    assert np.all(out[1:] == 7.0) and not np.any(out[0] == 7.0)
+    # without object space the clip without hierarchy is fine
+    out = context.decompress_poses(np.array([h_without], dtype=np.uint32), times[:1])
+    assert helpers.exact(out[0], ob.oracle_decompress_tracks(without.blob, 0.0))
+
+    # a base clip with another number of tracks, an unknown base clip
+    before = context.rejected_instance_count()
+    out = np.full((2, 21, 12), 7.0, dtype=np.float32)
+    context.decompress_poses(np.array([h_with, h_with], dtype=np.uint32), times[:2], additive_format=1, base_clips=np.array([h_other, 999], dtype=np.uint32),
+                             base_sample_times=times[:2], out=out, num_tracks=21)
+    assert context.rejected_instance_count() == before + 2 and np.all(out == 7.0)
+
+    # hierarchies must be sorted parent first, sized like the clip, and belong to a transform clip
+    for bad in (np.array([0] * 19, dtype=np.uint32), np.arange(1, 21, dtype=np.uint32)):
+        with pytest.raises(runtime.AclHipError) as error:
+            context.set_clip_hierarchy(h_with, bad)
+        assert error.value.status == runtime.ERROR_INVALID_ARGUMENT
+    with pytest.raises(runtime.AclHipError):
+        context.set_clip_hierarchy(h_scalar, parents)
+    with pytest.raises(runtime.AclHipError) as error:
+        context.set_clip_hierarchy(4242, parents)
+    assert error.value.status == runtime.ERROR_UNKNOWN_CLIP
+
+    # settings a consumer cannot work with
+    handles = np.array([h_with], dtype=np.uint32)
+    for overrides in (dict(per_track_rounding=1), dict(normalization=runtime.NORMALIZE_ALWAYS), dict(default_rotation_mode=runtime.DEFAULT_SKIPPED)):
+        with pytest.raises(runtime.AclHipError) as error:
+            context.decompress_poses(handles, times[:1], params=runtime.default_params(**overrides))
+        assert error.value.status == runtime.ERROR_INVALID_ARGUMENT
+    with pytest.raises(runtime.AclHipError):
+        context.decompress_poses(handles, times[:1], additive_format=7)
+    with pytest.raises(runtime.AclHipError):       # an additive format without any base
+        context.decompress_poses(handles, times[:1], additive_format=1)
+
+    # replacing a hierarchy takes effect
+    chain = np.concatenate([[runtime.NO_PARENT], np.arange(0, 19)]).astype(np.uint32)
+    context.set_clip_hierarchy(h_with, chain)
+    out = context.decompress_poses(handles, times[:1], object_space=True)
+    assert helpers.exact(out[0], ob.oracle_local_to_object_space(chain, ob.oracle_decompress_tracks(with_hierarchy.blob, 0.0)))
+    for handle in (h_with, h_without, h_other, h_scalar):
+        context.unregister_clip(handle)
+
+
+def test_pose_too_large_for_lds():
+    with runtime.Context(0) as context:
+        big = synth.build_clip(seed=91, num_tracks=1800, num_samples=4)
+        handle = context.register_clip(big.blob)
+        handles, times = np.array([handle], dtype=np.uint32), np.zeros(1, dtype=np.float32)
+        # one image fits (1800 * 48 = 86 400 bytes), two do not
+        out = context.decompress_poses(handles, times)
+        assert helpers.exact(out[0], ob.oracle_decompress_tracks(big.blob, 0.0))
+        with pytest.raises(runtime.AclHipError) as error:
+            context.decompress_poses(handles, times, additive_format=1, base_clips=handles, base_sample_times=times)
+        assert error.value.status == runtime.ERROR_INVALID_ARGUMENT
+
+
+def test_full_size_batch_properties(context):
+    """65 536 instances (BASELINE's batch): the fused kernel equals decode + host-side consumers on a sample of instances, and an
+    identity additive (additive0 with an identity pose buffer as the ADDITIVE side is not expressible; instead: relative onto an
+    identity base) leaves the decode untouched apart from the multiplication by one."""
+    import torch
+    clip = synth.build_clip(seed=7, num_tracks=100, num_samples=301)
+    handle = context.register_clip(clip.blob)
+    rng = np.random.default_rng(0)
+    parents = random_hierarchy(rng, 100, 10)
+    context.set_clip_hierarchy(handle, parents)
+    n = 65536
+    times = torch.from_numpy(rng.uniform(0.0, clip.duration, size=n).astype(np.float32)).cuda()
+    handles = torch.full((n,), handle, dtype=torch.int32).cuda()
+    poses = torch.zeros((n, 100, 12), dtype=torch.float32, device="cuda")
+    consumers = runtime.PoseConsumers()
+    consumers.object_space = 1
+    context.decompress_poses_batch(handles.data_ptr(), times.data_ptr(), n, poses.data_ptr(), 4800, consumers)
+    torch.cuda.synchronize()
+    got = poses.cpu().numpy()
+    host_times = times.cpu().numpy()
+    for i in rng.integers(0, n, size=64):
+        local = ob.oracle_decompress_tracks(clip.blob, float(host_times[i]))
+        assert helpers.exact(got[i], ob.oracle_local_to_object_space(parents, local))
+    # object space rotations stay normalized, whatever the depth
+    lengths = np.linalg.norm(got[:, :, 0:4], axis=2)
+    assert np.abs(lengths - 1.0).max() < 1.0e-5
+    context.unregister_clip(handle)
+    assert context.rejected_instance_count() >= 0

@@ -127,3 +127,36 @@ def test_cpp_context_on_scalar_track_lists(scalar_mirror_binary, tmp_path, track
         expected = ob.oracle_scalar_decompress_tracks(clip.blob, float(t))
         assert np.array_equal(values[i, 0].view(np.uint32), expected.view(np.uint32))
         assert np.array_equal(values[i, 1].view(np.uint32), expected.view(np.uint32))     # decompress_track == decompress_tracks
+
+
+@pytest.fixture(scope="module")
+def pose_consumers_mirror_binary(tmp_path_factory):
+    out = tmp_path_factory.mktemp("cpp") / "pose_consumers_mirror_test"
+    lib_dir = os.path.dirname(runtime.library_path())
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", os.path.join(ROOT, "tests", "cpp", "pose_consumers_mirror_test.cpp"),
+                    "-L" + lib_dir, "-laclhip", "-Wl,-rpath," + lib_dir, "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("name", ["biped_40_scale", "rig_100_two_roots"])
+def test_cpp_context_pose_consumers(pose_consumers_mirror_binary, tmp_path, name):
+    """decompress_pose of the C++ mirror == the oracle's decode -> apply_additive_to_base -> local_to_object_space, bit for bit"""
+    import helpers
+    case = helpers.load_consumer_golden(name)
+    paths = {key: tmp_path / key for key in ("additive.acl", "base.acl", "parents.bin", "times.txt", "poses.bin")}
+    case["additive_blob"].tofile(paths["additive.acl"])
+    case["base_blob"].tofile(paths["base.acl"])
+    case["parents"].astype(np.uint32).tofile(paths["parents.bin"])
+    times = case["times"][:5]
+    paths["times.txt"].write_text("\n".join(f"{float(a)!r} {float(b)!r}" for a, b in times))
+    result = subprocess.run([pose_consumers_mirror_binary] + [str(paths[key]) for key in ("additive.acl", "base.acl", "parents.bin", "times.txt", "poses.bin")])
+    assert result.returncode == 0
+    num_tracks = case["parents"].size
+    poses = np.fromfile(paths["poses.bin"], dtype=np.float32).reshape(times.shape[0], 4, 2, num_tracks, 12)
+    for i, (additive_time, base_time) in enumerate(times):
+        additive_pose = ob.oracle_decompress_tracks(case["additive_blob"], float(additive_time))
+        base_pose = ob.oracle_decompress_tracks(case["base_blob"], float(base_time))
+        for additive_format in range(4):
+            local = ob.oracle_apply_additive_to_base(additive_format, base_pose, additive_pose)
+            assert helpers.exact(poses[i, additive_format, 0], local)
+            assert helpers.exact(poses[i, additive_format, 1], ob.oracle_local_to_object_space(case["parents"], local))
