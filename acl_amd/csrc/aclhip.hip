@@ -412,10 +412,10 @@ namespace aclhip
 	// Up to 8 instances per workgroup, one wave64 per clip instance to decode: the (additive) clip instance and, when the base is a clip,
 	// its base clip instance in a second wave, each into its own LDS image; the two are combined per transform
 	// (apply_additive_to_base, core/additive_utils.h:150). local_to_object_space (compression/transform_pose_utils.h:35) is a walk
-	// down the hierarchy, one depth after the other, and a depth of a 100 bone skeleton is 4-18 transforms wide: done per wave it
-	// would leave most lanes idle for some 130 instructions per depth. So the workgroup's FIRST wave walks all its instances at
-	// once, lanes <-> (instance, transform of the current depth), from copies of the hierarchies the waves left in LDS next to
-	// their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
+	// down the hierarchy, parents first, and a depth of a 100 bone skeleton is 4-18 transforms wide: done per wave it would leave
+	// most lanes idle for some 135 instructions per depth. So the workgroup's FIRST wave walks all its instances at once, lanes <->
+	// (instance, transform of the current step of the schedule aclhip_set_clip_hierarchy made), from copies of the schedules the
+	// waves left in LDS next to their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
 	// HBM happens on the image the decode already holds.
 	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
 	constexpr uint32_t k_consumer_max_instances = 8;
@@ -427,7 +427,7 @@ namespace aclhip
 		unsigned long long* __restrict__ rejected_count)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-		__shared__ uint32_t walk_levels[k_consumer_max_instances];		// depths to walk per instance of the workgroup; 0: nothing to do
+		__shared__ uint32_t walk_levels[k_consumer_max_instances];		// steps to walk per instance of the workgroup; 0: nothing to do
 
 		const bool has_base = consumers.additive_format != 0;
 		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
@@ -484,12 +484,13 @@ namespace aclhip
 					decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					if (object_space)
 					{
-						// num_levels | total words | level_end[num_levels] | pad | {transform, parent} pairs by depth
-						const ACLHIP_CONSTANT uint32_t* hierarchy = as_constant(clip.hierarchy);
-						num_levels = hierarchy[0];
-						const uint32_t num_words = hierarchy[1];
+						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
+						// num_steps | words | step_end[num_steps] | pad | {transform, parent} pairs in step order
+						const uint32_t* schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
+						num_levels = as_constant(schedule)[0];
+						const uint32_t num_words = as_constant(schedule)[1];
 						for (uint32_t word = lane; word < num_words; word += k_wave_size)
-							hierarchy_copy[word] = clip.hierarchy[word];
+							hierarchy_copy[word] = schedule[word];
 					}
 				}
 			}
@@ -520,30 +521,30 @@ namespace aclhip
 
 			if (wave_in_block == 0)
 			{
-				// lanes <-> (instance slot, transform of the current depth): slot = lane % instances, the lanes of a slot stride over its
-				// depth. A transform's parent sits at a lower depth: final by the time it is read.
+				// lanes <-> (instance slot, transform of the current step): slot = lane % instances, lane / instances picks the slot's
+				// transform inside the step. A transform's parent was scheduled in an earlier step: final by the time it is read.
 				const uint32_t walk_slot = lane & ((1u << log2_instances_per_block) - 1u);
 				const uint32_t first = lane >> log2_instances_per_block;
-				const uint32_t stride = k_wave_size >> log2_instances_per_block;
 				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
-				const uint32_t* slot_hierarchy = reinterpret_cast<const uint32_t*>(slot_image + lds_quads_per_image * (base_is_clip ? 2u : 1u));
-				const uint32_t slot_levels = walk_levels[walk_slot];
-				const uint2* pairs = reinterpret_cast<const uint2*>(slot_hierarchy + ((2u + slot_levels + 1u) & ~1u));
+				const uint32_t* slot_schedule = reinterpret_cast<const uint32_t*>(slot_image + lds_quads_per_image * (base_is_clip ? 2u : 1u));
+				const uint32_t slot_steps = walk_levels[walk_slot];
+				const uint2* pairs = reinterpret_cast<const uint2*>(slot_schedule + ((2u + slot_steps + 1u) & ~1u));
 
-				uint32_t level_start = 0;
-				for (uint32_t level = 0; __any(int(level < slot_levels)) != 0; ++level)
+				uint32_t step_start = 0;
+				for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
 				{
-					if (level < slot_levels)
+					if (step < slot_steps)
 					{
-						const uint32_t level_end = slot_hierarchy[2 + level];
-						for (uint32_t pair_index = level_start + first; pair_index < level_end; pair_index += stride)
+						const uint32_t step_end = slot_schedule[2 + step];
+						const uint32_t pair_index = step_start + first;
+						if (pair_index < step_end)
 						{
 							const uint2 pair = pairs[pair_index];		// x: transform, y: its parent
 							qvv object = qvv_mul(load_qvv(slot_image, pair.x), load_qvv(slot_image, pair.y));
 							object.rotation = quat_normalize(object.rotation);
 							store_qvv(slot_image, pair.x, object);
 						}
-						level_start = level_end;
+						step_start = step_end;
 					}
 					wave_lds_barrier();
 				}
@@ -1043,7 +1044,7 @@ struct aclhip_context
 	uint32_t d_clips_capacity = 0;
 	unsigned long long* d_rejected = nullptr;
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
-	uint32_t max_hierarchy_words = 0;		// largest hierarchy image (aclhip_set_clip_hierarchy) among registered clips
+	uint32_t max_hierarchy_words = 0;		// largest walk schedule (aclhip_set_clip_hierarchy) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
@@ -2516,45 +2517,85 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (entry.info.num_tracks != num_tracks)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u parent indices for a clip of %u tracks", num_tracks, entry.info.num_tracks);
 
-		// depth of every transform; local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order
-		// and needs parents first, which makes the result independent of the order INSIDE a depth: lanes take one depth at a time
-		std::vector<uint32_t> depth(num_tracks, 0);
-		uint32_t num_levels = 0;
+		// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first:
+		// any order that keeps a parent ahead of its children gives the same bits. The kernel takes up to P transforms per step,
+		// P = 64 lanes / instances per workgroup, so the walk is scheduled here, once: at every step the P ready transforms with the
+		// longest chain of descendants below them (Hu's algorithm: optimal for unit-time tasks on a forest). A 100 bone character
+		// of 13 depths, 4-18 wide, takes 13 steps of 8 instead of 20.
+		std::vector<uint32_t> height(num_tracks, 1);
+		std::vector<uint32_t> first_child(size_t(num_tracks) + 1, 0), children(num_tracks, 0);
+		const auto is_root = [&](uint32_t i) { return i == 0 || parent_indices[i] == ACLHIP_NO_PARENT; };
 		for (uint32_t i = 1; i < num_tracks; ++i)
 		{
-			const uint32_t parent = parent_indices[i];
-			if (parent == ACLHIP_NO_PARENT)
+			if (is_root(i))
 				continue;
-			if (parent >= i)
-				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", i, parent);
-			depth[i] = depth[parent] + 1;
-			num_levels = std::max(num_levels, depth[i]);
+			if (parent_indices[i] >= i)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", i, parent_indices[i]);
+			first_child[parent_indices[i] + 1]++;
+		}
+		for (uint32_t i = num_tracks; i-- > 1;)
+			if (!is_root(i))
+				height[parent_indices[i]] = std::max(height[parent_indices[i]], height[i] + 1);
+		for (uint32_t i = 0; i < num_tracks; ++i)
+			first_child[i + 1] += first_child[i];
+		{
+			std::vector<uint32_t> cursor(first_child.begin(), first_child.end() - 1);
+			for (uint32_t i = 1; i < num_tracks; ++i)
+				if (!is_root(i))
+					children[cursor[parent_indices[i]]++] = i;
 		}
 
-		// num_levels | total words | level_end[num_levels] | pad to 8 bytes | {transform, parent} of depth 1, depth 2, ...
-		const uint32_t header_words = (2 + num_levels + 1) & ~1u;
-		std::vector<uint32_t> level_end(num_levels, 0);
-		for (uint32_t i = 1; i < num_tracks; ++i)
-			if (depth[i] != 0)
-				level_end[depth[i] - 1]++;
-		for (uint32_t level = 1; level < num_levels; ++level)
-			level_end[level] += level_end[level - 1];
-		const uint32_t num_pairs = num_levels != 0 ? level_end[num_levels - 1] : 0;
-		std::vector<uint32_t> image(size_t(header_words) + size_t(num_pairs) * 2, 0);
-		image[0] = num_levels;
-		std::vector<uint32_t> cursor(num_levels, 0);
-		for (uint32_t level = 1; level < num_levels; ++level)
-			cursor[level] = level_end[level - 1];
-		for (uint32_t i = 1; i < num_tracks; ++i)
+		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
+		// num_steps | words of this schedule | step_end[num_steps] | pad to 8 bytes | {transform, parent} pairs in step order
+		std::vector<uint32_t> image(4, 0);
+		uint32_t max_schedule_words = 0;
+		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)
 		{
-			if (depth[i] == 0)
-				continue;
-			const uint32_t slot = cursor[depth[i] - 1]++;
-			image[header_words + size_t(slot) * 2 + 0] = i;
-			image[header_words + size_t(slot) * 2 + 1] = parent_indices[i];
+			const uint32_t transforms_per_step = 64u >> log2_instances;
+			std::vector<uint32_t> step_end, pairs;
+			// ready transforms, the one with the longest chain below it (then the lowest index) on top
+			const auto less_urgent = [&](uint32_t a, uint32_t b) { return height[a] != height[b] ? height[a] < height[b] : a > b; };
+			std::vector<uint32_t> ready;
+			for (uint32_t i = 0; i < num_tracks; ++i)
+				if (is_root(i))
+					for (uint32_t c = first_child[i]; c < first_child[i + 1]; ++c)
+						ready.push_back(children[c]);
+			std::make_heap(ready.begin(), ready.end(), less_urgent);
+			std::vector<uint32_t> taken;
+			while (!ready.empty())
+			{
+				taken.clear();
+				while (!ready.empty() && taken.size() < transforms_per_step)
+				{
+					std::pop_heap(ready.begin(), ready.end(), less_urgent);
+					taken.push_back(ready.back());
+					ready.pop_back();
+				}
+				for (uint32_t transform : taken)
+				{
+					pairs.push_back(transform);
+					pairs.push_back(parent_indices[transform]);
+					for (uint32_t c = first_child[transform]; c < first_child[transform + 1]; ++c)
+					{
+						ready.push_back(children[c]);
+						std::push_heap(ready.begin(), ready.end(), less_urgent);
+					}
+				}
+				step_end.push_back(uint32_t(pairs.size() / 2));
+			}
+
+			const uint32_t num_steps = uint32_t(step_end.size());
+			const uint32_t header_words = (2 + num_steps + 1) & ~1u;
+			const uint32_t schedule_words = header_words + uint32_t(pairs.size());
+			const uint32_t offset = uint32_t(image.size());
+			image[log2_instances] = offset;
+			image.resize(size_t(offset) + schedule_words, 0);
+			image[offset + 0] = num_steps;
+			image[offset + 1] = schedule_words;
+			std::copy(step_end.begin(), step_end.end(), image.begin() + offset + 2);
+			std::copy(pairs.begin(), pairs.end(), image.begin() + offset + header_words);
+			max_schedule_words = std::max(max_schedule_words, schedule_words);
 		}
-		image[1] = uint32_t(image.size());
-		std::copy(level_end.begin(), level_end.end(), image.begin() + 2);
 
 		device_guard guard(context->device);
 		uint32_t* d_hierarchy = nullptr;
@@ -2574,7 +2615,7 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (entry.d_hierarchy != nullptr)
 			(void)hipFree(entry.d_hierarchy);
 		entry.d_hierarchy = d_hierarchy;
-		context->max_hierarchy_words = std::max(context->max_hierarchy_words, uint32_t(image.size()));
+		context->max_hierarchy_words = std::max(context->max_hierarchy_words, max_schedule_words);
 		return ACLHIP_OK;
 	});
 }

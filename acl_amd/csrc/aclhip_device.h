@@ -116,7 +116,7 @@ namespace aclhip
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
 		uint32_t db_clip_header_offset;			// into db_headers
 		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
-		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: num_levels | level_end[num_levels] | {child, parent} pairs by level; or null
+		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: walk schedules for 1 / 2 / 4 / 8 instances per workgroup; or null
 	};
 
 	static_assert(sizeof(device_clip) == 128, "layout");
