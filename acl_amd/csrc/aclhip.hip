@@ -331,7 +331,7 @@ namespace aclhip
 				kind = kind == 2 ? 0u : kind + 1u;
 			}
 			if (store)
-				pose[r * k_wave_size] = value;
+				store_streaming(&pose[r * k_wave_size], value);
 		}
 	}
 
@@ -559,7 +559,7 @@ namespace aclhip
 		const uint32_t num_quads = num_tracks * 3u;
 		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
 		for (uint32_t quad = role * k_wave_size + lane; quad < num_quads; quad += waves_per_instance * k_wave_size)
-			pose[quad] = image[quad];
+			store_streaming(&pose[quad], image[quad]);
 	}
 
 	// The instance list of convert_track_list's sampling loop (compression/impl/convert.impl.h:161-166): one instance per sample at
@@ -720,9 +720,7 @@ namespace aclhip
 			value[c] = is_constant ? range[c] : lerped;
 		}
 
-		#pragma unroll
-		for (uint32_t c = 0; c < C; ++c)
-			destination[c] = value[c];
+		store_streaming_floats<C>(destination, value);
 	}
 
 	__device__ __forceinline__ void decode_scalar_track_any(uint32_t num_components, const uint8_t* blob, const scalar_track_header* headers, const float* ranges,
@@ -990,7 +988,7 @@ namespace aclhip
 			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
 				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
 			if (store)
-				transforms[size_t(instance) * 3 + kind] = value;
+				store_streaming(&transforms[size_t(instance) * 3 + kind], f32x4{ value.x, value.y, value.z, value.w });
 		}
 	}
 }
@@ -1006,7 +1004,7 @@ namespace
 	{
 		bool in_use = false;
 		uint32_t database = ACLHIP_INVALID_HANDLE;
-		void* device_memory = nullptr;		// one allocation: blob | base pose | quad map | animated tracks
+		void* device_memory = nullptr;		// one piece of a slab: blob | base pose | quad map | animated tracks
 		uint32_t* d_hierarchy = nullptr;	// aclhip_set_clip_hierarchy
 		aclhip_clip_info info = {};
 		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
@@ -1048,7 +1046,88 @@ struct aclhip_context
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
+
+	// Clips live in a few large HBM slabs instead of one hipMalloc each: a batch that draws on hundreds of clips then touches a
+	// handful of large, contiguously mapped regions (fewer address translations to miss) and registration stops paying for an
+	// allocation per clip. Bump allocation inside a slab; a slab is recycled when its last clip is unregistered.
+	struct clip_slab { uint8_t* base = nullptr; size_t capacity = 0; size_t used = 0; uint32_t live = 0; };
+	std::vector<clip_slab> slabs;
 };
+
+namespace
+{
+	constexpr size_t k_slab_bytes = size_t(32) << 20;
+	constexpr size_t k_slab_alignment = 256;
+
+	// nullptr: out of device memory
+	uint8_t* allocate_clip_memory(aclhip_context* context, size_t bytes)
+	{
+		bytes = (bytes + k_slab_alignment - 1) & ~(k_slab_alignment - 1);
+		static const bool use_slabs = []() { const char* value = std::getenv("ACLHIP_CLIP_SLABS"); return value == nullptr || value[0] != '0'; }();
+		if (!use_slabs)
+		{
+			aclhip_context::clip_slab slab;
+			slab.capacity = bytes;
+			if (hipMalloc(reinterpret_cast<void**>(&slab.base), slab.capacity) != hipSuccess)
+				return nullptr;
+			slab.used = bytes;
+			slab.live = 1;
+			context->slabs.push_back(slab);
+			return slab.base;
+		}
+		if (bytes <= k_slab_bytes / 2)
+		{
+			for (size_t i = context->slabs.size(); i-- > 0;)
+			{
+				aclhip_context::clip_slab& slab = context->slabs[i];
+				if (slab.capacity == k_slab_bytes && slab.capacity - slab.used >= bytes)
+				{
+					uint8_t* memory = slab.base + slab.used;
+					slab.used += bytes;
+					slab.live++;
+					return memory;
+				}
+			}
+		}
+
+		// a new slab; clips larger than half a slab get one of their own size
+		aclhip_context::clip_slab slab;
+		slab.capacity = bytes <= k_slab_bytes / 2 ? k_slab_bytes : bytes;
+		if (hipMalloc(reinterpret_cast<void**>(&slab.base), slab.capacity) != hipSuccess)
+			return nullptr;
+		slab.used = bytes;
+		slab.live = 1;
+		context->slabs.push_back(slab);
+		return slab.base;
+	}
+
+	void free_clip_memory(aclhip_context* context, void* memory)
+	{
+		if (memory == nullptr)
+			return;
+		const uint8_t* address = static_cast<const uint8_t*>(memory);
+		for (size_t i = 0; i < context->slabs.size(); ++i)
+		{
+			aclhip_context::clip_slab& slab = context->slabs[i];
+			if (address < slab.base || address >= slab.base + slab.capacity)
+				continue;
+			if (--slab.live != 0)
+				return;
+			// empty: keep one shared slab around for the next registrations, give the rest back
+			bool another_empty = slab.capacity != k_slab_bytes;
+			for (size_t j = 0; j < context->slabs.size() && !another_empty; ++j)
+				another_empty = j != i && context->slabs[j].capacity == k_slab_bytes && context->slabs[j].live == 0;
+			if (another_empty)
+			{
+				(void)hipFree(slab.base);
+				context->slabs.erase(context->slabs.begin() + ptrdiff_t(i));
+			}
+			else
+				slab.used = 0;
+			return;
+		}
+	}
+}
 
 namespace
 {
@@ -1364,9 +1443,8 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 	{
 		device_guard guard(context->device);
 		(void)hipDeviceSynchronize();
-		for (host_clip& clip : context->clips)
-			if (clip.in_use && clip.device_memory != nullptr)
-				(void)hipFree(clip.device_memory);
+		for (aclhip_context::clip_slab& slab : context->slabs)
+			(void)hipFree(slab.base);
 		for (host_clip& clip : context->clips)
 			if (clip.in_use && clip.d_hierarchy != nullptr)
 				(void)hipFree(clip.d_hierarchy);
@@ -1496,8 +1574,8 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 		return status;
 	}
 
-	uint8_t* d_memory = nullptr;
-	if (hipMalloc(reinterpret_cast<void**>(&d_memory), total_bytes) != hipSuccess)
+	uint8_t* d_memory = allocate_clip_memory(context, total_bytes);
+	if (d_memory == nullptr)
 	{
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
@@ -1521,7 +1599,7 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
 		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
 	{
-		(void)hipFree(d_memory);
+		free_clip_memory(context, d_memory);
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
 	}
@@ -1908,8 +1986,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		return status;
 	}
 
-	uint8_t* d_memory = nullptr;
-	if (hipMalloc(reinterpret_cast<void**>(&d_memory), total_bytes) != hipSuccess)
+	uint8_t* d_memory = allocate_clip_memory(context, total_bytes);
+	if (d_memory == nullptr)
 	{
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
@@ -1949,7 +2027,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		// compressed_database::contains core/impl/compressed_database.impl.h:123-140)
 		if (database >= context->databases.size() || !context->databases[database].in_use)
 		{
-			(void)hipFree(d_memory);
+			free_clip_memory(context, d_memory);
 			context->free_slots.push_back(slot);
 			return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
 		}
@@ -1964,7 +2042,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 		if (!contained)
 		{
-			(void)hipFree(d_memory);
+			free_clip_memory(context, d_memory);
 			context->free_slots.push_back(slot);
 			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "the database does not contain this clip");
 		}
@@ -1977,7 +2055,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
 		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
 	{
-		(void)hipFree(d_memory);
+		free_clip_memory(context, d_memory);
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
 	}
@@ -2049,7 +2127,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	std::memset(&cleared, 0, sizeof(cleared));
 	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
 	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
-	ACLHIP_CHECK_HIP(context, hipFree(context->clips[clip].device_memory));
+	free_clip_memory(context, context->clips[clip].device_memory);
 	if (context->clips[clip].d_hierarchy != nullptr)
 		(void)hipFree(context->clips[clip].d_hierarchy);
 	const uint32_t bound_database = context->clips[clip].database;

@@ -11,7 +11,8 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaclhip.so")
+# ACLHIP_LIBRARY: another build of the same library (A/B measurements of kernel variants, see tools/)
+_LIB_PATH = os.environ.get("ACLHIP_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libaclhip.so")
 
 ROUND_NONE, ROUND_FLOOR, ROUND_CEIL, ROUND_NEAREST, ROUND_PER_TRACK = 0, 1, 2, 3, 4
 LOOP_CLAMP, LOOP_WRAP, LOOP_AS_COMPRESSED = 0, 1, 2

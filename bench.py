@@ -54,7 +54,9 @@ def build_workload(name, rank):
                 rotation_default=0.02, rotation_constant=float(0.98 - animated),
                 wrap=int(spec_rng.uniform() < 0.1), strip_keyframes=int(spec_rng.uniform() < 0.1),
                 min_bits=int(spec_rng.integers(5, 10)), max_bits=int(spec_rng.integers(12, 19))))
-        clip_indices = rng.integers(0, 256, size=INSTANCES_PER_GPU).astype(np.uint32)
+        # measurement aid: ACLHIP_BENCH_CLIP_SUBSET=K draws the instances from the first K of the 256 clips only
+        subset = int(os.environ.get("ACLHIP_BENCH_CLIP_SUBSET", "256"))
+        clip_indices = rng.integers(0, subset, size=INSTANCES_PER_GPU).astype(np.uint32)
     elif name == "cinematic":
         clips = [synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,
                                   scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)]
@@ -195,6 +197,8 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar", "object_space", "additive_object_space"])
     parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
+    parser.add_argument("--clip-xcd-affinity", action="store_true",
+                        help="experiment: order the instance list so that workgroup b (4 instances) only sees clips with index %% 8 == b %% 8, i.e. every clip stays in one XCD's L2")
     parser.add_argument("--no-cpu-baseline", action="store_true")
     args = parser.parse_args()
 
@@ -228,7 +232,27 @@ def main():
     from acl_amd import runtime
 
     clips, clip_indices, times = build_workload(args.workload, rank)
-    if args.sort_by_clip:
+    if args.clip_xcd_affinity:
+        # workgroups are dealt to the 8 XCDs round robin; 4 waves = 4 instances per workgroup
+        lists = [list(np.flatnonzero(clip_indices % 8 == x)) for x in range(8)]
+        if args.sort_by_clip:
+            lists = [sorted(l, key=lambda i: clip_indices[i]) for l in lists]
+        order, leftovers = [], []
+        quota = clip_indices.size // 8 // 4 * 4
+        for x in range(8):
+            leftovers += lists[x][quota:]
+            lists[x] = lists[x][:quota]
+        for x in range(8):
+            while len(lists[x]) < quota:
+                lists[x].append(leftovers.pop())
+        for k in range(0, quota, 4):
+            for x in range(8):
+                order += lists[x][k:k + 4]
+        order += leftovers
+        order = np.array(order, dtype=np.int64)
+        assert np.array_equal(np.sort(order), np.arange(clip_indices.size))
+        clip_indices, times = clip_indices[order], times[order]
+    elif args.sort_by_clip:
         order = np.argsort(clip_indices, kind="stable")
         clip_indices, times = clip_indices[order], times[order]
 
