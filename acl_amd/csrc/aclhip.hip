@@ -294,7 +294,9 @@ namespace aclhip
 		for (uint32_t r = 0; r < k_rows; ++r)
 			staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
 
-		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad + lane;
+		// (the row is read here, not in the prologue: one SGPR pair less across the decode)
+		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(row) * pose_stride_bytes) + first_quad + lane;
 
 		// any-settings: rows are 64 quads apart and 64 % 3 == 1, so a lane's sub-track kind advances by one per row
 		const uint32_t lane_quad = first_quad + lane;
@@ -1341,6 +1343,7 @@ namespace
 		out.default_values = params->default_values;
 		out.track_rounding_policies = params->track_rounding_policies;
 		out.instance_rounding_policies = params->instance_rounding_policies;
+		out.instance_rows = nullptr;
 		out.rounding_policy = params->rounding_policy;
 		out.looping_policy = params->looping_policy;
 		out.normalization = params->normalization;
@@ -2547,6 +2550,98 @@ extern "C" aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context,
 
 	device_guard guard(context->device);
 	return launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_batch_rows(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* rows,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (num_instances == 0)
+		return ACLHIP_OK;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+	device_params.instance_rows = rows;
+
+	device_guard guard(context->device);
+	return launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+// Work order for batches that draw on many clips. Workgroup b of a launch runs on XCD b % 8 (each XCD has its own 4 MB L2) and
+// holds k_waves_per_block consecutive (instance, pose window) work items: dealing the instances out so that every clip is only
+// ever decoded on ONE XCD, next to its other instances, leaves each L2 with an eighth of the clips to keep.
+extern "C" aclhip_status aclhip_order_instances_for_locality(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order)
+{
+	if ((clips == nullptr || out_order == nullptr) && num_instances != 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	constexpr uint32_t k_num_xcds = 8;
+	uint32_t windows_per_instance = 1;
+	if (context != nullptr)
+	{
+		std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+		windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+	}
+	// instances per workgroup; poses of several windows fill whole workgroups on their own, only the clip order matters then
+	const uint32_t group = std::max<uint32_t>(k_waves_per_block / windows_per_instance, 1);
+
+	return guarded(const_cast<aclhip_context*>(context), [&]() -> aclhip_status
+	{
+		// per XCD: its instances, bucketed by clip (stable: instances of a clip keep their relative order)
+		std::vector<uint32_t> sorted(num_instances);
+		for (uint32_t i = 0; i < num_instances; ++i)
+			sorted[i] = i;
+		std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b)
+		{
+			const uint32_t xcd_a = clips[a] % k_num_xcds, xcd_b = clips[b] % k_num_xcds;
+			return xcd_a != xcd_b ? xcd_a < xcd_b : clips[a] < clips[b];
+		});
+		uint32_t list_begin[k_num_xcds + 1] = {};
+		for (uint32_t i = 0; i < num_instances; ++i)
+			list_begin[clips[sorted[i]] % k_num_xcds + 1]++;
+		for (uint32_t x = 0; x < k_num_xcds; ++x)
+			list_begin[x + 1] += list_begin[x];
+
+		// deal whole workgroups out round robin; an XCD whose list runs dry takes from the longest remaining list
+		uint32_t cursor[k_num_xcds];
+		for (uint32_t x = 0; x < k_num_xcds; ++x)
+			cursor[x] = list_begin[x];
+		uint32_t written = 0;
+		for (uint32_t workgroup = 0; written < num_instances; ++workgroup)
+		{
+			uint32_t source = workgroup % k_num_xcds;
+			if (cursor[source] == list_begin[source + 1])
+			{
+				uint32_t longest = 0;
+				for (uint32_t x = 0; x < k_num_xcds; ++x)
+					if (list_begin[x + 1] - cursor[x] > longest)
+					{
+						longest = list_begin[x + 1] - cursor[x];
+						source = x;
+					}
+			}
+			const uint32_t take = std::min<uint32_t>(group, list_begin[source + 1] - cursor[source]);
+			for (uint32_t k = 0; k < take; ++k)
+				out_order[written++] = sorted[cursor[source]++];
+			// a short tail would shift every later workgroup's XCD: pad it from the longest list
+			for (uint32_t k = take; k < group && written < num_instances; ++k)
+			{
+				uint32_t longest = 0, from = 0;
+				for (uint32_t x = 0; x < k_num_xcds; ++x)
+					if (list_begin[x + 1] - cursor[x] > longest)
+					{
+						longest = list_begin[x + 1] - cursor[x];
+						from = x;
+					}
+				out_order[written++] = sorted[cursor[from]++];
+			}
+		}
+		return ACLHIP_OK;
+	});
 }
 
 extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,

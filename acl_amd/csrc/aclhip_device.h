@@ -140,6 +140,7 @@ namespace aclhip
 		const float* default_values;
 		const uint8_t* track_rounding_policies;
 		const uint8_t* instance_rounding_policies;
+		const uint32_t* instance_rows;	// pose kernels: row of the pose buffer each instance writes, or null (row = instance index)
 		uint8_t rounding_policy;
 		uint8_t looping_policy;
 		uint8_t normalization;

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_database_stream_in", "aclhip_database_stream_out",
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
+    "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
     "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
@@ -147,6 +148,8 @@ def load_library():
     lib.aclhip_decompress_scalar_track_batch.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_decompress_scalar_tracks_host.argtypes = [vp, vp, vp, u32, pparams, vp, u64]
     lib.aclhip_decompress_scalar_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64]
+    lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
+    lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
     lib.aclhip_set_clip_hierarchy.argtypes = [vp, u32, vp, u32]
     lib.aclhip_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp]
@@ -171,6 +174,16 @@ def check_database(database, bulk_data_medium=None, bulk_data_low=None, check_ha
     message = ctypes.create_string_buffer(512)
     status = load_library().aclhip_check_database(array.ctypes.data, array.size, _host_ptr(medium), _host_ptr(low), 1 if check_hash else 0, message, 512)
     return status, message.value.decode()
+
+
+def order_instances_for_locality(clips):
+    """aclhip_order_instances_for_locality without a context (poses of one wavefront): host only, no GPU needed."""
+    clips = np.ascontiguousarray(clips, dtype=np.uint32)
+    order = np.empty(clips.size, dtype=np.uint32)
+    status = load_library().aclhip_order_instances_for_locality(None, clips.ctypes.data, clips.size, order.ctypes.data)
+    if status != 0:
+        raise AclHipError(status, "aclhip_order_instances_for_locality failed")
+    return order
 
 
 def default_params(**overrides):
@@ -282,6 +295,18 @@ class Context:
         """seek + decompress_tracks for every instance. All pointers are device addresses (ints)."""
         params = params if params is not None else default_params()
         self._check(self._lib.aclhip_decompress_tracks_batch(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream))
+
+    def decompress_tracks_batch_rows(self, clips_ptr, times_ptr, rows_ptr, num_instances, poses_ptr, pose_stride_bytes, params=None, stream=None):
+        """aclhip_decompress_tracks_batch with the pose of instance i stored at row rows[i] (device array)."""
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_tracks_batch_rows(self._handle, clips_ptr, times_ptr, rows_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream))
+
+    def order_instances_for_locality(self, clips):
+        """Host only: the permutation aclhip_order_instances_for_locality computes for the instance list `clips`."""
+        clips = np.ascontiguousarray(clips, dtype=np.uint32)
+        order = np.empty(clips.size, dtype=np.uint32)
+        self._check(self._lib.aclhip_order_instances_for_locality(self._handle, clips.ctypes.data, clips.size, order.ctypes.data))
+        return order
 
     def decompress_track_batch(self, clips_ptr, times_ptr, tracks_ptr, num_instances, out_ptr, params=None, stream=None):
         params = params if params is not None else default_params()

@@ -197,9 +197,11 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar", "object_space", "additive_object_space"])
     parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
-    parser.add_argument("--clip-xcd-affinity", action="store_true",
-                        help="experiment: order the instance list so that workgroup b (4 instances) only sees clips with index %% 8 == b %% 8, i.e. every clip stays in one XCD's L2")
-    parser.add_argument("--no-cpu-baseline", action="store_true")
+    parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
+    parser.add_argument("--order-for-locality", action="store_true",
+                        help="decode in the order aclhip_order_instances_for_locality gives (every clip on one XCD); the poses are stored in that order")
+    parser.add_argument("--keep-rows", action="store_true",
+                        help="with --order-for-locality: store every pose in its instance's ORIGINAL row (aclhip_decompress_tracks_batch_rows)")
     args = parser.parse_args()
 
     import torch
@@ -232,27 +234,7 @@ def main():
     from acl_amd import runtime
 
     clips, clip_indices, times = build_workload(args.workload, rank)
-    if args.clip_xcd_affinity:
-        # workgroups are dealt to the 8 XCDs round robin; 4 waves = 4 instances per workgroup
-        lists = [list(np.flatnonzero(clip_indices % 8 == x)) for x in range(8)]
-        if args.sort_by_clip:
-            lists = [sorted(l, key=lambda i: clip_indices[i]) for l in lists]
-        order, leftovers = [], []
-        quota = clip_indices.size // 8 // 4 * 4
-        for x in range(8):
-            leftovers += lists[x][quota:]
-            lists[x] = lists[x][:quota]
-        for x in range(8):
-            while len(lists[x]) < quota:
-                lists[x].append(leftovers.pop())
-        for k in range(0, quota, 4):
-            for x in range(8):
-                order += lists[x][k:k + 4]
-        order += leftovers
-        order = np.array(order, dtype=np.int64)
-        assert np.array_equal(np.sort(order), np.arange(clip_indices.size))
-        clip_indices, times = clip_indices[order], times[order]
-    elif args.sort_by_clip:
+    if args.sort_by_clip:
         order = np.argsort(clip_indices, kind="stable")
         clip_indices, times = clip_indices[order], times[order]
 
@@ -273,6 +255,19 @@ def main():
     # bytes of one instance's output row: 48 per transform track (rtm::qvvf), 4 per component of a scalar track
     pose_stride = max_tracks * (4 * clips[0].num_components if is_scalar else 48)
 
+    # --order-for-locality: the library lays the instance list out (host side, setup), the poses still land in the caller's rows
+    d_rows = None
+    ordering_ms = None
+    if args.order_for_locality:
+        if is_scalar or args.workload in ("object_space", "additive_object_space"):
+            raise SystemExit("--order-for-locality applies to the pose kernels")
+        ordering_t0 = time.perf_counter()
+        order = context.order_instances_for_locality(handles[clip_indices])
+        ordering_ms = (time.perf_counter() - ordering_t0) * 1e3
+        clip_indices, times = clip_indices[order], times[order]
+        if args.keep_rows:
+            d_rows = torch.from_numpy(order.astype(np.int32)).to(device)
+
     d_clips = torch.from_numpy(handles[clip_indices].astype(np.int32)).to(device)
     d_times = torch.from_numpy(times).to(device)
     d_poses = torch.empty((num_instances, pose_stride // 4), dtype=torch.float32, device=device)
@@ -284,6 +279,9 @@ def main():
     lib = runtime.load_library()
     launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
     launch = lib.aclhip_decompress_scalar_tracks_batch if is_scalar else lib.aclhip_decompress_tracks_batch
+    if d_rows is not None:
+        launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), d_rows.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
+        launch = lib.aclhip_decompress_tracks_batch_rows
 
     # pose consumers: the same decode with the additive apply / local -> object space fused in
     consumers = None
@@ -399,7 +397,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": {"one_clip": "64k instances of one CMU-shaped 100-bone clip, random sample times, quatf_drop_w_variable + vector3f_variable (BASELINE.json configs[1])",
-                             "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else ""),
+                             "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else "") + (", decoded in aclhip_order_instances_for_locality order" + (", poses scattered back to their original rows" if args.keep_rows else "") if args.order_for_locality else ""),
                              "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)",
                              "database": "64k instances per GPU over 16 database-bound 100-bone clips, low importance tier streamed in chunk by chunk on the decode stream during the timed steps (BASELINE.json configs[4] shape, committed fixture)",
                              "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
@@ -408,6 +406,7 @@ def main():
                 "instances_per_gpu": int(num_instances),
                 "bones": int(max_tracks),
                 "distinct_clips": len(clips),
+                "ordering_ms": None if ordering_ms is None else round(ordering_ms, 3),     # aclhip_order_instances_for_locality on the host (setup, not timed)
                 "registration_ms_total": round(registration_ms, 3),      # validate + derive tables + upload, all clips (setup, not timed)
                 "pose_bytes": int(pose_stride),
                 "sharding": f"instances split over {world_size} rank(s), no collective on the data path",
