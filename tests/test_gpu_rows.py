@@ -63,3 +63,28 @@ def test_rows_scatter_into_a_larger_buffer():
             assert helpers.exact(poses[rows[i]], ob.oracle_decompress_tracks(clip.blob, float(times[i])))
         untouched = np.setdiff1d(np.arange(num_rows), rows)
         assert np.all(poses[untouched] == 7.0)
+
+
+def test_clip_memory_is_recycled_across_registrations():
+    """clips share 32 MB slabs (bump allocation, a slab is recycled when its last clip goes): churn must neither leak slabs nor
+    disturb clips that stay"""
+    rng = np.random.default_rng(8)
+    with runtime.Context(0) as context:
+        keeper = synth.build_clip(seed=900, num_tracks=30, num_samples=40)
+        keeper_handle = context.register_clip(keeper.blob)
+        keeper_times = rng.uniform(0.0, keeper.duration, size=8).astype(np.float32)
+        expected = context.decompress_tracks(np.full(8, keeper_handle, dtype=np.uint32), keeper_times)
+        free_before = torch.cuda.mem_get_info()[0]
+        big = synth.build_clip(seed=901, num_tracks=2500, num_samples=400)       # larger than half a slab? no: exercises a large piece
+        for generation in range(6):
+            clips = [synth.build_clip(seed=1000 + generation * 40 + i, num_tracks=60, num_samples=200) for i in range(40)] + [big]
+            handles = [context.register_clip(c.blob) for c in clips]
+            probe = int(rng.integers(0, len(clips)))
+            t = np.array([clips[probe].duration * 0.37], dtype=np.float32)
+            got = context.decompress_tracks(np.array([handles[probe]], dtype=np.uint32), t)
+            assert helpers.exact(got[0], ob.oracle_decompress_tracks(clips[probe].blob, float(t[0])))
+            for handle in handles:
+                context.unregister_clip(handle)
+            assert helpers.exact(context.decompress_tracks(np.full(8, keeper_handle, dtype=np.uint32), keeper_times), expected)
+        # six generations of 41 clips did not grow the footprint by more than a couple of slabs
+        assert free_before - torch.cuda.mem_get_info()[0] < 3 * 32 * 1024 * 1024
