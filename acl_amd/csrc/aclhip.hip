@@ -1051,8 +1051,17 @@ struct aclhip_context
 
 	// Clips live in a few large HBM slabs instead of one hipMalloc each: a batch that draws on hundreds of clips then touches a
 	// handful of large, contiguously mapped regions (fewer address translations to miss) and registration stops paying for an
-	// allocation per clip. Bump allocation inside a slab; a slab is recycled when its last clip is unregistered.
-	struct clip_slab { uint8_t* base = nullptr; size_t capacity = 0; size_t used = 0; uint32_t live = 0; };
+	// allocation per clip. Bump allocation inside a slab; freeing rolls the bump pointer back over every freed piece at the top,
+	// and a slab is recycled when its last clip is unregistered.
+	struct clip_slab
+	{
+		struct piece { size_t offset, size; bool live; };
+		uint8_t* base = nullptr;
+		size_t capacity = 0;
+		size_t used = 0;
+		uint32_t live = 0;
+		std::vector<piece> pieces;		// in address order
+	};
 	std::vector<clip_slab> slabs;
 };
 
@@ -1074,6 +1083,7 @@ namespace
 				return nullptr;
 			slab.used = bytes;
 			slab.live = 1;
+			slab.pieces.push_back({ 0, bytes, true });
 			context->slabs.push_back(slab);
 			return slab.base;
 		}
@@ -1085,6 +1095,7 @@ namespace
 				if (slab.capacity == k_slab_bytes && slab.capacity - slab.used >= bytes)
 				{
 					uint8_t* memory = slab.base + slab.used;
+					slab.pieces.push_back({ slab.used, bytes, true });
 					slab.used += bytes;
 					slab.live++;
 					return memory;
@@ -1099,6 +1110,7 @@ namespace
 			return nullptr;
 		slab.used = bytes;
 		slab.live = 1;
+		slab.pieces.push_back({ 0, bytes, true });
 		context->slabs.push_back(slab);
 		return slab.base;
 	}
@@ -1113,6 +1125,14 @@ namespace
 			aclhip_context::clip_slab& slab = context->slabs[i];
 			if (address < slab.base || address >= slab.base + slab.capacity)
 				continue;
+			for (aclhip_context::clip_slab::piece& piece : slab.pieces)
+				if (slab.base + piece.offset == address)
+					piece.live = false;
+			while (!slab.pieces.empty() && !slab.pieces.back().live)
+			{
+				slab.used = slab.pieces.back().offset;
+				slab.pieces.pop_back();
+			}
 			if (--slab.live != 0)
 				return;
 			// empty: keep one shared slab around for the next registrations, give the rest back
