@@ -231,3 +231,38 @@ def test_full_size_batch_properties(context):
     assert np.abs(lengths - 1.0).max() < 1.0e-5
     context.unregister_clip(handle)
     assert context.rejected_instance_count() >= 0
+
+
+def test_database_bound_clips_follow_the_tiers_in_object_space():
+    """pose consumers decode through the same seek as the pose kernels: a clip bound to a compressed_database picks its keyframes
+    from whatever tiers are resident -- object space of the reference's golden poses after every stream_in / stream_out request"""
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    rng = np.random.default_rng(17)
+    with runtime.Context(0) as context:
+        database = context.register_database(case["database"], case["bulk_medium"], case["bulk_low"])
+        clips = [context.register_clip_with_database(clip, database) for clip in case["clips"]]
+        num_tracks = [ob.oracle().aclo_num_tracks(clip.ctypes.data) for clip in case["clips"]]
+        parents = [random_hierarchy(rng, n, parent_span=6, extra_roots=1) for n in num_tracks]
+        for clip, clip_parents in zip(clips, parents):
+            context.set_clip_hierarchy(clip, clip_parents)
+        num_times = case["times"].shape[1]
+        max_tracks = case["poses"].shape[4]
+        handles = np.repeat(np.array(clips, dtype=np.uint32), num_times)
+        times = case["times"].reshape(-1)
+
+        def check(state):
+            poses = context.decompress_poses(handles, times, object_space=True, num_tracks=max_tracks)
+            for c in range(len(clips)):
+                for i in range(num_times):
+                    local = case["poses"][state, c, 0, i, :num_tracks[c]].copy()      # policy 0 = none
+                    local[:, 7] = 0.0
+                    local[:, 11] = 0.0
+                    expected = ob.oracle_local_to_object_space(parents[c], local)
+                    assert helpers.exact(poses[c * num_times + i, :num_tracks[c]], expected), (state, c, i)
+
+        assert int(case["policies"][0]) == 0
+        check(0)
+        for state, (tier, num_chunks, stream_in) in enumerate(case["ops"]):
+            (context.database_stream_in if stream_in else context.database_stream_out)(database, int(tier), int(num_chunks))
+            check(state + 1)
+        assert context.rejected_instance_count() == 0
