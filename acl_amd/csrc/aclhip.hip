@@ -487,7 +487,7 @@ namespace aclhip
 					if (object_space)
 					{
 						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
-						// num_steps | words | step_end[num_steps] | pad | {transform, parent} pairs in step order
+						// num_steps | words | step_end[num_steps] | transform | parent << 16 in step order
 						const uint32_t* schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
 						num_levels = as_constant(schedule)[0];
 						const uint32_t num_words = as_constant(schedule)[1];
@@ -521,7 +521,9 @@ namespace aclhip
 				walk_levels[slot] = num_levels;
 			__syncthreads();
 
-			if (wave_in_block == 0)
+			// the walking wave rotates with the workgroup index: waves land on SIMDs by their index inside the workgroup, and walks that
+			// all ran on a CU's first SIMD would queue there
+			if (wave_in_block == (blockIdx.x & ((blockDim.x / k_wave_size) - 1u)))
 			{
 				// lanes <-> (instance slot, transform of the current step): slot = lane % instances, lane / instances picks the slot's
 				// transform inside the step. A transform's parent was scheduled in an earlier step: final by the time it is read.
@@ -530,7 +532,7 @@ namespace aclhip
 				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
 				const uint32_t* slot_schedule = reinterpret_cast<const uint32_t*>(slot_image + lds_quads_per_image * (base_is_clip ? 2u : 1u));
 				const uint32_t slot_steps = walk_levels[walk_slot];
-				const uint2* pairs = reinterpret_cast<const uint2*>(slot_schedule + ((2u + slot_steps + 1u) & ~1u));
+				const uint32_t* pairs = slot_schedule + 2u + slot_steps;
 
 				uint32_t step_start = 0;
 				for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
@@ -541,10 +543,10 @@ namespace aclhip
 						const uint32_t pair_index = step_start + first;
 						if (pair_index < step_end)
 						{
-							const uint2 pair = pairs[pair_index];		// x: transform, y: its parent
-							qvv object = qvv_mul(load_qvv(slot_image, pair.x), load_qvv(slot_image, pair.y));
+							const uint32_t pair = pairs[pair_index];		// transform | parent << 16
+							qvv object = qvv_mul(load_qvv(slot_image, pair & 0xFFFFu), load_qvv(slot_image, pair >> 16));
 							object.rotation = quat_normalize(object.rotation);
-							store_qvv(slot_image, pair.x, object);
+							store_qvv(slot_image, pair & 0xFFFFu, object);
 						}
 						step_start = step_end;
 					}
@@ -2709,6 +2711,8 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "clip %u is a scalar track list: no hierarchy", clip);
 		if (entry.info.num_tracks != num_tracks)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u parent indices for a clip of %u tracks", num_tracks, entry.info.num_tracks);
+		if (num_tracks > 0xFFFFu)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u transforms: the pose consumers end at 3413", num_tracks);
 
 		// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first:
 		// any order that keeps a parent ahead of its children gives the same bits. The kernel takes up to P transforms per step,
@@ -2739,7 +2743,8 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		}
 
 		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
-		// num_steps | words of this schedule | step_end[num_steps] | pad to 8 bytes | {transform, parent} pairs in step order
+		// num_steps | words of this schedule | step_end[num_steps] | transform | parent << 16, in step order (16 bits each: the
+		// consumers' LDS images end at 3413 transforms; every word of the copy a wave keeps in LDS costs residency)
 		std::vector<uint32_t> image(4, 0);
 		uint32_t max_schedule_words = 0;
 		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)
@@ -2766,19 +2771,18 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 				}
 				for (uint32_t transform : taken)
 				{
-					pairs.push_back(transform);
-					pairs.push_back(parent_indices[transform]);
+					pairs.push_back(transform | (parent_indices[transform] << 16));
 					for (uint32_t c = first_child[transform]; c < first_child[transform + 1]; ++c)
 					{
 						ready.push_back(children[c]);
 						std::push_heap(ready.begin(), ready.end(), less_urgent);
 					}
 				}
-				step_end.push_back(uint32_t(pairs.size() / 2));
+				step_end.push_back(uint32_t(pairs.size()));
 			}
 
 			const uint32_t num_steps = uint32_t(step_end.size());
-			const uint32_t header_words = (2 + num_steps + 1) & ~1u;
+			const uint32_t header_words = 2 + num_steps;
 			const uint32_t schedule_words = header_words + uint32_t(pairs.size());
 			const uint32_t offset = uint32_t(image.size());
 			image[log2_instances] = offset;
