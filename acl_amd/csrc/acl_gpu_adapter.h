@@ -6,8 +6,10 @@
 // reference's own context.
 #pragma once
 
+#include <acl/core/compressed_database.h>
 #include <acl/core/compressed_tracks.h>
 #include <acl/core/track_writer.h>
+#include <acl/decompression/database/database.h>
 #include <acl/decompression/decompression_settings.h>
 
 #include "aclhip.hpp"
@@ -83,11 +85,66 @@ namespace acl_gpu
 		};
 	}
 
+	// acl::database_context<settings> (includes/acl/decompression/database/database.h:69-201) on the GPU. The reference pulls bulk data
+	// through two database_streamer objects while it decodes; here the GPU side owns the residency, so what initialize() takes is
+	// the bytes those streamers would serve (what debug_database_streamer is constructed with), and a streaming request is a stream
+	// ordered copy + metadata update: nothing is ever "in progress" for the caller to poll.
+	template<class database_settings_type>
+	class database_context
+	{
+	public:
+		// reference: initialize(allocator, database) -- bulk data inline (database.h:110)
+		bool initialize(const acl::compressed_database& database) { return m_impl.initialize(device(), &database, database.get_size()); }
+		// reference: initialize(allocator, database, medium_tier_streamer, low_tier_streamer) (database.h:116)
+		bool initialize(const acl::compressed_database& database, const uint8_t* bulk_data_medium, const uint8_t* bulk_data_low)
+		{
+			return m_impl.initialize(device(), &database, database.get_size(), bulk_data_medium, bulk_data_low);
+		}
+		bool is_initialized() const { return m_impl.is_initialized(); }
+		void reset() { m_impl.reset(); }
+		bool is_bound_to(const acl::compressed_database& database) const { return m_impl.is_bound_to(&database); }
+		bool contains(const acl::compressed_tracks& tracks) const { return m_impl.contains(&tracks); }
+		bool is_streamed_in(acl::quality_tier tier) const { return m_impl.is_streamed_in(static_cast<aclhip::quality_tier>(tier)); }
+		bool is_streaming(acl::quality_tier tier) const { return m_impl.is_streaming(static_cast<aclhip::quality_tier>(tier)); }
+		acl::database_stream_request_result stream_in(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U)
+		{
+			return convert(m_impl.stream_in(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream));
+		}
+		acl::database_stream_request_result stream_out(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U)
+		{
+			return convert(m_impl.stream_out(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream));
+		}
+
+		const aclhip::database_context<aclhip::default_database_settings>& get() const { return m_impl; }
+
+	private:
+		static acl::database_stream_request_result convert(aclhip::database_stream_request_result result)
+		{
+			switch (result)
+			{
+			case aclhip::database_stream_request_result::done:						return acl::database_stream_request_result::done;
+			case aclhip::database_stream_request_result::dispatched:				return acl::database_stream_request_result::dispatched;
+			case aclhip::database_stream_request_result::streaming_in_progress:		return acl::database_stream_request_result::streaming_in_progress;
+			case aclhip::database_stream_request_result::context_not_initialized:	return acl::database_stream_request_result::context_not_initialized;
+			case aclhip::database_stream_request_result::invalid_database_tier:		return acl::database_stream_request_result::invalid_database_tier;
+			default:																return acl::database_stream_request_result::no_free_streaming_requests;
+			}
+		}
+
+		aclhip::database_context<aclhip::default_database_settings> m_impl;
+	};
+
 	template<class settings_type>
 	class decompression_context
 	{
 	public:
 		bool initialize(const acl::compressed_tracks& tracks) { return m_impl.initialize(device(), &tracks, tracks.get_size()); }
+		// reference: initialize(tracks, database_context) (decompress.h:108): false when the database does not contain the clip
+		template<class database_settings_type>
+		bool initialize(const acl::compressed_tracks& tracks, const database_context<database_settings_type>& database)
+		{
+			return m_impl.initialize(&tracks, tracks.get_size(), database.get());
+		}
 		bool is_initialized() const { return m_impl.is_initialized(); }
 		void reset() { m_impl.reset(); }
 		bool relocated(const acl::compressed_tracks& tracks) { return m_impl.relocated(&tracks); }

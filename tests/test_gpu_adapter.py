@@ -39,3 +39,30 @@ def test_reference_context_and_gpu_adapter_agree_bit_for_bit(tmp_path):
     result = subprocess.run([BINARY] + paths, capture_output=True, text=True, timeout=600)
     assert result.returncode == 0, f"exit code {result.returncode}\n{result.stdout}\n{result.stderr}"
     assert result.stdout.count("bit identical") == len(paths)
+
+
+DATABASE_BINARY = os.path.join(os.path.dirname(BINARY), "database_adapter_parity_test")
+
+
+@pytest.mark.skipif(not os.path.exists(DATABASE_BINARY), reason="oracle/_ref/database_adapter_parity_test not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name", helpers.database_golden_cases())
+def test_reference_database_context_and_gpu_adapter_agree_bit_for_bit(tmp_path, name):
+    """acl::database_context fed by the reference's debug_database_streamer next to acl_gpu::database_context, one process, the
+    fixture's script of stream_in / stream_out requests (incl. partial tiers and holes): same request results, same poses after
+    every request"""
+    case = helpers.load_database_golden(name)
+    files = {}
+    for key in ("database", "bulk_medium", "bulk_low"):
+        files[key] = tmp_path / f"{key}.bin"
+        case[key].tofile(files[key])
+    ops_path = tmp_path / "ops.txt"
+    ops_path.write_text("".join(f"{int(tier)} {int(num_chunks)} {int(stream_in)}\n" for tier, num_chunks, stream_in in case["ops"]))
+    clip_paths = []
+    for index, clip in enumerate(case["clips"]):
+        path = tmp_path / f"clip_{index}.acl"
+        clip.tofile(path)
+        clip_paths.append(str(path))
+    result = subprocess.run([DATABASE_BINARY, str(files["database"]), str(files["bulk_medium"]), str(files["bulk_low"]), str(ops_path)] + clip_paths,
+                            capture_output=True, text=True, timeout=300)
+    assert result.returncode == 0, f"exit code {result.returncode}\n{result.stdout}\n{result.stderr}"
+    assert f"{len(case['ops'])} requests, {len(clip_paths)} clips" in result.stdout
