@@ -2712,7 +2712,7 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (entry.info.num_tracks != num_tracks)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u parent indices for a clip of %u tracks", num_tracks, entry.info.num_tracks);
 		if (num_tracks > 0xFFFFu)
-			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u transforms: the pose consumers end at 3413", num_tracks);
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u transforms: the pose consumers end at about 3400", num_tracks);
 
 		// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first:
 		// any order that keeps a parent ahead of its children gives the same bits. The kernel takes up to P transforms per step,
@@ -2744,7 +2744,7 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 
 		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
 		// num_steps | words of this schedule | step_end[num_steps] | transform | parent << 16, in step order (16 bits each: the
-		// consumers' LDS images end at 3413 transforms; every word of the copy a wave keeps in LDS costs residency)
+		// consumers' LDS images end at about 3400 transforms; every word of the copy a wave keeps in LDS costs residency)
 		std::vector<uint32_t> image(4, 0);
 		uint32_t max_schedule_words = 0;
 		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)

@@ -311,8 +311,9 @@ typedef struct aclhip_pose_consumers
  * restricted to what a consumer can work with -- the track_writer's own default sub-track modes, no per track rounding,
  * normalization != always -- else ACLHIP_ERROR_INVALID_ARGUMENT. Instances the kernel refuses (and counts, see
  * aclhip_get_rejected_instance_count) leave their pose untouched: unknown or scalar clips, object_space for a clip without
- * hierarchy, a base clip with another number of tracks. Poses are limited by the 160 KiB of LDS a wave can use: 3413
- * transforms, 1706 when the base is a clip (ACLHIP_ERROR_INVALID_ARGUMENT when a registered clip is larger).
+ * hierarchy, a base clip with another number of tracks. Poses are limited by the 160 KiB of LDS a workgroup can use: about
+ * 3400 transforms (3100 with object space, 1700 when the base is a clip); ACLHIP_ERROR_INVALID_ARGUMENT when the largest
+ * registered clip does not fit.
  * Asynchronous on `stream`. */
 aclhip_status aclhip_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream);
