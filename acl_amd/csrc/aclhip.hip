@@ -429,7 +429,8 @@ namespace aclhip
 		unsigned long long* __restrict__ rejected_count)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-		__shared__ uint32_t walk_levels[k_consumer_max_instances];		// steps to walk per instance of the workgroup; 0: nothing to do
+		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do
+		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
 
 		const bool has_base = consumers.additive_format != 0;
 		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
@@ -446,7 +447,10 @@ namespace aclhip
 		uint8_t* instance_lds = dynamic_lds + size_t(slot) * lds_bytes_per_instance;
 		f32x4* image = reinterpret_cast<f32x4*>(instance_lds);
 		f32x4* base_image = image + lds_quads_per_image;
-		uint32_t* hierarchy_copy = reinterpret_cast<uint32_t*>(base_is_clip ? base_image + lds_quads_per_image : base_image);
+		// one LDS copy of the walk schedule per workgroup, behind the instances' images: the instances of a workgroup usually share
+		// a skeleton (identical hierarchies are one image, see aclhip_set_clip_hierarchy), and every word kept per instance costs residency
+		uint32_t* shared_schedule = reinterpret_cast<uint32_t*>(dynamic_lds + (size_t(lds_bytes_per_instance) << log2_instances_per_block));
+		const uint32_t* schedule = nullptr;
 
 		uint32_t num_tracks = 0;		// stays 0 for a wave without work: past the batch, refused instance, empty track list
 		uint32_t num_levels = 0;
@@ -488,11 +492,12 @@ namespace aclhip
 					{
 						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
 						// num_steps | words | step_end[num_steps] | transform | parent << 16 in step order
-						const uint32_t* schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
+						schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
 						num_levels = as_constant(schedule)[0];
+						// every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then)
 						const uint32_t num_words = as_constant(schedule)[1];
 						for (uint32_t word = lane; word < num_words; word += k_wave_size)
-							hierarchy_copy[word] = schedule[word];
+							shared_schedule[word] = schedule[word];
 					}
 				}
 			}
@@ -518,7 +523,10 @@ namespace aclhip
 		if (object_space)
 		{
 			if (lane == 0 && role == 0)
+			{
 				walk_levels[slot] = num_levels;
+				walk_schedules[slot] = schedule;
+			}
 			__syncthreads();
 
 			// the walking wave rotates with the workgroup index: waves land on SIMDs by their index inside the workgroup, and walks that
@@ -530,28 +538,48 @@ namespace aclhip
 				const uint32_t walk_slot = lane & ((1u << log2_instances_per_block) - 1u);
 				const uint32_t first = lane >> log2_instances_per_block;
 				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
-				const uint32_t* slot_schedule = reinterpret_cast<const uint32_t*>(slot_image + lds_quads_per_image * (base_is_clip ? 2u : 1u));
 				const uint32_t slot_steps = walk_levels[walk_slot];
-				const uint32_t* pairs = slot_schedule + 2u + slot_steps;
+				const uint32_t* slot_schedule = walk_schedules[walk_slot];
 
-				uint32_t step_start = 0;
-				for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
+				const auto walk = [&](const auto* schedule_words)
 				{
-					if (step < slot_steps)
+					const auto* pairs = schedule_words + 2u + slot_steps;
+					uint32_t step_start = 0;
+					for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
 					{
-						const uint32_t step_end = slot_schedule[2 + step];
-						const uint32_t pair_index = step_start + first;
-						if (pair_index < step_end)
+						if (step < slot_steps)
 						{
-							const uint32_t pair = pairs[pair_index];		// transform | parent << 16
-							qvv object = qvv_mul(load_qvv(slot_image, pair & 0xFFFFu), load_qvv(slot_image, pair >> 16));
-							object.rotation = quat_normalize(object.rotation);
-							store_qvv(slot_image, pair & 0xFFFFu, object);
+							const uint32_t step_end = schedule_words[2 + step];
+							const uint32_t pair_index = step_start + first;
+							if (pair_index < step_end)
+							{
+								const uint32_t pair = pairs[pair_index];		// transform | parent << 16
+								qvv object = qvv_mul(load_qvv(slot_image, pair & 0xFFFFu), load_qvv(slot_image, pair >> 16));
+								object.rotation = quat_normalize(object.rotation);
+								store_qvv(slot_image, pair & 0xFFFFu, object);
+							}
+							step_start = step_end;
 						}
-						step_start = step_end;
+						wave_lds_barrier();
 					}
-					wave_lds_barrier();
+				};
+
+				// all instances that walk follow the same schedule? then the shared LDS copy is theirs; otherwise each reads its own
+				// from global memory (rare: mixed skeletons inside one workgroup)
+				// the rest of the workgroup waits for this wave: it goes first on its SIMD
+				__builtin_amdgcn_s_setprio(3);
+				const uint64_t walkers = __ballot(slot_steps != 0);
+				if (walkers != 0)
+				{
+					const uint32_t leader = uint32_t(__builtin_ctzll(walkers));
+					const uint64_t mine = reinterpret_cast<uint64_t>(slot_schedule);
+					const uint64_t first_schedule = (uint64_t(__shfl(uint32_t(mine >> 32), int(leader))) << 32) | __shfl(uint32_t(mine), int(leader));
+					if (__all(int(slot_steps == 0 || mine == first_schedule)) != 0)
+						walk(static_cast<const uint32_t*>(shared_schedule));
+					else
+						walk(as_constant(slot_schedule));
 				}
+				__builtin_amdgcn_s_setprio(0);
 			}
 			__syncthreads();
 		}
@@ -1055,6 +1083,11 @@ struct aclhip_context
 	// handful of large, contiguously mapped regions (fewer address translations to miss) and registration stops paying for an
 	// allocation per clip. Bump allocation inside a slab; freeing rolls the bump pointer back over every freed piece at the top,
 	// and a slab is recycled when its last clip is unregistered.
+	// Walk schedules (aclhip_set_clip_hierarchy), one image per distinct hierarchy: clips of one skeleton share it, which is also
+	// what lets a workgroup whose instances share a skeleton keep a single copy in LDS
+	struct hierarchy_image { std::vector<uint32_t> parents; uint32_t* d_image = nullptr; uint32_t num_users = 0; };
+	std::vector<hierarchy_image> hierarchies;
+
 	struct clip_slab
 	{
 		struct piece { size_t offset, size; bool live; };
@@ -1115,6 +1148,21 @@ namespace
 		slab.pieces.push_back({ 0, bytes, true });
 		context->slabs.push_back(slab);
 		return slab.base;
+	}
+
+	void release_hierarchy(aclhip_context* context, const uint32_t* d_image)
+	{
+		for (size_t i = 0; i < context->hierarchies.size(); ++i)
+		{
+			if (context->hierarchies[i].d_image != d_image)
+				continue;
+			if (--context->hierarchies[i].num_users == 0)
+			{
+				(void)hipFree(context->hierarchies[i].d_image);
+				context->hierarchies.erase(context->hierarchies.begin() + ptrdiff_t(i));
+			}
+			return;
+		}
 	}
 
 	void free_clip_memory(aclhip_context* context, void* memory)
@@ -1470,9 +1518,8 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 		(void)hipDeviceSynchronize();
 		for (aclhip_context::clip_slab& slab : context->slabs)
 			(void)hipFree(slab.base);
-		for (host_clip& clip : context->clips)
-			if (clip.in_use && clip.d_hierarchy != nullptr)
-				(void)hipFree(clip.d_hierarchy);
+		for (aclhip_context::hierarchy_image& hierarchy : context->hierarchies)
+			(void)hipFree(hierarchy.d_image);
 		for (host_database& db : context->databases)
 		{
 			if (!db.in_use)
@@ -2154,7 +2201,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
 	free_clip_memory(context, context->clips[clip].device_memory);
 	if (context->clips[clip].d_hierarchy != nullptr)
-		(void)hipFree(context->clips[clip].d_hierarchy);
+		release_hierarchy(context, context->clips[clip].d_hierarchy);
 	const uint32_t bound_database = context->clips[clip].database;
 	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
 		context->databases[bound_database].num_bound_clips--;
@@ -2795,10 +2842,29 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		}
 
 		device_guard guard(context->device);
-		uint32_t* d_hierarchy = nullptr;
-		if (hipMalloc(reinterpret_cast<void**>(&d_hierarchy), image.size() * sizeof(uint32_t)) != hipSuccess)
-			return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed", image.size() * sizeof(uint32_t));
-		hipError_t hip_status = hipMemcpy(d_hierarchy, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+
+		// an identical hierarchy (another clip of the same skeleton) is already on the device?
+		const std::vector<uint32_t> canonical = [&]()
+		{
+			std::vector<uint32_t> parents(parent_indices, parent_indices + num_tracks);
+			for (uint32_t i = 0; i < num_tracks; ++i)
+				if (is_root(i))
+					parents[i] = ACLHIP_NO_PARENT;
+			return parents;
+		}();
+		aclhip_context::hierarchy_image* shared = nullptr;
+		for (aclhip_context::hierarchy_image& candidate : context->hierarchies)
+			if (candidate.parents == canonical)
+				shared = &candidate;
+
+		uint32_t* d_hierarchy = shared != nullptr ? shared->d_image : nullptr;
+		hipError_t hip_status = hipSuccess;
+		if (shared == nullptr)
+		{
+			if (hipMalloc(reinterpret_cast<void**>(&d_hierarchy), image.size() * sizeof(uint32_t)) != hipSuccess)
+				return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed", image.size() * sizeof(uint32_t));
+			hip_status = hipMemcpy(d_hierarchy, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+		}
 		// launches in flight may still walk the hierarchy that is being replaced
 		if (hip_status == hipSuccess)
 			hip_status = hipDeviceSynchronize();
@@ -2806,11 +2872,22 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			hip_status = hipMemcpy(reinterpret_cast<uint8_t*>(context->d_clips + clip) + offsetof(device_clip, hierarchy), &d_hierarchy, sizeof(d_hierarchy), hipMemcpyHostToDevice);
 		if (hip_status != hipSuccess)
 		{
-			(void)hipFree(d_hierarchy);
+			if (shared == nullptr)
+				(void)hipFree(d_hierarchy);
 			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the hierarchy failed: %s", hipGetErrorString(hip_status));
 		}
+		if (shared != nullptr)
+			shared->num_users++;
+		else
+		{
+			aclhip_context::hierarchy_image created;
+			created.parents = canonical;
+			created.d_image = d_hierarchy;
+			created.num_users = 1;
+			context->hierarchies.push_back(std::move(created));
+		}
 		if (entry.d_hierarchy != nullptr)
-			(void)hipFree(entry.d_hierarchy);
+			release_hierarchy(context, entry.d_hierarchy);
 		entry.d_hierarchy = d_hierarchy;
 		context->max_hierarchy_words = std::max(context->max_hierarchy_words, max_schedule_words);
 		return ACLHIP_OK;
@@ -2838,22 +2915,22 @@ namespace
 
 		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
 		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
-		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64);
-		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (base_is_clip ? 2 : 1)
-			+ (consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0);
-		constexpr size_t k_lds_bytes = 160 * 1024 - 64;		// the kernel's few static words
-		if (lds_bytes_per_instance > k_lds_bytes)
-			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per instance)", context->max_pose_quads / 3, lds_bytes_per_instance);
+		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
+		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (base_is_clip ? 2 : 1);
+		const size_t lds_schedule_bytes = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0;
+		constexpr size_t k_lds_bytes = 160 * 1024 - 128;		// the kernel's few static words
+		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per instance)", context->max_pose_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
 		uint32_t log2_instances_per_block = 2;
 		if (const char* forced = std::getenv("ACLHIP_CONSUMER_LOG2_INSTANCES"))
 			log2_instances_per_block = std::min<uint32_t>(uint32_t(forced[0] - '0'), 3);
-		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) > k_lds_bytes / 3)
+		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) + lds_schedule_bytes > k_lds_bytes / 3)
 			log2_instances_per_block--;
 		const uint32_t instances_per_block = 1u << log2_instances_per_block;
 		const uint32_t waves_per_block = instances_per_block * (base_is_clip ? 2 : 1);
 		const uint32_t num_blocks = (num_instances + instances_per_block - 1) / instances_per_block;
-		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block;
-		if (lds_bytes > 64 * 1024 - 64)		// above the default limit
+		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block + lds_schedule_bytes;
+		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
 			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(decompress_poses_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
 
 		consumer_params device_consumers;

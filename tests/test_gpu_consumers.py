@@ -266,3 +266,31 @@ def test_database_bound_clips_follow_the_tiers_in_object_space():
             (context.database_stream_in if stream_in else context.database_stream_out)(database, int(tier), int(num_chunks))
             check(state + 1)
         assert context.rejected_instance_count() == 0
+
+
+def test_mixed_skeletons_inside_one_workgroup():
+    """instances of one workgroup usually share a skeleton and walk from one LDS copy of its schedule; when they do not, every
+    instance follows its own (different hierarchies, different sizes, clips without one next to clips with one)"""
+    rng = np.random.default_rng(23)
+    with runtime.Context(0) as context:
+        specs = [dict(seed=601, num_tracks=50, num_samples=30), dict(seed=602, num_tracks=50, num_samples=30, has_scale=1),
+                 dict(seed=603, num_tracks=23, num_samples=30), dict(seed=604, num_tracks=50, num_samples=20)]
+        clips = [synth.build_clip(**spec) for spec in specs]
+        handles = [context.register_clip(c.blob) for c in clips]
+        parents = [random_hierarchy(rng, 50, 5), random_hierarchy(rng, 50, 20, extra_roots=2), random_hierarchy(rng, 23, 3), None]
+        parents[3] = parents[0].copy()              # same skeleton as clip 0: one shared schedule image
+        for handle, clip_parents in zip(handles, parents):
+            context.set_clip_hierarchy(handle, clip_parents)
+        n = 257
+        which = rng.integers(0, len(clips), size=n)
+        times = np.array([rng.uniform(0.0, clips[c].duration) for c in which], dtype=np.float32)
+        got = context.decompress_poses(np.array([handles[c] for c in which], dtype=np.uint32), times, object_space=True, num_tracks=50)
+        for i in range(n):
+            c = which[i]
+            local = ob.oracle_decompress_tracks(clips[c].blob, float(times[i]))
+            assert helpers.exact(got[i, :clips[c].num_tracks], ob.oracle_local_to_object_space(parents[c], local)), (i, c)
+        # dropping one user of the shared image leaves the other intact
+        context.unregister_clip(handles[0])
+        got = context.decompress_poses(np.full(8, handles[3], dtype=np.uint32), times[:8] * 0.0, object_space=True, num_tracks=50)
+        assert helpers.exact(got[0], ob.oracle_local_to_object_space(parents[3], ob.oracle_decompress_tracks(clips[3].blob, 0.0)))
+        assert context.rejected_instance_count() == 0
