@@ -6,13 +6,18 @@
 //       sub-tracks decode in place into the LDS image (bit unpack, segment + clip range, W, lerp, normalize), the window streams
 //       out 1 KiB per store instruction. The second entry point is the same body with per track rounding, the non default
 //       default sub-track modes and always-normalize compiled in.
+//   decompress_poses_consumer_kernel   the same decode, whole pose per wave, followed by what callers do next with a local pose -- apply
+//                                      an additive clip onto its base, local -> object space -- before the pose leaves LDS.
 //   decompress_track_kernel            one thread per (instance, bone) request; the registration time plan replaces the
 //                                      reference's O(track index) skip over preceding widths.
 //   decompress_scalar_tracks_kernel    scalar track lists: one wave64 per (instance, 256 tracks), lanes <-> tracks.
 //   decompress_scalar_track_kernel     scalar track lists: one thread per (instance, track) request.
 //   apply_tier_metadata_kernel         publishes / retires database tier metadata behind a stream ordered bulk copy.
 //
-// Host side: context and clip / database registries, blob validation, registration time tables, launches.
+// Every output store is a streaming store (store_streaming, aclhip_device.h): poses must not evict clip data from the L2s.
+//
+// Host side: context and clip / database registries (clips live in shared HBM slabs), blob validation, registration time tables,
+// walk schedules of hierarchies, locality order of instance lists, launches.
 //
 // Build (acl_amd/build.py): hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -mllvm -amdgpu-kernarg-preload-count=16 aclhip.hip -ldl -o ../lib/libaclhip.so
 #include <hip/hip_runtime.h>
