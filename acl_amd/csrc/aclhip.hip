@@ -2746,6 +2746,119 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 
 // ---- pose consumers ------------------------------------------------------------------------------------------------
 
+namespace
+{
+	// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first: any
+	// order that keeps a parent ahead of its children gives the same bits. The consumer kernel takes up to P transforms per step,
+	// P = 64 lanes / instances per workgroup, so the walk is scheduled on the host, once per hierarchy: at every step the P ready
+	// transforms with the longest chain of descendants below them (Hu's algorithm: optimal for unit-time tasks on a forest). A
+	// 100 bone character of 13 depths, 4-18 wide, takes 14 steps of 8 instead of 19 (12, its depth, at 16 per step).
+	struct hierarchy_tree
+	{
+		std::vector<uint32_t> height;			// transforms on the longest chain from this one down to a leaf
+		std::vector<uint32_t> first_child;		// [num_tracks + 1] into children
+		std::vector<uint32_t> children;
+		std::vector<uint8_t> is_root;
+	};
+
+	// false: transform out_misplaced does not follow its parent
+	bool build_hierarchy_tree(const uint32_t* parent_indices, uint32_t num_tracks, hierarchy_tree& out, uint32_t& out_misplaced)
+	{
+		out.height.assign(num_tracks, 1);
+		out.first_child.assign(size_t(num_tracks) + 1, 0);
+		out.children.assign(num_tracks, 0);
+		out.is_root.assign(num_tracks, 0);
+		for (uint32_t i = 0; i < num_tracks; ++i)
+		{
+			// transform 0 is a root whatever its parent index says: the reference never reads it
+			out.is_root[i] = (i == 0 || parent_indices[i] == ACLHIP_NO_PARENT) ? 1 : 0;
+			if (out.is_root[i])
+				continue;
+			if (parent_indices[i] >= i)
+			{
+				out_misplaced = i;
+				return false;
+			}
+			out.first_child[parent_indices[i] + 1]++;
+		}
+		for (uint32_t i = num_tracks; i-- > 1;)
+			if (!out.is_root[i])
+				out.height[parent_indices[i]] = std::max(out.height[parent_indices[i]], out.height[i] + 1);
+		for (uint32_t i = 0; i < num_tracks; ++i)
+			out.first_child[i + 1] += out.first_child[i];
+		std::vector<uint32_t> cursor(out.first_child.begin(), out.first_child.end() - 1);
+		for (uint32_t i = 1; i < num_tracks; ++i)
+			if (!out.is_root[i])
+				out.children[cursor[parent_indices[i]]++] = i;
+		return true;
+	}
+
+	// out_transforms: every transform that has a parent, in the order it is computed; step s covers [out_step_end[s - 1], out_step_end[s])
+	void schedule_hierarchy_walk(const hierarchy_tree& tree, uint32_t num_tracks, uint32_t transforms_per_step, std::vector<uint32_t>& out_step_end, std::vector<uint32_t>& out_transforms)
+	{
+		out_step_end.clear();
+		out_transforms.clear();
+		// ready transforms, the one with the longest chain below it (then the lowest index) on top
+		const auto less_urgent = [&](uint32_t a, uint32_t b) { return tree.height[a] != tree.height[b] ? tree.height[a] < tree.height[b] : a > b; };
+		std::vector<uint32_t> ready;
+		for (uint32_t i = 0; i < num_tracks; ++i)
+			if (tree.is_root[i])
+				for (uint32_t c = tree.first_child[i]; c < tree.first_child[i + 1]; ++c)
+					ready.push_back(tree.children[c]);
+		std::make_heap(ready.begin(), ready.end(), less_urgent);
+		std::vector<uint32_t> taken;
+		while (!ready.empty())
+		{
+			taken.clear();
+			while (!ready.empty() && taken.size() < transforms_per_step)
+			{
+				std::pop_heap(ready.begin(), ready.end(), less_urgent);
+				taken.push_back(ready.back());
+				ready.pop_back();
+			}
+			// their children become ready for the NEXT step
+			for (uint32_t transform : taken)
+			{
+				out_transforms.push_back(transform);
+				for (uint32_t c = tree.first_child[transform]; c < tree.first_child[transform + 1]; ++c)
+				{
+					ready.push_back(tree.children[c]);
+					std::push_heap(ready.begin(), ready.end(), less_urgent);
+				}
+			}
+			out_step_end.push_back(uint32_t(out_transforms.size()));
+		}
+	}
+}
+
+extern "C" aclhip_status aclhip_plan_hierarchy_walk(const uint32_t* parent_indices, uint32_t num_tracks, uint32_t transforms_per_step, uint32_t* out_steps, uint32_t* out_num_steps)
+{
+	if ((parent_indices == nullptr && num_tracks != 0) || out_num_steps == nullptr || transforms_per_step == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	return guarded(nullptr, [&]() -> aclhip_status
+	{
+		hierarchy_tree tree;
+		uint32_t misplaced = 0;
+		if (!build_hierarchy_tree(parent_indices, num_tracks, tree, misplaced))
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		std::vector<uint32_t> step_end, transforms;
+		schedule_hierarchy_walk(tree, num_tracks, transforms_per_step, step_end, transforms);
+		*out_num_steps = uint32_t(step_end.size());
+		if (out_steps != nullptr)
+		{
+			std::fill(out_steps, out_steps + num_tracks, 0u);
+			uint32_t begin = 0;
+			for (uint32_t step = 0; step < step_end.size(); ++step)
+			{
+				for (uint32_t k = begin; k < step_end[step]; ++k)
+					out_steps[transforms[k]] = step + 1;
+				begin = step_end[step];
+			}
+		}
+		return ACLHIP_OK;
+	});
+}
+
 extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks)
 {
 	if (context == nullptr)
@@ -2766,33 +2879,11 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (num_tracks > 0xFFFFu)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u transforms: the pose consumers end at about 3400", num_tracks);
 
-		// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first:
-		// any order that keeps a parent ahead of its children gives the same bits. The kernel takes up to P transforms per step,
-		// P = 64 lanes / instances per workgroup, so the walk is scheduled here, once: at every step the P ready transforms with the
-		// longest chain of descendants below them (Hu's algorithm: optimal for unit-time tasks on a forest). A 100 bone character
-		// of 13 depths, 4-18 wide, takes 13 steps of 8 instead of 20.
-		std::vector<uint32_t> height(num_tracks, 1);
-		std::vector<uint32_t> first_child(size_t(num_tracks) + 1, 0), children(num_tracks, 0);
+		hierarchy_tree tree;
+		uint32_t misplaced = 0;
+		if (!build_hierarchy_tree(parent_indices, num_tracks, tree, misplaced))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", misplaced, parent_indices[misplaced]);
 		const auto is_root = [&](uint32_t i) { return i == 0 || parent_indices[i] == ACLHIP_NO_PARENT; };
-		for (uint32_t i = 1; i < num_tracks; ++i)
-		{
-			if (is_root(i))
-				continue;
-			if (parent_indices[i] >= i)
-				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", i, parent_indices[i]);
-			first_child[parent_indices[i] + 1]++;
-		}
-		for (uint32_t i = num_tracks; i-- > 1;)
-			if (!is_root(i))
-				height[parent_indices[i]] = std::max(height[parent_indices[i]], height[i] + 1);
-		for (uint32_t i = 0; i < num_tracks; ++i)
-			first_child[i + 1] += first_child[i];
-		{
-			std::vector<uint32_t> cursor(first_child.begin(), first_child.end() - 1);
-			for (uint32_t i = 1; i < num_tracks; ++i)
-				if (!is_root(i))
-					children[cursor[parent_indices[i]]++] = i;
-		}
 
 		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
 		// num_steps | words of this schedule | step_end[num_steps] | transform | parent << 16, in step order (16 bits each: the
@@ -2801,37 +2892,10 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		uint32_t max_schedule_words = 0;
 		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)
 		{
-			const uint32_t transforms_per_step = 64u >> log2_instances;
 			std::vector<uint32_t> step_end, pairs;
-			// ready transforms, the one with the longest chain below it (then the lowest index) on top
-			const auto less_urgent = [&](uint32_t a, uint32_t b) { return height[a] != height[b] ? height[a] < height[b] : a > b; };
-			std::vector<uint32_t> ready;
-			for (uint32_t i = 0; i < num_tracks; ++i)
-				if (is_root(i))
-					for (uint32_t c = first_child[i]; c < first_child[i + 1]; ++c)
-						ready.push_back(children[c]);
-			std::make_heap(ready.begin(), ready.end(), less_urgent);
-			std::vector<uint32_t> taken;
-			while (!ready.empty())
-			{
-				taken.clear();
-				while (!ready.empty() && taken.size() < transforms_per_step)
-				{
-					std::pop_heap(ready.begin(), ready.end(), less_urgent);
-					taken.push_back(ready.back());
-					ready.pop_back();
-				}
-				for (uint32_t transform : taken)
-				{
-					pairs.push_back(transform | (parent_indices[transform] << 16));
-					for (uint32_t c = first_child[transform]; c < first_child[transform + 1]; ++c)
-					{
-						ready.push_back(children[c]);
-						std::push_heap(ready.begin(), ready.end(), less_urgent);
-					}
-				}
-				step_end.push_back(uint32_t(pairs.size()));
-			}
+			schedule_hierarchy_walk(tree, num_tracks, 64u >> log2_instances, step_end, pairs);
+			for (uint32_t& pair : pairs)
+				pair |= parent_indices[pair] << 16;
 
 			const uint32_t num_steps = uint32_t(step_end.size());
 			const uint32_t header_words = 2 + num_steps;

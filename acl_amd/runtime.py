@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
-    "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
+    "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
 
@@ -151,6 +151,7 @@ def load_library():
     lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
+    lib.aclhip_plan_hierarchy_walk.argtypes = [vp, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_set_clip_hierarchy.argtypes = [vp, u32, vp, u32]
     lib.aclhip_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp]
     lib.aclhip_decompress_poses_host.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64]
@@ -184,6 +185,17 @@ def order_instances_for_locality(clips):
     if status != 0:
         raise AclHipError(status, "aclhip_order_instances_for_locality failed")
     return order
+
+
+def plan_hierarchy_walk(parent_indices, transforms_per_step):
+    """aclhip_plan_hierarchy_walk (host only): (number of steps, 1-based step per transform with 0 for roots)"""
+    parents = np.ascontiguousarray(parent_indices, dtype=np.uint32)
+    steps = np.zeros(parents.size, dtype=np.uint32)
+    num_steps = ctypes.c_uint32(0)
+    status = load_library().aclhip_plan_hierarchy_walk(parents.ctypes.data, parents.size, int(transforms_per_step), steps.ctypes.data, ctypes.byref(num_steps))
+    if status != 0:
+        raise AclHipError(status, "aclhip_plan_hierarchy_walk: transforms must be sorted parent first")
+    return num_steps.value, steps
 
 
 def default_params(**overrides):

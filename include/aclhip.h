@@ -297,6 +297,13 @@ typedef enum aclhip_additive_format
  * num_tracks must be the clip's. Replaces a previous hierarchy of the clip; synchronizes the device. */
 aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks);
 
+/* Host only (no GPU work): how aclhip_set_clip_hierarchy schedules the object space walk of a hierarchy when up to
+ * `transforms_per_step` transforms can be computed at once (64 / 32 / 16 / 8 for 1 / 2 / 4 / 8 instances per workgroup): every
+ * transform is scheduled after its parent, at every step the ready transforms with the longest chain of descendants go first.
+ * *out_num_steps: steps the walk takes; out_steps (optional, num_tracks entries): the 1-based step of each transform, 0 for roots.
+ * ACLHIP_ERROR_INVALID_ARGUMENT when a transform precedes its parent. */
+aclhip_status aclhip_plan_hierarchy_walk(const uint32_t* parent_indices, uint32_t num_tracks, uint32_t transforms_per_step, uint32_t* out_steps, uint32_t* out_num_steps);
+
 typedef struct aclhip_pose_consumers
 {
 	uint32_t additive_format;			/* aclhip_additive_format: how each decoded instance combines with its base pose */
