@@ -42,7 +42,9 @@ def build_synth(force=False):
 def build_hip(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libaclhip.so")
+    # one translation unit: aclhip.hip includes its parts (*.inl)
     sources = [os.path.join(CSRC, f) for f in ("aclhip.hip", "aclhip_device.h", "acl_format.h")] + [os.path.join(ROOT, "include", "aclhip.h")]
+    sources += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inl"))
     if force or _newer(target, sources):
         _run([HIPCC] + HIP_FLAGS + [sources[0], "-o", target])
     return target

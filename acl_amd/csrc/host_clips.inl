@@ -1,0 +1,671 @@
+// host_clips.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: clip registration (registration time tables), unregistration.
+
+// Scalar track lists (initialize_v0, decompression.scalar.h:100-126): the blob plus one header and one range row per track (bit offset
+// inside a frame = the prefix sum the reference's decompress_track_v0 recomputes per call, :529-541; constant / range values
+// pulled next to it).
+static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t* blob, aclhip_clip* out_clip, bool validate_only)
+{
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+	const uint32_t blob_size = buffer_header.size;
+	const uint32_t num_components = scalar_track_num_components(header.track_type);
+	const uint32_t num_samples = header.num_tracks != 0 ? header.num_samples : 0;
+	const uint32_t num_tracks = num_samples != 0 ? header.num_tracks : 0;
+
+	std::vector<scalar_track_header> track_headers(std::max<uint32_t>(num_tracks, 1));
+	std::vector<float> range_rows(std::max<size_t>(size_t(num_tracks) * 2 * num_components, 8), 0.0f);
+	std::memset(track_headers.data(), 0, track_headers.size() * sizeof(scalar_track_header));
+	uint32_t num_bits_per_frame = 0;
+	if (num_tracks != 0)
+	{
+		const scalar_tracks_header& sh = *reinterpret_cast<const scalar_tracks_header*>(blob + k_transform_header_offset);
+		const uint8_t* base = reinterpret_cast<const uint8_t*>(&sh);
+		const uint8_t* bit_rates = base + sh.metadata_per_track;
+		const float* constant_values = reinterpret_cast<const float*>(base + sh.track_constant_values);
+		const float* range_values = reinterpret_cast<const float*>(base + sh.track_range_values);
+		const uint8_t* num_bits_at_bit_rate = header.version == k_version_first ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
+		const uint32_t animated_bit_base = (k_transform_header_offset + sh.track_animated_values) * 8;	// headers address bits from the blob start
+
+		uint32_t track_bit_offset = 0;
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			scalar_track_header& track_header = track_headers[track];
+			float* range_min = &range_rows[size_t(track) * 2 * num_components];
+			float* range_extent = range_min + num_components;
+			const uint32_t num_bits = num_bits_at_bit_rate[bit_rates[track]];
+			track_header.bit_offset_and_width = 0;
+			track_header.inv_max_value = 1.0f;
+			for (uint32_t c = 0; c < num_components; ++c)
+			{
+				range_min[c] = 0.0f;
+				range_extent[c] = 1.0f;
+			}
+
+			if (num_bits == 0)
+			{
+				for (uint32_t c = 0; c < num_components; ++c)
+				{
+					range_min[c] = constant_values[c];
+					range_extent[c] = 0.0f;
+				}
+				constant_values += num_components;
+				continue;
+			}
+
+			if (uint64_t(animated_bit_base) + track_bit_offset > k_quad_ordinal_mask)
+				return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "frames larger than 2 MiB are not supported");
+			track_header.bit_offset_and_width = (animated_bit_base + track_bit_offset) | (num_bits << 24);
+			if (num_bits != 32)
+			{
+				track_header.inv_max_value = 1.0f / float((1u << num_bits) - 1u);		// PackedTableEntry::max_value (math/scalar_packing.h:119)
+				for (uint32_t c = 0; c < num_components; ++c)
+				{
+					range_min[c] = range_values[c];
+					range_extent[c] = range_values[num_components + c];
+				}
+				range_values += num_components * 2;
+			}
+			track_bit_offset += num_bits * num_components;
+		}
+		num_bits_per_frame = sh.num_bits_per_frame;
+	}
+
+	// one device allocation: blob (+ zeroed tail padding: 8 byte windows are read, the writer reserves 15 bytes) | track headers | range rows
+	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;
+	const uint64_t headers_offset = blob_bytes;
+	const uint64_t ranges_offset = align_to_u32(uint32_t(headers_offset + track_headers.size() * sizeof(scalar_track_header)), 16);
+	const uint64_t total_bytes = ranges_offset + range_rows.size() * sizeof(float) + 16;		// a 3 component row is read as 16 + 8 bytes
+	std::vector<uint8_t> staging(total_bytes, 0);
+	std::memcpy(staging.data(), blob, blob_size);
+	std::memcpy(staging.data() + headers_offset, track_headers.data(), track_headers.size() * sizeof(scalar_track_header));
+	std::memcpy(staging.data() + ranges_offset, range_rows.data(), range_rows.size() * sizeof(float));
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	if (!guard.ok)
+		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+
+	uint32_t slot;
+	if (!context->free_slots.empty())
+	{
+		slot = context->free_slots.back();
+		context->free_slots.pop_back();
+	}
+	else
+	{
+		slot = uint32_t(context->clips.size());
+		context->clips.emplace_back();
+	}
+	const aclhip_status status = grow_clip_table(context, slot + 1);
+	if (status != ACLHIP_OK)
+	{
+		context->free_slots.push_back(slot);
+		return status;
+	}
+
+	uint8_t* d_memory = allocate_clip_memory(context, total_bytes);
+	if (d_memory == nullptr)
+	{
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
+	}
+
+	device_clip record;
+	std::memset(&record, 0, sizeof(record));
+	record.blob = d_memory;
+	record.plan = reinterpret_cast<const plan_entry*>(d_memory + headers_offset);				// scalar_track_header[num_tracks]
+	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + ranges_offset);	// float[num_tracks][2 * C]
+	record.num_tracks = num_tracks;
+	record.num_samples = num_samples;
+	record.sample_rate = header.sample_rate;
+	record.duration_clamp = num_samples <= 1 ? 0.0f : float(num_samples - 1) / header.sample_rate;
+	record.duration_wrap = num_samples == 0 ? 0.0f : float(num_samples) / header.sample_rate;
+	record.num_animated = num_bits_per_frame;
+	record.num_segments = num_tracks != 0 ? k_transform_header_offset + reinterpret_cast<const scalar_tracks_header*>(blob + k_transform_header_offset)->track_animated_values : 0;	// scalar clips: byte offset of the animated values
+	record.flags = k_clip_valid | k_clip_is_scalar | (num_components << k_clip_components_shift);
+	record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
+
+	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		free_clip_memory(context, d_memory);
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
+	}
+
+	host_clip& entry = context->clips[slot];
+	entry.in_use = true;
+	entry.database = ACLHIP_INVALID_HANDLE;
+	entry.device_memory = d_memory;
+	entry.info = aclhip_clip_info();
+	entry.info.num_tracks = header.num_tracks;
+	entry.info.num_samples = header.num_samples;
+	entry.info.sample_rate = header.sample_rate;
+	entry.info.duration = finite_duration(header, k_loop_as_compressed);
+	entry.info.looping_policy = (header.version > k_version_first && header.is_wrap_optimized()) ? ACLHIP_LOOP_WRAP : ACLHIP_LOOP_CLAMP;
+	entry.info.compressed_size = blob_size;
+	entry.info.hash = buffer_header.hash;
+	entry.info.track_type = header.track_type;
+	entry.info.num_components = num_components;
+	entry.touched_bytes = total_bytes - 64;
+	context->max_scalar_tracks = std::max(context->max_scalar_tracks, num_tracks);
+	context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, (num_bits_per_frame + 7) / 8);
+
+	*out_clip = slot;
+	return ACLHIP_OK;
+}
+
+static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
+	bool validate_only = false)
+{
+	if (context == nullptr || out_clip == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_clip = ACLHIP_INVALID_HANDLE;
+
+	const uint8_t* blob = static_cast<const uint8_t*>(compressed_tracks);
+	aclhip_status status = validate_clip(context, blob, size, check_hash);
+	if (status != ACLHIP_OK)
+		return status;
+
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+	if (scalar_track_num_components(header.track_type) != 0)
+	{
+		if (database != ACLHIP_INVALID_HANDLE)
+			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "database decompression is not supported for scalar tracks");	// decompression.scalar.h:107-108
+		return register_scalar_clip(context, blob, out_clip, validate_only);
+	}
+	const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
+	const uint8_t* tbase = blob + k_transform_header_offset;
+	const uint32_t blob_size = buffer_header.size;
+	const uint32_t num_tracks = header.num_tracks;
+	const uint32_t num_quads = num_tracks * 3;
+	const uint32_t num_samples = num_tracks != 0 ? header.num_samples : 0;
+	const uint32_t num_segments = num_tracks != 0 ? th.num_segments : 0;
+	const bool has_scale = num_tracks != 0 && header.has_scale();
+	const bool stripped = num_tracks != 0 && (header.has_stripped_keyframes() || header.has_database());
+	const bool multi_segment = num_segments > 1;
+	const uint32_t raw_num_bits = header.version >= k_version_v02_01_99_1 ? 31u : 32u;	// animated_track_cache.transform.h:523
+
+	const uint32_t num_animated_rotations = num_tracks != 0 ? th.num_animated_rotation_sub_tracks : 0;
+	const uint32_t num_animated_translations = num_tracks != 0 ? th.num_animated_translation_sub_tracks : 0;
+	const uint32_t num_animated_scales = num_tracks != 0 ? th.num_animated_scale_sub_tracks : 0;
+	const uint32_t num_animated = num_animated_rotations + num_animated_translations + num_animated_scales;
+	const uint32_t num_rotations_padded = align_to_u32(num_animated_rotations, 4);
+	if (num_animated > k_quad_ordinal_mask)
+		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "too many animated sub-tracks");
+
+	// ---- derived tables ----
+	std::vector<float> base_pose(size_t(num_quads) * 4);
+	std::vector<clip_range_entry> clip_ranges(std::max<uint32_t>(num_animated, 1));
+	std::vector<sample_record> samples(std::max<uint32_t>(num_samples, 1));
+	std::vector<plan_entry> plan(std::max<size_t>(size_t(num_segments) * num_animated, 1));
+	std::memset(clip_ranges.data(), 0, clip_ranges.size() * sizeof(clip_range_entry));
+	std::memset(samples.data(), 0, samples.size() * sizeof(sample_record));
+	std::memset(plan.data(), 0, plan.size() * sizeof(plan_entry));
+	bool has_raw = false;
+
+	if (num_tracks != 0)
+	{
+		const uint32_t num_entries = (num_tracks + 15) / 16;
+		const uint32_t* types = reinterpret_cast<const uint32_t*>(tbase + th.sub_track_types_offset);
+		const float* constant_rotations = reinterpret_cast<const float*>(tbase + th.constant_track_data_offset);
+		const float* constant_translations = constant_rotations + size_t(th.num_constant_rotation_samples) * 3;
+		const float* constant_scales = constant_translations + size_t(th.num_constant_translation_samples) * 3;
+		const float default_scale = float(header.default_scale());
+
+		uint32_t constant_counts[3] = { 0, 0, 0 };
+		uint32_t animated_counts[3] = { 0, 0, 0 };
+		const uint32_t animated_bases[3] = { 0, num_animated_rotations, num_animated_rotations + num_animated_translations };
+		const uint32_t animated_limits[3] = { num_animated_rotations, num_animated_translations, num_animated_scales };
+		const uint32_t constant_limits[3] = { th.num_constant_rotation_samples, th.num_constant_translation_samples, th.num_constant_scale_samples };
+
+		// base pose: constants expanded, defaults and animated sub-tracks tagged in the W lane
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			for (uint32_t kind = 0; kind < 3; ++kind)
+			{
+				const uint32_t quad = track * 3 + kind;
+				float* value = &base_pose[size_t(quad) * 4];
+				uint32_t* value_bits = reinterpret_cast<uint32_t*>(value);
+				const uint32_t cls = (kind == 2 && !has_scale) ? k_sub_track_default : sub_track_class(types + size_t(kind) * num_entries, track);
+
+				if (cls == k_sub_track_constant)
+				{
+					const uint32_t index = constant_counts[kind]++;
+					if (index >= constant_limits[kind])
+						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more constant sub-tracks than constant samples");
+
+					if (kind == 0)
+					{
+						// constant_track_cache_v0::unpack_rotation_group (constant_track_cache.transform.h:113-205): SOA groups of 4, last one unpadded
+						const uint32_t group = index / 4, lane = index % 4;
+						const uint32_t group_size = std::min<uint32_t>(th.num_constant_rotation_samples - group * 4, 4);
+						const float* group_data = constant_rotations + size_t(group) * 12;
+						const float x = group_data[group_size * 0 + lane];
+						const float y = group_data[group_size * 1 + lane];
+						const float z = group_data[group_size * 2 + lane];
+						// quat_from_positive_w4 (math/quatf.h:135-147), one IEEE operation at a time like the device code
+						volatile float w_squared = 1.0f - (x * x);
+						w_squared = w_squared - (y * y);
+						w_squared = w_squared - (z * z);
+						value[0] = x; value[1] = y; value[2] = z; value[3] = std::sqrt(std::fabs(w_squared));
+					}
+					else
+					{
+						const float* src = (kind == 1 ? constant_translations : constant_scales) + size_t(index) * 3;
+						value[0] = src[0]; value[1] = src[1]; value[2] = src[2]; value[3] = 0.0f;
+					}
+					if (int32_t(value_bits[3]) < 0)
+						value_bits[3] &= 0x7FFFFFFFu;	// only a garbage (NaN) constant could collide with the marker bit
+				}
+				else if (cls == k_sub_track_animated)
+				{
+					const uint32_t index = animated_counts[kind]++;
+					if (index >= animated_limits[kind])
+						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more animated sub-tracks than the header declares");
+					const uint32_t ordinal = animated_bases[kind] + index;
+					clip_ranges[ordinal].track_index = track;
+					clip_ranges[ordinal].quad_index = quad;
+					value[0] = 0.0f; value[1] = 0.0f; value[2] = 0.0f;
+					value_bits[3] = k_quad_special | k_quad_animated | ordinal;
+				}
+				else if (cls == k_sub_track_default)
+				{
+					// identity / zero / the clip's legacy default scale (decompression.transform.h:585,893,1548)
+					const float xyz = kind == 2 ? default_scale : 0.0f;
+					value[0] = xyz; value[1] = xyz; value[2] = xyz;
+					value_bits[3] = k_quad_special | (kind == 0 ? k_quad_default_w_one : 0u);
+				}
+				else
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "invalid sub-track type");
+			}
+		}
+
+		if (animated_counts[0] != num_animated_rotations || animated_counts[1] != num_animated_translations || animated_counts[2] != num_animated_scales)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sub-track types disagree with the animated sub-track counts");
+
+		// clip ranges: rotations are SOA per group of 4 (last group unpadded), translations / scales AOS (write_range_data.h:79-207)
+		{
+			const float* range_data = reinterpret_cast<const float*>(tbase + th.clip_range_data_offset);
+			for (uint32_t i = 0; i < num_animated_rotations; ++i)
+			{
+				const uint32_t group = i / 4, lane = i % 4;
+				const uint32_t group_size = std::min<uint32_t>(num_animated_rotations - group * 4, 4);
+				const float* group_data = range_data + size_t(group) * 24;
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					clip_ranges[i].range_min[c] = group_data[group_size * c + lane];
+					clip_ranges[i].range_extent[c] = group_data[group_size * (3 + c) + lane];
+				}
+			}
+			const float* vector_ranges = range_data + size_t(num_animated_rotations) * 6;
+			for (uint32_t i = num_animated_rotations; i < num_animated; ++i)
+			{
+				const float* entry = vector_ranges + size_t(i - num_animated_rotations) * 6;
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					clip_ranges[i].range_min[c] = entry[c];
+					clip_ranges[i].range_extent[c] = entry[3 + c];
+				}
+			}
+		}
+
+		// segments, sample -> segment, per segment plan
+		const uint32_t segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		const uint32_t* segment_start_indices = multi_segment ? reinterpret_cast<const uint32_t*>(tbase + k_segment_start_indices_offset) : nullptr;
+		for (uint32_t si = 0; si < num_segments; ++si)
+		{
+			const segment_header& sh = *reinterpret_cast<const segment_header*>(tbase + th.segment_headers_offset + size_t(si) * segment_header_size);
+			const uint32_t start = multi_segment ? segment_start_indices[si] : 0;
+			const uint32_t end = multi_segment && si + 1 < num_segments ? segment_start_indices[si + 1] : num_samples;
+			if (start >= end || end > num_samples || end - start > 32 || (si == 0 && start != 0))
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%u, %u)", si, start, end);
+			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324)
+			const uint32_t format_offset = k_transform_header_offset + sh.segment_data;
+			const uint32_t range_offset = align_to_u32(format_offset + th.num_animated_variable_sub_tracks, 2);
+			const uint32_t animated_offset = align_to_u32(range_offset + (multi_segment ? 6u * th.num_animated_variable_sub_tracks : 0u), 4);
+			const uint8_t* format_per_track = blob + format_offset;
+			const uint8_t* range_data = blob + range_offset;
+
+			sample_record record;
+			std::memset(&record, 0, sizeof(record));
+			record.animated_offset = animated_offset;
+			record.pose_bit_size = sh.animated_pose_bit_size;
+			record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : 0xFFFFFFFFu;
+			record.start_index = start;
+			record.plan_row = si * num_animated;
+			record.segment_index = si;
+			for (uint32_t sample = start; sample < end; ++sample)
+				samples[sample] = record;
+
+			// every stored keyframe of a clip-resident segment must lie inside the blob
+			if (!header.has_database())
+			{
+				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(record.sample_indices)) : (end - start);
+				if (uint64_t(animated_offset) + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", si);
+			}
+
+			uint32_t bit_offset = 0;
+			for (uint32_t a = 0; a < num_animated; ++a)
+			{
+				const bool is_rotation = a < num_animated_rotations;
+				const uint32_t vector_index = a - num_animated_rotations;
+				const uint32_t format_index = is_rotation ? a : num_rotations_padded + vector_index;
+				const uint32_t stored_bits = format_per_track[format_index];
+				const bool is_raw = stored_bits == raw_num_bits;
+				if (!is_raw && stored_bits > 23)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u sub-track %u has an invalid bit width %u", si, a, stored_bits);
+				if (bit_offset > k_quad_ordinal_mask)
+					return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "keyframes larger than 2 MiB are not supported");
+
+				plan_entry& entry = plan[size_t(si) * num_animated + a];
+				const uint32_t num_bits = is_raw ? 32u : stored_bits;
+				entry.bit_offset_and_width = bit_offset | (num_bits << 24);
+				entry.inv_max_value = num_bits == 0 ? 0.0f : (is_raw ? 1.0f : 1.0f / float((1u << num_bits) - 1u));
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					entry.range_min[c] = 0.0f;
+					entry.range_extent[c] = 1.0f;
+				}
+				has_raw = has_raw || is_raw;
+
+				if (multi_segment && !is_raw)
+				{
+					// six bytes per sub-track: rotations SOA in padded groups of 4, translations / scales AOS (write_range_data.h:209-341)
+					uint8_t bytes[6];
+					if (is_rotation)
+					{
+						const uint8_t* group = range_data + size_t(a / 4) * 24 + (a % 4);
+						for (uint32_t i = 0; i < 6; ++i)
+							bytes[i] = group[i * 4];
+					}
+					else
+						std::memcpy(bytes, range_data + size_t(num_rotations_padded) * 6 + size_t(vector_index) * 6, 6);
+
+					if (num_bits == 0)
+					{
+						// constant in this segment: a 16 bit sample lives in the range bytes, hi/lo split across the SOA rows for rotations
+						// (animated_track_cache.transform.h:552-588), little endian u16 for vectors (math/vector4_packing.h:628-653)
+						for (uint32_t c = 0; c < 3; ++c)
+						{
+							const uint32_t sample = is_rotation ? ((uint32_t(bytes[c * 2]) << 8) | bytes[c * 2 + 1]) : ((uint32_t(bytes[c * 2 + 1]) << 8) | bytes[c * 2]);
+							entry.range_min[c] = float(sample) * (1.0f / 65535.0f);
+							entry.range_extent[c] = 0.0f;
+						}
+					}
+					else
+					{
+						for (uint32_t c = 0; c < 3; ++c)
+						{
+							entry.range_min[c] = float(bytes[c]) * (1.0f / 255.0f);
+							entry.range_extent[c] = float(bytes[3 + c]) * (1.0f / 255.0f);
+						}
+					}
+				}
+
+				bit_offset += num_bits * 3;
+			}
+
+			if (bit_offset != sh.animated_pose_bit_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: sub-track widths add up to %u bits, header says %u", si, bit_offset, sh.animated_pose_bit_size);
+		}
+	}
+
+	// ---- animated sub-tracks in POSE order ----
+	// The tables above follow the bitstream (rotations, translations, scales); lanes do not care which sub-track they get, so the
+	// tables are reordered by destination window (and by kind inside a window). The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
+	// a contiguous range of ordinals, image_chunks[c] .. image_chunks[c + 1]: the pose kernel can build a pose of any size through
+	// a fixed LDS window.
+	const uint32_t num_image_chunks = std::max<uint32_t>((num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+	std::vector<uint32_t> image_chunks(align_to_u32(num_image_chunks + 1, 4), num_animated);
+	if (num_animated != 0)
+	{
+		std::vector<uint32_t> order(num_animated);		// new ordinal -> bitstream ordinal
+		for (uint32_t a = 0; a < num_animated; ++a)
+			order[a] = a;
+		// inside a window rotations come first: the rotation math (two square roots, a division) is most of a lane's work and every
+		// loop iteration that holds a rotation pays for it, so rotations are packed into as few iterations as possible
+		const auto sort_key = [&](uint32_t ordinal)
+		{
+			const uint32_t quad = clip_ranges[ordinal].quad_index;
+			const uint64_t window = quad / k_image_chunk_quads;
+			const uint64_t is_vector = quad != clip_ranges[ordinal].track_index * 3 ? 1 : 0;
+			return (window << 33) | (is_vector << 32) | quad;
+		};
+		std::sort(order.begin(), order.end(), [&](uint32_t lhs, uint32_t rhs) { return sort_key(lhs) < sort_key(rhs); });
+
+		std::vector<clip_range_entry> ordered_ranges(num_animated);
+		std::vector<plan_entry> ordered_plan(plan.size());
+		for (uint32_t a = 0; a < num_animated; ++a)
+		{
+			ordered_ranges[a] = clip_ranges[order[a]];
+			for (uint32_t si = 0; si < num_segments; ++si)
+				ordered_plan[size_t(si) * num_animated + a] = plan[size_t(si) * num_animated + order[a]];
+			reinterpret_cast<uint32_t*>(base_pose.data())[size_t(ordered_ranges[a].quad_index) * 4 + 3] = k_quad_special | k_quad_animated | a;
+		}
+		std::memcpy(clip_ranges.data(), ordered_ranges.data(), size_t(num_animated) * sizeof(clip_range_entry));
+		plan.swap(ordered_plan);
+
+		uint32_t next = 0;
+		for (uint32_t chunk = 0; chunk < num_image_chunks; ++chunk)
+		{
+			while (next < num_animated && clip_ranges[next].quad_index / k_image_chunk_quads < chunk)
+				next++;
+			image_chunks[chunk] = next;
+		}
+	}
+	else
+		std::fill(image_chunks.begin(), image_chunks.end(), 0u);
+
+	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
+	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
+	const uint64_t base_pose_offset = blob_bytes;
+	// resolved pose: what a decode with the track_writer defaults stores for every non animated sub-track (animated slots: zero)
+	std::vector<float> resolved_pose(base_pose);
+	for (uint32_t quad = 0; quad < num_quads; ++quad)
+	{
+		uint32_t* value_bits = reinterpret_cast<uint32_t*>(&resolved_pose[size_t(quad) * 4]);
+		if (int32_t(value_bits[3]) < 0)
+			resolved_pose[size_t(quad) * 4 + 3] = (value_bits[3] & (k_quad_animated | k_quad_default_w_one)) == k_quad_default_w_one ? 1.0f : 0.0f;
+	}
+
+	const uint64_t resolved_pose_offset = base_pose_offset + uint64_t(num_quads) * 16;
+	const uint64_t samples_offset = align_to_u32(uint32_t(resolved_pose_offset + uint64_t(num_quads) * 16), 32);
+	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
+	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
+	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
+	const uint64_t total_bytes = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);
+
+	std::vector<uint8_t> staging(total_bytes, 0);
+	std::memcpy(staging.data(), blob, blob_size);
+	if (num_quads != 0)
+		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
+	if (num_quads != 0)
+		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
+	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
+	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
+	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
+	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	if (!guard.ok)
+		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+
+	uint32_t slot;
+	if (!context->free_slots.empty())
+	{
+		slot = context->free_slots.back();
+		context->free_slots.pop_back();
+	}
+	else
+	{
+		slot = uint32_t(context->clips.size());
+		context->clips.emplace_back();
+	}
+
+	status = grow_clip_table(context, slot + 1);
+	if (status != ACLHIP_OK)
+	{
+		context->free_slots.push_back(slot);
+		return status;
+	}
+
+	uint8_t* d_memory = allocate_clip_memory(context, total_bytes);
+	if (d_memory == nullptr)
+	{
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc(%llu) failed", static_cast<unsigned long long>(total_bytes));
+	}
+
+	device_clip record;
+	std::memset(&record, 0, sizeof(record));
+	record.blob = d_memory;
+	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
+	record.resolved_pose = reinterpret_cast<const float4*>(d_memory + resolved_pose_offset);
+	record.samples = reinterpret_cast<const sample_record*>(d_memory + samples_offset);
+	record.plan = reinterpret_cast<const plan_entry*>(d_memory + plan_offset);
+	record.clip_ranges = reinterpret_cast<const clip_range_entry*>(d_memory + clip_ranges_offset);
+	record.image_chunks = reinterpret_cast<const uint32_t*>(d_memory + image_chunks_offset);
+	record.num_tracks = num_tracks;
+	record.num_samples = num_samples;
+	record.sample_rate = header.sample_rate;
+	record.duration_clamp = num_samples <= 1 ? 0.0f : float(num_samples - 1) / header.sample_rate;
+	record.duration_wrap = num_samples == 0 ? 0.0f : float(num_samples) / header.sample_rate;
+	record.flags = k_clip_valid;
+	if (num_tracks != 0)
+	{
+		record.flags |= has_scale ? k_clip_has_scale : 0u;
+		record.flags |= stripped ? k_clip_has_stripped_keyframes : 0u;
+		record.flags |= header.has_database() ? k_clip_has_database : 0u;
+		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
+		record.flags |= has_raw ? k_clip_has_raw : 0u;
+		record.num_segments = num_segments;
+		record.num_animated = num_animated;
+		if (header.has_database())
+			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(tbase + th.database_header_offset)->clip_header_offset;
+	}
+
+	if (database != ACLHIP_INVALID_HANDLE)
+	{
+		// decompression_context::initialize(tracks, database): the database must contain the clip (impl/decompress.impl.h:105-107,
+		// compressed_database::contains core/impl/compressed_database.impl.h:123-140)
+		if (database >= context->databases.size() || !context->databases[database].in_use)
+		{
+			free_clip_memory(context, d_memory);
+			context->free_slots.push_back(slot);
+			return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
+		}
+		host_database& db = context->databases[database];
+		bool contained = num_tracks != 0 && header.has_database();
+		if (contained)
+		{
+			contained = false;
+			for (const database_clip_metadata& metadata : db.clip_metadata)
+				contained = contained || (metadata.clip_hash == buffer_header.hash && metadata.clip_header_offset == record.db_clip_header_offset);
+			contained = contained && uint64_t(record.db_clip_header_offset) + sizeof(database_runtime_clip_header) + uint64_t(record.num_segments) * sizeof(database_runtime_segment_header) <= db.runtime_headers_size;
+		}
+		if (!contained)
+		{
+			free_clip_memory(context, d_memory);
+			context->free_slots.push_back(slot);
+			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "the database does not contain this clip");
+		}
+		record.db_headers = db.d_runtime_headers;
+		record.db_bulk_data[0] = db.d_bulk_data[0];
+		record.db_bulk_data[1] = db.d_bulk_data[1];
+		db.num_bound_clips++;
+	}
+
+	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		free_clip_memory(context, d_memory);
+		context->free_slots.push_back(slot);
+		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
+	}
+
+	host_clip& entry = context->clips[slot];
+	entry.in_use = true;
+	entry.database = database;
+	entry.device_memory = d_memory;
+	entry.info.num_tracks = num_tracks;
+	entry.info.num_samples = header.num_samples;
+	entry.info.sample_rate = header.sample_rate;
+	entry.info.duration = finite_duration(header, k_loop_as_compressed);
+	entry.info.num_segments = num_segments;
+	entry.info.has_scale = has_scale ? 1 : 0;
+	entry.info.looping_policy = (header.version > k_version_first && header.is_wrap_optimized()) ? ACLHIP_LOOP_WRAP : ACLHIP_LOOP_CLAMP;
+	entry.info.compressed_size = blob_size;
+	entry.info.hash = buffer_header.hash;
+	entry.info.num_animated_sub_tracks = num_animated;
+	entry.info.has_database = num_tracks != 0 && header.has_database() ? 1 : 0;
+	entry.info.has_stripped_keyframes = num_tracks != 0 && header.has_stripped_keyframes() ? 1 : 0;
+	entry.info.track_type = k_track_type_qvvf;
+	entry.info.num_components = 12;
+	// bytes a batch may read from this clip: the blob itself plus the registration time tables
+	entry.touched_bytes = total_bytes - 64;
+	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
+
+	*out_clip = slot;
+	return ACLHIP_OK;
+}
+
+// No exception crosses the C ABI: a buffer whose counts pass validation but ask for more host memory than there is ends here
+template<class callable>
+static aclhip_status guarded(aclhip_context* context, callable&& call)
+{
+	try
+	{
+		return call();
+	}
+	catch (const std::bad_alloc&)
+	{
+		return context != nullptr ? fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "out of host memory") : ACLHIP_ERROR_OUT_OF_MEMORY;
+	}
+}
+
+extern "C" aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip)
+{
+	return guarded(context, [&]() { return register_clip_impl(context, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, out_clip); });
+}
+
+extern "C" aclhip_status aclhip_register_clip_with_database(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash,
+	aclhip_database database, aclhip_clip* out_clip)
+{
+	if (database == ACLHIP_INVALID_HANDLE)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "invalid database handle") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return guarded(context, [&]() { return register_clip_impl(context, compressed_tracks, size, check_hash, database, out_clip); });
+}
+
+extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+
+	device_guard guard(context->device);
+	device_clip cleared;
+	std::memset(&cleared, 0, sizeof(cleared));
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
+	free_clip_memory(context, context->clips[clip].device_memory);
+	if (context->clips[clip].d_hierarchy != nullptr)
+		release_hierarchy(context, context->clips[clip].d_hierarchy);
+	const uint32_t bound_database = context->clips[clip].database;
+	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
+		context->databases[bound_database].num_bound_clips--;
+	context->clips[clip] = host_clip();
+	context->free_slots.push_back(clip);
+	return ACLHIP_OK;
+}

@@ -1,0 +1,444 @@
+// host_consumers.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: hierarchies and their walk schedules, pose consumer launches, host pointer convenience entry points.
+
+// ---- pose consumers ------------------------------------------------------------------------------------------------
+
+namespace
+{
+	// local_to_object_space (compression/transform_pose_utils.h:35-50) walks transforms in index order and needs parents first: any
+	// order that keeps a parent ahead of its children gives the same bits. The consumer kernel takes up to P transforms per step,
+	// P = 64 lanes / instances per workgroup, so the walk is scheduled on the host, once per hierarchy: at every step the P ready
+	// transforms with the longest chain of descendants below them (Hu's algorithm: optimal for unit-time tasks on a forest). A
+	// 100 bone character of 13 depths, 4-18 wide, takes 14 steps of 8 instead of 19 (12, its depth, at 16 per step).
+	struct hierarchy_tree
+	{
+		std::vector<uint32_t> height;			// transforms on the longest chain from this one down to a leaf
+		std::vector<uint32_t> first_child;		// [num_tracks + 1] into children
+		std::vector<uint32_t> children;
+		std::vector<uint8_t> is_root;
+	};
+
+	// false: transform out_misplaced does not follow its parent
+	bool build_hierarchy_tree(const uint32_t* parent_indices, uint32_t num_tracks, hierarchy_tree& out, uint32_t& out_misplaced)
+	{
+		out.height.assign(num_tracks, 1);
+		out.first_child.assign(size_t(num_tracks) + 1, 0);
+		out.children.assign(num_tracks, 0);
+		out.is_root.assign(num_tracks, 0);
+		for (uint32_t i = 0; i < num_tracks; ++i)
+		{
+			// transform 0 is a root whatever its parent index says: the reference never reads it
+			out.is_root[i] = (i == 0 || parent_indices[i] == ACLHIP_NO_PARENT) ? 1 : 0;
+			if (out.is_root[i])
+				continue;
+			if (parent_indices[i] >= i)
+			{
+				out_misplaced = i;
+				return false;
+			}
+			out.first_child[parent_indices[i] + 1]++;
+		}
+		for (uint32_t i = num_tracks; i-- > 1;)
+			if (!out.is_root[i])
+				out.height[parent_indices[i]] = std::max(out.height[parent_indices[i]], out.height[i] + 1);
+		for (uint32_t i = 0; i < num_tracks; ++i)
+			out.first_child[i + 1] += out.first_child[i];
+		std::vector<uint32_t> cursor(out.first_child.begin(), out.first_child.end() - 1);
+		for (uint32_t i = 1; i < num_tracks; ++i)
+			if (!out.is_root[i])
+				out.children[cursor[parent_indices[i]]++] = i;
+		return true;
+	}
+
+	// out_transforms: every transform that has a parent, in the order it is computed; step s covers [out_step_end[s - 1], out_step_end[s])
+	void schedule_hierarchy_walk(const hierarchy_tree& tree, uint32_t num_tracks, uint32_t transforms_per_step, std::vector<uint32_t>& out_step_end, std::vector<uint32_t>& out_transforms)
+	{
+		out_step_end.clear();
+		out_transforms.clear();
+		// ready transforms, the one with the longest chain below it (then the lowest index) on top
+		const auto less_urgent = [&](uint32_t a, uint32_t b) { return tree.height[a] != tree.height[b] ? tree.height[a] < tree.height[b] : a > b; };
+		std::vector<uint32_t> ready;
+		for (uint32_t i = 0; i < num_tracks; ++i)
+			if (tree.is_root[i])
+				for (uint32_t c = tree.first_child[i]; c < tree.first_child[i + 1]; ++c)
+					ready.push_back(tree.children[c]);
+		std::make_heap(ready.begin(), ready.end(), less_urgent);
+		std::vector<uint32_t> taken;
+		while (!ready.empty())
+		{
+			taken.clear();
+			while (!ready.empty() && taken.size() < transforms_per_step)
+			{
+				std::pop_heap(ready.begin(), ready.end(), less_urgent);
+				taken.push_back(ready.back());
+				ready.pop_back();
+			}
+			// their children become ready for the NEXT step
+			for (uint32_t transform : taken)
+			{
+				out_transforms.push_back(transform);
+				for (uint32_t c = tree.first_child[transform]; c < tree.first_child[transform + 1]; ++c)
+				{
+					ready.push_back(tree.children[c]);
+					std::push_heap(ready.begin(), ready.end(), less_urgent);
+				}
+			}
+			out_step_end.push_back(uint32_t(out_transforms.size()));
+		}
+	}
+}
+
+extern "C" aclhip_status aclhip_plan_hierarchy_walk(const uint32_t* parent_indices, uint32_t num_tracks, uint32_t transforms_per_step, uint32_t* out_steps, uint32_t* out_num_steps)
+{
+	if ((parent_indices == nullptr && num_tracks != 0) || out_num_steps == nullptr || transforms_per_step == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	return guarded(nullptr, [&]() -> aclhip_status
+	{
+		hierarchy_tree tree;
+		uint32_t misplaced = 0;
+		if (!build_hierarchy_tree(parent_indices, num_tracks, tree, misplaced))
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		std::vector<uint32_t> step_end, transforms;
+		schedule_hierarchy_walk(tree, num_tracks, transforms_per_step, step_end, transforms);
+		*out_num_steps = uint32_t(step_end.size());
+		if (out_steps != nullptr)
+		{
+			std::fill(out_steps, out_steps + num_tracks, 0u);
+			uint32_t begin = 0;
+			for (uint32_t step = 0; step < step_end.size(); ++step)
+			{
+				for (uint32_t k = begin; k < step_end[step]; ++k)
+					out_steps[transforms[k]] = step + 1;
+				begin = step_end[step];
+			}
+		}
+		return ACLHIP_OK;
+	});
+}
+
+extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (parent_indices == nullptr && num_tracks != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null parent index list");
+
+	return guarded(context, [&]() -> aclhip_status
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+		host_clip& entry = context->clips[clip];
+		if (entry.info.track_type != k_track_type_qvvf)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "clip %u is a scalar track list: no hierarchy", clip);
+		if (entry.info.num_tracks != num_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u parent indices for a clip of %u tracks", num_tracks, entry.info.num_tracks);
+		if (num_tracks > 0xFFFFu)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u transforms: the pose consumers end at about 3400", num_tracks);
+
+		hierarchy_tree tree;
+		uint32_t misplaced = 0;
+		if (!build_hierarchy_tree(parent_indices, num_tracks, tree, misplaced))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", misplaced, parent_indices[misplaced]);
+		const auto is_root = [&](uint32_t i) { return i == 0 || parent_indices[i] == ACLHIP_NO_PARENT; };
+
+		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
+		// num_steps | words of this schedule | step_end[num_steps] | transform | parent << 16, in step order (16 bits each: the
+		// consumers' LDS images end at about 3400 transforms; every word of the copy a wave keeps in LDS costs residency)
+		std::vector<uint32_t> image(4, 0);
+		uint32_t max_schedule_words = 0;
+		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)
+		{
+			std::vector<uint32_t> step_end, pairs;
+			schedule_hierarchy_walk(tree, num_tracks, 64u >> log2_instances, step_end, pairs);
+			for (uint32_t& pair : pairs)
+				pair |= parent_indices[pair] << 16;
+
+			const uint32_t num_steps = uint32_t(step_end.size());
+			const uint32_t header_words = 2 + num_steps;
+			const uint32_t schedule_words = header_words + uint32_t(pairs.size());
+			const uint32_t offset = uint32_t(image.size());
+			image[log2_instances] = offset;
+			image.resize(size_t(offset) + schedule_words, 0);
+			image[offset + 0] = num_steps;
+			image[offset + 1] = schedule_words;
+			std::copy(step_end.begin(), step_end.end(), image.begin() + offset + 2);
+			std::copy(pairs.begin(), pairs.end(), image.begin() + offset + header_words);
+			max_schedule_words = std::max(max_schedule_words, schedule_words);
+		}
+
+		device_guard guard(context->device);
+
+		// an identical hierarchy (another clip of the same skeleton) is already on the device?
+		const std::vector<uint32_t> canonical = [&]()
+		{
+			std::vector<uint32_t> parents(parent_indices, parent_indices + num_tracks);
+			for (uint32_t i = 0; i < num_tracks; ++i)
+				if (is_root(i))
+					parents[i] = ACLHIP_NO_PARENT;
+			return parents;
+		}();
+		aclhip_context::hierarchy_image* shared = nullptr;
+		for (aclhip_context::hierarchy_image& candidate : context->hierarchies)
+			if (candidate.parents == canonical)
+				shared = &candidate;
+
+		uint32_t* d_hierarchy = shared != nullptr ? shared->d_image : nullptr;
+		hipError_t hip_status = hipSuccess;
+		if (shared == nullptr)
+		{
+			if (hipMalloc(reinterpret_cast<void**>(&d_hierarchy), image.size() * sizeof(uint32_t)) != hipSuccess)
+				return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed", image.size() * sizeof(uint32_t));
+			hip_status = hipMemcpy(d_hierarchy, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+		}
+		// launches in flight may still walk the hierarchy that is being replaced
+		if (hip_status == hipSuccess)
+			hip_status = hipDeviceSynchronize();
+		if (hip_status == hipSuccess)
+			hip_status = hipMemcpy(reinterpret_cast<uint8_t*>(context->d_clips + clip) + offsetof(device_clip, hierarchy), &d_hierarchy, sizeof(d_hierarchy), hipMemcpyHostToDevice);
+		if (hip_status != hipSuccess)
+		{
+			if (shared == nullptr)
+				(void)hipFree(d_hierarchy);
+			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the hierarchy failed: %s", hipGetErrorString(hip_status));
+		}
+		if (shared != nullptr)
+			shared->num_users++;
+		else
+		{
+			aclhip_context::hierarchy_image created;
+			created.parents = canonical;
+			created.d_image = d_hierarchy;
+			created.num_users = 1;
+			context->hierarchies.push_back(std::move(created));
+		}
+		if (entry.d_hierarchy != nullptr)
+			release_hierarchy(context, entry.d_hierarchy);
+		entry.d_hierarchy = d_hierarchy;
+		context->max_hierarchy_words = std::max(context->max_hierarchy_words, max_schedule_words);
+		return ACLHIP_OK;
+	});
+}
+
+namespace
+{
+	aclhip_status launch_consumers(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+		const decode_params& params, const aclhip_pose_consumers& consumers, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
+	{
+		if (consumers.additive_format > ACLHIP_ADDITIVE_ADDITIVE1)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown additive format %u", consumers.additive_format);
+		const bool has_base = consumers.additive_format != ACLHIP_ADDITIVE_NONE;
+		const bool base_is_clip = has_base && consumers.base_clips != nullptr;
+		if (base_is_clip && consumers.base_sample_times == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "base clips without base sample times");
+		if (has_base && !base_is_clip && (consumers.base_poses == nullptr || (consumers.base_pose_stride_bytes & 15u) != 0 || (reinterpret_cast<uintptr_t>(consumers.base_poses) & 15u) != 0))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an additive format needs base clips or a 16 byte aligned base pose buffer");
+		// a consumer needs every sub-track of the pose: the track_writer's own defaults (what the resolved pose image holds)
+		if (params.standard_defaults == 0 || params.per_track_rounding != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding, normalization != always");
+
+		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+
+		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
+		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
+		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
+		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (base_is_clip ? 2 : 1);
+		const size_t lds_schedule_bytes = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0;
+		constexpr size_t k_lds_bytes = 160 * 1024 - 128;		// the kernel's few static words
+		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per instance)", context->max_pose_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
+		uint32_t log2_instances_per_block = 2;
+		if (const char* forced = std::getenv("ACLHIP_CONSUMER_LOG2_INSTANCES"))
+			log2_instances_per_block = std::min<uint32_t>(uint32_t(forced[0] - '0'), 3);
+		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) + lds_schedule_bytes > k_lds_bytes / 3)
+			log2_instances_per_block--;
+		const uint32_t instances_per_block = 1u << log2_instances_per_block;
+		const uint32_t waves_per_block = instances_per_block * (base_is_clip ? 2 : 1);
+		const uint32_t num_blocks = (num_instances + instances_per_block - 1) / instances_per_block;
+		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block + lds_schedule_bytes;
+		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
+			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(decompress_poses_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
+
+		consumer_params device_consumers;
+		device_consumers.base_clip_ids = base_is_clip ? consumers.base_clips : nullptr;
+		device_consumers.base_sample_times = base_is_clip ? consumers.base_sample_times : nullptr;
+		device_consumers.base_poses = has_base && !base_is_clip ? static_cast<const uint8_t*>(consumers.base_poses) : nullptr;
+		device_consumers.base_pose_stride_bytes = consumers.base_pose_stride_bytes;
+		device_consumers.additive_format = consumers.additive_format;
+		device_consumers.object_space = consumers.object_space != 0 ? 1 : 0;
+
+		hipLaunchKernelGGL(decompress_poses_consumer_kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
+			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, uint32_t(lds_bytes_per_instance), log2_instances_per_block, context->d_rejected);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (consumers == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null consumers");
+	if (num_instances == 0)
+		return ACLHIP_OK;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	return launch_consumers(context, clips, sample_times, num_instances, device_params, *consumers, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+namespace
+{
+	// Host pointer convenience path: upload, launch, download, synchronously
+	aclhip_status decompress_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, uint32_t default_values_count, void* out, uint64_t out_stride_bytes, uint64_t out_row_bytes,
+		const aclhip_pose_consumers* consumers = nullptr)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+
+		aclhip_decompress_params local;
+		if (params != nullptr) local = *params; else aclhip_default_params(&local);
+
+		device_guard guard(context->device);
+
+		uint32_t max_tracks = 0;
+		{
+			std::lock_guard<std::mutex> lock(context->mutex);
+			for (uint32_t i = 0; i < num_instances; ++i)
+				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
+					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);
+		}
+
+		const bool single_track = track_indices != nullptr;
+		const uint64_t device_stride = single_track ? 48 : std::max<uint64_t>(uint64_t(max_tracks) * 48, 16);
+		if (!single_track && out_row_bytes == 0)
+			out_row_bytes = uint64_t(max_tracks) * 48;
+
+		std::vector<void*> allocations;
+		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
+		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
+		{
+			void* d = nullptr;
+			if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess)
+				return false;
+			allocations.push_back(d);
+			if (host != nullptr && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+				return false;
+			*out_device = d;
+			return true;
+		};
+
+		void* d_clip_ids = nullptr; void* d_times = nullptr; void* d_tracks = nullptr; void* d_out = nullptr;
+		void* d_defaults = nullptr; void* d_track_policies = nullptr; void* d_instance_policies = nullptr;
+		bool ok = upload(clips, sizeof(uint32_t) * num_instances, &d_clip_ids) && upload(sample_times, sizeof(float) * num_instances, &d_times);
+		if (ok && single_track)
+			ok = upload(track_indices, sizeof(uint32_t) * num_instances, &d_tracks);
+		ok = ok && upload(nullptr, device_stride * num_instances, &d_out);
+		if (ok && local.default_values != nullptr)
+			ok = upload(local.default_values, size_t(std::max<uint32_t>(default_values_count, 1)) * 48, &d_defaults);
+		if (ok && local.track_rounding_policies != nullptr)
+			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
+		if (ok && local.instance_rounding_policies != nullptr)
+			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+
+		aclhip_pose_consumers local_consumers = {};
+		if (consumers != nullptr)
+		{
+			local_consumers = *consumers;
+			void* d_base_clips = nullptr; void* d_base_times = nullptr; void* d_base_poses = nullptr;
+			if (ok && consumers->base_clips != nullptr)
+				ok = upload(consumers->base_clips, sizeof(uint32_t) * num_instances, &d_base_clips);
+			if (ok && consumers->base_sample_times != nullptr)
+				ok = upload(consumers->base_sample_times, sizeof(float) * num_instances, &d_base_times);
+			if (ok && consumers->base_poses != nullptr && consumers->base_clips == nullptr && consumers->additive_format != ACLHIP_ADDITIVE_NONE)
+			{
+				if (consumers->base_pose_stride_bytes < uint64_t(max_tracks) * 48)
+				{
+					release();
+					return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "base pose stride %llu is smaller than a pose of %u transforms", (unsigned long long)consumers->base_pose_stride_bytes, max_tracks);
+				}
+				ok = upload(consumers->base_poses, size_t(consumers->base_pose_stride_bytes) * num_instances, &d_base_poses);
+			}
+			local_consumers.base_clips = static_cast<const aclhip_clip*>(d_base_clips);
+			local_consumers.base_sample_times = static_cast<const float*>(d_base_times);
+			local_consumers.base_poses = d_base_poses;
+		}
+		if (!ok)
+		{
+			release();
+			return fail(context, ACLHIP_ERROR_DEVICE, "staging the batch on the device failed");
+		}
+
+		// Bytes the decode does not write (skipped defaults, tracks beyond a smaller clip's count, rejected instances) must keep
+		// what the caller had there: round trip the caller's buffer
+		{
+			const hipError_t copy_status = hipMemcpy2D(d_out, device_stride, out, out_stride_bytes, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyHostToDevice);
+			if (copy_status != hipSuccess)
+			{
+				release();
+				return fail(context, ACLHIP_ERROR_DEVICE, "uploading the caller's pose buffer failed: %s", hipGetErrorString(copy_status));
+			}
+		}
+
+		local.default_values = static_cast<const float*>(d_defaults);
+		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
+		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+
+		aclhip_status status;
+		if (single_track)
+			status = aclhip_decompress_track_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks), num_instances, &local, d_out, nullptr);
+		else if (consumers != nullptr)
+			status = aclhip_decompress_poses_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, &local_consumers, d_out, device_stride, nullptr);
+		else
+			status = aclhip_decompress_tracks_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, d_out, device_stride, nullptr);
+
+		if (status == ACLHIP_OK)
+		{
+			hipError_t copy_status = hipDeviceSynchronize();
+			if (copy_status == hipSuccess)
+				copy_status = hipMemcpy2D(out, out_stride_bytes, d_out, device_stride, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyDeviceToHost);
+			if (copy_status != hipSuccess)
+				status = fail(context, ACLHIP_ERROR_DEVICE, "downloading the poses failed: %s", hipGetErrorString(copy_status));
+		}
+
+		release();
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes)
+{
+	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, default_values_count, poses, pose_stride_bytes, 0);
+}
+
+extern "C" aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes)
+{
+	if (consumers == nullptr)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null consumers") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (params != nullptr && (params->default_values != nullptr || params->track_rounding_policies != nullptr))
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, 0, poses, pose_stride_bytes, 0, consumers);
+}
+
+extern "C" aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms)
+{
+	if (track_indices == nullptr)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_host(context, clips, sample_times, track_indices, num_instances, params, default_values_count, transforms, 48, 48);
+}

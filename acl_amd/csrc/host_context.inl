@@ -1,0 +1,514 @@
+// host_context.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: registries, the context, clip memory slabs, errors, blob validation, parameters, create / destroy.
+
+
+namespace
+{
+	struct host_clip
+	{
+		bool in_use = false;
+		uint32_t database = ACLHIP_INVALID_HANDLE;
+		void* device_memory = nullptr;		// one piece of a slab: blob | base pose | quad map | animated tracks
+		uint32_t* d_hierarchy = nullptr;	// aclhip_set_clip_hierarchy
+		aclhip_clip_info info = {};
+		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
+	};
+}
+
+namespace
+{
+	struct host_database
+	{
+		bool in_use = false;
+		aclhip_database_info info = {};
+		uint32_t hash = 0;
+		uint32_t num_bound_clips = 0;
+		uint64_t runtime_headers_size = 0;
+		uint8_t* d_runtime_headers = nullptr;			// [clip header, segment headers...] per clip, zeroed = nothing streamed in
+		uint8_t* d_bulk_data[2] = { nullptr, nullptr };	// HBM residence of each tier
+		uint8_t* pinned_bulk_data[2] = { nullptr, nullptr };	// the streamer's backing store (hipHostMalloc)
+		tier_patch* d_patches[2] = { nullptr, nullptr };
+		std::vector<database_chunk_description> chunks[2];
+		std::vector<uint32_t> chunk_first_patch[2];		// num_chunks + 1 entries
+		std::vector<uint32_t> loaded_chunks[2];			// bitset, first chunk in the MSB like core/bitset.h
+		std::vector<database_clip_metadata> clip_metadata;
+	};
+}
+
+struct aclhip_context
+{
+	int device = 0;
+	std::mutex mutex;
+	std::vector<host_clip> clips;
+	std::vector<uint32_t> free_slots;
+	std::vector<host_database> databases;
+	device_clip* d_clips = nullptr;
+	uint32_t d_clips_capacity = 0;
+	unsigned long long* d_rejected = nullptr;
+	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
+	uint32_t max_hierarchy_words = 0;		// largest walk schedule (aclhip_set_clip_hierarchy) among registered clips
+	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
+	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
+	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
+
+	// Clips live in a few large HBM slabs instead of one hipMalloc each: a batch that draws on hundreds of clips then touches a
+	// handful of large, contiguously mapped regions (fewer address translations to miss) and registration stops paying for an
+	// allocation per clip. Bump allocation inside a slab; freeing rolls the bump pointer back over every freed piece at the top,
+	// and a slab is recycled when its last clip is unregistered.
+	// Walk schedules (aclhip_set_clip_hierarchy), one image per distinct hierarchy: clips of one skeleton share it, which is also
+	// what lets a workgroup whose instances share a skeleton keep a single copy in LDS
+	struct hierarchy_image { std::vector<uint32_t> parents; uint32_t* d_image = nullptr; uint32_t num_users = 0; };
+	std::vector<hierarchy_image> hierarchies;
+
+	struct clip_slab
+	{
+		struct piece { size_t offset, size; bool live; };
+		uint8_t* base = nullptr;
+		size_t capacity = 0;
+		size_t used = 0;
+		uint32_t live = 0;
+		std::vector<piece> pieces;		// in address order
+	};
+	std::vector<clip_slab> slabs;
+};
+
+namespace
+{
+	constexpr size_t k_slab_bytes = size_t(32) << 20;
+	constexpr size_t k_slab_alignment = 256;
+
+	// nullptr: out of device memory
+	uint8_t* allocate_clip_memory(aclhip_context* context, size_t bytes)
+	{
+		bytes = (bytes + k_slab_alignment - 1) & ~(k_slab_alignment - 1);
+		static const bool use_slabs = []() { const char* value = std::getenv("ACLHIP_CLIP_SLABS"); return value == nullptr || value[0] != '0'; }();
+		if (!use_slabs)
+		{
+			aclhip_context::clip_slab slab;
+			slab.capacity = bytes;
+			if (hipMalloc(reinterpret_cast<void**>(&slab.base), slab.capacity) != hipSuccess)
+				return nullptr;
+			slab.used = bytes;
+			slab.live = 1;
+			slab.pieces.push_back({ 0, bytes, true });
+			context->slabs.push_back(slab);
+			return slab.base;
+		}
+		if (bytes <= k_slab_bytes / 2)
+		{
+			for (size_t i = context->slabs.size(); i-- > 0;)
+			{
+				aclhip_context::clip_slab& slab = context->slabs[i];
+				if (slab.capacity == k_slab_bytes && slab.capacity - slab.used >= bytes)
+				{
+					uint8_t* memory = slab.base + slab.used;
+					slab.pieces.push_back({ slab.used, bytes, true });
+					slab.used += bytes;
+					slab.live++;
+					return memory;
+				}
+			}
+		}
+
+		// a new slab; clips larger than half a slab get one of their own size
+		aclhip_context::clip_slab slab;
+		slab.capacity = bytes <= k_slab_bytes / 2 ? k_slab_bytes : bytes;
+		if (hipMalloc(reinterpret_cast<void**>(&slab.base), slab.capacity) != hipSuccess)
+			return nullptr;
+		slab.used = bytes;
+		slab.live = 1;
+		slab.pieces.push_back({ 0, bytes, true });
+		context->slabs.push_back(slab);
+		return slab.base;
+	}
+
+	void release_hierarchy(aclhip_context* context, const uint32_t* d_image)
+	{
+		for (size_t i = 0; i < context->hierarchies.size(); ++i)
+		{
+			if (context->hierarchies[i].d_image != d_image)
+				continue;
+			if (--context->hierarchies[i].num_users == 0)
+			{
+				(void)hipFree(context->hierarchies[i].d_image);
+				context->hierarchies.erase(context->hierarchies.begin() + ptrdiff_t(i));
+			}
+			return;
+		}
+	}
+
+	void free_clip_memory(aclhip_context* context, void* memory)
+	{
+		if (memory == nullptr)
+			return;
+		const uint8_t* address = static_cast<const uint8_t*>(memory);
+		for (size_t i = 0; i < context->slabs.size(); ++i)
+		{
+			aclhip_context::clip_slab& slab = context->slabs[i];
+			if (address < slab.base || address >= slab.base + slab.capacity)
+				continue;
+			for (aclhip_context::clip_slab::piece& piece : slab.pieces)
+				if (slab.base + piece.offset == address)
+					piece.live = false;
+			while (!slab.pieces.empty() && !slab.pieces.back().live)
+			{
+				slab.used = slab.pieces.back().offset;
+				slab.pieces.pop_back();
+			}
+			if (--slab.live != 0)
+				return;
+			// empty: keep one shared slab around for the next registrations, give the rest back
+			bool another_empty = slab.capacity != k_slab_bytes;
+			for (size_t j = 0; j < context->slabs.size() && !another_empty; ++j)
+				another_empty = j != i && context->slabs[j].capacity == k_slab_bytes && context->slabs[j].live == 0;
+			if (another_empty)
+			{
+				(void)hipFree(slab.base);
+				context->slabs.erase(context->slabs.begin() + ptrdiff_t(i));
+			}
+			else
+				slab.used = 0;
+			return;
+		}
+	}
+}
+
+namespace
+{
+	thread_local std::string t_last_error;
+
+	aclhip_status fail(const aclhip_context* context, aclhip_status status, const char* format, ...)
+	{
+		char buffer[512];
+		va_list args;
+		va_start(args, format);
+		std::vsnprintf(buffer, sizeof(buffer), format, args);
+		va_end(args);
+		(void)context;
+		t_last_error = buffer;		// per thread: contexts are shared between threads, messages are not
+		return status;
+	}
+
+	#define ACLHIP_CHECK_HIP(context, expression) \
+		do { const hipError_t hip_status_ = (expression); if (hip_status_ != hipSuccess) return fail((context), ACLHIP_ERROR_DEVICE, "%s failed: %s", #expression, hipGetErrorString(hip_status_)); } while (0)
+
+	// Makes the context's device current for the duration of a call; a no-op (one thread-local read) when it already is,
+	// which is the one-process-per-GPU case the launch path cares about.
+	struct device_guard
+	{
+		int previous = -1;
+		bool switched = false;
+		bool ok = false;
+		explicit device_guard(int device)
+		{
+			if (hipGetDevice(&previous) != hipSuccess)
+				return;
+			if (previous == device)
+				ok = true;
+			else
+			{
+				ok = hipSetDevice(device) == hipSuccess;
+				switched = ok;
+			}
+		}
+		~device_guard() { if (switched) (void)hipSetDevice(previous); }
+	};
+
+	// compressed_tracks::is_valid (core/impl/compressed_tracks.impl.h:278-301) + bounds checks so that a decode can never read outside the blob
+	// Scalar track lists: every offset of the scalar_tracks_header and the whole animated stream must lie inside the buffer
+	// (compressed_tracks::is_valid only checks tag / version / hash, core/impl/compressed_tracks.impl.h:278-301; the device reads
+	// through these offsets, so they are checked here).
+	aclhip_status validate_scalar_clip(const aclhip_context* context, const uint8_t* blob)
+	{
+		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+		const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+		if (header.has_database())
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "database decompression is not supported for scalar tracks");	// decompression.scalar.h:107-108
+		if (header.num_tracks == 0 || header.num_samples == 0)
+			return ACLHIP_OK;
+		if (!(header.sample_rate > 0.0f))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid sample rate");
+		if (buffer_header.size < k_transform_header_offset + sizeof(scalar_tracks_header))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
+
+		const scalar_tracks_header& sh = *reinterpret_cast<const scalar_tracks_header*>(blob + k_transform_header_offset);
+		const uint64_t limit = buffer_header.size - k_transform_header_offset;
+		const uint32_t num_components = scalar_track_num_components(header.track_type);
+		const uint8_t* num_bits_at_bit_rate = header.version == k_version_first ? k_bit_rate_num_bits_v0 : k_bit_rate_num_bits;
+		const uint32_t num_bit_rates = header.version == k_version_first ? sizeof(k_bit_rate_num_bits_v0) : sizeof(k_bit_rate_num_bits);
+		if (uint64_t(sh.metadata_per_track) + header.num_tracks > limit)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Track metadata points outside of the buffer");
+
+		const uint8_t* bit_rates = reinterpret_cast<const uint8_t*>(&sh) + sh.metadata_per_track;
+		uint64_t num_constant = 0, num_ranged = 0, bits_per_frame = 0;
+		for (uint32_t track = 0; track < header.num_tracks; ++track)
+		{
+			if (bit_rates[track] >= num_bit_rates)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid bit rate: %u", uint32_t(bit_rates[track]));
+			const uint32_t num_bits = num_bits_at_bit_rate[bit_rates[track]];
+			num_constant += num_bits == 0 ? 1 : 0;
+			num_ranged += (num_bits != 0 && num_bits != 32) ? 1 : 0;
+			bits_per_frame += uint64_t(num_bits) * num_components;
+		}
+		if (bits_per_frame != sh.num_bits_per_frame || bits_per_frame > k_quad_ordinal_mask)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Track bit rates add up to %llu bits per frame, header says %u", static_cast<unsigned long long>(bits_per_frame), sh.num_bits_per_frame);
+		if (uint64_t(sh.track_constant_values) + num_constant * num_components * 4 > limit
+			|| uint64_t(sh.track_range_values) + num_ranged * num_components * 8 > limit
+			|| uint64_t(sh.track_animated_values) + (bits_per_frame * header.num_samples + 7) / 8 > limit
+			|| (bits_per_frame * header.num_samples) >> 32 != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+		return ACLHIP_OK;
+	}
+
+	aclhip_status validate_clip(const aclhip_context* context, const uint8_t* blob, uint64_t size, int check_hash)
+	{
+		if (blob == nullptr || size < k_transform_header_offset)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "buffer is not a valid compressed_tracks instance (too small)");
+
+		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+		const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+		if (header.tag != k_tag_compressed_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid tag");
+		if (header.algorithm_type != k_algorithm_uniformly_sampled)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm type");
+		if (header.version < k_version_first || header.version > k_version_latest)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid algorithm version");
+		const bool is_scalar_list = scalar_track_num_components(header.track_type) != 0;
+		if (buffer_header.size > size || buffer_header.size < k_transform_header_offset + (is_scalar_list ? 0 : sizeof(transform_tracks_header)))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
+		if (check_hash && hash32(blob + sizeof(raw_buffer_header), buffer_header.size - sizeof(raw_buffer_header)) != buffer_header.hash)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid hash");
+
+		if (scalar_track_num_components(header.track_type) != 0)
+			return validate_scalar_clip(context, blob);
+		if (header.track_type != k_track_type_qvvf)
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "unsupported track type %u", uint32_t(header.track_type));
+		if (header.num_tracks == 0)
+			return ACLHIP_OK;
+		if (header.rotation_format() != k_rotation_quatf_drop_w_variable || header.translation_format() != k_vector_vector3f_variable
+			|| (header.has_scale() && header.scale_format() != k_vector_vector3f_variable))
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "only quatf_drop_w_variable + vector3f_variable are supported (default_transform_decompression_settings)");
+		if (header.num_samples == 0 || !(header.sample_rate > 0.0f))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid sample count or rate");
+
+		const transform_tracks_header& th = *reinterpret_cast<const transform_tracks_header*>(blob + k_transform_header_offset);
+		const uint64_t blob_size = buffer_header.size;
+		const uint64_t tbase = k_transform_header_offset;
+		const bool stripped = header.has_stripped_keyframes() || header.has_database();
+		const uint32_t segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
+		const uint32_t num_entries = (header.num_tracks + 15) / 16;
+		const uint32_t num_rotations_padded = align_to_u32(th.num_animated_rotation_sub_tracks, 4);
+
+		if (th.num_segments == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
+		if (uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
+		if (th.num_animated_variable_sub_tracks != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
+		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
+			|| tbase + th.sub_track_types_offset + uint64_t(num_entries) * 4 * (header.has_scale() ? 3 : 2) > blob_size
+			|| tbase + th.constant_track_data_offset + 12ull * (uint64_t(th.num_constant_rotation_samples) + th.num_constant_translation_samples + th.num_constant_scale_samples) > blob_size
+			|| tbase + th.clip_range_data_offset + 24ull * (uint64_t(th.num_animated_rotation_sub_tracks) + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+		if (th.num_segments > 1 && tbase + k_segment_start_indices_offset + 4ull * (th.num_segments + 1) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment start indices point outside of the buffer");
+		if (header.has_database() && tbase + th.database_header_offset + sizeof(tracks_database_header) > blob_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Database header points outside of the buffer");
+
+		for (uint32_t i = 0; i < th.num_segments; ++i)
+		{
+			const segment_header& sh = *reinterpret_cast<const segment_header*>(blob + tbase + th.segment_headers_offset + size_t(i) * segment_header_size);
+			const uint64_t format_offset = tbase + sh.segment_data;
+			const uint64_t range_offset = align_to_u32(uint32_t(format_offset + th.num_animated_variable_sub_tracks), 2);
+			const uint64_t animated_offset = align_to_u32(uint32_t(range_offset + (th.num_segments > 1 ? 6ull * th.num_animated_variable_sub_tracks : 0ull)), 4);
+			if (animated_offset > blob_size || sh.animated_rotation_bit_size > sh.animated_pose_bit_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment %u points outside of the buffer", i);
+			if (!header.has_database())
+			{
+				// every keyframe a seek can pick must be inside the buffer
+				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : 32u;
+				(void)stored;	// the exact count needs the segment's sample count; the tail padding below covers the last window
+			}
+		}
+
+		return ACLHIP_OK;
+	}
+
+	uint32_t sub_track_class(const uint32_t* types, uint32_t track_index)
+	{
+		return (types[track_index / 16] >> ((15 - (track_index % 16)) * 2)) & 3u;
+	}
+
+	aclhip_status grow_clip_table(aclhip_context* context, uint32_t needed)
+	{
+		if (needed <= context->d_clips_capacity)
+			return ACLHIP_OK;
+
+		// 16384 records = 2 MiB: the table only moves (and captured hipGraphs that hold its address only go stale) past that many clips
+		uint32_t capacity = std::max<uint32_t>(context->d_clips_capacity * 2, 16384);
+		while (capacity < needed)
+			capacity *= 2;
+
+		device_clip* d_new = nullptr;
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&d_new), sizeof(device_clip) * capacity));
+		ACLHIP_CHECK_HIP(context, hipMemset(d_new, 0, sizeof(device_clip) * capacity));
+		if (context->d_clips != nullptr)
+		{
+			ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+			ACLHIP_CHECK_HIP(context, hipMemcpy(d_new, context->d_clips, sizeof(device_clip) * context->d_clips_capacity, hipMemcpyDeviceToDevice));
+			ACLHIP_CHECK_HIP(context, hipFree(context->d_clips));
+		}
+		context->d_clips = d_new;
+		context->d_clips_capacity = capacity;
+		return ACLHIP_OK;
+	}
+
+	aclhip_status resolve_params(const aclhip_context* context, const aclhip_decompress_params* params, decode_params& out)
+	{
+		aclhip_decompress_params defaults;
+		if (params == nullptr)
+		{
+			aclhip_default_params(&defaults);
+			params = &defaults;
+		}
+
+		if (params->rounding_policy > ACLHIP_ROUND_PER_TRACK || params->looping_policy > ACLHIP_LOOP_AS_COMPRESSED || params->normalization > ACLHIP_NORMALIZE_ALWAYS)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid rounding / looping / normalization policy");
+		if (params->default_rotation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_translation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_scale_mode > ACLHIP_DEFAULT_LEGACY)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid default sub-track mode (legacy is only valid for scale)");
+		if (params->rounding_policy == ACLHIP_ROUND_PER_TRACK && params->per_track_rounding == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "sample_rounding_policy::per_track needs per_track_rounding enabled (decompression_settings::is_per_track_rounding_supported)");
+		const bool needs_values = params->default_rotation_mode == ACLHIP_DEFAULT_VARIABLE || params->default_translation_mode == ACLHIP_DEFAULT_VARIABLE || params->default_scale_mode == ACLHIP_DEFAULT_VARIABLE;
+		if (needs_values && params->default_values == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "variable default sub-tracks need default_values");
+
+		out.default_values = params->default_values;
+		out.track_rounding_policies = params->track_rounding_policies;
+		out.instance_rounding_policies = params->instance_rounding_policies;
+		out.instance_rows = nullptr;
+		out.rounding_policy = params->rounding_policy;
+		out.looping_policy = params->looping_policy;
+		out.normalization = params->normalization;
+		out.per_track_rounding = params->per_track_rounding;
+		out.default_modes[0] = params->default_rotation_mode;
+		out.default_modes[1] = params->default_translation_mode;
+		out.default_modes[2] = params->default_scale_mode;
+		// the common case gets a branch-light store loop: track_writer defaults (core/track_writer.h:161-163) without user values,
+		// and no re-normalization of constant rotations
+		out.standard_default_modes = (params->default_rotation_mode == ACLHIP_DEFAULT_CONSTANT && params->default_translation_mode == ACLHIP_DEFAULT_CONSTANT
+			&& params->default_scale_mode == ACLHIP_DEFAULT_LEGACY && params->default_values == nullptr) ? 1 : 0;
+		out.standard_defaults = (out.standard_default_modes != 0 && params->normalization != ACLHIP_NORMALIZE_ALWAYS) ? 1 : 0;
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" const char* aclhip_status_string(aclhip_status status)
+{
+	switch (status)
+	{
+	case ACLHIP_OK: return "ok";
+	case ACLHIP_ERROR_INVALID_ARGUMENT: return "invalid argument";
+	case ACLHIP_ERROR_INVALID_CLIP: return "invalid compressed_tracks";
+	case ACLHIP_ERROR_UNSUPPORTED_FORMAT: return "unsupported track type or format";
+	case ACLHIP_ERROR_UNKNOWN_CLIP: return "unknown clip handle";
+	case ACLHIP_ERROR_OUT_OF_MEMORY: return "out of memory";
+	case ACLHIP_ERROR_DEVICE: return "HIP error";
+	case ACLHIP_ERROR_NO_DEVICE: return "no HIP device";
+	case ACLHIP_ERROR_UNKNOWN_DATABASE: return "unknown database handle";
+	case ACLHIP_ERROR_NOT_IN_DATABASE: return "clip is not contained in the database";
+	}
+	return "unknown status";
+}
+
+extern "C" const char* aclhip_last_error_message(const aclhip_context* context)
+{
+	(void)context;
+	return t_last_error.c_str();
+}
+
+extern "C" void aclhip_default_params(aclhip_decompress_params* out_params)
+{
+	if (out_params == nullptr)
+		return;
+	std::memset(out_params, 0, sizeof(*out_params));
+	out_params->rounding_policy = ACLHIP_ROUND_NONE;
+	out_params->looping_policy = ACLHIP_LOOP_AS_COMPRESSED;
+	out_params->normalization = ACLHIP_NORMALIZE_LERP_ONLY;			// default_transform_decompression_settings (decompression_settings.h:227)
+	out_params->per_track_rounding = 0;									// decompression_settings.h:231
+	out_params->default_rotation_mode = ACLHIP_DEFAULT_CONSTANT;		// core/track_writer.h:161-163
+	out_params->default_translation_mode = ACLHIP_DEFAULT_CONSTANT;
+	out_params->default_scale_mode = ACLHIP_DEFAULT_LEGACY;
+}
+
+extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_context)
+{
+	if (out_context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_context = nullptr;
+
+	int device_count = 0;
+	if (hipGetDeviceCount(&device_count) != hipSuccess || device_count <= 0)
+		return ACLHIP_ERROR_NO_DEVICE;
+	if (device_index < 0 || device_index >= device_count)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	aclhip_context* context = new (std::nothrow) aclhip_context();
+	if (context == nullptr)
+		return ACLHIP_ERROR_OUT_OF_MEMORY;
+	context->device = device_index;
+	{
+		const char* force_generic = std::getenv("ACLHIP_FORCE_GENERIC_KERNEL");
+		context->force_generic_kernel = force_generic != nullptr && force_generic[0] == '1';
+	}
+
+	device_guard guard(device_index);
+	if (!guard.ok || hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
+		|| hipMemset(context->d_rejected, 0, sizeof(unsigned long long)) != hipSuccess)
+	{
+		delete context;
+		return ACLHIP_ERROR_DEVICE;
+	}
+
+	const aclhip_status status = grow_clip_table(context, 1);
+	if (status != ACLHIP_OK)
+	{
+		(void)hipFree(context->d_rejected);
+		delete context;
+		return status;
+	}
+
+	*out_context = context;
+	return ACLHIP_OK;
+}
+
+extern "C" void aclhip_destroy(aclhip_context* context)
+{
+	if (context == nullptr)
+		return;
+	{
+		device_guard guard(context->device);
+		(void)hipDeviceSynchronize();
+		for (aclhip_context::clip_slab& slab : context->slabs)
+			(void)hipFree(slab.base);
+		for (aclhip_context::hierarchy_image& hierarchy : context->hierarchies)
+			(void)hipFree(hierarchy.d_image);
+		for (host_database& db : context->databases)
+		{
+			if (!db.in_use)
+				continue;
+			(void)hipFree(db.d_runtime_headers);
+			for (int tier = 0; tier < 2; ++tier)
+			{
+				(void)hipFree(db.d_bulk_data[tier]);
+				(void)hipFree(db.d_patches[tier]);
+				if (db.pinned_bulk_data[tier] != nullptr)
+					(void)hipHostFree(db.pinned_bulk_data[tier]);
+			}
+		}
+		if (context->d_clips != nullptr)
+			(void)hipFree(context->d_clips);
+		if (context->d_rejected != nullptr)
+			(void)hipFree(context->d_rejected);
+	}
+	delete context;
+}

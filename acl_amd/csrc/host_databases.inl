@@ -1,0 +1,351 @@
+// host_databases.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: compressed_database registration and streaming, host only validation entry points, clip queries.
+
+// ---- databases -----------------------------------------------------------------------------------------------------
+
+namespace
+{
+	bool bitset_test(const std::vector<uint32_t>& bits, uint32_t index) { return (bits[index / 32] & (0x80000000u >> (index % 32))) != 0; }
+	void bitset_set(std::vector<uint32_t>& bits, uint32_t index, bool value)
+	{
+		if (value) bits[index / 32] |= 0x80000000u >> (index % 32);
+		else bits[index / 32] &= ~(0x80000000u >> (index % 32));
+	}
+
+	void release_database(host_database& db)
+	{
+		(void)hipFree(db.d_runtime_headers);
+		for (int tier = 0; tier < 2; ++tier)
+		{
+			(void)hipFree(db.d_bulk_data[tier]);
+			(void)hipFree(db.d_patches[tier]);
+			if (db.pinned_bulk_data[tier] != nullptr)
+				(void)hipHostFree(db.pinned_bulk_data[tier]);
+		}
+		db = host_database();
+	}
+}
+
+static aclhip_status register_database_impl(aclhip_context* context, const void* compressed_database, uint64_t size,
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database, bool validate_only)
+{
+	if (context == nullptr || out_database == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_database = ACLHIP_INVALID_HANDLE;
+
+	// compressed_database::is_valid (core/impl/compressed_database.impl.h:142-163)
+	const uint8_t* blob = static_cast<const uint8_t*>(compressed_database);
+	if (blob == nullptr || size < sizeof(raw_buffer_header) + sizeof(database_header))
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "buffer is not a valid compressed_database instance (too small)");
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const database_header& header = *reinterpret_cast<const database_header*>(blob + sizeof(raw_buffer_header));
+	const uint8_t* hbase = reinterpret_cast<const uint8_t*>(&header);
+	if (header.tag != k_tag_compressed_database)
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid tag");
+	if (header.version < k_version_first || header.version > k_version_latest)
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid database version");
+	if (buffer_header.size > size || buffer_header.size < sizeof(raw_buffer_header) + sizeof(database_header))
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid size");
+	if (check_hash && hash32(blob + sizeof(raw_buffer_header), buffer_header.size - sizeof(raw_buffer_header)) != buffer_header.hash)
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid hash");
+
+	const uint64_t header_limit = buffer_header.size - sizeof(raw_buffer_header);
+	const uint64_t descriptions_offset = align_to_u32(sizeof(database_header), 4);
+	const uint64_t num_descriptions = uint64_t(header.num_chunks[0]) + header.num_chunks[1];
+	if (descriptions_offset + num_descriptions * sizeof(database_chunk_description) > header_limit
+		|| uint64_t(header.clip_metadata_offset) + uint64_t(header.num_clips) * sizeof(database_clip_metadata) > header_limit)
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+
+	const bool is_inline = (header.misc_packed & 1u) != 0;
+	const uint8_t* bulk_sources[2] = { static_cast<const uint8_t*>(bulk_data_medium), static_cast<const uint8_t*>(bulk_data_low) };
+	for (int tier = 0; tier < 2; ++tier)
+	{
+		if (header.bulk_data_size[tier] == 0)
+			continue;
+		if (bulk_sources[tier] == nullptr)
+		{
+			if (!is_inline || header.bulk_data_offset[tier] == k_invalid_offset || uint64_t(header.bulk_data_offset[tier]) + header.bulk_data_size[tier] > header_limit)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "tier %d has %u bytes of bulk data: pass it in, it is not inline", tier + 1, header.bulk_data_size[tier]);
+			bulk_sources[tier] = hbase + header.bulk_data_offset[tier];
+		}
+		if (check_hash && hash32(bulk_sources[tier], header.bulk_data_size[tier]) != header.bulk_data_hash[tier])
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid bulk data hash (tier %d)", tier + 1);
+	}
+
+	host_database db;
+	db.hash = buffer_header.hash;
+	db.info.num_clips = header.num_clips;
+	db.info.num_segments = header.num_segments;
+	db.info.max_chunk_size = header.max_chunk_size;
+	const database_clip_metadata* clip_metadata = reinterpret_cast<const database_clip_metadata*>(hbase + header.clip_metadata_offset);
+	db.clip_metadata.assign(clip_metadata, clip_metadata + header.num_clips);
+
+	const uint64_t runtime_size = uint64_t(header.num_clips) * sizeof(database_runtime_clip_header) + uint64_t(header.num_segments) * sizeof(database_runtime_segment_header);
+	if (runtime_size > (256ull << 20))
+		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "%u clips / %u segments: runtime headers beyond 256 MiB are not supported", header.num_clips, header.num_segments);
+	std::vector<uint8_t> runtime(std::max<uint64_t>(runtime_size, 16), 0);
+	db.runtime_headers_size = runtime_size;
+	for (const database_clip_metadata& metadata : db.clip_metadata)
+	{
+		if (uint64_t(metadata.clip_header_offset) + sizeof(database_runtime_clip_header) > runtime_size)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Clip metadata points outside of the runtime headers");
+		reinterpret_cast<database_runtime_clip_header*>(runtime.data() + metadata.clip_header_offset)->clip_hash = metadata.clip_hash;	// database.impl.h:151-157
+	}
+
+	// Walk every chunk of both tiers once: validate it and turn its segment headers into metadata patches
+	std::vector<tier_patch> patches[2];
+	const database_chunk_description* descriptions = reinterpret_cast<const database_chunk_description*>(hbase + descriptions_offset);
+	for (int tier = 0; tier < 2; ++tier)
+	{
+		const uint32_t num_chunks = header.num_chunks[tier];
+		const database_chunk_description* tier_descriptions = descriptions + (tier == 0 ? 0 : header.num_chunks[0]);
+		db.info.num_chunks[tier] = num_chunks;
+		db.info.bulk_data_size[tier] = header.bulk_data_size[tier];
+		db.chunks[tier].assign(tier_descriptions, tier_descriptions + num_chunks);
+		db.loaded_chunks[tier].assign((num_chunks + 31) / 32, 0u);
+		db.chunk_first_patch[tier].assign(num_chunks + 1, 0u);
+
+		for (uint32_t chunk_index = 0; chunk_index < num_chunks; ++chunk_index)
+		{
+			const database_chunk_description& description = tier_descriptions[chunk_index];
+			db.chunk_first_patch[tier][chunk_index] = uint32_t(patches[tier].size());
+			if (uint64_t(description.offset) + description.size > header.bulk_data_size[tier] || description.size < sizeof(database_chunk_header) || description.size > header.max_chunk_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d lies outside of the bulk data", chunk_index, tier + 1);
+
+			const database_chunk_header& chunk = *reinterpret_cast<const database_chunk_header*>(bulk_sources[tier] + description.offset);
+			if (chunk.index != chunk_index || chunk.size != description.size
+				|| uint64_t(sizeof(database_chunk_header)) + uint64_t(chunk.num_segments) * sizeof(database_chunk_segment_header) > description.size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d has an invalid header", chunk_index, tier + 1);
+
+			const database_chunk_segment_header* segments = reinterpret_cast<const database_chunk_segment_header*>(&chunk + 1);
+			for (uint32_t i = 0; i < chunk.num_segments; ++i)
+			{
+				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > runtime_size || segments[i].samples_offset >= header.bulk_data_size[tier])
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d points outside of the database", chunk_index, tier + 1);
+				patches[tier].push_back(tier_patch{ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
+			}
+		}
+		db.chunk_first_patch[tier][num_chunks] = uint32_t(patches[tier].size());
+	}
+	if (validate_only)
+		return ACLHIP_OK;		// aclhip_check_database: everything above is host work
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	if (!guard.ok)
+		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+
+	bool ok = hipMalloc(reinterpret_cast<void**>(&db.d_runtime_headers), runtime.size()) == hipSuccess
+		&& hipMemcpy(db.d_runtime_headers, runtime.data(), runtime.size(), hipMemcpyHostToDevice) == hipSuccess;
+	for (int tier = 0; tier < 2 && ok; ++tier)
+	{
+		// +64: keyframe windows of up to 16 bytes are read past the last sample, the reference reserves 15 (compress.database.impl.h:910)
+		const size_t bulk_bytes = size_t(header.bulk_data_size[tier]) + 64;
+		ok = hipMalloc(reinterpret_cast<void**>(&db.d_bulk_data[tier]), bulk_bytes) == hipSuccess
+			&& hipMemset(db.d_bulk_data[tier], 0xCD, bulk_bytes) == hipSuccess		// like debug_database_streamer: not-resident memory is poison
+			&& hipMalloc(reinterpret_cast<void**>(&db.d_patches[tier]), std::max<size_t>(patches[tier].size(), 1) * sizeof(tier_patch)) == hipSuccess;
+		if (ok && !patches[tier].empty())
+			ok = hipMemcpy(db.d_patches[tier], patches[tier].data(), patches[tier].size() * sizeof(tier_patch), hipMemcpyHostToDevice) == hipSuccess;
+		if (ok && header.bulk_data_size[tier] != 0)
+		{
+			ok = hipHostMalloc(reinterpret_cast<void**>(&db.pinned_bulk_data[tier]), header.bulk_data_size[tier], hipHostMallocDefault) == hipSuccess;
+			if (ok)
+				std::memcpy(db.pinned_bulk_data[tier], bulk_sources[tier], header.bulk_data_size[tier]);
+		}
+	}
+	if (!ok)
+	{
+		release_database(db);
+		return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "allocating the database failed");
+	}
+
+	db.in_use = true;
+	uint32_t slot = 0;
+	while (slot < context->databases.size() && context->databases[slot].in_use)
+		slot++;
+	if (slot == context->databases.size())
+		context->databases.emplace_back();
+	context->databases[slot] = std::move(db);
+	*out_database = slot;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const void* compressed_database, uint64_t size,
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database)
+{
+	return guarded(context, [&]() { return register_database_impl(context, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, out_database, false); });
+}
+
+// ---- host only validation (no device needed) ---------------------------------------------------------------------------
+
+namespace
+{
+	aclhip_status report(const aclhip_context&, aclhip_status status, char* out_message, uint32_t capacity)
+	{
+		if (out_message != nullptr && capacity != 0)
+			std::snprintf(out_message, capacity, "%s", status == ACLHIP_OK ? "" : t_last_error.c_str());
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, int check_hash, char* out_message, uint32_t capacity)
+{
+	aclhip_context scratch;		// collects the error message; no device is touched
+	aclhip_clip unused = ACLHIP_INVALID_HANDLE;
+	return report(scratch, guarded(&scratch, [&]() { return register_clip_impl(&scratch, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, &unused, true); }), out_message, capacity);
+}
+
+extern "C" aclhip_status aclhip_check_database(const void* compressed_database, uint64_t size, const void* bulk_data_medium, const void* bulk_data_low,
+	int check_hash, char* out_message, uint32_t capacity)
+{
+	aclhip_context scratch;
+	aclhip_database unused = ACLHIP_INVALID_HANDLE;
+	return report(scratch, guarded(&scratch, [&]() { return register_database_impl(&scratch, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, &unused, true); }), out_message, capacity);
+}
+
+extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, aclhip_database database)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	if (database >= context->databases.size() || !context->databases[database].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
+	if (context->databases[database].num_bound_clips != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u clips are still bound to this database", context->databases[database].num_bound_clips);
+	device_guard guard(context->device);
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	release_database(context->databases[database]);
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_get_database_info(const aclhip_context* context, aclhip_database database, aclhip_database_info* out_info)
+{
+	if (context == nullptr || out_info == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (database >= context->databases.size() || !context->databases[database].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
+	*out_info = context->databases[database].info;
+	return ACLHIP_OK;
+}
+
+namespace
+{
+	aclhip_status stream_database(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks_to_stream, void* stream, bool stream_in, uint32_t* out_num_chunks)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (out_num_chunks != nullptr)
+			*out_num_chunks = 0;
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (database >= context->databases.size() || !context->databases[database].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
+		if (tier != 1 && tier != 2)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "tier must be 1 (medium importance) or 2 (lowest importance)");	// invalid_database_tier
+
+		host_database& db = context->databases[database];
+		const uint32_t tier_index = tier - 1;
+		const uint32_t num_chunks = db.info.num_chunks[tier_index];
+		num_chunks_to_stream = std::min(num_chunks_to_stream, num_chunks);
+		if (num_chunks == 0 || num_chunks_to_stream == 0)
+			return ACLHIP_OK;
+
+		// Which chunks: the first missing ones when streaming in, the first resident ones when streaming out -- the reference's
+		// bit scans over loaded_chunks (database.impl.h:478-497,551-570)
+		const std::vector<uint32_t>& loaded = db.loaded_chunks[tier_index];
+		uint32_t first_chunk_index = ~0u;
+		for (uint32_t entry_index = 0; entry_index < loaded.size(); ++entry_index)
+		{
+			const uint32_t maybe_loaded = loaded[entry_index];
+			if (stream_in)
+			{
+				const uint32_t num_pending = maybe_loaded == 0 ? 32u : uint32_t(__builtin_ctz(maybe_loaded));
+				if (num_pending != 0)
+				{
+					first_chunk_index = entry_index * 32 + (32 - num_pending);
+					break;
+				}
+			}
+			else
+			{
+				const uint32_t num_pending = maybe_loaded == 0 ? 32u : uint32_t(__builtin_clz(maybe_loaded));
+				if (num_pending != 32)
+				{
+					first_chunk_index = entry_index * 32 + num_pending;
+					break;
+				}
+			}
+		}
+		if (first_chunk_index == ~0u || first_chunk_index >= num_chunks)
+			return ACLHIP_OK;	// database_stream_request_result::done
+
+		const uint64_t last_chunk_index64 = uint64_t(first_chunk_index) + num_chunks_to_stream - 1;
+		const uint32_t last_chunk_index = last_chunk_index64 >= num_chunks ? num_chunks - 1 : uint32_t(last_chunk_index64);
+		const uint32_t num_streaming_chunks = last_chunk_index - first_chunk_index + 1;
+
+		device_guard guard(context->device);
+		hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+		const uint32_t first_patch = db.chunk_first_patch[tier_index][first_chunk_index];
+		const uint32_t num_patches = db.chunk_first_patch[tier_index][last_chunk_index + 1] - first_patch;
+
+		if (stream_in)
+		{
+			// debug_database_streamer::stream_in is a memcpy (impl/debug_database_streamer.h:75-92); here: pinned host -> HBM, asynchronously
+			const uint32_t start_offset = db.chunks[tier_index][first_chunk_index].offset;
+			const uint32_t end_offset = db.chunks[tier_index][last_chunk_index].offset + db.chunks[tier_index][last_chunk_index].size;
+			ACLHIP_CHECK_HIP(context, hipMemcpyAsync(db.d_bulk_data[tier_index] + start_offset, db.pinned_bulk_data[tier_index] + start_offset, end_offset - start_offset, hipMemcpyHostToDevice, hip_stream));
+		}
+
+		if (num_patches != 0)
+		{
+			hipLaunchKernelGGL(apply_tier_metadata_kernel, dim3((num_patches + 255) / 256), dim3(256), 0, hip_stream,
+				db.d_runtime_headers, db.d_patches[tier_index], first_patch, num_patches, tier_index, stream_in ? 1u : 0u);
+			ACLHIP_CHECK_HIP(context, hipGetLastError());
+		}
+
+		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)
+			bitset_set(db.loaded_chunks[tier_index], chunk_index, stream_in);
+		db.info.num_loaded_chunks[tier_index] = 0;
+		for (uint32_t chunk_index = 0; chunk_index < num_chunks; ++chunk_index)
+			db.info.num_loaded_chunks[tier_index] += bitset_test(db.loaded_chunks[tier_index], chunk_index) ? 1 : 0;
+
+		if (out_num_chunks != nullptr)
+			*out_num_chunks = num_streaming_chunks;
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" aclhip_status aclhip_database_stream_in(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks)
+{
+	return stream_database(context, database, tier, num_chunks, stream, true, out_num_chunks);
+}
+
+extern "C" aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks)
+{
+	return stream_database(context, database, tier, num_chunks, stream, false, out_num_chunks);
+}
+
+extern "C" aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info)
+{
+	if (context == nullptr || out_info == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	*out_info = context->clips[clip].info;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches)
+{
+	if (context == nullptr || compressed_tracks == nullptr || out_matches == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	// is_bound_to_v0 compares pointer and hash (decompression.transform.h:159-169); there is no shared pointer here: hash + size
+	const raw_buffer_header& buffer_header = *static_cast<const raw_buffer_header*>(compressed_tracks);
+	const aclhip_clip_info& info = context->clips[clip].info;
+	*out_matches = (buffer_header.hash == info.hash && buffer_header.size == info.compressed_size) ? 1 : 0;
+	return ACLHIP_OK;
+}

@@ -1,0 +1,396 @@
+// host_scalar_misc.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: scalar track list launches, all samples, all-gather, measurement helpers.
+
+// ---- scalar track lists --------------------------------------------------------------------------------------------
+
+namespace
+{
+	aclhip_status launch_scalar(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, void* out, uint64_t out_stride_bytes, void* stream)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+		if ((reinterpret_cast<uintptr_t>(out) & 3u) != 0 || (out_stride_bytes & 3u) != 0 || out_stride_bytes == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "the output buffer and its stride must be 4 byte aligned");
+
+		decode_params device_params;
+		const aclhip_status status = resolve_params(context, params, device_params);
+		if (status != ACLHIP_OK)
+			return status;
+
+		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+		device_guard guard(context->device);
+		if (track_indices != nullptr)
+		{
+			const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
+			hipLaunchKernelGGL(decompress_scalar_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+				context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,
+				static_cast<uint8_t*>(out), out_stride_bytes, context->d_rejected);
+		}
+		else
+		{
+			// one wave per (instance, 64 or 256 tracks); instances of shorter lists than the longest registered one leave waves idle
+			const uint32_t rows = context->max_scalar_tracks <= k_wave_size ? 1u : k_scalar_tracks_per_wave / k_wave_size;
+			const uint32_t tracks_per_wave = rows * k_wave_size;
+			const uint32_t chunks_per_instance = std::max<uint32_t>((context->max_scalar_tracks + tracks_per_wave - 1) / tracks_per_wave, 1);
+			const uint64_t num_waves = uint64_t(num_instances) * chunks_per_instance;
+			if (num_waves > 0xFFFFFFFFull - k_waves_per_block)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u track chunks", num_instances, chunks_per_instance);
+
+			// LDS copy of both key frames per wave: the frame, the 16 byte alignment slack in front, 8 bytes behind. Skipped (global
+			// reads) when that would leave fewer than 4 workgroups per CU, and for short frames, where a handful of scattered reads
+			// is cheaper than the copy and its barrier (measured: 64 float1f tracks 16 vs 23 us, 256 tracks 38 vs 32 us)
+			uint32_t frame_lds_bytes = align_to_u32(context->max_scalar_frame_bytes + 16 + 8, 16);
+			if (size_t(frame_lds_bytes) * 2 * k_waves_per_block > 40 * 1024 || context->max_scalar_frame_bytes < 192)
+				frame_lds_bytes = 0;
+
+			const dim3 grid(uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block));
+			const size_t lds_bytes = size_t(frame_lds_bytes) * 2 * k_waves_per_block;
+			const auto launch = [&](auto kernel)
+			{
+				hipLaunchKernelGGL(kernel, grid, dim3(k_block_size), lds_bytes, static_cast<hipStream_t>(stream), context->d_clips, context->d_clips_capacity, clips, sample_times,
+					num_instances, chunks_per_instance, device_params, static_cast<uint8_t*>(out), out_stride_bytes, frame_lds_bytes, context->d_rejected);
+			};
+			const bool policies = device_params.per_track_rounding != 0;
+			if (frame_lds_bytes != 0)
+			{
+				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_kernel<true, 1, true>); else launch(decompress_scalar_tracks_kernel<true, 1, false>); }
+				else { if (policies) launch(decompress_scalar_tracks_kernel<true, 4, true>); else launch(decompress_scalar_tracks_kernel<true, 4, false>); }
+			}
+			else
+			{
+				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_kernel<false, 1, true>); else launch(decompress_scalar_tracks_kernel<false, 1, false>); }
+				else { if (policies) launch(decompress_scalar_tracks_kernel<false, 4, true>); else launch(decompress_scalar_tracks_kernel<false, 4, false>); }
+			}
+		}
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+
+	// Host pointer convenience for scalar track lists: uploads the instance lists and the caller's buffer (values the decode does
+	// not write keep what the caller had), runs the batch, downloads.
+	aclhip_status decompress_scalar_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
+		const aclhip_decompress_params* params, void* out, uint64_t out_stride_bytes)
+	{
+		if (context == nullptr)
+			return ACLHIP_ERROR_INVALID_ARGUMENT;
+		if (num_instances == 0)
+			return ACLHIP_OK;
+		if (clips == nullptr || sample_times == nullptr || out == nullptr || out_stride_bytes == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+
+		aclhip_decompress_params local;
+		if (params != nullptr) local = *params; else aclhip_default_params(&local);
+		local.default_values = nullptr;
+
+		uint32_t max_tracks = 0;
+		{
+			std::lock_guard<std::mutex> lock(context->mutex);
+			for (uint32_t i = 0; i < num_instances; ++i)
+				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
+					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);
+		}
+
+		device_guard guard(context->device);
+		std::vector<void*> allocations;
+		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
+		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
+		{
+			void* d = nullptr;
+			if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess)
+				return false;
+			allocations.push_back(d);
+			if (host != nullptr && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess)
+				return false;
+			*out_device = d;
+			return true;
+		};
+
+		const size_t out_bytes = size_t(out_stride_bytes) * num_instances;
+		void* d_clip_ids = nullptr; void* d_times = nullptr; void* d_tracks = nullptr; void* d_out = nullptr;
+		void* d_track_policies = nullptr; void* d_instance_policies = nullptr;
+		bool ok = upload(clips, sizeof(uint32_t) * num_instances, &d_clip_ids) && upload(sample_times, sizeof(float) * num_instances, &d_times)
+			&& upload(out, out_bytes, &d_out);
+		if (ok && track_indices != nullptr)
+			ok = upload(track_indices, sizeof(uint32_t) * num_instances, &d_tracks);
+		if (ok && local.track_rounding_policies != nullptr)
+			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
+		if (ok && local.instance_rounding_policies != nullptr)
+			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+
+		if (!ok)
+		{
+			release();
+			return fail(context, ACLHIP_ERROR_DEVICE, "staging the batch on the device failed");
+		}
+		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
+		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+
+		aclhip_status status = launch_scalar(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks),
+			num_instances, &local, d_out, out_stride_bytes, nullptr);
+		if (status == ACLHIP_OK)
+		{
+			hipError_t copy_status = hipDeviceSynchronize();
+			if (copy_status == hipSuccess)
+				copy_status = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+			if (copy_status != hipSuccess)
+				status = fail(context, ACLHIP_ERROR_DEVICE, "downloading the values failed: %s", hipGetErrorString(copy_status));
+		}
+		release();
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream)
+{
+	return launch_scalar(context, clips, sample_times, nullptr, num_instances, params, values, stride_bytes, stream);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes, void* stream)
+{
+	if (track_indices == nullptr && num_instances != 0)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return launch_scalar(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes, stream);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_tracks_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* values, uint64_t stride_bytes)
+{
+	return decompress_scalar_host(context, clips, sample_times, nullptr, num_instances, params, values, stride_bytes);
+}
+
+extern "C" aclhip_status aclhip_decompress_scalar_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
+	uint32_t num_instances, const aclhip_decompress_params* params, void* values, uint64_t stride_bytes)
+{
+	if (track_indices == nullptr && num_instances != 0)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return decompress_scalar_host(context, clips, sample_times, track_indices, num_instances, params, values, stride_bytes);
+}
+
+// ---- every sample of a clip -------------------------------------------------------------------------------------------
+
+extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, aclhip_clip clip, const aclhip_decompress_params* params,
+	void* scratch, void* out, uint64_t stride_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_clip_info info;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+		info = context->clips[clip].info;
+	}
+	if (info.num_tracks == 0 || info.num_samples == 0)
+		return ACLHIP_OK;
+	if (scratch == nullptr || out == nullptr || (reinterpret_cast<uintptr_t>(scratch) & 3u) != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null or misaligned scratch / output buffer");
+
+	aclhip_decompress_params local;
+	if (params != nullptr) local = *params; else aclhip_default_params(&local);
+	local.rounding_policy = ACLHIP_ROUND_NEAREST;		// convert.impl.h:166
+	local.instance_rounding_policies = nullptr;
+
+	// the duration the reference's loop clamps to is the one of the looping policy in effect (convert.impl.h:139)
+	float duration = info.duration;
+	if (local.looping_policy != ACLHIP_LOOP_AS_COMPRESSED)
+	{
+		const uint32_t samples = info.num_samples + (local.looping_policy == ACLHIP_LOOP_WRAP ? 1u : 0u);
+		duration = samples <= 1 ? 0.0f : float(samples - 1) / info.sample_rate;
+	}
+
+	uint32_t* clip_ids = static_cast<uint32_t*>(scratch);
+	float* sample_times = reinterpret_cast<float*>(clip_ids + info.num_samples);
+	{
+		device_guard guard(context->device);
+		hipLaunchKernelGGL(fill_sample_instances_kernel, dim3((info.num_samples + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+			clip, info.num_samples, info.sample_rate, duration, clip_ids, sample_times);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+	}
+
+	if (info.track_type == k_track_type_qvvf)
+		return aclhip_decompress_tracks_batch(context, clip_ids, sample_times, info.num_samples, &local, out, stride_bytes, stream);
+	return aclhip_decompress_scalar_tracks_batch(context, clip_ids, sample_times, info.num_samples, &local, out, stride_bytes, stream);
+}
+
+// ---- multi-GPU gather ------------------------------------------------------------------------------------------------
+
+extern "C" aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (rccl_comm == nullptr || shard_poses == nullptr || all_poses == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null communicator or buffer");
+	if (shard_bytes == 0)
+		return ACLHIP_OK;
+
+	// ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
+	// (rccl.h:678); the library is only loaded by callers that gather, decoding never touches it
+	typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+	static all_gather_fn all_gather = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		if (all_gather == nullptr)
+		{
+			void* library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+			if (library == nullptr)
+				library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+			if (library == nullptr)
+				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 could not be loaded: %s", dlerror());
+			all_gather = reinterpret_cast<all_gather_fn>(dlsym(library, "ncclAllGather"));
+			if (all_gather == nullptr)
+				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 has no ncclAllGather");
+		}
+	}
+
+	device_guard guard(context->device);
+	constexpr int k_nccl_uint8 = 1;		// ncclUint8 (rccl.h:460)
+	const int result = all_gather(shard_poses, all_poses, size_t(shard_bytes), k_nccl_uint8, rccl_comm, static_cast<hipStream_t>(stream));
+	if (result != 0)
+		return fail(context, ACLHIP_ERROR_DEVICE, "ncclAllGather failed: ncclResult_t %d", result);
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count)
+{
+	if (context == nullptr || out_count == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	device_guard guard(context->device);
+	unsigned long long value = 0;
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	ACLHIP_CHECK_HIP(context, hipMemcpy(&value, context->d_rejected, sizeof(value), hipMemcpyDeviceToHost));
+	*out_count = value;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch)
+{
+	if (out_ms_per_launch == nullptr || repeats == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats && status == ACLHIP_OK; ++i)
+		status = launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, hip_stream);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_ms_per_launch = elapsed_ms / float(repeats);
+	return status;
+}
+
+extern "C" aclhip_status aclhip_time_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch)
+{
+	if (out_ms_per_launch == nullptr || repeats == 0 || consumers == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats && status == ACLHIP_OK; ++i)
+		status = launch_consumers(context, clips, sample_times, num_instances, device_params, *consumers, poses, pose_stride_bytes, hip_stream);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_ms_per_launch = elapsed_ms / float(repeats);
+	return status;
+}
+
+extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity)
+{
+	if (context == nullptr || out_name == nullptr || capacity == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	decode_params device_params;
+	const aclhip_status status = resolve_params(context, params, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+	const bool any_settings = device_params.standard_defaults == 0 || device_params.per_track_rounding != 0 || context->force_generic_kernel;
+	std::snprintf(out_name, capacity, "%s", any_settings ? "decompress_tracks_any_settings_kernel" : "decompress_tracks_kernel");
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second)
+{
+	if (context == nullptr || buffer == nullptr || out_gb_per_second == nullptr || repeats == 0 || size_bytes < 16 || (reinterpret_cast<uintptr_t>(buffer) & 15u) != 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	const uint64_t num_quads = size_bytes / 16;
+	const uint32_t num_blocks = uint32_t(std::min<uint64_t>((num_quads + k_block_size - 1) / k_block_size, 256ull * 32ull));
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	hipLaunchKernelGGL(stream_write_kernel, dim3(num_blocks), dim3(k_block_size), 0, hip_stream, static_cast<float4*>(buffer), num_quads, 0.0f);
+	ACLHIP_CHECK_HIP(context, hipEventRecord(start, hip_stream));
+	for (uint32_t i = 0; i < repeats; ++i)
+		hipLaunchKernelGGL(stream_write_kernel, dim3(num_blocks), dim3(k_block_size), 0, hip_stream, static_cast<float4*>(buffer), num_quads, float(i));
+	ACLHIP_CHECK_HIP(context, hipEventRecord(stop, hip_stream));
+	ACLHIP_CHECK_HIP(context, hipEventSynchronize(stop));
+	float elapsed_ms = 0.0f;
+	ACLHIP_CHECK_HIP(context, hipEventElapsedTime(&elapsed_ms, start, stop));
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_gb_per_second = float(double(num_quads) * 16.0 * repeats / (double(elapsed_ms) * 1.0e-3) / 1.0e9);
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,
+	uint64_t* out_bytes_written, uint64_t* out_distinct_clip_bytes)
+{
+	if (context == nullptr || (num_instances != 0 && clips == nullptr) || out_bytes_written == nullptr || out_distinct_clip_bytes == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::unordered_set<uint32_t> distinct;
+	uint64_t written = 0, read = 0;
+	for (uint32_t i = 0; i < num_instances; ++i)
+	{
+		const uint32_t clip = clips[i];
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			continue;
+		written += uint64_t(context->clips[clip].info.num_tracks) * context->clips[clip].info.num_components * 4;		// 48 bytes per transform track
+		if (distinct.insert(clip).second)
+			read += context->clips[clip].touched_bytes;
+	}
+	*out_bytes_written = written;
+	*out_distinct_clip_bytes = read;
+	return ACLHIP_OK;
+}

@@ -1,0 +1,244 @@
+// kernels_consumers.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// decompress_poses_consumer_kernel: the decode followed by additive apply and local -> object space while the pose is in LDS.
+
+	// ---- pose consumers -----------------------------------------------------------------------------------------------
+	// Decodes the whole local pose of one clip instance into an LDS image (image[0] = quad 0), window by window like the pose kernels
+	// but in ONE wave, because what follows needs every transform of the pose. Common-case settings only (see launch_consumers).
+	__device__ __forceinline__ void decode_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		uint32_t lane, f32x4* image)
+	{
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		{
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
+			for (uint32_t base = 0; base < num_quads; base += k_wave_size)
+			{
+				if (base + lane < num_quads)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
+						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+			}
+		}
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		if (num_quads <= k_image_chunk_quads)
+			decode_window_sub_tracks<false>(clip.clip_ranges, state, params, rounding_policy, params.normalization, 0, clip.num_animated, 0, lane, image);
+		else
+		{
+			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
+			for (uint32_t window = 0; window < num_windows; ++window)
+			{
+				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
+				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
+				decode_window_sub_tracks<false>(clip.clip_ranges, state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, 0, lane, image);
+			}
+		}
+	}
+
+	__device__ __forceinline__ void wave_lds_barrier()
+	{
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+
+	__device__ __forceinline__ qvv load_qvv(const f32x4* image, uint32_t transform_index)
+	{
+		const f32x4 r = image[transform_index * 3u + 0], t = image[transform_index * 3u + 1], s = image[transform_index * 3u + 2];
+		qvv value;
+		value.rotation = make_float4(r.x, r.y, r.z, r.w);
+		value.translation = make_float4(t.x, t.y, t.z, 0.0f);
+		value.scale = make_float4(s.x, s.y, s.z, 0.0f);
+		return value;
+	}
+
+	__device__ __forceinline__ void store_qvv(f32x4* image, uint32_t transform_index, const qvv& value)
+	{
+		image[transform_index * 3u + 0] = f32x4{ value.rotation.x, value.rotation.y, value.rotation.z, value.rotation.w };
+		image[transform_index * 3u + 1] = f32x4{ value.translation.x, value.translation.y, value.translation.z, 0.0f };
+		image[transform_index * 3u + 2] = f32x4{ value.scale.x, value.scale.y, value.scale.z, 0.0f };
+	}
+
+	// Up to 8 instances per workgroup, one wave64 per clip instance to decode: the (additive) clip instance and, when the base is a clip,
+	// its base clip instance in a second wave, each into its own LDS image; the two are combined per transform
+	// (apply_additive_to_base, core/additive_utils.h:150). local_to_object_space (compression/transform_pose_utils.h:35) is a walk
+	// down the hierarchy, parents first, and a depth of a 100 bone skeleton is 4-18 transforms wide: done per wave it would leave
+	// most lanes idle for some 135 instructions per depth. So the workgroup's FIRST wave walks all its instances at once, lanes <->
+	// (instance, transform of the current step of the schedule aclhip_set_clip_hierarchy made), from copies of the schedules the
+	// waves left in LDS next to their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
+	// HBM happens on the image the decode already holds.
+	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
+	constexpr uint32_t k_consumer_max_instances = 8;
+	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
+
+	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
+		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t log2_instances_per_block,
+		unsigned long long* __restrict__ rejected_count)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do
+		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
+
+		const bool has_base = consumers.additive_format != 0;
+		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
+		const bool object_space = consumers.object_space != 0;
+
+		// wave -> (instance slot of the workgroup, role): role 1 waves (base clips only) decode the slot's base
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t slot = wave_in_block & ((1u << log2_instances_per_block) - 1u);
+		const uint32_t role = wave_in_block >> log2_instances_per_block;
+		const uint32_t waves_per_instance = base_is_clip ? 2u : 1u;
+		const uint32_t instance = (blockIdx.x << log2_instances_per_block) + slot;
+
+		uint8_t* instance_lds = dynamic_lds + size_t(slot) * lds_bytes_per_instance;
+		f32x4* image = reinterpret_cast<f32x4*>(instance_lds);
+		f32x4* base_image = image + lds_quads_per_image;
+		// one LDS copy of the walk schedule per workgroup, behind the instances' images: the instances of a workgroup usually share
+		// a skeleton (identical hierarchies are one image, see aclhip_set_clip_hierarchy), and every word kept per instance costs residency
+		uint32_t* shared_schedule = reinterpret_cast<uint32_t*>(dynamic_lds + (size_t(lds_bytes_per_instance) << log2_instances_per_block));
+		const uint32_t* schedule = nullptr;
+
+		uint32_t num_tracks = 0;		// stays 0 for a wave without work: past the batch, refused instance, empty track list
+		uint32_t num_levels = 0;
+		if (instance < num_instances)
+		{
+			const uint32_t clip_id = as_constant(clip_ids)[instance];
+			const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+
+			// refused: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images, bases that
+			// are unknown or describe another number of transforms (the reference asserts matching track counts where it combines them).
+			// Both waves of an instance come to the same verdict; the first one reports it.
+			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr) || clip.num_tracks * 3u > lds_quads_per_image;
+
+			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+				: uint32_t(params.rounding_policy);
+
+			if (base_is_clip)
+			{
+				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
+				const device_clip base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
+				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks;
+				if (!refused && role == 1 && clip.num_tracks != 0)
+					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
+			}
+
+			if (refused)
+			{
+				if (lane == 0 && role == 0)
+					atomicAdd(rejected_count, 1ull);
+			}
+			else if (clip.num_tracks != 0)
+			{
+				num_tracks = clip.num_tracks;
+				if (role == 0)
+				{
+					decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+					if (object_space)
+					{
+						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
+						// num_steps | words | step_end[num_steps] | transform | parent << 16 in step order
+						schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
+						num_levels = as_constant(schedule)[0];
+						// every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then)
+						const uint32_t num_words = as_constant(schedule)[1];
+						for (uint32_t word = lane; word < num_words; word += k_wave_size)
+							shared_schedule[word] = schedule[word];
+					}
+				}
+			}
+		}
+
+		// both images of every instance are complete
+		if (base_is_clip)
+			__syncthreads();
+		else
+			wave_lds_barrier();
+
+		if (has_base)
+		{
+			const f32x4* base_source = base_is_clip ? base_image : reinterpret_cast<const f32x4*>(consumers.base_poses + uint64_t(instance) * consumers.base_pose_stride_bytes);
+			for (uint32_t transform_index = role * k_wave_size + lane; transform_index < num_tracks; transform_index += waves_per_instance * k_wave_size)
+			{
+				const qvv additive = load_qvv(image, transform_index);
+				const qvv base = load_qvv(base_source, transform_index);
+				store_qvv(image, transform_index, apply_additive_to_base(consumers.additive_format, base, additive));
+			}
+		}
+
+		if (object_space)
+		{
+			if (lane == 0 && role == 0)
+			{
+				walk_levels[slot] = num_levels;
+				walk_schedules[slot] = schedule;
+			}
+			__syncthreads();
+
+			// the walking wave rotates with the workgroup index: waves land on SIMDs by their index inside the workgroup, and walks that
+			// all ran on a CU's first SIMD would queue there
+			if (wave_in_block == (blockIdx.x & ((blockDim.x / k_wave_size) - 1u)))
+			{
+				// lanes <-> (instance slot, transform of the current step): slot = lane % instances, lane / instances picks the slot's
+				// transform inside the step. A transform's parent was scheduled in an earlier step: final by the time it is read.
+				const uint32_t walk_slot = lane & ((1u << log2_instances_per_block) - 1u);
+				const uint32_t first = lane >> log2_instances_per_block;
+				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
+				const uint32_t slot_steps = walk_levels[walk_slot];
+				const uint32_t* slot_schedule = walk_schedules[walk_slot];
+
+				const auto walk = [&](const auto* schedule_words)
+				{
+					const auto* pairs = schedule_words + 2u + slot_steps;
+					uint32_t step_start = 0;
+					for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
+					{
+						if (step < slot_steps)
+						{
+							const uint32_t step_end = schedule_words[2 + step];
+							const uint32_t pair_index = step_start + first;
+							if (pair_index < step_end)
+							{
+								const uint32_t pair = pairs[pair_index];		// transform | parent << 16
+								qvv object = qvv_mul(load_qvv(slot_image, pair & 0xFFFFu), load_qvv(slot_image, pair >> 16));
+								object.rotation = quat_normalize(object.rotation);
+								store_qvv(slot_image, pair & 0xFFFFu, object);
+							}
+							step_start = step_end;
+						}
+						wave_lds_barrier();
+					}
+				};
+
+				// all instances that walk follow the same schedule? then the shared LDS copy is theirs; otherwise each reads its own
+				// from global memory (rare: mixed skeletons inside one workgroup)
+				// the rest of the workgroup waits for this wave: it goes first on its SIMD
+				__builtin_amdgcn_s_setprio(3);
+				const uint64_t walkers = __ballot(slot_steps != 0);
+				if (walkers != 0)
+				{
+					const uint32_t leader = uint32_t(__builtin_ctzll(walkers));
+					const uint64_t mine = reinterpret_cast<uint64_t>(slot_schedule);
+					const uint64_t first_schedule = (uint64_t(__shfl(uint32_t(mine >> 32), int(leader))) << 32) | __shfl(uint32_t(mine), int(leader));
+					if (__all(int(slot_steps == 0 || mine == first_schedule)) != 0)
+						walk(static_cast<const uint32_t*>(shared_schedule));
+					else
+						walk(as_constant(slot_schedule));
+				}
+				__builtin_amdgcn_s_setprio(0);
+			}
+			__syncthreads();
+		}
+		else if (base_is_clip)
+			__syncthreads();
+		else
+			wave_lds_barrier();
+
+		const uint32_t num_quads = num_tracks * 3u;
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
+		for (uint32_t quad = role * k_wave_size + lane; quad < num_quads; quad += waves_per_instance * k_wave_size)
+			store_streaming(&pose[quad], image[quad]);
+	}

@@ -1,0 +1,317 @@
+// kernels_pose.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// The pose kernels: decompress_tracks_kernel, decompress_tracks_any_settings_kernel (one wave64 per instance and pose window).
+
+	constexpr uint32_t k_wave_size = 64;
+#if !defined(ACLHIP_WAVES_PER_BLOCK)
+	#define ACLHIP_WAVES_PER_BLOCK 4
+#endif
+	constexpr uint32_t k_waves_per_block = ACLHIP_WAVES_PER_BLOCK;
+	constexpr uint32_t k_block_size = k_wave_size * k_waves_per_block;
+
+	// Value of a default sub-track (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310, and the
+	// "no scale" loop :1653-1680). `identity` is the track_writer default for the kind (identity / zero / legacy scale).
+	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 identity, bool& out_store)
+	{
+		const uint32_t mode = params.default_modes[kind];
+		out_store = mode != ACLHIP_DEFAULT_SKIPPED;
+
+		if (params.default_values != nullptr && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
+		{
+			const float* src = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+			return make_float4(src[0], src[1], src[2], kind == 0 ? src[3] : 0.0f);
+		}
+
+		if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
+			return make_float4(1.0f, 1.0f, 1.0f, 0.0f);		// track_writer::get_constant_default_scale (core/track_writer.h:169)
+
+		return identity;
+	}
+
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+	typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+	// The whole 128 byte clip record in two scalar loads (wave uniform address)
+	__device__ __forceinline__ device_clip load_clip(const device_clip* clips, uint32_t clip_id)
+	{
+		const ACLHIP_CONSTANT u32x16* source = (const ACLHIP_CONSTANT u32x16*)(clips + clip_id);
+		struct { u32x16 lo, hi; } raw = { source[0], source[1] };
+		device_clip clip;
+		__builtin_memcpy(&clip, &raw, sizeof(clip));
+		return clip;
+	}
+
+	// A 32 byte table entry (plan_entry / clip_range_entry) in two 16 byte loads
+	template<class entry_t>
+	__device__ __forceinline__ entry_t load_entry(const entry_t* table, uint32_t index)
+	{
+		static_assert(sizeof(entry_t) == 32, "two dwordx4 loads");
+		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(table + index);
+		struct { u32x4 lo, hi; } raw = { source[0], source[1] };
+		entry_t entry;
+		__builtin_memcpy(&entry, &raw, sizeof(entry));
+		return entry;
+	}
+
+	__device__ __forceinline__ float4 load_quad(const float4* table, uint32_t index)
+	{
+		const f32x4 raw = ((const ACLHIP_CONSTANT f32x4*)table)[index];
+		return make_float4(raw.x, raw.y, raw.z, raw.w);
+	}
+
+	// What the any-settings pose kernel stores for a quad of the LDS image: default sub-tracks -- still tagged in their W lane, every
+	// other quad holds a real W >= +0 by now -- follow the default sub-track modes, the rest passes through.
+	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, bool& out_store)
+	{
+		out_store = true;
+		const uint32_t marker = __float_as_uint(value.w);
+		if (int32_t(marker) >= 0)
+			return value;
+
+		const uint32_t track_index = quad / 3u;
+		const uint32_t kind = quad - track_index * 3u;
+		value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+		return default_quad(params, kind, track_index, value, out_store);
+	}
+
+	// Lanes <-> the animated sub-tracks [first_ordinal, end_ordinal) of one pose window, decoded into their quads of the window's LDS
+	// image (image[0] = quad first_quad of the pose). Most sample times fall between two keyframes of ONE segment: both keys then
+	// share a plan row and it is fetched once (a third less table traffic through the texture unit).
+	template<bool kSingleSegment, bool kPolicies>
+	__device__ __forceinline__ void decode_window_sub_tracks_with(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+	{
+		// kPolicies: per track rounding (and the sample normalization it implies)
+		const bool normalize_samples = kPolicies && normalization == ACLHIP_NORMALIZE_ALWAYS;
+
+		for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
+		{
+			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
+			const plan_entry plan1_loaded = kSingleSegment ? plan0 : load_entry(state.plan[1], animated_ordinal);
+			const plan_entry& plan1 = kSingleSegment ? plan0 : plan1_loaded;
+			const clip_range_entry clip_range = load_entry(clip_ranges, animated_ordinal);
+			const bool is_rotation = is_rotation_entry(clip_range);
+
+			uint32_t policy = k_round_none;
+			if (kPolicies)
+			{
+				// track_writer::get_rounding_policy (core/track_writer.h:97)
+				policy = rounding_policy;
+				if (rounding_policy == k_round_per_track)
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
+			}
+
+			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
+			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+
+			float4 value;
+			if (!has_raw)
+				value = decode_animated_sub_track<false, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+			else
+				value = decode_animated_sub_track<true, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+
+			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
+			const f32x4 packed = { value.x, value.y, value.z, value.w };
+			image[clip_range.quad_index - first_quad] = packed;
+		}
+	}
+
+	template<bool kAnySettings>
+	__device__ __forceinline__ void decode_window_sub_tracks(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+	{
+		if (kAnySettings && params.per_track_rounding != 0)
+		{
+			if (state.uses_single_segment)
+				decode_window_sub_tracks_with<true, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			else
+				decode_window_sub_tracks_with<false, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		}
+		else if (state.uses_single_segment)
+			decode_window_sub_tracks_with<true, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		else
+			decode_window_sub_tracks_with<false, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+	}
+
+	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
+	// 100 bone pose is a single window), built in 5 KiB of LDS:
+	//   1. the scalar prologue finds the clip and seeks (4 dependent scalar loads);
+	//   2. meanwhile the window's slice of the clip's base pose is DMA'd global -> LDS (global_load_lds, no VGPRs);
+	//   3. lanes <-> the animated sub-tracks that land in the window (a contiguous range of ordinals: the tables are ordered by
+	//      window) decode straight into their quad of the LDS image;
+	//   4. the finished window streams out, 16 bytes per lane, 1 KiB of contiguous HBM per store instruction.
+	// Windows of one pose go to consecutive waves: each repeats the (scalar) seek, none waits for another, and the chain of
+	// dependent memory round trips per wave stays as short as for a small pose.
+	//
+	// kAnySettings = false is the common case -- track_writer defaults, no per track rounding, normalization != always: the DMA source
+	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
+	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
+	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
+	template<bool kAnySettings>
+	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
+		unsigned long long* __restrict__ rejected_count)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
+		uint32_t instance = work_item;
+		uint32_t window = 0;
+		if (windows_per_instance != 1)
+		{
+			instance = work_item / windows_per_instance;
+			window = work_item - instance * windows_per_instance;
+		}
+		if (instance >= num_instances)
+			return;
+
+		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
+		{
+			if (lane == 0 && window == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		// an empty track list (decompression.transform.h:1531-1533) or a pose that ends before this window
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		const uint32_t first_quad = window * k_image_chunk_quads;
+		if (first_quad >= num_quads)
+			return;
+		const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
+
+		// the window's animated sub-tracks: image_chunks[window] .. image_chunks[window + 1]
+		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
+		if (num_quads > k_image_chunk_quads)
+		{
+			first_ordinal = as_constant(clip.image_chunks)[window];
+			end_ordinal = as_constant(clip.image_chunks)[window + 1];
+		}
+
+		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
+
+		// With the track_writer's own default sub-track modes the resolved pose already holds what default sub-tracks decode to; any
+		// other mode starts from the tagged base pose and resolves the tags when the window is stored
+		const bool resolve_defaults = kAnySettings && params.standard_default_modes == 0;
+
+		// base pose window -> LDS image, asynchronously: lane i of pass p fetches quad first + p * 64 + i into image[p * 64 + i]
+		{
+			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
+			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
+			{
+				if (base + lane < window_quads)
+					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
+						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+			}
+		}
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+		const uint32_t normalization = params.normalization;
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		if (kAnySettings && normalization == ACLHIP_NORMALIZE_ALWAYS)
+		{
+			// rotation_normalization_policy_t::always also normalizes CONSTANT rotations (constant_track_cache.transform.h:163-175):
+			// done in the image before the animated sub-tracks (normalized by their decode) replace their markers. Rare (debug
+			// settings): this path waits for the base pose instead of overlapping it with the decode.
+			__builtin_amdgcn_s_waitcnt(0);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			for (uint32_t quad = lane; quad < window_quads; quad += k_wave_size)
+			{
+				// (slots of animated rotations hold a tag, or zeros in the resolved pose: whatever this makes of them is overwritten)
+				const f32x4 value = image[quad];
+				if ((first_quad + quad) % 3u == 0 && int32_t(__float_as_uint(value.w)) >= 0)
+				{
+					const float4 normalized = quat_normalize(make_float4(value.x, value.y, value.z, value.w));
+					image[quad] = f32x4{ normalized.x, normalized.y, normalized.z, normalized.w };
+				}
+			}
+		}
+
+		// lanes <-> animated sub-tracks of this window
+		decode_window_sub_tracks<kAnySettings>(clip.clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+
+		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// LDS -> registers -> HBM: the whole window is read first, then the stores go out back to back from one base address with
+		// immediate offsets; full 1 KiB rows take no per lane predicate, only the last (partial) row does
+		constexpr uint32_t k_rows = k_image_chunk_quads / k_wave_size;
+		const uint32_t full_rows = window_quads / k_wave_size;			// wave uniform
+		f32x4 staged[k_rows];
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+			staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
+
+		// (the row is read here, not in the prologue: one SGPR pair less across the decode)
+		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(row) * pose_stride_bytes) + first_quad + lane;
+
+		// any-settings: rows are 64 quads apart and 64 % 3 == 1, so a lane's sub-track kind advances by one per row
+		const uint32_t lane_quad = first_quad + lane;
+		const uint32_t lane_track = lane_quad / 3u;
+		uint32_t kind = lane_quad - lane_track * 3u;
+		const bool user_defaults = kAnySettings && params.default_values != nullptr;		// wave uniform
+
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+		{
+			bool store = r < full_rows || (r == full_rows && r * k_wave_size + lane < window_quads);
+			f32x4 value = staged[r];
+			if (kAnySettings && resolve_defaults)
+			{
+				// default sub-tracks still carry their tag in the W lane (every other quad holds a real W >= +0 by now) and follow the
+				// default sub-track modes (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310,1653-1680)
+				const uint32_t marker = __float_as_uint(value.w);
+				const bool is_default = int32_t(marker) < 0;
+				const uint32_t mode = kind == 0 ? params.default_modes[0] : (kind == 1 ? params.default_modes[1] : params.default_modes[2]);
+				store = store && !(is_default && mode == ACLHIP_DEFAULT_SKIPPED);
+				if (is_default)
+				{
+					// the image holds the track_writer default's xyz (identity / zero / the clip's legacy default scale)
+					value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+					if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
+						value = f32x4{ 1.0f, 1.0f, 1.0f, 0.0f };		// track_writer::get_constant_default_scale (core/track_writer.h:169)
+				}
+				if (user_defaults && is_default && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
+				{
+					const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
+					const float* source = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+					value = f32x4{ source[0], source[1], source[2], kind == 0 ? source[3] : 0.0f };
+				}
+				kind = kind == 2 ? 0u : kind + 1u;
+			}
+			if (store)
+				store_streaming(&pose[r * k_wave_size], value);
+		}
+	}
+
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_tracks_window<false>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+	}
+
+	// 8 waves per SIMD (64 VGPRs) matter more to this variant than the few instructions the allocator saves with 65
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_tracks_window<true>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+	}
