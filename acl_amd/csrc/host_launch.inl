@@ -102,15 +102,39 @@ extern "C" aclhip_status aclhip_order_instances_for_locality(const aclhip_contex
 
 	return guarded(const_cast<aclhip_context*>(context), [&]() -> aclhip_status
 	{
-		// per XCD: its instances, bucketed by clip (stable: instances of a clip keep their relative order)
+		// per XCD: its instances, bucketed by clip (stable: instances of a clip keep their relative order). A counting sort when the
+		// handles are small numbers (they are slots of the registry), a comparison sort for arbitrary values
 		std::vector<uint32_t> sorted(num_instances);
+		uint32_t max_clip = 0;
 		for (uint32_t i = 0; i < num_instances; ++i)
-			sorted[i] = i;
-		std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b)
+			max_clip = std::max(max_clip, clips[i]);
+		if (uint64_t(max_clip) < uint64_t(num_instances) * 4 + 1024)
 		{
-			const uint32_t xcd_a = clips[a] % k_num_xcds, xcd_b = clips[b] % k_num_xcds;
-			return xcd_a != xcd_b ? xcd_a < xcd_b : clips[a] < clips[b];
-		});
+			std::vector<uint32_t> position(size_t(max_clip) + 2, 0);
+			for (uint32_t i = 0; i < num_instances; ++i)
+				position[clips[i]]++;
+			// first position of every clip in (clip % 8, clip) order
+			uint32_t next = 0;
+			for (uint32_t xcd = 0; xcd < k_num_xcds; ++xcd)
+				for (uint64_t clip = xcd; clip <= max_clip; clip += k_num_xcds)
+				{
+					const uint32_t count = position[clip];
+					position[clip] = next;
+					next += count;
+				}
+			for (uint32_t i = 0; i < num_instances; ++i)
+				sorted[position[clips[i]]++] = i;
+		}
+		else
+		{
+			for (uint32_t i = 0; i < num_instances; ++i)
+				sorted[i] = i;
+			std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b)
+			{
+				const uint32_t xcd_a = clips[a] % k_num_xcds, xcd_b = clips[b] % k_num_xcds;
+				return xcd_a != xcd_b ? xcd_a < xcd_b : clips[a] < clips[b];
+			});
+		}
 		uint32_t list_begin[k_num_xcds + 1] = {};
 		for (uint32_t i = 0; i < num_instances; ++i)
 			list_begin[clips[sorted[i]] % k_num_xcds + 1]++;
