@@ -203,6 +203,92 @@ extern "C" aclhip_status aclhip_check_database(const void* compressed_database, 
 	return report(scratch, guarded(&scratch, [&]() { return register_database_impl(&scratch, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, &unused, true); }), out_message, capacity);
 }
 
+// strip_database_quality_tier (compression/impl/compress.database.impl.h:1388-1525), host only: the compressed_database without one
+// of its two streamable tiers, byte for byte what the reference builds -- same layout arithmetic, chunk descriptions and clip
+// metadata copied, the stripped tier's counts zeroed and its hash set to hash32(nullptr, 0), buffer hash recomputed. Like the
+// reference, room for the remaining tier's bulk data is reserved (and its offset set) whether or not the bulk data is inline, and
+// only inline bulk data is copied.
+extern "C" aclhip_status aclhip_strip_database_tier(const void* compressed_database, uint64_t size, uint32_t tier, void* out_database, uint64_t capacity, uint64_t* out_size)
+{
+	if (out_size == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_size = 0;
+
+	// database.is_valid(true) (core/impl/compressed_database.impl.h:142-163)
+	const uint8_t* blob = static_cast<const uint8_t*>(compressed_database);
+	if (blob == nullptr || size < sizeof(raw_buffer_header) + sizeof(database_header) || (reinterpret_cast<uintptr_t>(blob) & 7u) != 0)
+		return ACLHIP_ERROR_INVALID_CLIP;
+	const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+	const database_header& header = *reinterpret_cast<const database_header*>(blob + sizeof(raw_buffer_header));
+	const uint8_t* hbase = reinterpret_cast<const uint8_t*>(&header);
+	if (header.tag != k_tag_compressed_database || header.version < k_version_first || header.version > k_version_latest
+		|| buffer_header.size > size || buffer_header.size < sizeof(raw_buffer_header) + sizeof(database_header)
+		|| hash32(blob + sizeof(raw_buffer_header), buffer_header.size - sizeof(raw_buffer_header)) != buffer_header.hash)
+		return ACLHIP_ERROR_INVALID_CLIP;
+	const uint64_t header_limit = buffer_header.size - sizeof(raw_buffer_header);
+	const uint32_t descriptions_offset = align_to_u32(uint32_t(sizeof(database_header)), 4);
+	if (uint64_t(descriptions_offset) + (uint64_t(header.num_chunks[0]) + header.num_chunks[1]) * sizeof(database_chunk_description) > header_limit
+		|| uint64_t(header.clip_metadata_offset) + uint64_t(header.num_clips) * sizeof(database_clip_metadata) > header_limit)
+		return ACLHIP_ERROR_INVALID_CLIP;
+
+	// the high importance tier lives inside the compressed_tracks; an empty tier cannot be stripped (:1396-1400)
+	if (tier != 1 && tier != 2)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	const uint32_t tier_index = tier - 1;
+	if (header.bulk_data_size[tier_index] == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	const bool is_inline = (header.misc_packed & 1u) != 0;
+	const uint32_t kept_index = 1 - tier_index;
+	const uint32_t num_kept_chunks = header.num_chunks[kept_index];
+	const uint32_t kept_bulk_size = header.bulk_data_size[kept_index];
+	if (is_inline && kept_bulk_size != 0 && (header.bulk_data_offset[kept_index] == k_invalid_offset || uint64_t(header.bulk_data_offset[kept_index]) + kept_bulk_size > header_limit))
+		return ACLHIP_ERROR_INVALID_CLIP;
+
+	// offsets relative to the database_header, in the reference's order: chunk descriptions (medium, low), clip metadata, bulk data
+	constexpr uint32_t k_bulk_data_alignment = 4;		// alignof(database_chunk_header) (core/compressed_database.h:170)
+	uint64_t offset = descriptions_offset;
+	const uint64_t kept_descriptions_offset = offset;		// the stripped tier has none: the kept tier's come first either way
+	offset += uint64_t(num_kept_chunks) * sizeof(database_chunk_description);
+	offset = (offset + 3) & ~uint64_t(3);
+	const uint64_t clip_metadata_offset = offset;
+	offset += uint64_t(header.num_clips) * sizeof(database_clip_metadata);
+	offset = (offset + sizeof(raw_buffer_header) + k_bulk_data_alignment - 1) / k_bulk_data_alignment * k_bulk_data_alignment - sizeof(raw_buffer_header);
+	const uint64_t bulk_data_offset = offset;
+	offset += kept_bulk_size;
+	const uint64_t total_size = sizeof(raw_buffer_header) + offset;
+	if (total_size > 0xFFFFFFFFull)
+		return ACLHIP_ERROR_INVALID_CLIP;
+
+	*out_size = total_size;
+	if (out_database == nullptr || capacity < total_size)
+		return out_database == nullptr && capacity == 0 ? ACLHIP_OK : ACLHIP_ERROR_INVALID_ARGUMENT;		// size query
+
+	uint8_t* out = static_cast<uint8_t*>(out_database);
+	std::memset(out, 0, total_size);
+	raw_buffer_header* out_buffer_header = reinterpret_cast<raw_buffer_header*>(out);
+	database_header* out_header = reinterpret_cast<database_header*>(out + sizeof(raw_buffer_header));
+	uint8_t* out_hbase = reinterpret_cast<uint8_t*>(out_header);
+	std::memcpy(out_header, &header, sizeof(database_header));
+	out_header->clip_metadata_offset = uint32_t(clip_metadata_offset);
+	out_header->bulk_data_offset[kept_index] = kept_bulk_size != 0 ? uint32_t(bulk_data_offset) : k_invalid_offset;
+	out_header->num_chunks[tier_index] = 0;
+	out_header->bulk_data_size[tier_index] = 0;
+	out_header->bulk_data_offset[tier_index] = k_invalid_offset;
+	out_header->bulk_data_hash[tier_index] = hash32(nullptr, 0);
+
+	const uint64_t source_descriptions_offset = kept_index == 0 ? descriptions_offset
+		: ((uint64_t(descriptions_offset) + uint64_t(header.num_chunks[0]) * sizeof(database_chunk_description) + 3) & ~uint64_t(3));
+	std::memcpy(out_hbase + kept_descriptions_offset, hbase + source_descriptions_offset, size_t(num_kept_chunks) * sizeof(database_chunk_description));
+	std::memcpy(out_hbase + clip_metadata_offset, hbase + header.clip_metadata_offset, size_t(header.num_clips) * sizeof(database_clip_metadata));
+	if (is_inline && kept_bulk_size != 0)
+		std::memcpy(out_hbase + bulk_data_offset, hbase + header.bulk_data_offset[kept_index], kept_bulk_size);
+
+	out_buffer_header->size = uint32_t(total_size);
+	out_buffer_header->hash = hash32(out_hbase, total_size - sizeof(raw_buffer_header));
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, aclhip_database database)
 {
 	if (context == nullptr)

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
-    "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
+    "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
 
@@ -151,6 +151,7 @@ def load_library():
     lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
+    lib.aclhip_strip_database_tier.argtypes = [vp, u64, u32, vp, u64, ctypes.POINTER(u64)]
     lib.aclhip_plan_hierarchy_walk.argtypes = [vp, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_set_clip_hierarchy.argtypes = [vp, u32, vp, u32]
     lib.aclhip_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp]
@@ -185,6 +186,20 @@ def order_instances_for_locality(clips):
     if status != 0:
         raise AclHipError(status, "aclhip_order_instances_for_locality failed")
     return order
+
+
+def strip_database_tier(database, tier):
+    """aclhip_strip_database_tier (host only): (status, stripped compressed_database as a 16 byte aligned uint8 array or None)"""
+    from .synth import aligned_bytes
+    array = np.frombuffer(database, dtype=np.uint8) if not isinstance(database, np.ndarray) else database
+    lib = load_library()
+    size = ctypes.c_uint64(0)
+    status = lib.aclhip_strip_database_tier(array.ctypes.data, array.size, int(tier), None, 0, ctypes.byref(size))
+    if status != 0:
+        return status, None
+    out = aligned_bytes(size.value)
+    status = lib.aclhip_strip_database_tier(array.ctypes.data, array.size, int(tier), out.ctypes.data, out.size, ctypes.byref(size))
+    return status, (out if status == 0 else None)
 
 
 def plan_hierarchy_walk(parent_indices, transforms_per_step):

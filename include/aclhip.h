@@ -197,6 +197,13 @@ aclhip_status aclhip_register_clip_with_database(aclhip_context* context, const 
 aclhip_status aclhip_database_stream_in(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
 aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
 
+/* Host only (no GPU work): strip_database_quality_tier (compression/compress.h:124, impl/compress.database.impl.h:1388-1525) --
+ * the compressed_database without its medium (tier 1) or low (tier 2) importance tier, byte for byte what the reference builds
+ * (it reserves room for the remaining tier's bulk data and sets its offset whether or not the bulk data is inline, and copies
+ * only inline bulk data; so does this). The input must pass is_valid(true). Call with out_database NULL / capacity 0 for the
+ * size. ACLHIP_ERROR_INVALID_ARGUMENT for the high importance tier (0) and for an empty tier, like the reference's errors. */
+aclhip_status aclhip_strip_database_tier(const void* compressed_database, uint64_t size, uint32_t tier, void* out_database, uint64_t capacity, uint64_t* out_size);
+
 /* ---- decompression ---------------------------------------------------------------------------- */
 
 /* Replaces, for every instance i in [0, num_instances):

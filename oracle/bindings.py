@@ -338,6 +338,8 @@ def ref_db():
         lib.aclref_db_stream.argtypes = [vp, i32, u32, i32]
         lib.aclref_db_decompress.argtypes = [vp, u32, f32, i32, vp]
         lib.aclref_db_destroy.argtypes = [vp]
+        lib.aclref_db_strip.argtypes = [vp, i32, i32, vp, u32]
+        lib.aclref_db_strip.restype = u32
         _ref_db = lib
     return _ref_db
 
@@ -393,6 +395,16 @@ class ReferenceDatabase:
         result = self._lib.aclref_db_decompress(self._handle, clip_index, ctypes.c_float(sample_time), rounding, out.ctypes.data)
         if result != 0:
             raise RuntimeError(f"aclref_db_decompress failed: {result}")
+        return out
+
+    def strip(self, tier, split):
+        """strip_database_quality_tier (compression/compress.h:124) of the inline or the split database; None when the reference refuses"""
+        from acl_amd.synth import aligned_bytes
+        size = self._lib.aclref_db_strip(self._handle, 1 if split else 0, tier, None, 0)
+        if size == 0:
+            return None
+        out = aligned_bytes(size)
+        assert self._lib.aclref_db_strip(self._handle, 1 if split else 0, tier, out.ctypes.data, size) == size
         return out
 
     def close(self):

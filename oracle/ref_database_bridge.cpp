@@ -175,6 +175,23 @@ extern "C"
 		return 0;
 	}
 
+	// strip_database_quality_tier (compression/compress.h:124): the database without its medium (1) or low (2) importance tier;
+	// split != 0 strips the database whose bulk data was split out. Returns the size of the stripped database, 0 on error.
+	uint32_t aclref_db_strip(void* handle, int split, int tier, void* out, uint32_t capacity)
+	{
+		built_database* b = static_cast<built_database*>(handle);
+		const acl::compressed_database& source = split ? *b->split : *b->database;
+		acl::compressed_database* stripped = nullptr;
+		const acl::error_result result = acl::strip_database_quality_tier(b->allocator, source, tier == 1 ? acl::quality_tier::medium_importance : acl::quality_tier::lowest_importance, stripped);
+		if (result.any() || stripped == nullptr)
+			return 0;
+		const uint32_t size = stripped->get_size();
+		if (out != nullptr && capacity >= size)
+			std::memcpy(out, stripped, size);
+		b->allocator.deallocate(stripped, size);
+		return size;
+	}
+
 	void aclref_db_destroy(void* handle)
 	{
 		built_database* b = static_cast<built_database*>(handle);

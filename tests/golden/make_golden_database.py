@@ -72,12 +72,19 @@ def main():
             results.append(ref.stream(tier, num_chunks, bool(stream_in)))
             snapshot(state + 1)
 
+        # strip_database_quality_tier of the inline and of the split database, both tiers (empty array: the reference refuses)
+        stripped = {}
+        for split in (0, 1):
+            for tier in (1, 2):
+                blob = ref.strip(tier, bool(split))
+                stripped[f"stripped_{'split' if split else 'inline'}_{'medium' if tier == 1 else 'low'}"] = np.asarray(blob) if blob is not None else np.zeros(0, np.uint8)
+
         offsets = np.cumsum([0] + [clip.size for clip in ref.clips]).astype(np.int64)
         path = os.path.join(HERE, "database", f"{name}.npz")
         np.savez_compressed(path, clips=np.concatenate(ref.clips), clip_offsets=offsets, database=np.asarray(ref.database),
                             database_inline=np.asarray(ref.database_inline), bulk_medium=np.asarray(ref.bulk[1]), bulk_low=np.asarray(ref.bulk[2]),
                             ops=np.array(ops, dtype=np.uint32), results=np.array(results, dtype=np.int32), times=times,
-                            policies=np.array(POLICIES, dtype=np.uint8), poses=poses)
+                            policies=np.array(POLICIES, dtype=np.uint8), poses=poses, **stripped)
         print(f"{name}: {os.path.getsize(path)} bytes, chunks {ref.num_chunks}, results {results}")
         ref.close()
 
