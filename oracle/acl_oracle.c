@@ -1279,3 +1279,88 @@ void aclo_local_to_object_space(const uint32_t* parent_indices, const float* loc
 		memcpy(out_object_pose + (uint64_t)i * 12, result, sizeof(result));
 	}
 }
+
+/* ---- small utilities the reference's unit tests pin (tests/sources/core/test_time_utils.cpp, test_bit_manip_utils.cpp,
+ * tests/sources/math/test_scalar_packing.cpp): exposed so that tests/test_oracle_kats.py can restate those tests ---- */
+
+/* core/impl/time_utils.impl.h:44-112 */
+uint32_t aclo_calculate_num_samples(float duration, float sample_rate)
+{
+	if (duration == 0.0f)
+		return 0;
+	if (isinf(duration))
+		return 1;
+	return (uint32_t)floorf((duration * sample_rate) + 0.5f) + 1;
+}
+
+float aclo_calculate_duration(uint32_t num_samples, float sample_rate)
+{
+	if (num_samples == 0)
+		return 0.0f;
+	if (num_samples == 1)
+		return INFINITY;
+	return (float)(num_samples - 1) / sample_rate;
+}
+
+float aclo_calculate_finite_duration(uint32_t num_samples, float sample_rate)
+{
+	if (num_samples <= 1)
+		return 0.0f;
+	return (float)(num_samples - 1) / sample_rate;
+}
+
+/* core/bit_manip_utils.h (the forms the database seek relies on: 32 bit) */
+uint32_t aclo_count_set_bits(uint32_t value) { return count_set_bits(value); }
+uint32_t aclo_count_leading_zeros(uint32_t value) { return count_leading_zeros(value); }
+uint32_t aclo_count_trailing_zeros(uint32_t value) { return count_trailing_zeros(value); }
+
+/* math/scalar_packing.h:40-68. rtm::scalar_round_symmetric: half away from zero (floor(x + 0.5) for the non-negative inputs here) */
+uint32_t aclo_pack_scalar_unsigned(float input, uint32_t num_bits)
+{
+	const uint32_t max_value = (1u << num_bits) - 1u;
+	return (uint32_t)floorf(input * (float)max_value + 0.5f);
+}
+
+float aclo_unpack_scalar_unsigned(uint32_t input, uint32_t num_bits)
+{
+	const uint32_t max_value = (1u << num_bits) - 1u;
+	const float inv_max_value = 1.0f / (float)max_value;
+	return (float)input * inv_max_value;
+}
+
+uint32_t aclo_pack_scalar_signed(float input, uint32_t num_bits) { return aclo_pack_scalar_unsigned((input * 0.5f) + 0.5f, num_bits); }
+float aclo_unpack_scalar_signed(uint32_t input, uint32_t num_bits) { return (aclo_unpack_scalar_unsigned(input, num_bits) * 2.0f) - 1.0f; }
+
+/* The field readers of the scalar decode, at any bit offset (math/scalar_packing.h:71-160) */
+float aclo_unpack_scalarf_32(const uint8_t* data, uint32_t bit_offset) { return unpack_component_32(data, bit_offset); }
+float aclo_unpack_scalarf_uXX(uint32_t num_bits, const uint8_t* data, uint32_t bit_offset) { return unpack_component_uXX(num_bits, data, bit_offset); }
+
+/* "scalar packing math" of test_scalar_packing.cpp:44-79 for num_bits in [first, last]: boundary values and the exhaustive
+ * unpack -> pack round trip, unsigned and signed. Returns the number of violations. */
+uint32_t aclo_selftest_scalar_packing(uint32_t first_num_bits, uint32_t last_num_bits)
+{
+	uint32_t num_errors = 0;
+	uint32_t num_bits, value;
+	for (num_bits = first_num_bits; num_bits <= last_num_bits; ++num_bits)
+	{
+		const uint32_t max_value = (1u << num_bits) - 1u;
+		num_errors += aclo_pack_scalar_unsigned(0.0f, num_bits) != 0;
+		num_errors += aclo_pack_scalar_unsigned(1.0f, num_bits) != max_value;
+		num_errors += aclo_unpack_scalar_unsigned(0, num_bits) != 0.0f;
+		num_errors += !(fabsf(aclo_unpack_scalar_unsigned(max_value, num_bits) - 1.0f) < 1.0e-6f);
+		num_errors += aclo_pack_scalar_signed(-1.0f, num_bits) != 0;
+		num_errors += aclo_pack_scalar_signed(1.0f, num_bits) != max_value;
+		num_errors += aclo_unpack_scalar_signed(0, num_bits) != -1.0f;
+		num_errors += !(fabsf(aclo_unpack_scalar_signed(max_value, num_bits) - 1.0f) < 1.0e-6f);
+		for (value = 0; value < max_value; ++value)
+		{
+			const float unpacked0 = aclo_unpack_scalar_unsigned(value, num_bits);
+			const float unpacked1 = aclo_unpack_scalar_signed(value, num_bits);
+			if (aclo_pack_scalar_unsigned(unpacked0, num_bits) != value || unpacked0 < 0.0f || unpacked0 > 1.0f)
+				num_errors++;
+			if (aclo_pack_scalar_signed(unpacked1, num_bits) != value || unpacked1 < -1.0f || unpacked1 > 1.0f)
+				num_errors++;
+		}
+	}
+	return num_errors;
+}

@@ -121,6 +121,22 @@ uint32_t aclo_scalar_num_components(const void* blob);
 int aclo_scalar_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out);
 int aclo_scalar_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_value);
 
+/* Small utilities pinned by the reference's unit tests (tests/sources/core/test_time_utils.cpp:35-57, test_bit_manip_utils.cpp:31-60,
+ * tests/sources/math/test_scalar_packing.cpp:44-140); see tests/test_oracle_kats.py */
+uint32_t aclo_calculate_num_samples(float duration, float sample_rate);		/* core/impl/time_utils.impl.h:44-57 */
+float aclo_calculate_duration(uint32_t num_samples, float sample_rate);			/* :59-70 */
+float aclo_calculate_finite_duration(uint32_t num_samples, float sample_rate);	/* :102-112 */
+uint32_t aclo_count_set_bits(uint32_t value);
+uint32_t aclo_count_leading_zeros(uint32_t value);
+uint32_t aclo_count_trailing_zeros(uint32_t value);
+uint32_t aclo_pack_scalar_unsigned(float input, uint32_t num_bits);				/* math/scalar_packing.h:40-68 */
+float aclo_unpack_scalar_unsigned(uint32_t input, uint32_t num_bits);
+uint32_t aclo_pack_scalar_signed(float input, uint32_t num_bits);
+float aclo_unpack_scalar_signed(uint32_t input, uint32_t num_bits);
+float aclo_unpack_scalarf_32(const uint8_t* data, uint32_t bit_offset);			/* math/scalar_packing.h:71-110 */
+float aclo_unpack_scalarf_uXX(uint32_t num_bits, const uint8_t* data, uint32_t bit_offset);	/* :113-160 */
+uint32_t aclo_selftest_scalar_packing(uint32_t first_num_bits, uint32_t last_num_bits);
+
 /* Pose consumers: core/additive_utils.h:128-160 and compression/transform_pose_utils.h:35-50 over poses of
  * 12 floats per transform. See acl_oracle.c for what is restated from Realtime Math and how it is pinned. */
 void aclo_quat_mul(const float lhs[4], const float rhs[4], float out[4]);

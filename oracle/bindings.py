@@ -90,6 +90,29 @@ def oracle():
         lib.aclo_scalar_num_components.restype = u32
         lib.aclo_scalar_decompress_tracks.argtypes = [vp, f32, i32, ctypes.POINTER(Options), vp]
         lib.aclo_scalar_decompress_track.argtypes = [vp, f32, i32, ctypes.POINTER(Options), u32, vp]
+        lib.aclo_calculate_num_samples.argtypes = [f32, f32]
+        lib.aclo_calculate_num_samples.restype = u32
+        lib.aclo_calculate_duration.argtypes = [u32, f32]
+        lib.aclo_calculate_duration.restype = f32
+        lib.aclo_calculate_finite_duration.argtypes = [u32, f32]
+        lib.aclo_calculate_finite_duration.restype = f32
+        for name in ("aclo_count_set_bits", "aclo_count_leading_zeros", "aclo_count_trailing_zeros"):
+            getattr(lib, name).argtypes = [u32]
+            getattr(lib, name).restype = u32
+        lib.aclo_pack_scalar_unsigned.argtypes = [f32, u32]
+        lib.aclo_pack_scalar_unsigned.restype = u32
+        lib.aclo_pack_scalar_signed.argtypes = [f32, u32]
+        lib.aclo_pack_scalar_signed.restype = u32
+        lib.aclo_unpack_scalar_unsigned.argtypes = [u32, u32]
+        lib.aclo_unpack_scalar_unsigned.restype = f32
+        lib.aclo_unpack_scalar_signed.argtypes = [u32, u32]
+        lib.aclo_unpack_scalar_signed.restype = f32
+        lib.aclo_unpack_scalarf_32.argtypes = [vp, u32]
+        lib.aclo_unpack_scalarf_32.restype = f32
+        lib.aclo_unpack_scalarf_uXX.argtypes = [u32, vp, u32]
+        lib.aclo_unpack_scalarf_uXX.restype = f32
+        lib.aclo_selftest_scalar_packing.argtypes = [u32, u32]
+        lib.aclo_selftest_scalar_packing.restype = u32
         lib.aclo_quat_mul.argtypes = [vp, vp, vp]
         lib.aclo_quat_mul.restype = None
         lib.aclo_qvv_mul.argtypes = [vp, vp, vp]

@@ -184,3 +184,69 @@ def test_memcpy_bits():
     ob.oracle().aclo_memcpy_bits(dst.ctypes.data, 5, src.ctypes.data, 24, 8)      # copy zeros over ones
     bits = np.unpackbits(dst)
     assert bits[5:13].sum() == 0 and bits[:5].sum() == 5 and bits[13:].sum() == 51
+
+
+def test_time_utils():
+    # tests/sources/core/test_time_utils.cpp:35-57
+    lib = ob.oracle()
+    inf = float("inf")
+    assert lib.aclo_calculate_num_samples(0.0, 30.0) == 0
+    assert lib.aclo_calculate_num_samples(1.0, 30.0) == 31
+    assert lib.aclo_calculate_num_samples(1.0, 24.0) == 25
+    assert lib.aclo_calculate_num_samples(F(1.0) / F(30.0), 30.0) == 2
+    assert lib.aclo_calculate_num_samples(inf, 30.0) == 1
+    assert lib.aclo_calculate_duration(0, 30.0) == 0.0
+    assert lib.aclo_calculate_duration(1, 30.0) == inf
+    assert lib.aclo_calculate_duration(1, 8.0) == inf
+    assert abs(lib.aclo_calculate_duration(31, 30.0) - 1.0) < 1.0e-8
+    assert abs(lib.aclo_calculate_duration(9, 8.0) - 1.0) < 1.0e-8
+    assert lib.aclo_calculate_finite_duration(0, 30.0) == 0.0
+    assert lib.aclo_calculate_finite_duration(1, 30.0) == 0.0
+    assert lib.aclo_calculate_finite_duration(1, 8.0) == 0.0
+    assert abs(lib.aclo_calculate_finite_duration(31, 30.0) - 1.0) < 1.0e-8
+    assert abs(lib.aclo_calculate_finite_duration(9, 8.0) - 1.0) < 1.0e-8
+
+
+def test_bit_manip_utils():
+    # tests/sources/core/test_bit_manip_utils.cpp:31-60, the 32 bit forms the database seek uses
+    lib = ob.oracle()
+    for value, expected in ((0x00000000, 0), (0x00000001, 1), (0x10000000, 1), (0x10101001, 4), (0xFFFFFFFF, 32)):
+        assert lib.aclo_count_set_bits(value) == expected
+    for value, expected in ((0x00000000, 32), (0x00000001, 31), (0x00000002, 30), (0x80000000, 0), (0x40000000, 1)):
+        assert lib.aclo_count_leading_zeros(value) == expected
+    for value, expected in ((0x00000000, 32), (0x00000001, 0), (0x00000002, 1), (0x80000000, 31), (0x40000000, 30)):
+        assert lib.aclo_count_trailing_zeros(value) == expected
+
+
+def test_scalar_packing_math():
+    # tests/sources/math/test_scalar_packing.cpp:44-79: boundaries and the exhaustive unpack -> pack round trip for 1..22 bits
+    assert ob.oracle().aclo_selftest_scalar_packing(1, 22) == 0
+
+
+def test_unpack_scalarf_32_at_bit_offsets():
+    # test_scalar_packing.cpp:81-117: a big endian fp32 at bit offsets {0,1,5,31,32,33,63,64,65,93}
+    lib = ob.oracle()
+    for value in (F(6123.123812), F(19237.01293127), F(0.913912387), F(-0.1816253)):
+        big_endian = np.array([value], dtype=np.float32).view(np.uint32).byteswap().view(np.uint8)
+        for offset in (0, 1, 5, 31, 32, 33, 63, 64, 65, 93):
+            buf = np.zeros(32, dtype=np.uint8)
+            lib.aclo_memcpy_bits(buf.ctypes.data, offset, big_endian.ctypes.data, 0, 32)
+            assert F(lib.aclo_unpack_scalarf_32(buf.ctypes.data, offset)) == value
+
+
+def test_unpack_scalarf_uXX_at_bit_offsets():
+    # test_scalar_packing.cpp:119-166 (test_unpack_scalarf_uXX_unsafe): every value of widths 1..12 and samples of 13..23, written big
+    # endian at the test's bit offsets, read back exactly as float(value) * (1 / max)
+    lib = ob.oracle()
+    rng = np.random.default_rng(0)
+    for num_bits in range(1, 24):
+        max_value = (1 << num_bits) - 1
+        values = range(max_value + 1) if num_bits <= 8 else [0, 1, max_value - 1, max_value] + list(rng.integers(0, max_value + 1, size=60))
+        for value in values:
+            field = np.array([int(value) << (32 - num_bits)], dtype=np.uint32).byteswap().view(np.uint8)       # the field in the top bits, big endian
+            for offset in (0, 1, 5, 31, 32, 33, 63, 64, 65, 93):
+                buf = np.zeros(32, dtype=np.uint8)
+                lib.aclo_memcpy_bits(buf.ctypes.data, offset, field.ctypes.data, 0, num_bits)
+                expected = F(int(value)) * (F(1.0) / F(max_value))
+                assert F(lib.aclo_unpack_scalarf_uXX(num_bits, buf.ctypes.data, offset)) == expected
+                assert abs(lib.aclo_unpack_scalar_unsigned(int(value), num_bits) - expected) == 0.0
