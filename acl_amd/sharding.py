@@ -48,3 +48,23 @@ def all_gather_poses(local_poses, num_instances, group=None):
         return gathered
     pieces = [gathered[r * largest: r * largest + sizes[r]] for r in range(world_size)]
     return torch.cat(pieces, dim=0)
+
+
+def stream_database_everywhere(context, database, tier, num_chunks, stream_in=True, src=0, group=None, stream=None):
+    """Streamed database tiers are replicated per GPU (every rank registers the database with its own context), so their residency
+    must advance identically everywhere: rank `src` decides the request -- (tier, num_chunks, in or out), the arguments of the other
+    ranks are ignored -- it is broadcast, every rank applies it to its own context (aclhip_database_stream_in / _out, asynchronous
+    on `stream`), and the ranks check that they moved the same number of chunks. Returns that number.
+    SURVEY.md section 8(e): "streaming state advanced identically on all ranks (broadcast of 'chunks [a, b) now resident')"."""
+    device = torch.device("cuda", context.device_index) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    request = torch.tensor([int(tier), int(num_chunks), 1 if stream_in else 0], dtype=torch.int64, device=device)
+    dist.broadcast(request, src=src, group=group)
+    tier, num_chunks, stream_in = (int(v) for v in request.tolist())
+    apply = context.database_stream_in if stream_in else context.database_stream_out
+    moved = int(apply(database, tier, num_chunks, stream=stream))
+
+    spread = torch.tensor([moved, -moved], dtype=torch.int64, device=device)
+    dist.all_reduce(spread, op=dist.ReduceOp.MAX, group=group)
+    if int(spread[0]) != -int(spread[1]):
+        raise RuntimeError(f"database residency diverged between ranks: this rank moved {moved} chunks, others between {-int(spread[1])} and {int(spread[0])}")
+    return moved

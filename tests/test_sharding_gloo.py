@@ -60,3 +60,64 @@ def test_two_ranks_shard_and_all_gather(tmp_path, num_instances):
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port, num_instances, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+class _RecordingContext:
+    """stands in for runtime.Context on a box without GPUs: a database of 5 + 3 chunks whose residency is tracked like
+    aclhip_database_stream_in / _out would (first `loaded` chunks of a tier are resident)"""
+    device_index = 0
+
+    def __init__(self, skew=0):
+        self.loaded = {1: 0, 2: 0}
+        self.total = {1: 5, 2: 3}
+        self.calls = []
+        self.skew = skew
+
+    def database_stream_in(self, database, tier, num_chunks, stream=None):
+        moved = max(min(num_chunks, self.total[tier] - self.loaded[tier]) - self.skew, 0)
+        self.loaded[tier] += moved
+        self.calls.append(("in", tier, num_chunks))
+        return moved
+
+    def database_stream_out(self, database, tier, num_chunks, stream=None):
+        moved = min(num_chunks, self.loaded[tier])
+        self.loaded[tier] -= moved
+        self.calls.append(("out", tier, num_chunks))
+        return moved
+
+
+def _streaming_worker(rank, world_size, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world_size)
+    try:
+        context = _RecordingContext()
+        # only rank 0's arguments count: rank 1 passes nonsense and still ends up in the same state
+        script = [(1, 2, True), (2, 0xFFFFFFFF, True), (1, 1, False), (1, 0xFFFFFFFF, True)]
+        moved = []
+        for tier, num_chunks, stream_in in script:
+            mine = (tier, num_chunks, stream_in) if rank == 0 else (2, 12345, not stream_in)
+            moved.append(sharding.stream_database_everywhere(context, 0, *mine, src=0))
+        assert moved == [2, 3, 1, 4]
+        assert context.loaded == {1: 5, 2: 3}
+        assert context.calls == [("in", 1, 2), ("in", 2, 0xFFFFFFFF), ("out", 1, 1), ("in", 1, 0xFFFFFFFF)]
+
+        # a rank whose residency diverges is noticed by everyone
+        diverging = _RecordingContext(skew=1 if rank == 1 else 0)
+        try:
+            sharding.stream_database_everywhere(diverging, 0, 1, 3, True, src=0)
+            raised = False
+        except RuntimeError:
+            raised = True
+        assert raised
+        open(os.path.join(result_dir, f"stream_ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_advance_database_residency_together(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_streaming_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "stream_ok0") and os.path.exists(tmp_path / "stream_ok1")
