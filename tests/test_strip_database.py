@@ -72,3 +72,36 @@ def test_live_against_the_reference(seed):
                     assert status == runtime.OK and np.array_equal(stripped, expected)
     finally:
         reference.close()
+
+
+def _fnv1a32(data):
+    data = np.ascontiguousarray(data)
+    return ob.oracle().aclo_hash32(data.ctypes.data, data.size)     # hash32 (core/hash.h:86-99)
+
+
+@pytest.mark.parametrize("seed", range(2))
+def test_corrupt_headers_with_valid_hashes_never_crash_the_stripper(seed):
+    """is_valid(true) only proves the bytes are the ones that were hashed: counts and offsets of a re-hashed, corrupted header must be
+    refused or handled, never followed out of the buffer"""
+    rng = np.random.default_rng(200 + seed)
+    survived = 0
+    for name in helpers.database_golden_cases():
+        case = helpers.load_database_golden(name)
+        for key in ("database_inline", "database"):
+            original = case[key]
+            for _ in range(120):
+                database = synth.aligned_bytes(original.size)
+                database[:] = original
+                for _ in range(int(rng.integers(1, 4))):
+                    at = int(rng.integers(8, 64)) if rng.uniform() < 0.8 else int(rng.integers(8, original.size))     # the database_header sits at [8, 64)
+                    database[at] = int(rng.integers(0, 256))
+                size = original.size if rng.uniform() < 0.9 else int(rng.integers(64, original.size))
+                if rng.uniform() < 0.8:
+                    database[0:4] = np.frombuffer(np.uint32(size).tobytes(), dtype=np.uint8)
+                    database[4:8] = np.frombuffer(np.uint32(_fnv1a32(database[8:size])).tobytes(), dtype=np.uint8)
+                for tier in (1, 2):
+                    status, stripped = runtime.strip_database_tier(database[:size], tier)
+                    if status == runtime.OK:
+                        survived += 1
+                        assert stripped.size >= 64 and int(np.frombuffer(stripped[:4].tobytes(), dtype=np.uint32)[0]) == stripped.size
+    assert survived > 0         # some corruptions only touch fields the stripper copies through
