@@ -24,6 +24,21 @@ int main(int argc, char** argv)
 	if (strcmp(aclhip_status_string(ACLHIP_OK), aclhip_status_string(ACLHIP_ERROR_INVALID_CLIP)) == 0)
 		return 4;
 
+	/* the other host only entry points: a decode order, a walk schedule (a chain of four under one root: three steps) */
+	{
+		const aclhip_clip clips[6] = { 9, 1, 9, 8, 1, 9 };
+		const uint32_t parents[5] = { ACLHIP_NO_PARENT, 0, 1, 2, 0 };
+		uint32_t order[6], steps[5], num_steps = 0, seen = 0, i;
+		if (aclhip_order_instances_for_locality(NULL, clips, 6, order) != ACLHIP_OK)
+			return 20;
+		for (i = 0; i < 6; ++i)
+			seen |= 1u << order[i];
+		if (seen != 63u)
+			return 21;		/* a permutation */
+		if (aclhip_plan_hierarchy_walk(parents, 5, 8, steps, &num_steps) != ACLHIP_OK || num_steps != 3 || steps[0] != 0 || steps[1] != 1 || steps[4] != 1 || steps[3] != 3)
+			return 22;
+	}
+
 	file = fopen(argv[1], "rb");
 	if (file == NULL)
 		return 5;

@@ -87,9 +87,9 @@ def test_header_is_plain_c_and_host_entry_points_work_without_a_gpu(tmp_path):
 
 
 def test_cpp_mirror_and_its_drivers_compile_warning_free():
-    """acl_amd/csrc/aclhip.hpp (the C++ mirror of decompression_context / database_context / track_writer) and the three
+    """acl_amd/csrc/aclhip.hpp (the C++ mirror of decompression_context / database_context / track_writer) and the
     programs that drive it on the GPU box build with g++ -Wall -Wextra -Werror here (they run under -m gpu)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for source in ("context_mirror_test.cpp", "database_mirror_test.cpp", "scalar_mirror_test.cpp"):
+    for source in ("context_mirror_test.cpp", "database_mirror_test.cpp", "scalar_mirror_test.cpp", "pose_consumers_mirror_test.cpp"):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", os.path.join(root, "tests", "cpp", source)], check=True)
