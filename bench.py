@@ -379,6 +379,12 @@ def main():
     if rejected != 0:
         raise SystemExit(f"the kernel rejected {rejected} instances")
 
+    # committed PMC measurements are per instance order: random (the default), or the library's locality order
+    traffic_key = args.workload
+    if args.order_for_locality:
+        traffic_key = None if args.keep_rows else args.workload + ", aclhip_order_instances_for_locality order"
+    elif args.sort_by_clip:
+        traffic_key = None
     kernel_name = "decompress_scalar_tracks_kernel" if is_scalar else ("decompress_poses_consumer_kernel" if consumers is not None else context.tracks_kernel_name(params))
     if rank == 0:
         total_poses = num_instances * world_size * args.steps
@@ -417,7 +423,7 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, kernel_name),
+                "traffic": measured_traffic(traffic_key, kernel_name),
                 "kernel": kernel_name,
                 "kernel_ms": kernel_ms,
                 "kernel_ms_back_to_back": kernel_ms_back_to_back,
