@@ -1,0 +1,55 @@
+/* The call sequences INTEGRATION.md shows (sections 1, 3, 4b), as one C99 translation unit that must compile and link against
+ * libaclhip.so with the signatures the document uses. Never run: tests/test_capi_symbols.py only builds it. */
+#include "aclhip.h"
+
+#include <stddef.h>
+
+int integration_example(const void* tracks, uint64_t tracks_size, const void* compressed_db, uint64_t db_size, const void* bulk_medium, const void* bulk_low,
+	const aclhip_clip* d_clips, const float* d_times, const uint32_t* d_bones, uint32_t num_instances, void* d_poses, void* d_transforms, uint32_t max_tracks,
+	const uint32_t* parent_indices, uint32_t num_tracks, const aclhip_clip* d_base_clips, const float* d_base_times,
+	const aclhip_clip* host_clips, uint32_t* order, const uint32_t* d_rows, void* hip_stream)
+{
+	aclhip_context* gpu = NULL;
+	aclhip_clip clip, db_clip;
+	aclhip_database db;
+	aclhip_decompress_params params;
+	aclhip_pose_consumers consumers;
+	char message[256];
+	uint32_t moved = 0;
+	aclhip_status s;
+
+	/* section 1 */
+	if (aclhip_create(0, &gpu) != ACLHIP_OK)
+		return 1;
+	s = aclhip_register_clip(gpu, tracks, tracks_size, 0, &clip);
+	if (s == ACLHIP_ERROR_INVALID_CLIP)
+		(void)aclhip_check_clip(tracks, tracks_size, 0, message, sizeof(message));
+	aclhip_default_params(&params);
+	params.rounding_policy = ACLHIP_ROUND_NONE;
+	s = aclhip_decompress_tracks_batch(gpu, d_clips, d_times, num_instances, &params, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+	s = aclhip_decompress_track_batch(gpu, d_clips, d_times, d_bones, num_instances, &params, d_transforms, hip_stream);
+	s = aclhip_order_instances_for_locality(gpu, host_clips, num_instances, order);
+	s = aclhip_decompress_tracks_batch_rows(gpu, d_clips, d_times, d_rows, num_instances, &params, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+
+	/* section 3 */
+	s = aclhip_register_database(gpu, compressed_db, db_size, bulk_medium, bulk_low, 0, &db);
+	s = aclhip_register_clip_with_database(gpu, tracks, tracks_size, 0, db, &db_clip);
+	s = aclhip_database_stream_in(gpu, db, 1, 4, hip_stream, &moved);
+	s = aclhip_database_stream_out(gpu, db, 2, ~0u, hip_stream, &moved);
+
+	/* section 4b */
+	s = aclhip_set_clip_hierarchy(gpu, clip, parent_indices, num_tracks);
+	consumers.additive_format = ACLHIP_ADDITIVE_ADDITIVE1;
+	consumers.object_space = 1;
+	consumers.base_clips = d_base_clips;
+	consumers.base_sample_times = d_base_times;
+	consumers.base_poses = NULL;
+	consumers.base_pose_stride_bytes = 0;
+	s = aclhip_decompress_poses_batch(gpu, d_clips, d_times, num_instances, &params, &consumers, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+
+	(void)aclhip_unregister_clip(gpu, db_clip);
+	(void)aclhip_unregister_database(gpu, db);
+	(void)aclhip_unregister_clip(gpu, clip);
+	aclhip_destroy(gpu);
+	return s == ACLHIP_OK ? 0 : 2;
+}

@@ -84,6 +84,9 @@ def test_header_is_plain_c_and_host_entry_points_work_without_a_gpu(tmp_path):
     corrupt.tofile(broken)
     assert subprocess.run([str(binary), str(valid), "valid"]).returncode == 0
     assert subprocess.run([str(binary), str(broken), "invalid"]).returncode == 0
+    # the call sequences of INTEGRATION.md: must compile as C99 and link with the signatures the document shows
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-shared", "-fPIC", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c", "integration_example.c"), "-L" + lib_dir, "-laclhip", "-Wl,--no-undefined", "-o", str(tmp_path / "libintegration_example.so")], check=True)
 
 
 def test_cpp_mirror_and_its_drivers_compile_warning_free():
