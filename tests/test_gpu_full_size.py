@@ -199,6 +199,15 @@ def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
     d_times = torch.zeros(n, dtype=torch.float32, device=device)
     d_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
     d_values = torch.zeros((n, 64), dtype=torch.float32, device=device)
+    # the same frame also takes object space poses (pose consumers) and poses stored in other rows
+    parents = synth.humanoid_hierarchy(100)
+    ctx.set_clip_hierarchy(handle, parents)
+    consumers = runtime.PoseConsumers()
+    consumers.object_space = 1
+    d_object_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+    rows = rng.permutation(n).astype(np.int32)
+    d_rows = torch.from_numpy(rows).to(device)
+    d_scattered = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
 
     graph = torch.cuda.CUDAGraph()
     capture_stream = torch.cuda.Stream(device)
@@ -206,6 +215,8 @@ def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
         stream_handle = torch.cuda.current_stream(device).cuda_stream
         ctx.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, stream=stream_handle)
         ctx.decompress_scalar_tracks_batch(d_curve_clips.data_ptr(), d_times.data_ptr(), n, d_values.data_ptr(), 256, stream=stream_handle)
+        ctx.decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_object_poses.data_ptr(), 4800, consumers, stream=stream_handle)
+        ctx.decompress_tracks_batch_rows(d_clips.data_ptr(), d_times.data_ptr(), d_rows.data_ptr(), n, d_scattered.data_ptr(), 4800, stream=stream_handle)
 
     for frame in range(3):
         times = rng.uniform(0.0, min(clip.duration, curves.duration), size=n).astype(np.float32)
@@ -216,6 +227,10 @@ def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
         for i in rng.choice(n, size=32, replace=False):
             assert helpers.bit_equal(poses[i], ob.oracle_decompress_tracks(clip.blob, float(times[i])))
             assert helpers.exact(values[i], ob.oracle_scalar_decompress_tracks(curves.blob, float(times[i]))[:, 0])
+        object_poses, scattered = d_object_poses.cpu().numpy(), d_scattered.cpu().numpy()
+        assert helpers.exact(scattered[rows], poses)
+        for i in rng.choice(n, size=8, replace=False):
+            assert helpers.exact(object_poses[i], ob.oracle_local_to_object_space(parents, ob.oracle_decompress_tracks(clip.blob, float(times[i]))))
     assert ctx.rejected_instance_count() == 0
     ctx.unregister_clip(handle)
     ctx.unregister_clip(curve_handle)
