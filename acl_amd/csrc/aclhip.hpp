@@ -599,7 +599,13 @@ namespace aclhip
 			const float sample_time = m_sample_time;
 			if (track_index != nullptr)
 				return aclhip_decompress_track_host(m_device->get(), &m_clip, &sample_time, track_index, 1, &params, default_count, out) == ACLHIP_OK;
-			return aclhip_decompress_tracks_host(m_device->get(), &m_clip, &sample_time, 1, &params, default_count, out, uint64_t(out_tracks) * 48) == ACLHIP_OK;
+			// the writer's static output switches (track_writer::skip_all_*, core/track_writer.h:181-183): what it skips is not stored
+			aclhip_output_desc output = {};
+			output.layout = ACLHIP_LAYOUT_QVV48;
+			output.skip_rotations = track_writer_type::skip_all_rotations() ? 1 : 0;
+			output.skip_translations = track_writer_type::skip_all_translations() ? 1 : 0;
+			output.skip_scales = track_writer_type::skip_all_scales() ? 1 : 0;
+			return aclhip_decompress_tracks_host_out(m_device->get(), &m_clip, &sample_time, 1, &params, default_count, &output, out, uint64_t(out_tracks) * 48) == ACLHIP_OK;
 		}
 
 		template<class track_writer_type>

@@ -148,6 +148,8 @@ namespace aclhip
 		uint8_t default_modes[3];
 		uint8_t standard_defaults;		// 1 when default sub-tracks take the track_writer defaults (identity / zero / legacy scale) and normalization != always
 		uint8_t standard_default_modes;	// 1 when default sub-tracks take the track_writer defaults, whatever the normalization policy
+		uint8_t layout;					// aclhip_pose_layout (aclhip_output_desc)
+		uint8_t skip_mask;				// bit k: sub-tracks of kind k (rotation / translation / scale) are not stored
 	};
 
 	// What happens to a decoded (local space) pose before it is stored (aclhip_pose_consumers resolved to device pointers)

@@ -151,8 +151,10 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	entry.info.track_type = header.track_type;
 	entry.info.num_components = num_components;
 	entry.touched_bytes = total_bytes - 64;
-	context->max_scalar_tracks = std::max(context->max_scalar_tracks, num_tracks);
-	context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, (num_bits_per_frame + 7) / 8);
+	entry.scalar_tracks = num_tracks;
+	entry.scalar_frame_bytes = (num_bits_per_frame + 7) / 8;
+	context->max_scalar_tracks = std::max(context->max_scalar_tracks, entry.scalar_tracks);
+	context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, entry.scalar_frame_bytes);
 
 	*out_clip = slot;
 	return ACLHIP_OK;
@@ -207,6 +209,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	std::memset(samples.data(), 0, samples.size() * sizeof(sample_record));
 	std::memset(plan.data(), 0, plan.size() * sizeof(plan_entry));
 	bool has_raw = false;
+	std::vector<uint32_t> segment_pose_bit_sizes(num_segments, 0u);
 
 	if (num_tracks != 0)
 	{
@@ -335,6 +338,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			std::memset(&record, 0, sizeof(record));
 			record.animated_offset = animated_offset;
 			record.pose_bit_size = sh.animated_pose_bit_size;
+			segment_pose_bit_sizes[si] = sh.animated_pose_bit_size;
 			record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : 0xFFFFFFFFu;
 			record.start_index = start;
 			record.plan_row = si * num_animated;
@@ -342,13 +346,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			for (uint32_t sample = start; sample < end; ++sample)
 				samples[sample] = record;
 
-			// every stored keyframe of a clip-resident segment must lie inside the blob
-			if (!header.has_database())
-			{
-				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(record.sample_indices)) : (end - start);
-				if (uint64_t(animated_offset) + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
-					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", si);
-			}
+			// (validate_clip checked these offsets in 64 bit arithmetic, and that every keyframe the clip stores lies inside the blob)
 
 			uint32_t bit_offset = 0;
 			for (uint32_t a = 0; a < num_animated; ++a)
@@ -578,10 +576,31 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			context->free_slots.push_back(slot);
 			return fail(context, ACLHIP_ERROR_NOT_IN_DATABASE, "the database does not contain this clip");
 		}
+		// every keyframe a tier holds for this clip must lie inside that tier's bulk data: the chunk segment headers only carry an
+		// offset, the size of a keyframe is the clip's (animated_pose_bit_size of the segment)
+		for (uint32_t si = 0; contained && si < num_segments; ++si)
+		{
+			const uint32_t segment_header_offset = record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header));
+			const uint64_t pose_bit_size = segment_pose_bit_sizes[si];
+			for (int tier = 0; tier < 2; ++tier)
+			{
+				const std::vector<tier_patch>& patches = db.patches_by_header[tier];
+				auto patch = std::lower_bound(patches.begin(), patches.end(), segment_header_offset,
+					[](const tier_patch& entry, uint32_t offset) { return entry.segment_header_offset < offset; });
+				for (; patch != patches.end() && patch->segment_header_offset == segment_header_offset; ++patch)
+					if (uint64_t(patch->samples_offset) + (uint64_t(__builtin_popcount(patch->sample_indices)) * pose_bit_size + 7) / 8 > db.info.bulk_data_size[tier])
+						contained = false;
+			}
+		}
+		if (!contained)
+		{
+			free_clip_memory(context, d_memory);
+			context->free_slots.push_back(slot);
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "the database's keyframes for this clip lie outside of its bulk data");
+		}
 		record.db_headers = db.d_runtime_headers;
 		record.db_bulk_data[0] = db.d_bulk_data[0];
 		record.db_bulk_data[1] = db.d_bulk_data[1];
-		db.num_bound_clips++;
 	}
 
 	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
@@ -591,6 +610,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
 	}
+	if (database != ACLHIP_INVALID_HANDLE)
+		context->databases[database].num_bound_clips++;
 
 	host_clip& entry = context->clips[slot];
 	entry.in_use = true;
@@ -612,6 +633,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.info.num_components = 12;
 	// bytes a batch may read from this clip: the blob itself plus the registration time tables
 	entry.touched_bytes = total_bytes - 64;
+	entry.pose_quads = num_quads;
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
 
 	*out_clip = slot;
@@ -665,7 +687,11 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	const uint32_t bound_database = context->clips[clip].database;
 	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
 		context->databases[bound_database].num_bound_clips--;
+	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
 	context->free_slots.push_back(clip);
+	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
+		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))
+		recompute_launch_maxima(context);
 	return ACLHIP_OK;
 }

@@ -215,7 +215,11 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 		if (entry.d_hierarchy != nullptr)
 			release_hierarchy(context, entry.d_hierarchy);
 		entry.d_hierarchy = d_hierarchy;
+		const bool held_maximum = entry.hierarchy_words != 0 && entry.hierarchy_words == context->max_hierarchy_words;
+		entry.hierarchy_words = max_schedule_words;
 		context->max_hierarchy_words = std::max(context->max_hierarchy_words, max_schedule_words);
+		if (held_maximum && max_schedule_words < context->max_hierarchy_words)
+			recompute_launch_maxima(context);
 		return ACLHIP_OK;
 	});
 }
@@ -300,7 +304,7 @@ namespace
 	// Host pointer convenience path: upload, launch, download, synchronously
 	aclhip_status decompress_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices, uint32_t num_instances,
 		const aclhip_decompress_params* params, uint32_t default_values_count, void* out, uint64_t out_stride_bytes, uint64_t out_row_bytes,
-		const aclhip_pose_consumers* consumers = nullptr)
+		const aclhip_pose_consumers* consumers = nullptr, const aclhip_output_desc* output = nullptr)
 	{
 		if (context == nullptr)
 			return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -308,6 +312,9 @@ namespace
 			return ACLHIP_OK;
 		if (clips == nullptr || sample_times == nullptr || out == nullptr)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or output buffer");
+		const uint32_t bytes_per_track = output != nullptr ? aclhip_layout_bytes_per_track(output->layout) : 48u;
+		if (bytes_per_track == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown pose layout %u", output->layout);
 
 		aclhip_decompress_params local;
 		if (params != nullptr) local = *params; else aclhip_default_params(&local);
@@ -323,9 +330,9 @@ namespace
 		}
 
 		const bool single_track = track_indices != nullptr;
-		const uint64_t device_stride = single_track ? 48 : std::max<uint64_t>(uint64_t(max_tracks) * 48, 16);
+		const uint64_t device_stride = single_track ? 48 : std::max<uint64_t>((uint64_t(max_tracks) * bytes_per_track + 15) & ~uint64_t(15), 16);
 		if (!single_track && out_row_bytes == 0)
-			out_row_bytes = uint64_t(max_tracks) * 48;
+			out_row_bytes = uint64_t(max_tracks) * bytes_per_track;
 
 		std::vector<void*> allocations;
 		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
@@ -347,6 +354,15 @@ namespace
 		if (ok && single_track)
 			ok = upload(track_indices, sizeof(uint32_t) * num_instances, &d_tracks);
 		ok = ok && upload(nullptr, device_stride * num_instances, &d_out);
+		aclhip_output_desc local_output = {};
+		if (output != nullptr)
+		{
+			local_output = *output;
+			void* d_rows = nullptr;
+			if (ok && output->rows != nullptr)
+				ok = upload(output->rows, sizeof(uint32_t) * num_instances, &d_rows);
+			local_output.rows = static_cast<const uint32_t*>(d_rows);
+		}
 		if (ok && local.default_values != nullptr)
 			ok = upload(local.default_values, size_t(std::max<uint32_t>(default_values_count, 1)) * 48, &d_defaults);
 		if (ok && local.track_rounding_policies != nullptr)
@@ -403,7 +419,8 @@ namespace
 		else if (consumers != nullptr)
 			status = aclhip_decompress_poses_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, &local_consumers, d_out, device_stride, nullptr);
 		else
-			status = aclhip_decompress_tracks_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, d_out, device_stride, nullptr);
+			status = aclhip_decompress_tracks_batch_out(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local,
+				output != nullptr ? &local_output : nullptr, d_out, device_stride, nullptr);
 
 		if (status == ACLHIP_OK)
 		{
@@ -423,6 +440,12 @@ extern "C" aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, 
 	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes)
 {
 	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, default_values_count, poses, pose_stride_bytes, 0);
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_host_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, uint32_t default_values_count, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes)
+{
+	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, default_values_count, poses, pose_stride_bytes, 0, nullptr, output);
 }
 
 extern "C" aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,

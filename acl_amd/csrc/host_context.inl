@@ -12,6 +12,8 @@ namespace
 		uint32_t* d_hierarchy = nullptr;	// aclhip_set_clip_hierarchy
 		aclhip_clip_info info = {};
 		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
+		// what this clip asks of a launch (the context keeps the maxima over its live clips)
+		uint32_t pose_quads = 0, hierarchy_words = 0, scalar_tracks = 0, scalar_frame_bytes = 0;
 	};
 }
 
@@ -32,6 +34,7 @@ namespace
 		std::vector<uint32_t> chunk_first_patch[2];		// num_chunks + 1 entries
 		std::vector<uint32_t> loaded_chunks[2];			// bitset, first chunk in the MSB like core/bitset.h
 		std::vector<database_clip_metadata> clip_metadata;
+		std::vector<tier_patch> patches_by_header[2];	// every chunk segment of the tier, sorted by segment_header_offset (bounds checks when a clip is bound)
 	};
 }
 
@@ -59,6 +62,10 @@ struct aclhip_context
 	// what lets a workgroup whose instances share a skeleton keep a single copy in LDS
 	struct hierarchy_image { std::vector<uint32_t> parents; uint32_t* d_image = nullptr; uint32_t num_users = 0; };
 	std::vector<hierarchy_image> hierarchies;
+
+	// buffers of other processes mapped by aclhip_peer_open_buffer: the pointer handed out and the allocation it lies in
+	struct peer_mapping { void* buffer; void* base; };
+	std::vector<peer_mapping> peer_mappings;
 
 	struct clip_slab
 	{
@@ -120,6 +127,21 @@ namespace
 		slab.pieces.push_back({ 0, bytes, true });
 		context->slabs.push_back(slab);
 		return slab.base;
+	}
+
+	// Launch sizing follows the LIVE clips: when the clip that set a maximum goes away the maxima are taken again
+	void recompute_launch_maxima(aclhip_context* context)
+	{
+		context->max_pose_quads = context->max_hierarchy_words = context->max_scalar_tracks = context->max_scalar_frame_bytes = 0;
+		for (const host_clip& clip : context->clips)
+		{
+			if (!clip.in_use)
+				continue;
+			context->max_pose_quads = std::max(context->max_pose_quads, clip.pose_quads);
+			context->max_hierarchy_words = std::max(context->max_hierarchy_words, clip.hierarchy_words);
+			context->max_scalar_tracks = std::max(context->max_scalar_tracks, clip.scalar_tracks);
+			context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, clip.scalar_frame_bytes);
+		}
 	}
 
 	void release_hierarchy(aclhip_context* context, const uint32_t* d_image)
@@ -315,20 +337,27 @@ namespace
 		if (header.has_database() && tbase + th.database_header_offset + sizeof(tracks_database_header) > blob_size)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Database header points outside of the buffer");
 
+		const uint32_t* segment_start_indices = th.num_segments > 1 ? reinterpret_cast<const uint32_t*>(blob + tbase + k_segment_start_indices_offset) : nullptr;
 		for (uint32_t i = 0; i < th.num_segments; ++i)
 		{
 			const segment_header& sh = *reinterpret_cast<const segment_header*>(blob + tbase + th.segment_headers_offset + size_t(i) * segment_header_size);
-			const uint64_t format_offset = tbase + sh.segment_data;
-			const uint64_t range_offset = align_to_u32(uint32_t(format_offset + th.num_animated_variable_sub_tracks), 2);
-			const uint64_t animated_offset = align_to_u32(uint32_t(range_offset + (th.num_segments > 1 ? 6ull * th.num_animated_variable_sub_tracks : 0ull)), 4);
-			if (animated_offset > blob_size || sh.animated_rotation_bit_size > sh.animated_pose_bit_size)
+			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324) in 64 bit arithmetic: segment_data is
+			// an untrusted 32 bit offset, a value near 2^32 must not wrap into the buffer
+			const uint64_t format_offset = tbase + uint64_t(sh.segment_data);
+			const uint64_t range_offset = (format_offset + th.num_animated_variable_sub_tracks + 1u) & ~uint64_t(1);
+			const uint64_t animated_offset = (range_offset + (th.num_segments > 1 ? 6ull * th.num_animated_variable_sub_tracks : 0ull) + 3u) & ~uint64_t(3);
+			if (sh.segment_data == 0xFFFFFFFFu || animated_offset > blob_size || sh.animated_rotation_bit_size > sh.animated_pose_bit_size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment %u points outside of the buffer", i);
-			if (!header.has_database())
-			{
-				// every keyframe a seek can pick must be inside the buffer
-				const uint32_t stored = stripped ? uint32_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : 32u;
-				(void)stored;	// the exact count needs the segment's sample count; the tail padding below covers the last window
-			}
+
+			// every keyframe the clip itself stores (all of them, or the ones its sample_indices keep when keyframes were stripped or
+			// moved to a database) must lie inside the buffer
+			const uint64_t start = th.num_segments > 1 ? segment_start_indices[i] : 0;
+			const uint64_t end = th.num_segments > 1 && i + 1 < th.num_segments ? segment_start_indices[i + 1] : header.num_samples;
+			if (start >= end || end > header.num_samples || end - start > 32)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%llu, %llu)", i, static_cast<unsigned long long>(start), static_cast<unsigned long long>(end));
+			const uint64_t stored = stripped ? uint64_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : end - start;
+			if (animated_offset + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", i);
 		}
 
 		return ACLHIP_OK;
@@ -386,6 +415,8 @@ namespace
 		out.track_rounding_policies = params->track_rounding_policies;
 		out.instance_rounding_policies = params->instance_rounding_policies;
 		out.instance_rows = nullptr;
+		out.layout = ACLHIP_LAYOUT_QVV48;
+		out.skip_mask = 0;
 		out.rounding_policy = params->rounding_policy;
 		out.looping_policy = params->looping_policy;
 		out.normalization = params->normalization;

@@ -126,6 +126,9 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 			}
 		}
 		db.chunk_first_patch[tier][num_chunks] = uint32_t(patches[tier].size());
+		db.patches_by_header[tier] = patches[tier];
+		std::sort(db.patches_by_header[tier].begin(), db.patches_by_header[tier].end(),
+			[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; });
 	}
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_database: everything above is host work

@@ -21,14 +21,13 @@ namespace
 		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
 		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
 		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
-		if (any_settings)
-			hipLaunchKernelGGL(decompress_tracks_any_settings_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
-				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
-		else
-			hipLaunchKernelGGL(decompress_tracks_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
-				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
-				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
+		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0;
+		const auto kernel = any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)
+			: (compact ? decompress_tracks_compact_kernel : decompress_tracks_kernel);
+		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
+			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}
@@ -77,6 +76,49 @@ extern "C" aclhip_status aclhip_decompress_tracks_batch_rows(aclhip_context* con
 	if (status != ACLHIP_OK)
 		return status;
 	device_params.instance_rows = rows;
+
+	device_guard guard(context->device);
+	return launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+namespace
+{
+	// aclhip_output_desc -> decode_params
+	aclhip_status apply_output_desc(aclhip_context* context, const aclhip_output_desc* output, decode_params& params)
+	{
+		if (output == nullptr)
+			return ACLHIP_OK;
+		if (output->layout > ACLHIP_LAYOUT_QV32)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown pose layout %u", output->layout);
+		params.layout = uint8_t(output->layout);
+		params.skip_mask = uint8_t((output->skip_rotations != 0 ? 1u : 0u) | (output->skip_translations != 0 ? 2u : 0u) | (output->skip_scales != 0 ? 4u : 0u));
+		if (output->layout == ACLHIP_LAYOUT_QV32)
+			params.skip_mask |= 4u;
+		params.instance_rows = output->rows;
+		return ACLHIP_OK;
+	}
+}
+
+extern "C" uint32_t aclhip_layout_bytes_per_track(uint32_t layout)
+{
+	return layout == ACLHIP_LAYOUT_QVV48 ? 48u : (layout == ACLHIP_LAYOUT_QVV40 ? 40u : (layout == ACLHIP_LAYOUT_QV32 ? 32u : 0u));
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_batch_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	aclhip_status status = check_batch_arguments(context, clips, sample_times, num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (num_instances == 0)
+		return ACLHIP_OK;
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status == ACLHIP_OK)
+		status = apply_output_desc(context, output, device_params);
+	if (status != ACLHIP_OK)
+		return status;
 
 	device_guard guard(context->device);
 	return launch_tracks(context, clips, sample_times, num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));

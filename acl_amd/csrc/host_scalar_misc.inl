@@ -257,6 +257,88 @@ extern "C" aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* 
 	return ACLHIP_OK;
 }
 
+// Peer gather: the poses are wanted on ONE GPU (the renderer's). Every other GPU then pushes its shard over its own xGMI link straight
+// into that GPU's buffer -- seven links into the destination work concurrently, nothing travels twice -- instead of a ring collective
+// that also hands every shard to every rank. One process per GPU: the destination exports its buffer as a HIP IPC handle
+// (64 bytes, carried by whatever the processes already talk over), the others map it and copy device to device.
+extern "C" aclhip_status aclhip_peer_export_buffer(aclhip_context* context, void* device_buffer, uint8_t* out_handle)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (device_buffer == nullptr || out_handle == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null buffer or handle");
+	static_assert(sizeof(hipIpcMemHandle_t) + sizeof(uint64_t) == ACLHIP_PEER_HANDLE_BYTES, "handle size");
+	device_guard guard(context->device);
+	// an IPC handle names a whole allocation: buffers carved out of a larger one (a caching allocator's block) travel as base + offset
+	hipDeviceptr_t base = nullptr;
+	size_t allocation_size = 0;
+	ACLHIP_CHECK_HIP(context, hipMemGetAddressRange(&base, &allocation_size, device_buffer));
+	hipIpcMemHandle_t handle;
+	ACLHIP_CHECK_HIP(context, hipIpcGetMemHandle(&handle, base));
+	const uint64_t offset = uint64_t(static_cast<const uint8_t*>(device_buffer) - static_cast<const uint8_t*>(base));
+	std::memcpy(out_handle, &handle, sizeof(handle));
+	std::memcpy(out_handle + sizeof(handle), &offset, sizeof(offset));
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_peer_open_buffer(aclhip_context* context, const uint8_t* handle, void** out_device_buffer)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (handle == nullptr || out_device_buffer == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null handle");
+	*out_device_buffer = nullptr;
+	device_guard guard(context->device);
+	hipIpcMemHandle_t ipc_handle;
+	uint64_t offset = 0;
+	std::memcpy(&ipc_handle, handle, sizeof(ipc_handle));
+	std::memcpy(&offset, handle + sizeof(ipc_handle), sizeof(offset));
+	void* base = nullptr;
+	ACLHIP_CHECK_HIP(context, hipIpcOpenMemHandle(&base, ipc_handle, hipIpcMemLazyEnablePeerAccess));
+	std::lock_guard<std::mutex> lock(context->mutex);
+	context->peer_mappings.push_back({ static_cast<uint8_t*>(base) + offset, base });
+	*out_device_buffer = static_cast<uint8_t*>(base) + offset;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_peer_close_buffer(aclhip_context* context, void* device_buffer)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (device_buffer == nullptr)
+		return ACLHIP_OK;
+	void* base = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		for (size_t i = 0; i < context->peer_mappings.size(); ++i)
+			if (context->peer_mappings[i].buffer == device_buffer)
+			{
+				base = context->peer_mappings[i].base;
+				context->peer_mappings.erase(context->peer_mappings.begin() + ptrdiff_t(i));
+				break;
+			}
+	}
+	if (base == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "not a buffer aclhip_peer_open_buffer returned");
+	device_guard guard(context->device);
+	ACLHIP_CHECK_HIP(context, hipIpcCloseMemHandle(base));
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_push_poses_to_peer(aclhip_context* context, void* peer_buffer, uint64_t offset_bytes, const void* shard_poses, uint64_t shard_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (peer_buffer == nullptr || shard_poses == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null buffer");
+	if (shard_bytes == 0)
+		return ACLHIP_OK;
+	device_guard guard(context->device);
+	// unified addressing: the runtime sees a peer mapped destination and drives the copy over the link between the two GPUs (SDMA)
+	ACLHIP_CHECK_HIP(context, hipMemcpyAsync(static_cast<uint8_t*>(peer_buffer) + offset_bytes, shard_poses, shard_bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count)
 {
 	if (context == nullptr || out_count == nullptr)

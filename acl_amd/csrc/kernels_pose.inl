@@ -147,7 +147,7 @@
 	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
 	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
 	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
-	template<bool kAnySettings>
+	template<bool kAnySettings, bool kCompactOutput>
 	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
@@ -260,7 +260,8 @@
 
 		// (the row is read here, not in the prologue: one SGPR pair less across the decode)
 		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
-		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(row) * pose_stride_bytes) + first_quad + lane;
+		uint8_t* pose_bytes = poses + uint64_t(row) * pose_stride_bytes;
+		f32x4* pose = reinterpret_cast<f32x4*>(pose_bytes) + first_quad + lane;
 
 		// any-settings: rows are 64 quads apart and 64 % 3 == 1, so a lane's sub-track kind advances by one per row
 		const uint32_t lane_quad = first_quad + lane;
@@ -294,24 +295,72 @@
 					const float* source = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
 					value = f32x4{ source[0], source[1], source[2], kind == 0 ? source[3] : 0.0f };
 				}
-				kind = kind == 2 ? 0u : kind + 1u;
 			}
-			if (store)
-				store_streaming(&pose[r * k_wave_size], value);
+
+			if (!kCompactOutput)
+			{
+				if (store)
+					store_streaming(&pose[r * k_wave_size], value);
+			}
+			else
+			{
+				// aclhip_output_desc: sub-track kinds the writer skips (track_writer::skip_all_*, core/track_writer.h:181-183) are not
+				// stored; the compact layouts drop the padding lanes (QVV40: rotation xyzw | translation xyz | scale xyz, what the
+				// reference's benchmark counts per bone, tools/acl_decompressor/sources/benchmark.cpp:146) or the scale altogether
+				// (QV32: rotation xyzw | translation xyz 0). Lanes keep their image quad: the stores of a row still cover one contiguous
+				// span of the pose, minus the dropped pieces.
+				const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
+				store = store && ((params.skip_mask >> kind) & 1u) == 0;
+				if (params.layout == ACLHIP_LAYOUT_QVV48)
+				{
+					if (store)
+						store_streaming(&pose[r * k_wave_size], value);
+				}
+				else if (params.layout == ACLHIP_LAYOUT_QV32)
+				{
+					if (store && kind != 2)
+						store_streaming(pose_bytes + size_t(track_index * 2u + kind) * 16, value);
+				}
+				else
+				{
+					uint8_t* address = pose_bytes + size_t(track_index) * 40 + (kind == 0 ? 0u : (kind == 1 ? 16u : 28u));
+					if (store && kind == 0)
+						store_streaming(address, value);
+					if (store && kind != 0)
+					{
+						const float xyz[3] = { value.x, value.y, value.z };
+						store_streaming_floats<3>(reinterpret_cast<float*>(address), xyz);
+					}
+				}
+			}
+			if (kAnySettings || kCompactOutput)
+				kind = kind == 2 ? 0u : kind + 1u;
 		}
 	}
 
-	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
-		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	#define ACLHIP_POSE_KERNEL_ARGUMENTS const device_clip* __restrict__ clips, uint32_t num_clips, \
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance, \
+		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count
+	#define ACLHIP_POSE_KERNEL_FORWARD clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count
+
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+		decompress_tracks_window<false, false>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
+	__global__ __launch_bounds__(k_block_size) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// 8 waves per SIMD (64 VGPRs) matter more to this variant than the few instructions the allocator saves with 65
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
-		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<true>(clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count);
+		decompress_tracks_window<true, false>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_window<true, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}

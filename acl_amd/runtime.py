@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
+    "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
+    "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
@@ -53,6 +55,35 @@ class PoseConsumers(ctypes.Structure):
         ("additive_format", ctypes.c_uint32), ("object_space", ctypes.c_uint32),
         ("base_clips", ctypes.c_void_p), ("base_sample_times", ctypes.c_void_p), ("base_poses", ctypes.c_void_p), ("base_pose_stride_bytes", ctypes.c_uint64),
     ]
+
+
+class OutputDesc(ctypes.Structure):
+    """aclhip_output_desc"""
+    _fields_ = [
+        ("layout", ctypes.c_uint32), ("skip_rotations", ctypes.c_uint8), ("skip_translations", ctypes.c_uint8), ("skip_scales", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
+        ("rows", ctypes.c_void_p),
+    ]
+
+
+PEER_HANDLE_BYTES = 72      # ACLHIP_PEER_HANDLE_BYTES
+LAYOUT_QVV48, LAYOUT_QVV40, LAYOUT_QV32 = 0, 1, 2  # aclhip_pose_layout
+LAYOUTS = {"qvv48": (LAYOUT_QVV48, 48), "qvv40": (LAYOUT_QVV40, 40), "qv32": (LAYOUT_QV32, 32)}     # name -> (aclhip_pose_layout, bytes per track)
+
+
+def relayout_pose(pose, layout, skip=(False, False, False), into=None):
+    """Test helper (numpy, host): what a [..., num_tracks, 12] QVV48 pose looks like through `layout` with the sub-track kinds of
+    `skip` (rotation, translation, scale) left untouched. Returns [..., num_tracks, floats per track]; skipped pieces keep the
+    values of `into` (zeros when it is not given)."""
+    pose = np.asarray(pose, dtype=np.float32)
+    columns = {LAYOUT_QVV48: ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]), LAYOUT_QVV40: ([0, 1, 2, 3], [4, 5, 6], [7, 8, 9]), LAYOUT_QV32: ([0, 1, 2, 3], [4, 5, 6, 7], [])}[layout]
+    sources = ([0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11])
+    width = {LAYOUT_QVV48: 12, LAYOUT_QVV40: 10, LAYOUT_QV32: 8}[layout]
+    out = np.zeros(pose.shape[:-1] + (width,), dtype=np.float32) if into is None else np.array(into, dtype=np.float32, copy=True)
+    for kind in range(3):
+        if skip[kind] or not columns[kind]:
+            continue
+        out[..., columns[kind]] = pose[..., sources[kind][: len(columns[kind])]]
+    return out
 
 
 ADDITIVE_NONE, ADDITIVE_RELATIVE, ADDITIVE_ADDITIVE0, ADDITIVE_ADDITIVE1 = 0, 1, 2, 3  # aclhip_additive_format
@@ -151,6 +182,15 @@ def load_library():
     lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
+    poutput = ctypes.POINTER(OutputDesc)
+    lib.aclhip_peer_export_buffer.argtypes = [vp, vp, vp]
+    lib.aclhip_peer_open_buffer.argtypes = [vp, vp, ctypes.POINTER(vp)]
+    lib.aclhip_peer_close_buffer.argtypes = [vp, vp]
+    lib.aclhip_push_poses_to_peer.argtypes = [vp, vp, u64, vp, u64, vp]
+    lib.aclhip_decompress_tracks_batch_out.argtypes = [vp, vp, vp, u32, pparams, poutput, vp, u64, vp]
+    lib.aclhip_decompress_tracks_host_out.argtypes = [vp, vp, vp, u32, pparams, u32, poutput, vp, u64]
+    lib.aclhip_layout_bytes_per_track.argtypes = [u32]
+    lib.aclhip_layout_bytes_per_track.restype = u32
     lib.aclhip_strip_database_tier.argtypes = [vp, u64, u32, vp, u64, ctypes.POINTER(u64)]
     lib.aclhip_plan_hierarchy_walk.argtypes = [vp, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_set_clip_hierarchy.argtypes = [vp, u32, vp, u32]
@@ -328,6 +368,11 @@ class Context:
         params = params if params is not None else default_params()
         self._check(self._lib.aclhip_decompress_tracks_batch_rows(self._handle, clips_ptr, times_ptr, rows_ptr, num_instances, ctypes.byref(params), poses_ptr, pose_stride_bytes, stream))
 
+    def decompress_tracks_batch_out(self, clips_ptr, times_ptr, num_instances, poses_ptr, pose_stride_bytes, output, params=None, stream=None):
+        """aclhip_decompress_tracks_batch with an OutputDesc (layout, skipped sub-track kinds, rows)."""
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_tracks_batch_out(self._handle, clips_ptr, times_ptr, num_instances, ctypes.byref(params), ctypes.byref(output), poses_ptr, pose_stride_bytes, stream))
+
     def order_instances_for_locality(self, clips):
         """Host only: the permutation aclhip_order_instances_for_locality computes for the instance list `clips`."""
         clips = np.ascontiguousarray(clips, dtype=np.uint32)
@@ -493,6 +538,24 @@ class Context:
     def all_gather_poses(self, rccl_comm, shard_ptr, all_ptr, shard_bytes, stream=None):
         """One RCCL all-gather of pose shards (rank order); `rccl_comm` is an ncclComm_t handle (int / c_void_p)."""
         self._check(self._lib.aclhip_all_gather_poses(self._handle, rccl_comm, shard_ptr, all_ptr, shard_bytes, stream))
+
+    # ---- peer gather (aclhip_peer_*): one GPU collects every rank's shard over xGMI ----
+    def peer_export_buffer(self, buffer_ptr):
+        handle = (ctypes.c_uint8 * PEER_HANDLE_BYTES)()
+        self._check(self._lib.aclhip_peer_export_buffer(self._handle, buffer_ptr, handle))
+        return bytes(handle)
+
+    def peer_open_buffer(self, handle):
+        raw = (ctypes.c_uint8 * PEER_HANDLE_BYTES)(*handle)
+        pointer = ctypes.c_void_p()
+        self._check(self._lib.aclhip_peer_open_buffer(self._handle, raw, ctypes.byref(pointer)))
+        return pointer.value
+
+    def peer_close_buffer(self, buffer_ptr):
+        self._check(self._lib.aclhip_peer_close_buffer(self._handle, buffer_ptr))
+
+    def push_poses_to_peer(self, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream=None):
+        self._check(self._lib.aclhip_push_poses_to_peer(self._handle, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream))
 
     def rejected_instance_count(self):
         count = ctypes.c_uint64(0)

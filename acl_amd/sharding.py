@@ -50,6 +50,43 @@ def all_gather_poses(local_poses, num_instances, group=None):
     return torch.cat(pieces, dim=0)
 
 
+class PeerGather:
+    """Gather of every rank's pose shard onto ONE GPU (rank `dst`) by peer writes (aclhip_peer_* in the C ABI): the destination
+    exports its buffer once (a 72 byte handle: HIP IPC handle + offset, broadcast over torch.distributed), every rank maps it and `push` copies its
+    shard device to device to `rank * shard_bytes` -- each remote shard over its own xGMI link, all of the destination's links busy
+    at once, nothing sent twice. `push` is asynchronous on `stream`; the destination may read `gathered` after every rank's stream has
+    drained and the ranks have met (the caller's barrier). SURVEY 8(e)."""
+
+    def __init__(self, context, shard_bytes, rank, world_size, dst=0, device=None, group=None):
+        self.context, self.shard_bytes, self.rank, self.world_size, self.dst = context, int(shard_bytes), rank, world_size, dst
+        self.gathered = None
+        self.peer_ptr = None
+        handle = torch.zeros(72, dtype=torch.uint8)       # ACLHIP_PEER_HANDLE_BYTES
+        if rank == dst:
+            self.gathered = torch.empty(world_size * self.shard_bytes, dtype=torch.uint8, device=device)
+            exported = context.peer_export_buffer(self.gathered.data_ptr())
+            if len(exported) != 72:
+                raise ValueError("a peer handle is ACLHIP_PEER_HANDLE_BYTES = 72 bytes")
+            handle = torch.frombuffer(bytearray(exported), dtype=torch.uint8).clone()
+        on_device = dist.get_backend(group) == "nccl"
+        if on_device:
+            handle = handle.to(device)
+        dist.broadcast(handle, src=dst, group=group)
+        if rank == dst:
+            self.target_ptr = self.gathered.data_ptr()
+        else:
+            self.peer_ptr = context.peer_open_buffer(bytes(handle.cpu().tolist()))
+            self.target_ptr = self.peer_ptr
+
+    def push(self, shard_ptr, stream=None):
+        self.context.push_poses_to_peer(self.target_ptr, self.rank * self.shard_bytes, shard_ptr, self.shard_bytes, stream)
+
+    def close(self):
+        if self.peer_ptr is not None:
+            self.context.peer_close_buffer(self.peer_ptr)
+            self.peer_ptr = None
+
+
 def stream_database_everywhere(context, database, tier, num_chunks, stream_in=True, src=0, group=None, stream=None):
     """Streamed database tiers are replicated per GPU (every rank registers the database with its own context), so their residency
     must advance identically everywhere: rank `src` decides the request -- (tier, num_chunks, in or out), the arguments of the other

@@ -6,16 +6,21 @@
 A "step" is one launch of aclhip_decompress_tracks_batch (seek + decompress_tracks for every instance of the
 batch). Inputs (registered clips, instance lists) and the pose buffer are resident in HBM before the timed region.
 Workloads (BASELINE.json configs):
-    one_clip   64k instances of one CMU-shaped 100-bone clip, random sample times       (configs[1], the default)
+    one_clip   64k instances of one CMU-shaped 100-bone clip, random sample times       (configs[1], the default = the headline)
     256_clips  64k instances drawn from 256 distinct 100-bone clips                      (configs[2])
     cinematic  64k instances per GPU of a 300-bone rig with scale, multi-segment         (configs[3], per GPU shard)
-    database   64k instances over 16 database-bound 100-bone clips; the low importance tier is streamed in chunk by chunk
-               on the decode stream while the batches run                                   (configs[4] shape, committed fixture)
+    database   64 database-bound 100-bone clips (medium 0 % / low 50 %), the low importance tier is streamed in chunk by chunk
+               on the decode stream while the batches run                                   (configs[4], committed fixture)
     scalar     64k instances of one 256-curve float1f track list (blend shape weights)      
+    object_space / additive_object_space   the pose consumers fused into the decode         
 With N > 1 every rank decodes its own shard of instances (weak scaling, no data-path collective); rank 0 prints ONE
-JSON line with the whole-job poses/sec, the roofline of the decode kernel and, at N = 1, the CPU baseline.
+JSON line with the whole-job poses/sec and the roofline of the decode kernel. At N = 1 the default run also measures, in the same
+process and OUTSIDE the timed region, the other north-star configs ("workloads"), a footprint sweep of the headline batch, the
+compact output layouts, and the CPU baseline (a pinned thread sweep of the reference's own decoder). At N > 1 the pose gather
+(RCCL all-gather, peer-to-peer writes into rank 0) is timed separately from the decode ("gather").
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -28,22 +33,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak (about 6.3 TB/s achievable)
+XGMI_LINK_GBPS = 153.0     # one xGMI link, one direction (7 links per GPU)
 INSTANCES_PER_GPU = 65536
 
+WORKLOAD_TEXT = {
+    "one_clip": "64k instances of one CMU-shaped 100-bone clip, random sample times, quatf_drop_w_variable + vector3f_variable (BASELINE.json configs[1])",
+    "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])",
+    "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)",
+    "database": "instances over 64 database-bound 100-bone clips (medium 0 % / low 50 %), low importance tier streamed in chunk by chunk on the decode stream "
+                "during the timed steps (BASELINE.json configs[4], committed fixture)",
+    "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
+    "object_space": "the one_clip batch with local -> object space fused into the decode (pose consumers, SURVEY 8 f3)",
+    "additive_object_space": "64k instances per GPU: an additive clip applied (additive1) onto a base clip instance decoded by the same wave, then local -> object space (SURVEY 8 f3)",
+}
 
-def build_workload(name, rank):
+
+def build_workload(name, rank, num_instances):
     """Returns (list of SyntheticClip, instance->clip index array, sample times) for this rank's shard."""
     from acl_amd import synth
 
     rng = np.random.default_rng(1000 + rank)
     if name in ("one_clip", "object_space"):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
-        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+        clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "additive_object_space":
-        # instance = additive clip 1 applied onto base clip 0 (instance i's base time is drawn in main), then local -> object space
+        # instance = additive clip 1 applied onto base clip 0 (instance i's base time is drawn in Job), then local -> object space
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0),
                  synth.build_clip(seed=12, num_tracks=100, num_samples=121, sample_rate=30.0, rotation_constant=0.5, translation_constant=0.8)]
-        clip_indices = np.ones(INSTANCES_PER_GPU, dtype=np.uint32)
+        clip_indices = np.ones(num_instances, dtype=np.uint32)
     elif name == "256_clips":
         clips = []
         spec_rng = np.random.default_rng(3)
@@ -56,18 +73,18 @@ def build_workload(name, rank):
                 min_bits=int(spec_rng.integers(5, 10)), max_bits=int(spec_rng.integers(12, 19))))
         # measurement aid: ACLHIP_BENCH_CLIP_SUBSET=K draws the instances from the first K of the 256 clips only
         subset = int(os.environ.get("ACLHIP_BENCH_CLIP_SUBSET", "256"))
-        clip_indices = rng.integers(0, subset, size=INSTANCES_PER_GPU).astype(np.uint32)
+        clip_indices = rng.integers(0, subset, size=num_instances).astype(np.uint32)
     elif name == "cinematic":
         clips = [synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,
                                   scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)]
-        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+        clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "scalar":
         # 1 % of the curves at the raw bit rate: what the reference's compressor leaves for tracks it cannot quantize within precision
         clips = [synth.build_scalar_clip(seed=9, track_type=0, num_tracks=256, num_samples=120, sample_rate=60.0, raw_fraction=0.01)]
-        clip_indices = np.zeros(INSTANCES_PER_GPU, dtype=np.uint32)
+        clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "database":
         clips = load_database_fixture()["clips"]
-        clip_indices = rng.integers(0, len(clips), size=INSTANCES_PER_GPU).astype(np.uint32)
+        clip_indices = rng.integers(0, len(clips), size=num_instances).astype(np.uint32)
     else:
         raise ValueError(f"unknown workload {name}")
 
@@ -87,106 +104,382 @@ class FixtureClip:
         self.num_tracks, self.num_samples = int(header[2]), int(header[3])
         self.sample_rate = float(np.frombuffer(bytes(self.blob[24:28]), dtype=np.float32)[0])
         self.duration = float(np.float32(self.num_samples - 1) / np.float32(self.sample_rate)) if self.num_samples > 1 else 0.0
+        self.num_components = 12
+
+
+_database_fixture = None
 
 
 def load_database_fixture():
-    """tests/golden/bench/database_16_clips_100_bones.npz: clips + database + bulk data written by the reference's build_database
+    """tests/golden/bench/database_64_clips_100_bones.npz: clips + database + bulk data written by the reference's build_database
     (tests/golden/make_bench_database.py); the reference itself does not exist on the GPU box."""
-    from acl_amd import synth
-    data = np.load(os.path.join(ROOT, "tests", "golden", "bench", "database_16_clips_100_bones.npz"))
-    offsets = data["clip_offsets"]
+    global _database_fixture
+    if _database_fixture is None:
+        from acl_amd import synth
+        data = np.load(os.path.join(ROOT, "tests", "golden", "bench", "database_64_clips_100_bones.npz"))
+        offsets = data["clip_offsets"]
 
-    def aligned(array):
-        out = synth.aligned_bytes(max(array.size, 1))
-        out[: array.size] = array
-        return out[: array.size]
+        def aligned(array):
+            out = synth.aligned_bytes(max(array.size, 1))
+            out[: array.size] = array
+            return out[: array.size]
 
-    return {"clips": [FixtureClip(data["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)],
-            "database": aligned(data["database"]), "bulk_medium": aligned(data["bulk_medium"]), "bulk_low": aligned(data["bulk_low"])}
-
-
-def cpu_baseline_scalar(clips, clip_indices, times, row_floats):
-    """cpu_baseline for scalar track lists: the reference's decoder on all host cores (kind "reference") or the C restatement."""
-    import ctypes
-    from oracle import bindings as ob  # cpu_baseline leg only
-
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sample = min(clip_indices.size, 65536)
-    indices = np.ascontiguousarray(clip_indices[:sample], dtype=np.uint32)
-    sample_times = np.ascontiguousarray(times[:sample], dtype=np.float32)
-    blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
-    if ob.have_ref_scalar():
-        lib = ob.ref_scalar()
-        probe = lib.aclref_scalar_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, min(sample, 8192), row_floats, cores, 1)
-        repeats = int(max(1, min(400, 1.0 / max(probe / min(sample, 8192) * sample, 1e-9))))
-        seconds = min(lib.aclref_scalar_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, row_floats, cores, repeats) for _ in range(3))
-        return {"value": sample / seconds, "unit": "poses/s", "cores": cores, "kind": "reference",
-                "sample": f"{sample} instances of the same list, seek+decompress_tracks, reference headers (default_scalar_decompression_settings), "
-                          f"{cores} threads, warm cache, best of 3 rounds of {repeats} passes"}
-    sample = min(sample, 4096)
-    options = ob.default_options()
-    out = np.zeros(row_floats, dtype=np.float32)
-    t0 = time.perf_counter()
-    for i in range(sample):
-        ob.oracle().aclo_scalar_decompress_tracks(clips[indices[i]].blob.ctypes.data, ctypes.c_float(sample_times[i]), 0, ctypes.byref(options), out.ctypes.data)
-    seconds = time.perf_counter() - t0
-    return {"value": sample / seconds, "unit": "poses/s", "cores": 1, "kind": "port",
-            "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c) called from Python, 1 thread"}
+        _database_fixture = {"clips": [FixtureClip(data["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)],
+                             "database": aligned(data["database"]), "bulk_medium": aligned(data["bulk_medium"]), "bulk_low": aligned(data["bulk_low"])}
+    return _database_fixture
 
 
-def cpu_baseline(clips, clip_indices, times, max_tracks):
-    """Times the reference's own decoder (oracle/_ref, kind "reference") -- or the C restatement (kind "port") when the
-    reference build is absent -- on a bounded sample of the same instance list, on this box's host cores."""
-    import ctypes
-    from oracle import bindings as ob  # cpu_baseline leg: the oracle is the baseline being measured here, never the product
+# ---- one workload resident on one GPU ---------------------------------------------------------------------------------------
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    sample = min(clip_indices.size, 65536)
-    indices = np.ascontiguousarray(clip_indices[:sample], dtype=np.uint32)
-    sample_times = np.ascontiguousarray(times[:sample], dtype=np.float32)
+class Job:
+    """Registered clips, instance list and pose buffer of one workload in HBM, and the launch through the C ABI.
+    order: "random" (as drawn), "by_clip" (host bucketed), "locality" (aclhip_order_instances_for_locality on the host).
+    layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
-    if ob.have_ref():
-        lib = ob.ref()
-        blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
-        # calibrate so that the timed part is roughly 15-25 s of CPU work in total (about 2-3 s of wall time on all cores)
-        probe = lib.aclref_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, min(sample, 8192), max_tracks, cores, 1, None)
-        per_pose = probe / min(sample, 8192)
-        repeats = int(max(1, min(400, 1.0 / max(per_pose * sample, 1e-9))))
-        # three rounds (threads are created once per round and walk the list `repeats` times), best round counts
-        seconds = min(lib.aclref_bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, max_tracks, cores, repeats, None) for _ in range(3))
-        return {"value": sample / seconds, "unit": "poses/s", "cores": cores, "kind": "reference",
-                "sample": f"{sample} instances of the same list, seek+decompress_tracks, reference headers (AVX2 build, benchmark settings), "
-                          f"{cores} threads, warm cache, best of 3 rounds of {repeats} passes"}
+    def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48"):
+        import torch
+        from acl_amd import runtime, synth
 
-    lib = ob.oracle()
-    options = ob.default_options()
-    sample = min(sample, 16384)
-    out = np.zeros((sample, max_tracks * 12), dtype=np.float32)
-    blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
-    best = 1e30
-    for _ in range(3):
+        self.name, self.order, self.layout, self.keep_rows = name, order, layout, keep_rows
+        self.torch, self.runtime = torch, runtime
+        self.device = torch.device("cuda", device_index)
+        self.lib = runtime.load_library()
+        self.clips, clip_indices, times = build_workload(name, rank, num_instances)
+        self.is_scalar = name == "scalar"
+        self.context = runtime.Context(device_index)
+        context = self.context
+
         t0 = time.perf_counter()
-        lib.aclo_decompress_tracks_batch(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, 0, ctypes.byref(options), out.ctypes.data, max_tracks * 12)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": sample / best, "unit": "poses/s", "cores": 1, "kind": "port",
-            "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c), 1 thread, best of 3"}
+        self.database = None
+        if name == "database":
+            fixture = load_database_fixture()
+            self.database = context.register_database(fixture["database"], fixture["bulk_medium"] if fixture["bulk_medium"].size else None,
+                                                      fixture["bulk_low"] if fixture["bulk_low"].size else None)
+            self.handles = np.array([context.register_clip_with_database(c.blob, self.database) for c in self.clips], dtype=np.uint32)
+        else:
+            self.handles = np.array([context.register_clip(c.blob) for c in self.clips], dtype=np.uint32)
+        self.registration_ms = (time.perf_counter() - t0) * 1e3
+
+        self.max_tracks = max(c.num_tracks for c in self.clips)
+        self.num_instances = int(clip_indices.size)
+        # bytes of one instance's output row: 48 / 40 / 32 per transform track by layout, 4 per component of a scalar track
+        bytes_per_track = 4 * self.clips[0].num_components if self.is_scalar else runtime.LAYOUTS[layout][1]
+        self.pose_stride = (self.max_tracks * bytes_per_track + 15) // 16 * 16
+
+        self.ordering_ms = None
+        self.d_rows = None
+        if order == "by_clip":
+            permutation = np.argsort(clip_indices, kind="stable")
+            clip_indices, times = clip_indices[permutation], times[permutation]
+        elif order == "locality":
+            t0 = time.perf_counter()
+            permutation = context.order_instances_for_locality(self.handles[clip_indices])
+            self.ordering_ms = (time.perf_counter() - t0) * 1e3
+            clip_indices, times = clip_indices[permutation], times[permutation]
+            if keep_rows:
+                self.d_rows = torch.from_numpy(permutation.astype(np.int32)).to(self.device)
+        self.clip_indices, self.times = clip_indices, times
+
+        self.d_clips = torch.from_numpy(self.handles[clip_indices].astype(np.int32)).to(self.device)
+        self.d_times = torch.from_numpy(times).to(self.device)
+        self.d_poses = torch.empty((self.num_instances, self.pose_stride // 4), dtype=torch.float32, device=self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.params = runtime.default_params()
+        self.consumers = None
+        self.output = None
+
+        handle, n = context._handle, self.num_instances
+        clips_ptr, times_ptr, poses_ptr, stream_ptr = self.d_clips.data_ptr(), self.d_times.data_ptr(), self.d_poses.data_ptr(), self.stream.cuda_stream
+        if self.is_scalar:
+            self._launch, self._args = self.lib.aclhip_decompress_scalar_tracks_batch, (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), poses_ptr, self.pose_stride, stream_ptr)
+        elif name in ("object_space", "additive_object_space"):
+            parents = synth.humanoid_hierarchy(self.max_tracks)     # 13 depths, 4-18 transforms wide
+            for clip_handle in self.handles:
+                context.set_clip_hierarchy(int(clip_handle), parents)
+            self.consumers = runtime.PoseConsumers()
+            self.consumers.object_space = 1
+            if name == "additive_object_space":
+                base_rng = np.random.default_rng(2000 + rank)
+                self.d_base_clips = torch.full((n,), int(self.handles[0]), dtype=torch.int32, device=self.device)
+                self.d_base_times = torch.from_numpy(base_rng.uniform(0.0, self.clips[0].duration, size=n).astype(np.float32)).to(self.device)
+                self.consumers.additive_format = runtime.ADDITIVE_ADDITIVE1
+                self.consumers.base_clips = self.d_base_clips.data_ptr()
+                self.consumers.base_sample_times = self.d_base_times.data_ptr()
+            self._launch = self.lib.aclhip_decompress_poses_batch
+            self._args = (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), ctypes.byref(self.consumers), poses_ptr, self.pose_stride, stream_ptr)
+        elif layout != "qvv48" or self.d_rows is not None:
+            self.output = runtime.OutputDesc()
+            self.output.layout = runtime.LAYOUTS[layout][0]
+            if self.d_rows is not None:
+                self.output.rows = self.d_rows.data_ptr()
+            self._launch = self.lib.aclhip_decompress_tracks_batch_out
+            self._args = (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), ctypes.byref(self.output), poses_ptr, self.pose_stride, stream_ptr)
+        else:
+            self._launch, self._args = self.lib.aclhip_decompress_tracks_batch, (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), poses_ptr, self.pose_stride, stream_ptr)
+
+    def step(self):
+        status = self._launch(*self._args)
+        if status != 0:
+            raise SystemExit(f"the batch launch failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
+
+    def prewarm(self, seconds):
+        """Device pre-warm (setup, not one of the W warm-up steps): an idle MI355X needs a few ms of work before its clocks settle.
+        Returns the number of launches it took."""
+        launches = 0
+        deadline = time.perf_counter() + seconds
+        while time.perf_counter() < deadline:
+            for _ in range(64):
+                self.step()
+            launches += 64
+            self.torch.cuda.synchronize(self.device)
+        return launches
+
+    def kernel_ms(self, repeats):
+        """Average device time of one launch: HIP events recorded on the launch stream around `repeats` back-to-back launches."""
+        start, stop = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        start.record(self.stream)
+        for _ in range(repeats):
+            self.step()
+        stop.record(self.stream)
+        stop.synchronize()
+        return float(start.elapsed_time(stop)) / repeats
+
+    def kernel_name(self):
+        if self.is_scalar:
+            return "decompress_scalar_tracks_kernel"
+        if self.consumers is not None:
+            return "decompress_poses_consumer_kernel"
+        return self.context.tracks_kernel_name(self.params)
+
+    def algorithmic_bytes(self):
+        """Compulsory-HBM model: bytes written for every instance (in the output layout) + every distinct clip's touched bytes once."""
+        written, read = self.context.batch_algorithmic_bytes(self.handles[self.clip_indices])
+        if not self.is_scalar:
+            written = written // 48 * self.runtime.LAYOUTS[self.layout][1]
+        if self.name == "additive_object_space":
+            read += self.context.batch_algorithmic_bytes(self.handles[:1])[1]        # the base clip is read too; one pose per instance is written
+        return written + read
+
+    def stream_schedule(self, steps):
+        """database workload: the tiers arrive one chunk at a time, evenly spread over `steps` launches, on the decode stream"""
+        if self.database is None:
+            return {}
+        info = self.context.database_info(self.database)
+        runtime = self.runtime
+        pending = [(tier, 1) for tier in (runtime.TIER_MEDIUM_IMPORTANCE, runtime.TIER_LOWEST_IMPORTANCE) for _ in range(info.num_chunks[tier - 1])]
+        return {(k + 1) * steps // (len(pending) + 1): request for k, request in enumerate(pending)}
+
+    def close(self):
+        self.torch.cuda.synchronize(self.device)
+        rejected = self.context.rejected_instance_count()
+        for handle in self.handles:
+            self.context.unregister_clip(int(handle))
+        if self.database is not None:
+            self.context.unregister_database(self.database)
+        self.context.close()
+        if rejected != 0:
+            raise SystemExit(f"the kernel rejected {rejected} instances ({self.name})")
 
 
-def measured_traffic(workload, kernel_name):
+def measured_traffic(key, kernel_name):
     """HBM bytes per launch of the decode kernel from rocprofv3 PMC passes of this same command, committed under profiles/
     (FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KiB units, FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md). None when no committed measurement matches the workload and kernel."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
+    if key is None or not os.path.exists(path):
         return None
     try:
         entries = json.load(open(path))
     except ValueError:
         return None
     for entry in entries:
-        if entry.get("workload") == workload and entry.get("kernel") == kernel_name:
+        if entry.get("workload") == key and entry.get("kernel") == kernel_name:
             return entry.get("traffic_bytes_per_launch")
     return None
+
+
+def traffic_key_of(workload, order, layout, keep_rows=False):
+    if keep_rows:
+        return None
+    key = workload
+    if order != "random":
+        key += f", {order} order"
+    if layout != "qvv48":
+        key += f", {layout}"
+    return key
+
+
+def measure_job(name, rank, device_index, repeats=300, **job_options):
+    """One entry of "workloads" / "footprint_sweep" / "layouts": the kernel's mean launch time (HIP events on the launch stream)
+    over `repeats` launches after a short pre-warm, against the algorithmic bytes of the batch."""
+    job = Job(name, rank, device_index, **job_options)
+    try:
+        job.prewarm(0.05)
+        if job.database is not None:
+            # the low importance tier arrives chunk by chunk between the launches, like in the headline database run
+            schedule = job.stream_schedule(repeats)
+            start, stop = job.torch.cuda.Event(enable_timing=True), job.torch.cuda.Event(enable_timing=True)
+            start.record(job.stream)
+            for i in range(repeats):
+                if i in schedule:
+                    job.context.database_stream_in(job.database, schedule[i][0], schedule[i][1], stream=job.stream.cuda_stream)
+                job.step()
+            stop.record(job.stream)
+            stop.synchronize()
+            kernel_ms = float(start.elapsed_time(stop)) / repeats
+        else:
+            kernel_ms = job.kernel_ms(repeats)
+        algorithmic = job.algorithmic_bytes()
+        achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
+        kernel = job.kernel_name()
+        return {
+            "workload": traffic_key_of(name, job.order, job.layout, job.keep_rows) or f"{name}, {job.order} order, rows kept",
+            "config": WORKLOAD_TEXT[name],
+            "order": job.order,
+            "layout": job.layout,
+            "instances": job.num_instances,
+            "bones": job.max_tracks,
+            "distinct_clips": len(job.clips),
+            "pose_bytes": job.pose_stride,
+            "kernel": kernel,
+            "kernel_ms": kernel_ms,
+            "poses_per_s": job.num_instances / (kernel_ms * 1e-3),
+            "algorithmic_bytes": int(algorithmic),
+            "achieved": achieved,
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
+            "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
+            "launches_timed": repeats,
+        }
+    finally:
+        job.close()
+
+
+# ---- CPU baseline -----------------------------------------------------------------------------------------------------------
+
+def cgroup_cpu_max():
+    """The container's CPU quota: "max" or "<quota> <period>" of cgroup v2 (cpu.max), or the v1 pair; None when unreadable."""
+    try:
+        return open("/sys/fs/cgroup/cpu.max").read().strip()
+    except OSError:
+        pass
+    try:
+        quota = open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip()
+        period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+        return f"{quota} {period}"
+    except OSError:
+        return None
+
+
+def cpu_baseline(clips, clip_indices, times, row_units, is_scalar):
+    """Times the reference's own decoder (oracle/_ref, kind "reference") -- or the C restatement (kind "port") when the
+    reference build is absent -- on the same instance list on this box's host cores: PINNED threads that start together and decode
+    for a fixed wall-clock window per point (oracle/bench_harness.h), swept over thread counts; `value` is the best point."""
+    from oracle import bindings as ob  # cpu_baseline leg: the oracle is the baseline being measured here, never the product
+
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sample = min(clip_indices.size, 65536)
+    indices = np.ascontiguousarray(clip_indices[:sample], dtype=np.uint32)
+    sample_times = np.ascontiguousarray(times[:sample], dtype=np.float32)
+    blob_ptrs = (ctypes.c_void_p * len(clips))(*[c.blob.ctypes.data for c in clips])
+    description = {"unit": "poses/s", "nproc": nproc, "cgroup_cpu_max": cgroup_cpu_max()}
+
+    have_reference = ob.have_ref_scalar() if is_scalar else ob.have_ref()
+    if have_reference:
+        lib = ob.ref_scalar() if is_scalar else ob.ref()
+        bench = lib.aclref_scalar_bench_timed if is_scalar else lib.aclref_bench_timed
+        seconds = float(os.environ.get("ACLHIP_BENCH_CPU_SECONDS", "1.0"))
+        points = sorted({t for t in (1, 8, 32, 64, 128, 256) if t < nproc} | {nproc})
+        sweep = {}
+        for threads in points:
+            sweep[str(threads)] = bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, row_units, threads, seconds, 1, None)
+        best_threads = max(sweep, key=lambda k: sweep[k])
+        description.update({
+            "value": sweep[best_threads], "cores": int(best_threads), "threads_at_best": int(best_threads), "kind": "reference",
+            "per_thread_1t": sweep[str(points[0])] / points[0], "sweep": sweep,
+            "sample": f"{sample} instances of the same list statically partitioned over the threads, seek + decompress_tracks, reference headers "
+                      f"({'default_scalar_decompression_settings' if is_scalar else 'AVX2 build, benchmark settings (benchmark.cpp:94-101)'}), one context and one private output "
+                      f"buffer per thread (warm cache), threads pinned to the CPUs of the affinity mask and started together, {seconds:g} s wall clock per point of the thread sweep",
+        })
+        return description
+
+    lib = ob.oracle()
+    options = ob.default_options()
+    sample = min(sample, 4096 if is_scalar else 16384)
+    best = 1e30
+    if is_scalar:
+        out = np.zeros(row_units, dtype=np.float32)
+        t0 = time.perf_counter()
+        for i in range(sample):
+            lib.aclo_scalar_decompress_tracks(clips[indices[i]].blob.ctypes.data, ctypes.c_float(sample_times[i]), 0, ctypes.byref(options), out.ctypes.data)
+        best = time.perf_counter() - t0
+    else:
+        out = np.zeros((sample, row_units * 12), dtype=np.float32)
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lib.aclo_decompress_tracks_batch(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, 0, ctypes.byref(options), out.ctypes.data, row_units * 12)
+            best = min(best, time.perf_counter() - t0)
+    description.update({"value": sample / best, "cores": 1, "threads_at_best": 1, "kind": "port", "per_thread_1t": sample / best, "sweep": {"1": sample / best},
+                        "sample": f"{sample} instances of the same list, scalar C restatement (oracle/acl_oracle.c), 1 thread"})
+    return description
+
+
+# ---- pose gather (N > 1) ----------------------------------------------------------------------------------------------------
+
+def measure_gather(job, dist, rank, world_size, mode, repeats=5):
+    """Times the gather of every rank's pose shard, separately from the decode: "rccl" = one all-gather (every rank receives every
+    shard, torch.distributed = RCCL over xGMI); "p2p" = every rank copies its shard into rank 0's buffer through a peer mapping
+    (hipIpc + hipMemcpyAsync device to device: rank 0's seven inbound links work concurrently, nothing else moves).
+    Returns the entries of the "gather" object; errors are reported, never raised (the decode numbers stand on their own)."""
+    from acl_amd import sharding
+    torch = job.torch
+    shard = job.d_poses
+    shard_bytes = shard.numel() * 4
+    on_device = dist.get_backend() == "nccl"
+    result = {"shard_bytes": int(shard_bytes)}
+    modes = ("rccl", "p2p") if mode == "both" else (mode,)
+
+    def timed(enqueue):
+        torch.cuda.synchronize(job.device)
+        dist.barrier()
+        best = 1e30
+        for _ in range(repeats):
+            dist.barrier()
+            t0 = time.perf_counter()
+            enqueue()
+            torch.cuda.synchronize(job.device)
+            dist.barrier()
+            best = min(best, time.perf_counter() - t0)
+        slowest = torch.tensor([best], dtype=torch.float64, device=job.device if on_device else "cpu")
+        dist.all_reduce(slowest, op=dist.ReduceOp.MAX)
+        return float(slowest.item()) * 1e3
+
+    if "rccl" in modes:
+        try:
+            source = shard if on_device else shard.cpu()
+            gathered = torch.empty((world_size * shard.shape[0], shard.shape[1]), dtype=shard.dtype, device=source.device)
+            ms = timed(lambda: dist.all_gather_into_tensor(gathered, source))
+            result["rccl_all_gather_ms"] = ms
+            # every rank receives (W - 1) shards
+            result["rccl_all_gather_gbps_into_each_rank"] = (world_size - 1) * shard_bytes / (ms * 1e-3) / 1e9
+            del gathered
+        except Exception as error:      # noqa: BLE001 -- reported in the line
+            result["rccl_all_gather_error"] = repr(error)[:300]
+    if "p2p" in modes:
+        gather = None
+        try:
+            gather = sharding.PeerGather(job.context, shard_bytes, rank, world_size, device=job.device)
+            ms = timed(lambda: gather.push(shard.data_ptr(), stream=job.stream.cuda_stream))
+            result["p2p_to_rank0_ms"] = ms
+            result["p2p_gbps_into_rank0"] = (world_size - 1) * shard_bytes / (ms * 1e-3) / 1e9     # rank 0's own shard is a local copy
+            result["p2p_gbps_per_link"] = shard_bytes / (ms * 1e-3) / 1e9                          # each remote shard travels over its own link
+            result["p2p_link_frac_of_153_gbps"] = result["p2p_gbps_per_link"] / XGMI_LINK_GBPS
+        except Exception as error:      # noqa: BLE001
+            result["p2p_error"] = repr(error)[:300]
+        finally:
+            if gather is not None:
+                gather.close()
+    return result
 
 
 def main():
@@ -195,14 +488,23 @@ def main():
     # the clocks of an idle MI355X take a few ms to ramp: the defaults warm up for ~30 ms and time ~0.1 s
     parser.add_argument("--steps", type=int, default=2000)
     parser.add_argument("--warmup", type=int, default=500)
-    parser.add_argument("--workload", default="one_clip", choices=["one_clip", "256_clips", "cinematic", "database", "scalar", "object_space", "additive_object_space"])
-    parser.add_argument("--sort-by-clip", action="store_true", help="bucket the instance list by clip before upload (256_clips)")
+    parser.add_argument("--workload", default="one_clip", choices=sorted(WORKLOAD_TEXT))
+    parser.add_argument("--instances", type=int, default=INSTANCES_PER_GPU, help="instances per GPU")
+    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality"],
+                        help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup)")
+    parser.add_argument("--keep-rows", action="store_true", help="with --order locality: store every pose in its instance's ORIGINAL row")
+    parser.add_argument("--layout", default="qvv48", choices=["qvv48", "qvv40", "qv32"], help="output layout (aclhip_output_desc)")
     parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
-    parser.add_argument("--order-for-locality", action="store_true",
-                        help="decode in the order aclhip_order_instances_for_locality gives (every clip on one XCD); the poses are stored in that order")
-    parser.add_argument("--keep-rows", action="store_true",
-                        help="with --order-for-locality: store every pose in its instance's ORIGINAL row (aclhip_decompress_tracks_batch_rows)")
+    parser.add_argument("--no-extras", action="store_true", help="only the headline workload: no other workloads, footprint sweep, layouts")
+    parser.add_argument("--gather", default="both", choices=["none", "rccl", "p2p", "both"], help="N > 1: time the pose gather after the decode (reported separately)")
+    # kept for the scripts of round 1
+    parser.add_argument("--sort-by-clip", action="store_true", help="same as --order by_clip")
+    parser.add_argument("--order-for-locality", action="store_true", help="same as --order locality")
     args = parser.parse_args()
+    if args.sort_by_clip:
+        args.order = "by_clip"
+    if args.order_for_locality:
+        args.order = "locality"
 
     import torch
     import torch.distributed as dist
@@ -231,119 +533,33 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    from acl_amd import runtime
-
-    clips, clip_indices, times = build_workload(args.workload, rank)
-    if args.sort_by_clip:
-        order = np.argsort(clip_indices, kind="stable")
-        clip_indices, times = clip_indices[order], times[order]
-
-    context = runtime.Context(device_index)
-    registration_t0 = time.perf_counter()
-    is_scalar = args.workload == "scalar"
-    database = None
-    if args.workload == "database":
-        fixture = load_database_fixture()
-        database = context.register_database(fixture["database"], fixture["bulk_medium"] if fixture["bulk_medium"].size else None,
-                                             fixture["bulk_low"] if fixture["bulk_low"].size else None)
-        handles = np.array([context.register_clip_with_database(c.blob, database) for c in clips], dtype=np.uint32)
-    else:
-        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
-    registration_ms = (time.perf_counter() - registration_t0) * 1e3
-    max_tracks = max(c.num_tracks for c in clips)
-    num_instances = clip_indices.size
-    # bytes of one instance's output row: 48 per transform track (rtm::qvvf), 4 per component of a scalar track
-    pose_stride = max_tracks * (4 * clips[0].num_components if is_scalar else 48)
-
-    # --order-for-locality: the library lays the instance list out (host side, setup), the poses still land in the caller's rows
-    d_rows = None
-    ordering_ms = None
-    if args.order_for_locality:
-        if is_scalar or args.workload in ("object_space", "additive_object_space"):
-            raise SystemExit("--order-for-locality applies to the pose kernels")
-        ordering_t0 = time.perf_counter()
-        order = context.order_instances_for_locality(handles[clip_indices])
-        ordering_ms = (time.perf_counter() - ordering_t0) * 1e3
-        clip_indices, times = clip_indices[order], times[order]
-        if args.keep_rows:
-            d_rows = torch.from_numpy(order.astype(np.int32)).to(device)
-
-    d_clips = torch.from_numpy(handles[clip_indices].astype(np.int32)).to(device)
-    d_times = torch.from_numpy(times).to(device)
-    d_poses = torch.empty((num_instances, pose_stride // 4), dtype=torch.float32, device=device)
-    stream = torch.cuda.current_stream(device)
-    params = runtime.default_params()
-
-    # raw pointers once: the timed loop is nothing but K asynchronous launches through the C ABI
-    import ctypes
-    lib = runtime.load_library()
-    launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
-    launch = lib.aclhip_decompress_scalar_tracks_batch if is_scalar else lib.aclhip_decompress_tracks_batch
-    if d_rows is not None:
-        launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), d_rows.data_ptr(), num_instances, ctypes.byref(params), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
-        launch = lib.aclhip_decompress_tracks_batch_rows
-
-    # pose consumers: the same decode with the additive apply / local -> object space fused in
-    consumers = None
-    if args.workload in ("object_space", "additive_object_space"):
-        from acl_amd import synth
-        parents = synth.humanoid_hierarchy(max_tracks)     # 13 depths, 4-18 transforms wide
-        for handle in handles:
-            context.set_clip_hierarchy(int(handle), parents)
-        consumers = runtime.PoseConsumers()
-        consumers.object_space = 1
-        if args.workload == "additive_object_space":
-            base_rng = np.random.default_rng(2000 + rank)
-            d_base_clips = torch.full((num_instances,), int(handles[0]), dtype=torch.int32, device=device)
-            d_base_times = torch.from_numpy(base_rng.uniform(0.0, clips[0].duration, size=num_instances).astype(np.float32)).to(device)
-            consumers.additive_format = runtime.ADDITIVE_ADDITIVE1
-            consumers.base_clips = d_base_clips.data_ptr()
-            consumers.base_sample_times = d_base_times.data_ptr()
-        launch_args = (context._handle, d_clips.data_ptr(), d_times.data_ptr(), num_instances, ctypes.byref(params), ctypes.byref(consumers), d_poses.data_ptr(), pose_stride, stream.cuda_stream)
-        launch = lib.aclhip_decompress_poses_batch
-
-    def step():
-        status = launch(*launch_args)
-        if status != 0:
-            raise SystemExit(f"the batch launch failed: {status}")
-
-    # device pre-warm (setup, not one of the W warm-up steps): an idle MI355X needs a few ms of work before its clocks settle
-    # (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
     profiling = os.environ.get("ACLHIP_BENCH_PROFILING", "0") == "1"
-    prewarm_deadline = time.perf_counter() + (0.0 if profiling else 0.15)
-    while time.perf_counter() < prewarm_deadline:
-        for _ in range(64):
-            step()
-        torch.cuda.synchronize(device)
+    job = Job(args.workload, rank, device_index, num_instances=args.instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout)
 
+    # device pre-warm (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
+    prewarm_launches = 0 if profiling else job.prewarm(0.15)
     for _ in range(args.warmup):
-        step()
+        job.step()
 
     # HIP events on the launch stream cut the timed region into chunks of launches; (chunk time / launches in it) averaged over the
     # region is the kernel's mean duration including the (~1 us) launch boundary
     chunk = max(1, min(100, args.steps // 10))
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // chunk + 2)]
+    stream_schedule = job.stream_schedule(args.steps)
 
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     num_marks = 0
-    # database workload: the tiers arrive one chunk at a time, evenly spread over the timed steps, on the decode stream
-    stream_schedule = {}
-    if database is not None:
-        info = context.database_info(database)
-        pending = [(tier, 1) for tier in (runtime.TIER_MEDIUM_IMPORTANCE, runtime.TIER_LOWEST_IMPORTANCE) for _ in range(info.num_chunks[tier - 1])]
-        for k, request in enumerate(pending):
-            stream_schedule[(k + 1) * args.steps // (len(pending) + 1)] = request
     for i in range(args.steps):
         if i % chunk == 0:
-            marks[num_marks].record(stream)
+            marks[num_marks].record(job.stream)
             num_marks += 1
         if i in stream_schedule:
-            context.database_stream_in(database, stream_schedule[i][0], stream_schedule[i][1], stream=stream.cuda_stream)
-        step()
-    marks[num_marks].record(stream)
+            job.context.database_stream_in(job.database, stream_schedule[i][0], stream_schedule[i][1], stream=job.stream.cuda_stream)
+        job.step()
+    marks[num_marks].record(job.stream)
     num_marks += 1
     torch.cuda.synchronize(device)
     if distributed:
@@ -351,43 +567,29 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if distributed:
-        elapsed_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        elapsed_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(elapsed_tensor, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed_tensor.item())
 
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
     kernel_ms = float(marks[0].elapsed_time(marks[num_marks - 1])) / args.steps
-    # the same launches back to back from C (no host pacing), for reference
-    repeats = 1 if profiling else max(10, min(args.steps, 100))
-    if is_scalar:
-        kernel_ms_back_to_back = None
-    elif consumers is not None:
-        kernel_ms_back_to_back = context.time_decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
-                                                                     consumers, repeats=repeats, params=params, stream=stream.cuda_stream)
-    else:
-        kernel_ms_back_to_back = context.time_decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), num_instances, d_poses.data_ptr(), pose_stride,
-                                                                      repeats=repeats, params=params, stream=stream.cuda_stream)
-    bytes_written, bytes_read = context.batch_algorithmic_bytes(handles[clip_indices])
-    if args.workload == "additive_object_space":
-        bytes_read += context.batch_algorithmic_bytes(handles[:1])[1]        # the base clip is read too; one pose per instance is written
-    algorithmic_bytes = bytes_written + bytes_read
+    kernel_ms_back_to_back = None if profiling else job.kernel_ms(max(10, min(args.steps, 100)))
+    algorithmic_bytes = job.algorithmic_bytes()
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+    fill_gbps = job.context.measure_write_bandwidth(job.d_poses.data_ptr(), job.num_instances * job.pose_stride, repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
 
-    write_ceiling_gbps = context.measure_write_bandwidth(d_poses.data_ptr(), num_instances * pose_stride, repeats=1 if profiling else 20, stream=stream.cuda_stream)
+    gather = None
+    if distributed and args.gather != "none":
+        gather = measure_gather(job, dist, rank, world_size, args.gather)
 
-    rejected = context.rejected_instance_count()
-    if rejected != 0:
-        raise SystemExit(f"the kernel rejected {rejected} instances")
-
-    # committed PMC measurements are per instance order: random (the default), or the library's locality order
-    traffic_key = args.workload
-    if args.order_for_locality:
-        traffic_key = None if args.keep_rows else args.workload + ", aclhip_order_instances_for_locality order"
-    elif args.sort_by_clip:
-        traffic_key = None
-    kernel_name = "decompress_scalar_tracks_kernel" if is_scalar else ("decompress_poses_consumer_kernel" if consumers is not None else context.tracks_kernel_name(params))
+    kernel_name = job.kernel_name()
+    result = None
     if rank == 0:
-        total_poses = num_instances * world_size * args.steps
+        total_poses = job.num_instances * world_size * args.steps
+        workload_text = WORKLOAD_TEXT[args.workload]
+        if args.order != "random":
+            workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order"}[args.order]
+            workload_text += ", poses scattered back to their original rows" if args.keep_rows else ""
         result = {
             "metric": "poses/sec (whole node), 64k clip instances x 100 bones per GPU, seek + decompress_tracks",
             "value": total_poses / elapsed,
@@ -402,19 +604,15 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": {"one_clip": "64k instances of one CMU-shaped 100-bone clip, random sample times, quatf_drop_w_variable + vector3f_variable (BASELINE.json configs[1])",
-                             "256_clips": "64k instances drawn from 256 distinct 100-bone clips (BASELINE.json configs[2])" + (", bucketed by clip" if args.sort_by_clip else "") + (", decoded in aclhip_order_instances_for_locality order" + (", poses scattered back to their original rows" if args.keep_rows else "") if args.order_for_locality else ""),
-                             "cinematic": "64k instances per GPU of a 300-bone rig with scale tracks, multi-segment (BASELINE.json configs[3] shard)",
-                             "database": "64k instances per GPU over 16 database-bound 100-bone clips, low importance tier streamed in chunk by chunk on the decode stream during the timed steps (BASELINE.json configs[4] shape, committed fixture)",
-                             "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
-                             "object_space": "the one_clip batch with local -> object space fused into the decode (pose consumers, SURVEY 8 f3)",
-                             "additive_object_space": "64k instances per GPU: an additive clip applied (additive1) onto a base clip instance decoded by the same wave, then local -> object space (SURVEY 8 f3)"}[args.workload],
-                "instances_per_gpu": int(num_instances),
-                "bones": int(max_tracks),
-                "distinct_clips": len(clips),
-                "ordering_ms": None if ordering_ms is None else round(ordering_ms, 3),     # aclhip_order_instances_for_locality on the host (setup, not timed)
-                "registration_ms_total": round(registration_ms, 3),      # validate + derive tables + upload, all clips (setup, not timed)
-                "pose_bytes": int(pose_stride),
+                "workload": workload_text,
+                "instances_per_gpu": int(job.num_instances),
+                "bones": int(job.max_tracks),
+                "distinct_clips": len(job.clips),
+                "layout": args.layout,
+                "ordering_ms": None if job.ordering_ms is None else round(job.ordering_ms, 3),     # aclhip_order_instances_for_locality on the host (setup, not timed)
+                "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload, all clips (setup, not timed)
+                "prewarm_launches": int(prewarm_launches),                   # untimed launches before the W warm-up steps (clock ramp)
+                "pose_bytes": int(job.pose_stride),
                 "sharding": f"instances split over {world_size} rank(s), no collective on the data path",
             },
             "roofline": {
@@ -423,31 +621,48 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved_gbps / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(traffic_key, kernel_name),
+                "traffic": measured_traffic(traffic_key_of(args.workload, args.order, args.layout, args.keep_rows), kernel_name),
                 "kernel": kernel_name,
                 "kernel_ms": kernel_ms,
                 "kernel_ms_back_to_back": kernel_ms_back_to_back,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
-                "measured_write_stream_gbps": write_ceiling_gbps,
+                "plain_store_stream_gbps": fill_gbps,      # a plain 16 B per lane store sweep over the same pose buffer, for scale (not a ceiling: DESIGN.md 6)
             },
         }
+        if gather is not None:
+            result["gather"] = gather
+
+    headline = (job.clips, job.clip_indices, job.times, job.pose_stride // 4 if job.is_scalar else job.max_tracks, job.is_scalar, job.database is not None, job.consumers is not None)
+    job.close()
+
+    extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU
+    if rank == 0 and extras:
+        # the other north-star configs, measured in this process outside the timed region (about 0.2 s of launches each)
+        result["workloads"] = [
+            measure_job("256_clips", rank, device_index),
+            measure_job("256_clips", rank, device_index, order="locality"),
+            measure_job("cinematic", rank, device_index, repeats=150),
+            measure_job("database", rank, device_index),
+        ]
+        result["footprint_sweep"] = [
+            {key: entry[key] for key in ("instances", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}
+            for entry in (measure_job("one_clip", rank, device_index, num_instances=n, repeats=200) for n in (32768, 65536, 131072))]
+        result["layouts"] = [
+            {key: entry[key] for key in ("layout", "pose_bytes", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}
+            for entry in (measure_job("one_clip", rank, device_index, layout=layout) for layout in ("qvv48", "qvv40", "qv32"))]
+
+    if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:
-            if is_scalar:
-                result["cpu_baseline"] = cpu_baseline_scalar(clips, clip_indices, times, pose_stride // 4)
-            else:
-                result["cpu_baseline"] = cpu_baseline(clips, clip_indices, times, max_tracks)
-                if database is not None:
-                    # the reference's database_context is not part of the CPU bridge that travels to the GPU box
-                    result["cpu_baseline"]["sample"] += "; clips bound WITHOUT their database (highest importance tier only)"
-                if consumers is not None:
-                    result["cpu_baseline"]["sample"] += "; decode of the (additive) clip only, the consumers are not part of the CPU timing"
+            clips, clip_indices, times, row_units, is_scalar, has_database, has_consumers = headline
+            result["cpu_baseline"] = cpu_baseline(clips, clip_indices, times, row_units, is_scalar)
+            if has_database:
+                # the reference's database_context is not part of the CPU bridge that travels to the GPU box
+                result["cpu_baseline"]["sample"] += "; clips bound WITHOUT their database (highest importance tier only)"
+            if has_consumers:
+                result["cpu_baseline"]["sample"] += "; decode of the (additive) clip only, the consumers are not part of the CPU timing"
+            result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
 
-    for handle in handles:
-        context.unregister_clip(int(handle))
-    if database is not None:
-        context.unregister_database(database)
-    context.close()
     if distributed:
         dist.destroy_process_group()
 

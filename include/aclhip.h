@@ -100,6 +100,29 @@ typedef struct aclhip_decompress_params
 	const uint8_t* instance_rounding_policies;	/* DEVICE pointer or NULL: one aclhip_rounding_policy per instance, overrides rounding_policy */
 } aclhip_decompress_params;
 
+/* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
+ * (core/track_writer.h:161-216). A writer decides per sub-track kind whether it wants it at all -- skip_all_rotations /
+ * skip_all_translations / skip_all_scales (:181-183) -- and the writer's own pose type decides how wide a bone is: the
+ * reference's debug writer stores rtm::qvvf (48 bytes, core/impl/debug_track_writer.h:61-62), its benchmark counts
+ * sizeof(rtm::quatf) + 2 * sizeof(rtm::float3f) = 40 bytes per bone (tools/acl_decompressor/sources/benchmark.cpp:146), engines
+ * that ignore scale keep 32. The decode sits on the HBM write roofline, so bytes per pose are poses per second. */
+typedef enum aclhip_pose_layout
+{
+	ACLHIP_LAYOUT_QVV48 = 0,				/* per track: rotation xyzw | translation xyz 0 | scale xyz 0 (rtm::qvvf), the default */
+	ACLHIP_LAYOUT_QVV40 = 1,				/* per track: rotation xyzw | translation xyz | scale xyz, 10 packed floats */
+	ACLHIP_LAYOUT_QV32 = 2					/* per track: rotation xyzw | translation xyz 0; scales are not written (implies skip_scales) */
+} aclhip_pose_layout;
+
+typedef struct aclhip_output_desc
+{
+	uint32_t layout;						/* aclhip_pose_layout */
+	uint8_t skip_rotations;					/* track_writer::skip_all_rotations(): no rotation is written, its bytes in the pose buffer are left untouched */
+	uint8_t skip_translations;				/* track_writer::skip_all_translations() */
+	uint8_t skip_scales;					/* track_writer::skip_all_scales() */
+	uint8_t reserved0;
+	const uint32_t* rows;					/* DEVICE pointer or NULL: pose of instance i goes to row rows[i] (distinct) instead of row i */
+} aclhip_output_desc;
+
 typedef struct aclhip_clip_info
 {
 	uint32_t num_tracks;
@@ -223,6 +246,15 @@ aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclh
 aclhip_status aclhip_decompress_tracks_batch_rows(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* rows,
 	uint32_t num_instances, const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream);
 
+/* aclhip_decompress_tracks_batch with an output descriptor (NULL = QVV48, nothing skipped, row i): the pose of instance i starts at
+ * (char*)poses + row * pose_stride_bytes and holds num_tracks records of 48 / 40 / 32 bytes in the chosen layout;
+ * pose_stride_bytes must be a multiple of 16 and at least that size. Same values as the QVV48 decode, compared through the layout. */
+aclhip_status aclhip_decompress_tracks_batch_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes, void* stream);
+
+/* Bytes one track takes in a pose of `layout` (48 / 40 / 32); 0 for an unknown layout. */
+uint32_t aclhip_layout_bytes_per_track(uint32_t layout);
+
 /* Host only (no GPU work): a decode order for a batch that draws on many clips -- a permutation of [0, num_instances) for the
  * instance list `clips` (HOST array) under which every clip is decoded on ONE XCD (workgroup b of a launch runs on XCD b % 8,
  * each XCD has its own L2), next to its other instances. Use: clips'[k] = clips[out_order[k]], sample_times'[k] =
@@ -244,6 +276,9 @@ aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhi
 	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes);
 aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms);
+/* aclhip_decompress_tracks_host with an output descriptor (output->rows: HOST pointer or NULL). Skipped sub-track kinds keep what `poses` held. */
+aclhip_status aclhip_decompress_tracks_host_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	const aclhip_decompress_params* params, uint32_t default_values_count, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes);
 
 /* ---- scalar track lists (float1f / float2f / float3f / float4f / vector4f) ------------------------
  * aclhip_register_clip accepts them like transform clips (decompression_context::initialize dispatches on the track type,
@@ -344,6 +379,22 @@ aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip
  * receives world_size * shard_bytes bytes in rank order (in place when shard_poses == all_poses + rank * shard_bytes).
  * DEVICE pointers; asynchronous on `stream`. librccl.so.1 is loaded on first use: ACLHIP_ERROR_DEVICE when it is absent. */
 aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream);
+
+/* Peer gather: when ONE GPU wants every pose (the one that renders), each other GPU pushes its shard straight into that GPU's
+ * buffer over its own xGMI link -- the destination's seven links work concurrently and no shard travels twice -- instead of a ring
+ * collective that also gives every rank every shard. One process per GPU:
+ *   destination:  aclhip_peer_export_buffer(ctx, all_poses, handle)     72 opaque bytes (a HIP IPC memory handle + offset), sent to the
+ *                                                                      other processes by whatever they already talk over
+ *   every source: aclhip_peer_open_buffer(ctx, handle, &peer)           maps the destination's buffer (once)
+ *                 aclhip_push_poses_to_peer(ctx, peer, rank * shard_bytes, shard_poses, shard_bytes, stream)   per batch, asynchronous
+ *                 aclhip_peer_close_buffer(ctx, peer)
+ * The destination copies its own shard with the same call on its own pointer. The caller orders the destination's reads after the
+ * pushes (a barrier between the processes, or events it shares). No reference counterpart (the reference is single threaded CPU code). */
+#define ACLHIP_PEER_HANDLE_BYTES 72
+aclhip_status aclhip_peer_export_buffer(aclhip_context* context, void* device_buffer, uint8_t* out_handle);
+aclhip_status aclhip_peer_open_buffer(aclhip_context* context, const uint8_t* handle, void** out_device_buffer);
+aclhip_status aclhip_peer_close_buffer(aclhip_context* context, void* device_buffer);
+aclhip_status aclhip_push_poses_to_peer(aclhip_context* context, void* peer_buffer, uint64_t offset_bytes, const void* shard_poses, uint64_t shard_bytes, void* stream);
 
 /* Number of instances the kernels refused since the context was created (unknown clip handle, track index out of range):
  * the reference silently returns in those cases (impl/decompression.transform.h:1532-1537,1766-1768). */

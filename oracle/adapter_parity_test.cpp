@@ -126,6 +126,11 @@ namespace
 
 int main(int argc, char** argv)
 {
+	if (!acl_gpu::device().is_valid())
+	{
+		std::fprintf(stderr, "no usable HIP device: aclhip_create failed (this program needs a GPU)\n");
+		return 99;
+	}
 	for (int arg = 1; arg < argc; ++arg)
 	{
 		FILE* file = std::fopen(argv[arg], "rb");

@@ -149,6 +149,8 @@ def ref(asserting=False):
         lib.aclref_decompress_many.argtypes = [vp, vp, u32, i32, i32, i32, i32, vp]
         lib.aclref_bench.argtypes = [vp, vp, vp, u32, u32, u32, u32, vp]
         lib.aclref_bench.restype = ctypes.c_double
+        lib.aclref_bench_timed.argtypes = [vp, vp, vp, u32, u32, u32, ctypes.c_double, i32, vp]
+        lib.aclref_bench_timed.restype = ctypes.c_double
         _ref[key] = lib
     return _ref[key]
 
@@ -176,6 +178,37 @@ def oracle_decompress_tracks(blob, sample_time, rounding=ROUND_NONE, options=Non
     result = lib.aclo_decompress_tracks(blob.ctypes.data, ctypes.c_float(sample_time), rounding, ctypes.byref(options), out.ctypes.data)
     if result != 0:
         raise RuntimeError(f"aclo_decompress_tracks failed: {result}")
+    return out
+
+
+def oracle_decompress_tracks_batch(blobs, clip_indices, sample_times, max_tracks, rounding=ROUND_NONE, options=None, out=None, threads=None):
+    """seek + decompress_tracks for EVERY instance (blobs[clip_indices[i]], sample_times[i]) through the C restatement
+    (aclo_decompress_tracks_batch), split over host threads (ctypes releases the GIL). Returns [count, max_tracks, 12] float32;
+    rows of clips with fewer tracks keep what `out` held (zeros when it is allocated here)."""
+    import concurrent.futures
+    import os
+    lib = oracle()
+    count = int(len(clip_indices))
+    indices = np.ascontiguousarray(clip_indices, dtype=np.uint32)
+    times = np.ascontiguousarray(sample_times, dtype=np.float32)
+    if out is None:
+        out = np.zeros((count, max_tracks, 12), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    blob_ptrs = (ctypes.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    if threads is None:
+        threads = max(1, min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    piece = max(256, (count + threads - 1) // threads)
+
+    def run(first):
+        n = min(piece, count - first)
+        result = lib.aclo_decompress_tracks_batch(blob_ptrs, indices[first:].ctypes.data, times[first:].ctypes.data, n, rounding, ctypes.byref(options),
+                                                  out[first:].ctypes.data, max_tracks * 12)
+        if result != 0:
+            raise RuntimeError(f"aclo_decompress_tracks_batch failed: {result}")
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(run, range(0, count, piece)))
     return out
 
 
@@ -296,6 +329,8 @@ def ref_scalar():
         lib.aclref_scalar_compress.restype = u32
         lib.aclref_scalar_bench.argtypes = [vp, vp, vp, u32, u32, u32, u32]
         lib.aclref_scalar_bench.restype = ctypes.c_double
+        lib.aclref_scalar_bench_timed.argtypes = [vp, vp, vp, u32, u32, u32, ctypes.c_double, i32, vp]
+        lib.aclref_scalar_bench_timed.restype = ctypes.c_double
         _ref_scalar = lib
     return _ref_scalar
 

@@ -102,6 +102,11 @@ namespace
 
 int main(int argc, char** argv)
 {
+	if (!acl_gpu::device().is_valid())
+	{
+		std::fprintf(stderr, "no usable HIP device: aclhip_create failed (this program needs a GPU)\n");
+		return 99;
+	}
 	if (argc < 6)
 		return 100;
 	aligned_file database_file, bulk_medium, bulk_low;

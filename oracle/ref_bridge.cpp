@@ -15,10 +15,13 @@
 #include <acl/decompression/decompress.h>
 #include <acl/decompression/decompression_settings.h>
 
+#include "bench_harness.h"
+
 #include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -268,5 +271,63 @@ extern "C"
 		const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
 
 		return elapsed / double(repeats);
+	}
+
+	// CPU baseline, self-describing variant (bench.py cpu_baseline leg): the same work per instance as aclref_bench -- one
+	// decompression_context per thread re-initialised when the clip changes, seek + decompress_tracks with the benchmark settings
+	// (benchmark.cpp:94-101,249-254) into a private pose buffer (warm cache: the favourable case for the CPU) -- but on PINNED
+	// threads that start together and run for a fixed wall-clock window (oracle/bench_harness.h). Thread t walks instances
+	// [count * t / T, count * (t + 1) / T) again and again. Returns poses per second of all threads together.
+	double aclref_bench_timed(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+		uint32_t max_tracks, uint32_t num_threads, double seconds, int pin, uint64_t* out_total_poses)
+	{
+		if (count == 0)
+			return 0.0;
+		if (num_threads == 0)
+			num_threads = 1;
+		auto make_worker = [&](uint32_t thread_index)
+		{
+			struct worker_state
+			{
+				std::vector<float> scratch;
+				acl::decompression_context<benchmark_settings> context;
+				const void* bound = nullptr;
+				uint32_t begin = 0, end = 0, cursor = 0;
+			};
+			std::shared_ptr<worker_state> state = std::make_shared<worker_state>();
+			state->scratch.resize(size_t(max_tracks) * 12);
+			state->begin = uint32_t((uint64_t(count) * thread_index) / num_threads);
+			state->end = uint32_t((uint64_t(count) * (thread_index + 1)) / num_threads);
+			if (state->end == state->begin)		// more threads than instances: share the list
+			{
+				state->begin = thread_index % count;
+				state->end = state->begin + 1;
+			}
+			state->cursor = state->begin;
+			return [state, blobs, clip_indices, sample_times]() -> uint64_t
+			{
+				worker_state& w = *state;
+				constexpr uint32_t k_poses_per_step = 32;
+				for (uint32_t k = 0; k < k_poses_per_step; ++k)
+				{
+					const uint32_t i = w.cursor;
+					w.cursor = w.cursor + 1 == w.end ? w.begin : w.cursor + 1;
+					const void* blob = blobs[clip_indices[i]];
+					if (blob != w.bound)
+					{
+						w.context.initialize(*static_cast<const acl::compressed_tracks*>(blob));
+						w.bound = blob;
+					}
+					writer_identity writer;
+					writer.out = w.scratch.data();
+					writer.defaults = nullptr;
+					writer.per_track_policies = nullptr;
+					w.context.seek(sample_times[i], acl::sample_rounding_policy::none);
+					w.context.decompress_tracks(writer);
+				}
+				return k_poses_per_step;
+			};
+		};
+		return bench_harness::run_timed(num_threads, seconds, pin != 0, make_worker, out_total_poses);
 	}
 }

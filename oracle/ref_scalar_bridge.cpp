@@ -12,10 +12,13 @@
 #include <acl/decompression/decompress.h>
 #include <acl/decompression/decompression_settings.h>
 
+#include "bench_harness.h"
+
 #include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -201,5 +204,57 @@ extern "C"
 		for (std::thread& t : threads)
 			t.join();
 		return std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count() / double(repeats);
+	}
+
+	// The pinned, time based variant (oracle/bench_harness.h), see aclref_bench_timed in ref_bridge.cpp. Returns track lists per second.
+	double aclref_scalar_bench_timed(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+		uint32_t max_row_floats, uint32_t num_threads, double seconds, int pin, uint64_t* out_total)
+	{
+		if (count == 0)
+			return 0.0;
+		if (num_threads == 0)
+			num_threads = 1;
+		auto make_worker = [&](uint32_t thread_index)
+		{
+			struct worker_state
+			{
+				std::vector<float> scratch;
+				acl::decompression_context<default_settings> context;
+				const void* bound = nullptr;
+				uint32_t begin = 0, end = 0, cursor = 0;
+			};
+			std::shared_ptr<worker_state> state = std::make_shared<worker_state>();
+			state->scratch.resize(max_row_floats + 4);
+			state->begin = uint32_t((uint64_t(count) * thread_index) / num_threads);
+			state->end = uint32_t((uint64_t(count) * (thread_index + 1)) / num_threads);
+			if (state->end == state->begin)
+			{
+				state->begin = thread_index % count;
+				state->end = state->begin + 1;
+			}
+			state->cursor = state->begin;
+			return [state, blobs, clip_indices, sample_times]() -> uint64_t
+			{
+				worker_state& w = *state;
+				constexpr uint32_t k_lists_per_step = 32;
+				for (uint32_t k = 0; k < k_lists_per_step; ++k)
+				{
+					const uint32_t i = w.cursor;
+					w.cursor = w.cursor + 1 == w.end ? w.begin : w.cursor + 1;
+					const void* blob = blobs[clip_indices[i]];
+					if (blob != w.bound)
+					{
+						w.context.initialize(*static_cast<const acl::compressed_tracks*>(blob));
+						w.bound = blob;
+					}
+					scalar_writer writer;
+					writer.out = w.scratch.data();
+					w.context.seek(sample_times[i], acl::sample_rounding_policy::none);
+					w.context.decompress_tracks(writer);
+				}
+				return k_lists_per_step;
+			};
+		};
+		return bench_harness::run_timed(num_threads, seconds, pin != 0, make_worker, out_total);
 	}
 }

@@ -102,6 +102,22 @@ def load_database_golden(name):
     return case
 
 
+def load_bench_database():
+    """tests/golden/bench/database_64_clips_100_bones.npz (make_bench_database.py): BASELINE.json configs[4] as written --
+    64 clips bound to one database built by the reference's build_database with its default tier proportions."""
+    from acl_amd import synth
+
+    def aligned(array):
+        out = synth.aligned_bytes(max(array.size, 1))
+        out[: array.size] = array
+        return out[: array.size] if array.size else out[:0]
+
+    data = np.load(os.path.join(GOLDEN_DIR, "bench", "database_64_clips_100_bones.npz"))
+    offsets = data["clip_offsets"]
+    return {"clips": [aligned(data["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)],
+            "database": aligned(data["database"]), "bulk_medium": aligned(data["bulk_medium"]), "bulk_low": aligned(data["bulk_low"])}
+
+
 # ---- scalar track list fixtures (tests/golden/scalar/*.npz, see make_golden_scalar.py) ----
 SCALAR_GOLDEN_DIR = os.path.join(GOLDEN_DIR, "scalar")
 

@@ -1,0 +1,98 @@
+"""The N > 1 path with real device memory on the ONE GPU the test box has: several processes share cuda:0 (gloo carries the control
+messages), every rank decodes its shard with its own aclhip context and the shards are gathered
+  * by peer writes into rank 0's buffer (aclhip_peer_* / sharding.PeerGather: HIP IPC mapping + device to device copies), and
+  * through bench.py's own N > 1 control flow (ACLHIP_BENCH_BACKEND=gloo dry run of `torchrun bench.py --gpus N`).
+On an 8-GPU node the same code runs one rank per GPU over RCCL / xGMI. Needs a GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _peer_worker(rank, world_size, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from acl_amd import runtime, sharding, synth
+        from oracle import bindings as ob
+
+        clip = synth.build_clip(seed=9, num_tracks=61, num_samples=50, has_scale=1)
+        num_instances = 1000 * world_size
+        rng = np.random.default_rng(99)                  # same instance list on every rank
+        times = rng.uniform(0.0, clip.duration, size=num_instances).astype(np.float32)
+        begin, end = sharding.shard_bounds(num_instances, rank, world_size)
+
+        context = runtime.Context(0)
+        handle = context.register_clip(clip.blob)
+        device = torch.device("cuda", 0)
+        d_clips = torch.full((end - begin,), handle, dtype=torch.int32, device=device)
+        d_times = torch.from_numpy(times[begin:end]).to(device)
+        d_shard = torch.zeros((end - begin, clip.num_tracks, 12), dtype=torch.float32, device=device)
+        stream = torch.cuda.current_stream(device)
+        shard_bytes = d_shard.numel() * 4
+        gather = sharding.PeerGather(context, shard_bytes, rank, world_size, dst=0, device=device)
+        for _ in range(2):      # the mapping is reused batch after batch
+            context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), end - begin, d_shard.data_ptr(), clip.num_tracks * 48, stream=stream.cuda_stream)
+            gather.push(d_shard.data_ptr(), stream=stream.cuda_stream)
+            stream.synchronize()
+            dist.barrier()
+            if rank == 0:
+                gathered = gather.gathered.cpu().numpy().view(np.float32).reshape(num_instances, clip.num_tracks, 12)
+                expected = ob.oracle_decompress_tracks_batch([clip.blob], np.zeros(num_instances, dtype=np.uint32), times, clip.num_tracks)
+                assert np.array_equal(gathered.view(np.uint32), expected.view(np.uint32))
+                gather.gathered.zero_()
+            dist.barrier()
+        gather.close()
+        context.unregister_clip(handle)
+        context.close()
+        open(os.path.join(result_dir, f"peer_ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size", [2, 4])
+def test_peer_gather_between_processes(tmp_path, world_size):
+    import torch.multiprocessing as mp
+    mp.spawn(_peer_worker, args=(world_size, _free_port(), str(tmp_path)), nprocs=world_size, join=True)
+    assert all(os.path.exists(tmp_path / f"peer_ok{rank}") for rank in range(world_size))
+
+
+@pytest.mark.parametrize("world_size,workload,instances", [(2, "one_clip", 8192), (8, "cinematic", 1024), (4, "database", 4096)])
+def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, instances):
+    """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` exactly as the driver launches it, ranks sharing the one
+    GPU (ACLHIP_BENCH_BACKEND=gloo): the line must carry the whole-job rate and both gathers, timed separately from the decode."""
+    env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--workload", workload, "--instances", str(instances), "--gather", "both"]
+    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert completed.returncode == 0, completed.stderr[-3000:]
+    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, completed.stdout[-2000:]
+    result = json.loads(lines[0])
+    assert result["n_gpus"] == world_size and result["scaling"] == "weak" and result["value"] > 0
+    assert result["config"]["instances_per_gpu"] == instances
+    gather = result["gather"]
+    assert "p2p_error" not in gather and "rccl_all_gather_error" not in gather, gather
+    assert gather["p2p_to_rank0_ms"] > 0 and gather["rccl_all_gather_ms"] > 0
+    assert gather["shard_bytes"] == instances * result["config"]["pose_bytes"]

@@ -65,6 +65,32 @@ def test_targeted_corruptions_are_refused_with_a_reason():
     assert runtime.check_clip(_patched(curves.blob, 52, "<B", 99), check_hash=False)[0] != 0    # first bit rate
 
 
+def test_segment_offsets_near_uint32_max_do_not_wrap_into_the_buffer():
+    """segment_header::segment_data is an untrusted 32 bit offset: values near 2^32 used to wrap past the bounds check
+     and the registration then read 4 GiB out of bounds."""
+    for name in ("raw_and_constant_rates", "cmu_100", "single_segment", "stripped", "cinematic_300"):
+        clip = synth.build_clip(**CLIP_SPECS[name])
+        blob = clip.blob
+        transform_header = 32
+        num_segments, = struct.unpack_from("<I", blob, transform_header)
+        segment_headers_offset, = struct.unpack_from("<I", blob, transform_header + 36)
+        first = transform_header + segment_headers_offset
+        for segment in range(min(num_segments, 3)):
+            for size in (16, 20):
+                at = first + segment * size + 12        # segment_data is the last u32 of segment_header (both variants start with it)
+                if at + 4 > blob.size:
+                    continue
+                for value in (0xFFFFFFDF, 0xFFFFFFFF, 0xFFFFFF00, 0x80000000, blob.size, blob.size - 1):
+                    status, message = runtime.check_clip(_patched(blob, at, "<I", value), check_hash=False)
+                    # a patched field that is not segment_data (wrong header size guess) may leave a valid clip: never a crash
+                    assert status in (0, 2, 3), (name, segment, size, hex(value), message)
+        # the exact field of the first segment: it must be refused
+        offset_of_segment_data = first + 12
+        for value in (0xFFFFFFDF, 0xFFFFFFFF, 0xFFFFFF00, 0x80000000):
+            status, message = runtime.check_clip(_patched(blob, offset_of_segment_data, "<I", value), check_hash=False)
+            assert status == 2 and "outside" in message, (name, hex(value), message)
+
+
 def test_database_corruptions_are_refused():
     case = helpers.load_database_golden("three_clips_4k_chunks")
     database, medium, low = case["database"], case["bulk_medium"], case["bulk_low"]

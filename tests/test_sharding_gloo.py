@@ -62,6 +62,77 @@ def test_two_ranks_shard_and_all_gather(tmp_path, num_instances):
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
 
 
+def test_eight_ranks_shard_and_all_gather(tmp_path):
+    """the node shape of BASELINE.json configs[3] / [4]: 8 ranks, shards that differ by one instance (43 = 8 * 5 + 3)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(8, port, 43, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{rank}") for rank in range(8))
+
+
+class _PeerContext:
+    """stands in for runtime.Context on a box without GPUs: "device buffers" are host tensors, a peer handle is the name of a file
+    every process can map (what the HIP IPC handle is on the GPU box)"""
+
+    def __init__(self, directory):
+        self.directory = directory
+        self.mapped = {}
+
+    def peer_export_buffer(self, buffer_ptr):
+        name = b"gathered.bin"
+        return name + b"\0" * (72 - len(name))
+
+    def peer_open_buffer(self, handle):
+        path = os.path.join(self.directory, handle.rstrip(b"\0").decode())
+        mapped = np.memmap(path, dtype=np.uint8, mode="r+")
+        self.mapped[id(mapped)] = mapped
+        return id(mapped)
+
+    def peer_close_buffer(self, pointer):
+        self.mapped.pop(pointer).flush()
+
+    def push_poses_to_peer(self, peer_ptr, offset_bytes, shard, shard_bytes, stream=None):
+        self.mapped[peer_ptr][offset_bytes: offset_bytes + shard_bytes] = shard
+        self.mapped[peer_ptr].flush()
+
+
+def _peer_worker(rank, world_size, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        shard_bytes = 480
+        path = os.path.join(result_dir, "gathered.bin")
+        context = _PeerContext(result_dir)
+        if rank == 0:
+            np.zeros(world_size * shard_bytes, dtype=np.uint8).tofile(path)
+        dist.barrier()
+        gather = sharding.PeerGather(context, shard_bytes, rank, world_size, dst=0, device="cpu")
+        if rank == 0:
+            # the destination writes through its own buffer: stand in for it with the same mapping the others use
+            gather.target_ptr = context.peer_open_buffer(context.peer_export_buffer(0))
+        shard = np.full(shard_bytes, rank + 1, dtype=np.uint8)
+        gather.push(shard)
+        dist.barrier()
+        if rank == 0:
+            gathered = np.fromfile(path, dtype=np.uint8).reshape(world_size, shard_bytes)
+            assert (gathered == np.arange(1, world_size + 1, dtype=np.uint8)[:, None]).all()
+        gather.close()
+        open(os.path.join(result_dir, f"peer_ok{rank}"), "w").close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_gather_protocol_places_every_shard(tmp_path):
+    """sharding.PeerGather: handle broadcast from the destination, every rank pushes its shard to rank * shard_bytes"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_peer_worker, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert all(os.path.exists(tmp_path / f"peer_ok{rank}") for rank in range(4))
+
+
 class _RecordingContext:
     """stands in for runtime.Context on a box without GPUs: a database of 5 + 3 chunks whose residency is tracked like
     aclhip_database_stream_in / _out would (first `loaded` chunks of a tier are resident)"""
