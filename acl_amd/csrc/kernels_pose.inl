@@ -74,23 +74,124 @@
 		return default_quad(params, kind, track_index, value, out_store);
 	}
 
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+	__device__ __forceinline__ plan_entry load_plan_entry(const plan_entry* row, uint32_t ordinal)
+	{
+		const u32x2 raw = ((const ACLHIP_CONSTANT u32x2*)row)[ordinal];
+		return plan_entry{ raw.x, raw.y };
+	}
+
+	// Where the tables of a pose window's animated sub-tracks are and how its bit offsets start
+	struct window_tables
+	{
+		const plan_entry* plan;					// [num_segments][num_animated]
+		const clip_range_entry* clip_ranges;	// [num_animated]
+		const uint32_t* window_adjust;			// [num_segments][num_windows][4] or null (single window poses: a window local prefix sum IS the bit offset)
+		uint32_t num_animated;
+		uint32_t num_windows;
+		uint32_t window;
+		bool has_segment_ranges;				// num_segments > 1
+	};
+
+	__device__ __forceinline__ window_tables window_tables_of(const device_clip& clip, uint32_t window)
+	{
+		window_tables tables;
+		tables.plan = clip.plan;
+		tables.clip_ranges = clip.clip_ranges;
+		tables.num_animated = clip.num_animated;
+		tables.num_windows = (clip.num_tracks * 3u + k_image_chunk_quads - 1) / k_image_chunk_quads;
+		tables.window_adjust = tables.num_windows > 1 ? clip.image_chunks + ((tables.num_windows + 1 + 3) & ~3u) : nullptr;
+		tables.window = window;
+		tables.has_segment_ranges = clip.num_segments > 1;
+		return tables;
+	}
+
 	// Lanes <-> the animated sub-tracks [first_ordinal, end_ordinal) of one pose window, decoded into their quads of the window's LDS
-	// image (image[0] = quad first_quad of the pose). Most sample times fall between two keyframes of ONE segment: both keys then
-	// share a plan row and it is fetched once (a third less table traffic through the texture unit).
-	template<bool kSingleSegment, bool kPolicies>
-	__device__ __forceinline__ void decode_window_sub_tracks_with(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+	// image (image[0] = quad first_quad of the pose), 64 per pass. A pass:
+	//   1. every lane fetches its 8 byte plan entry (two when the keys straddle two segments -- most sample times fall between two
+	//      keyframes of ONE segment and its row is fetched once) and its clip range; the NEXT pass's entries are requested before this
+	//      pass's arithmetic starts, so a window of several passes pays one memory round trip for them, not one per pass;
+	//   2. bit offsets: a wavefront prefix sum over the widths (3 * num_bits bits per sub-track; the window's sub-tracks are in
+	//      bitstream order), carried from pass to pass in an SGPR, plus -- poses of several windows -- the window's per kind constant;
+	//   3. the keyframe bits of both keys (four loads in flight), 1 / (2^w - 1) from the table, unpack, ranges, W, lerp, normalize.
+	template<bool kPolicies>
+	__device__ __forceinline__ void decode_window_sub_tracks_with(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
 	{
+		if (first_ordinal >= end_ordinal)
+			return;
+
 		// kPolicies: per track rounding (and the sample normalization it implies)
 		const bool normalize_samples = kPolicies && normalization == ACLHIP_NORMALIZE_ALWAYS;
+		const bool single_segment = state.uses_single_segment;		// wave uniform
+		const plan_entry* plan_row0 = tables.plan + size_t(state.segment_index[0]) * tables.num_animated;
+		const plan_entry* plan_row1 = tables.plan + size_t(state.segment_index[1]) * tables.num_animated;
 
-		for (uint32_t animated_ordinal = first_ordinal + lane; animated_ordinal < end_ordinal; animated_ordinal += k_wave_size)
+		// poses of several windows: what a window local prefix sum lacks, per sub-track kind, for each key's segment (scalar loads)
+		u32x4 adjust0 = { 0, 0, 0, 0 }, adjust1 = { 0, 0, 0, 0 };
+		const bool multi_window = tables.window_adjust != nullptr;
+		if (multi_window)
 		{
-			const plan_entry plan0 = load_entry(state.plan[0], animated_ordinal);
-			const plan_entry plan1_loaded = kSingleSegment ? plan0 : load_entry(state.plan[1], animated_ordinal);
-			const plan_entry& plan1 = kSingleSegment ? plan0 : plan1_loaded;
-			const clip_range_entry clip_range = load_entry(clip_ranges, animated_ordinal);
-			const bool is_rotation = is_rotation_entry(clip_range);
+			const ACLHIP_CONSTANT u32x4* adjust = (const ACLHIP_CONSTANT u32x4*)tables.window_adjust;
+			adjust0 = adjust[size_t(state.segment_index[0]) * tables.num_windows + tables.window];
+			adjust1 = adjust[size_t(state.segment_index[1]) * tables.num_windows + tables.window];
+		}
+
+		uint32_t carry0 = 0, carry1 = 0;		// bits of the window's sub-tracks before this pass (wave uniform)
+
+		uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
+		plan_entry entry0 = load_plan_entry(plan_row0, ordinal);
+		plan_entry entry1 = single_segment ? entry0 : load_plan_entry(plan_row1, ordinal);
+		clip_range_entry clip_range = load_entry(tables.clip_ranges, ordinal);
+
+		for (uint32_t base = first_ordinal; base < end_ordinal; base += k_wave_size)
+		{
+			const bool valid = base + lane < end_ordinal;
+			const plan_entry current0 = entry0, current1 = entry1;
+			const clip_range_entry current_range = clip_range;
+
+			// the next pass's table entries travel while this pass computes
+			if (base + k_wave_size < end_ordinal)
+			{
+				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
+				entry0 = load_plan_entry(plan_row0, ordinal);
+				entry1 = single_segment ? entry0 : load_plan_entry(plan_row1, ordinal);
+				clip_range = load_entry(tables.clip_ranges, ordinal);
+			}
+
+			const bool is_rotation = is_rotation_entry(current_range);
+			const uint32_t kind = current_range.quad_index - current_range.track_index * 3u;
+
+			sub_track_key key0, key1;
+			expand_plan_entry(current0, tables.has_segment_ranges, key0);
+			if (single_segment)
+				key1 = key0;
+			else
+				expand_plan_entry(current1, tables.has_segment_ranges, key1);
+
+			// bit offsets: prefix sum of the widths (raw = 96 bits, constant in the segment = none)
+			const uint32_t bits0 = valid ? key0.num_bits * 3u : 0u;
+			const uint32_t inclusive0 = wave_inclusive_scan(bits0);
+			uint32_t relative0 = carry0 + (inclusive0 - bits0);
+			carry0 += __builtin_amdgcn_readlane(inclusive0, 63);
+			uint32_t relative1 = relative0;
+			if (!single_segment)
+			{
+				const uint32_t bits1 = valid ? key1.num_bits * 3u : 0u;
+				const uint32_t inclusive1 = wave_inclusive_scan(bits1);
+				relative1 = carry1 + (inclusive1 - bits1);
+				carry1 += __builtin_amdgcn_readlane(inclusive1, 63);
+			}
+			if (multi_window)
+			{
+				relative0 += kind == 0 ? adjust0.x : (kind == 1 ? adjust0.y : adjust0.z);
+				relative1 += kind == 0 ? adjust1.x : (kind == 1 ? adjust1.y : adjust1.z);
+			}
+			key0.bit_offset = state.key_frame_bit_offsets[0] + relative0;
+			key1.bit_offset = state.key_frame_bit_offsets[1] + relative1;
+			key0.inv_max_value = ((const ACLHIP_CONSTANT float*)k_inv_max_value)[key0.num_bits];
+			key1.inv_max_value = single_segment ? key0.inv_max_value : ((const ACLHIP_CONSTANT float*)k_inv_max_value)[key1.num_bits];
 
 			uint32_t policy = k_round_none;
 			if (kPolicies)
@@ -98,39 +199,32 @@
 				// track_writer::get_rounding_policy (core/track_writer.h:97)
 				policy = rounding_policy;
 				if (rounding_policy == k_round_per_track)
-					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[clip_range.track_index] : k_round_none;
+					policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[current_range.track_index] : k_round_none;
 			}
 
 			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
-			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+			const bool has_raw = __any(int(key0.num_bits == 32u || key1.num_bits == 32u)) != 0;
 
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<false, kPolicies>(state, key0, key1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 			else
-				value = decode_animated_sub_track<true, kPolicies>(state, plan0, plan1, clip_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<true, kPolicies>(state, key0, key1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
-			const f32x4 packed = { value.x, value.y, value.z, value.w };
-			image[clip_range.quad_index - first_quad] = packed;
+			if (valid)
+				image[current_range.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
 		}
 	}
 
 	template<bool kAnySettings>
-	__device__ __forceinline__ void decode_window_sub_tracks(const clip_range_entry* __restrict__ clip_ranges, const seek_state& state, const decode_params& params,
+	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
 	{
 		if (kAnySettings && params.per_track_rounding != 0)
-		{
-			if (state.uses_single_segment)
-				decode_window_sub_tracks_with<true, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
-			else
-				decode_window_sub_tracks_with<false, true>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
-		}
-		else if (state.uses_single_segment)
-			decode_window_sub_tracks_with<true, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			decode_window_sub_tracks_with<true>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 		else
-			decode_window_sub_tracks_with<false, false>(clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			decode_window_sub_tracks_with<false>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -241,7 +335,7 @@
 		}
 
 		// lanes <-> animated sub-tracks of this window
-		decode_window_sub_tracks<kAnySettings>(clip.clip_ranges, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip, window), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -249,9 +343,69 @@
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults)
+		{
+			// Compact layouts, nothing else skipped (the common use): the window is RE-TILED on its way out -- lanes <-> consecutive 16 byte
+			// pieces of the OUTPUT, gathered from the QVV48 image in LDS -- so that every store instruction still writes 1 KiB of
+			// contiguous HBM. Windows hold whole tracks (k_image_chunk_quads is a multiple of 3) and an even number of them, so a window's
+			// output starts 16 byte aligned in both layouts. (Storing per image quad instead leaves holes between the lanes of a store:
+			// 76 us instead of 33 us for the QV32 headline batch, partial cache lines at both ends of every instruction.)
+			const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
+			const uint32_t first_track = first_quad / 3u;
+			const uint32_t window_tracks = window_quads / 3u;
+			if (params.layout == ACLHIP_LAYOUT_QV32)
+			{
+				f32x4* out = reinterpret_cast<f32x4*>(poses + uint64_t(row) * pose_stride_bytes + size_t(first_track) * 32);
+				const uint32_t out_quads = window_tracks * 2u;
+				constexpr uint32_t k_out_rows = (k_image_chunk_quads / 3u * 2u + k_wave_size - 1) / k_wave_size;
+				f32x4 staged_out[k_out_rows];
+				#pragma unroll
+				for (uint32_t r = 0; r < k_out_rows; ++r)
+				{
+					const uint32_t piece = min(r * k_wave_size + lane, out_quads - 1);
+					staged_out[r] = image[(piece >> 1) * 3u + (piece & 1u)];
+				}
+				#pragma unroll
+				for (uint32_t r = 0; r < k_out_rows; ++r)
+					if (r * k_wave_size + lane < out_quads)
+						store_streaming(&out[r * k_wave_size + lane], staged_out[r]);
+			}
+			else
+			{
+				// QVV40: float f of a track's 10 comes from float f + (f >= 7) of its QVV48 record (the padding lane of the translation is dropped)
+				float* out = reinterpret_cast<float*>(poses + uint64_t(row) * pose_stride_bytes + size_t(first_track) * 40);
+				const float* image_floats = reinterpret_cast<const float*>(image);
+				const uint32_t out_floats = window_tracks * 10u;
+				constexpr uint32_t k_out_rows = (k_image_chunk_quads / 3u * 10u / 4u + k_wave_size) / k_wave_size;
+				#pragma unroll
+				for (uint32_t r = 0; r < k_out_rows; ++r)
+				{
+					const uint32_t first_float = (r * k_wave_size + lane) * 4u;
+					float piece[4];
+					#pragma unroll
+					for (uint32_t j = 0; j < 4; ++j)
+					{
+						const uint32_t f = min(first_float + j, out_floats - 1);
+						const uint32_t track = f / 10u;
+						const uint32_t component = f - track * 10u;
+						piece[j] = image_floats[track * 12u + component + (component >= 7u ? 1u : 0u)];
+					}
+					if (first_float + 4u <= out_floats)
+						store_streaming_floats<4>(out + first_float, piece);
+					else if (first_float + 2u <= out_floats)
+					{
+						// an odd number of tracks ends on half a piece
+						const float half[2] = { piece[0], piece[1] };
+						store_streaming_floats<2>(out + first_float, half);
+					}
+				}
+			}
+			return;
+		}
+
 		// LDS -> registers -> HBM: the whole window is read first, then the stores go out back to back from one base address with
 		// immediate offsets; full 1 KiB rows take no per lane predicate, only the last (partial) row does
-		constexpr uint32_t k_rows = k_image_chunk_quads / k_wave_size;
+		constexpr uint32_t k_rows = (k_image_chunk_quads + k_wave_size - 1) / k_wave_size;
 		const uint32_t full_rows = window_quads / k_wave_size;			// wave uniform
 		f32x4 staged[k_rows];
 		#pragma unroll
@@ -343,13 +497,13 @@
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count
 	#define ACLHIP_POSE_KERNEL_FORWARD clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count
 
-	__global__ __launch_bounds__(k_block_size) void decompress_tracks_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_window<false, false>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
-	__global__ __launch_bounds__(k_block_size) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}

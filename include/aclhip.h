@@ -235,7 +235,7 @@ aclhip_status aclhip_strip_database_tier(const void* compressed_database, uint64
  * with writer.write_rotation/translation/scale storing into
  *     (char*)poses + i * pose_stride_bytes + track_index * 48.
  * clips / sample_times / poses are DEVICE pointers; pose_stride_bytes must be a multiple of 16 and at least
- * 48 * num_tracks of the largest clip referenced. One wavefront decodes one window of 320 pose quads (106 tracks) of one instance. */
+ * 48 * num_tracks of the largest clip referenced. One wavefront decodes one window of 318 pose quads (106 tracks) of one instance. */
 aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream);
 

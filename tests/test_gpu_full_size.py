@@ -163,9 +163,10 @@ def test_database_tiers_streamed_in_while_batches_run(setup):
     times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
     stream = torch.cuda.Stream(device)
 
-    # (stream_in?, tier, num_chunks): chunk by chunk, a partial stream_out that leaves a hole, everything, a request with nothing left
+    # (stream_in?, tier, num_chunks): chunk by chunk, a partial stream_out that leaves a hole (the reference does not refill holes,
+    # database.impl.h:478-497), the rest, requests with nothing left to do, everything out and back in
     schedule = [None, (True, 2, 1), (True, 2, 1), (True, 2, 3), (True, 2, 5), (False, 2, 4), (True, 2, 2), (True, 2, 0xFFFFFFFF),
-                (True, 1, 0xFFFFFFFF), (True, 2, 0xFFFFFFFF)]
+                (True, 1, 0xFFFFFFFF), (True, 2, 0xFFFFFFFF), (False, 2, 0xFFFFFFFF), (True, 2, 0xFFFFFFFF)]
     previous = None
     for request in schedule:
         moved = 0
