@@ -43,21 +43,20 @@ namespace aclhip
 		uint32_t segment_and_local;		// segment index << 5 | index of the sample inside its segment (a segment holds at most 32 samples)
 	};
 
-	// One per (segment, animated sub-track), 8 bytes: the sub-track's bit width in that segment and its segment range as the blob
-	// stores it -- six bytes, expanded in-lane to float(u8) * (1/255) exactly as the reference does per pose
-	// (animated_track_cache.transform.h:188-196, math/vector4_packing.h:781-818). Widths: 1..23 = quantized, 32 = raw fp32 (ranges
-	// ignored), 0 = constant in the segment: nothing is read from the keyframes, the six bytes ARE the sample, 3 x u16
-	// (animated_track_cache.transform.h:552-588, math/vector4_packing.h:628-653; stored here as x | y << 16 | z << 32 whatever the
-	// blob's byte order for the sub-track kind). WHERE the bits of a sub-track sit inside a keyframe is not stored: the sub-tracks of
-	// a pose window are laid out in bitstream order (rotations, translations, scales; by track inside a kind), so the bit offset is a
-	// wavefront prefix sum over the widths (decode_window_sub_tracks) -- the CPU's serial count_animated_group_bit_size
-	// (animated_track_cache.transform.h:1105-1192) as one DPP scan. 32 bytes per entry in round 1 (offset, 1/(2^w-1) and the ranges as
-	// floats): a batch that draws on hundreds of clips fetches a plan row per pose and a quarter of the bytes is a quarter of the
-	// L2 misses.
-	struct alignas(8) plan_entry
+	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
+	// how to expand them, ready to use. Widths: 1..23 = quantized, 0 = constant in the segment (the 16 bit sample is pre-converted into
+	// range_min, range_extent = 0, nothing is read), 32 = raw fp32 (ranges ignored).
+	// Segment range values are float(u8) * (1/255) exactly as the reference computes them per pose
+	// (animated_track_cache.transform.h:188-196, math/vector4_packing.h:781-818); single segment clips get min 0 / extent 1.
+	// (Round 2 measured the compact alternative -- 8 byte entries expanded in-lane, bit offsets from a wavefront prefix sum over the
+	// widths: it halves the L2 miss traffic of mixed-clip batches and costs ~58 VALU instructions per 64 sub-tracks, which these
+	// VALU-issue-bound kernels pay in full: +11 % on one clip, +43 % on the 300-bone rig. profiles/r02_experiment_compact_plan_tables.txt)
+	struct alignas(16) plan_entry
 	{
-		uint32_t width_and_range_lo;	// num_bits | range byte 0 << 8 | byte 1 << 16 | byte 2 << 24      (bytes 0..2: min.xyz)
-		uint32_t range_hi;				// range byte 3 | byte 4 << 8 | byte 5 << 16                          (bytes 3..5: extent.xyz)
+		uint32_t bit_offset_and_width;	// bit offset inside the keyframe (low 24 bits) | num_bits << 24
+		float inv_max_value;			// 1 / (2^num_bits - 1) (math/vector4_packing.h:927-935); 0 for width 0 (nothing is read), 1 for width 32
+		float range_min[3];
+		float range_extent[3];
 	};
 
 	// One per animated sub-track, 32 bytes: clip range (AOS copy of the blob's clip range data, which is SOA per group of 4
@@ -82,14 +81,17 @@ namespace aclhip
 
 	static_assert(sizeof(scalar_track_header) == 8, "layout");
 	static_assert(sizeof(sample_record) == 16, "layout");
-	static_assert(sizeof(plan_entry) == 8, "layout");
+	static_assert(sizeof(plan_entry) == 32, "layout");
 	static_assert(sizeof(clip_range_entry) == 32, "layout");
 
-	// Animated sub-tracks are numbered by destination window: the ones that land in a window of k_image_chunk_quads consecutive
-	// quads form a contiguous range of ordinals, in bitstream order inside the window (rotations, translations, scales; by track).
+	// Animated sub-tracks are numbered by destination, not in bitstream order: the ones that land in a window of
+	// k_image_chunk_quads consecutive quads form a contiguous range of ordinals, rotations first.
 	// 318 = 106 whole tracks: a window never splits a track, and its first track is even -- what the compact output layouts
 	// need for windows that start 16 byte aligned (kernels_pose.inl)
-	constexpr uint32_t k_image_chunk_quads = 318;
+#if !defined(ACLHIP_WINDOW_QUADS)
+	#define ACLHIP_WINDOW_QUADS 312
+#endif
+	constexpr uint32_t k_image_chunk_quads = ACLHIP_WINDOW_QUADS;
 
 	__device__ __forceinline__ bool is_rotation_entry(const clip_range_entry& entry) { return entry.quad_index == entry.track_index * 3u; }
 
@@ -106,7 +108,7 @@ namespace aclhip
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
 		const sample_record* samples;			// [num_samples]
 		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
-		const plan_entry* plan;					// [num_segments][num_animated], followed by uint32_t bit_offsets[num_segments][num_animated] (single track requests); scalar clips: scalar_track_header[num_tracks]
+		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
 		const clip_range_entry* clip_ranges;	// [num_animated]; scalar clips: float[num_tracks][2 * C] range rows
 		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
 		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
@@ -119,8 +121,7 @@ namespace aclhip
 		uint32_t num_segments;
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
 		uint32_t db_clip_header_offset;			// into db_headers
-		const uint32_t* image_chunks;			// [W + 1 padded to 4] first animated ordinal of every pose window (W = ceil(3 * num_tracks / k_image_chunk_quads)), followed,
-												// when W > 1, by uint32_t window_adjust[num_segments][W][4]: what to add to a window local prefix sum of widths (per sub-track kind)
+		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
 		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: walk schedules for 1 / 2 / 4 / 8 instances per workgroup; or null
 	};
 
@@ -182,14 +183,18 @@ namespace aclhip
 	// non-temporal hint (global_store ... sc0 sc1 nt) the write stream passes through the XCD's 4 MB L2 without evicting what the
 	// decode keeps re-reading there -- clip records, table rows, keyframes. A batch that draws on 256 clips (30 MB of clip data)
 	// takes 62 us instead of 94 us, a single-clip batch is unchanged (50 us); nt alone costs the single-clip batch 10 us, sc0 / sc1
-	// alone change nothing. No builtin emits this combination, hence the inline assembly.
+	// alone change nothing. No builtin emits this combination for global stores, hence the inline assembly -- which hides
+	// from the compiler that these ARE stores: a VMEM store of more than 8 bytes reads its data VGPRs for two more cycles on gfx940+
+	// and a VALU write to them in that window corrupts what is stored (the compiler pads its own stores with s_nop 1; it cannot see
+	// inside an asm). Every store below therefore carries its own `s_nop 1`. Found the hard way: the compact-output kernel reused a
+	// data register one instruction after a store and wrote the loop counter into rotation.x under load.
 	typedef float f32x4_store __attribute__((ext_vector_type(4)));
 	typedef float f32x3_store __attribute__((ext_vector_type(3)));
 	typedef float f32x2_store __attribute__((ext_vector_type(2)));
 
 	__device__ __forceinline__ void store_streaming(void* address, f32x4_store value)
 	{
-		asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(address), "v"(value) : "memory");
+		asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(value) : "memory");
 	}
 
 	// C packed floats (4 byte aligned)
@@ -202,9 +207,9 @@ namespace aclhip
 		else if constexpr (C == 2)
 			asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" :: "v"(address), "v"(f32x2_store{ value[0], value[1] }) : "memory");
 		else if constexpr (C == 3)
-			asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt" :: "v"(address), "v"(f32x3_store{ value[0], value[1], value[2] }) : "memory");
+			asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(f32x3_store{ value[0], value[1], value[2] }) : "memory");
 		else
-			asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" :: "v"(address), "v"(f32x4_store{ value[0], value[1], value[2], value[3] }) : "memory");
+			asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(f32x4_store{ value[0], value[1], value[2], value[3] }) : "memory");
 	}
 
 	// One 16 byte sample record in a single (scalar, when the index is wave uniform) load
@@ -362,83 +367,20 @@ namespace aclhip
 		return v;
 	}
 
-	// 1 / (2^num_bits - 1) (PackedTableEntry::max_value reciprocal, math/vector4_packing.h:927-935); [0] (constant in segment: nothing is
-	// read, the quantized value is 0) = 0, [32] (raw) = 1. A 132 byte table every lane indexes with its width: L1 resident.
-	__device__ __constant__ const float k_inv_max_value[33] = {
-		0.0f, 1.0f / 1.0f, 1.0f / 3.0f, 1.0f / 7.0f, 1.0f / 15.0f, 1.0f / 31.0f, 1.0f / 63.0f, 1.0f / 127.0f, 1.0f / 255.0f, 1.0f / 511.0f, 1.0f / 1023.0f, 1.0f / 2047.0f,
-		1.0f / 4095.0f, 1.0f / 8191.0f, 1.0f / 16383.0f, 1.0f / 32767.0f, 1.0f / 65535.0f, 1.0f / 131071.0f, 1.0f / 262143.0f, 1.0f / 524287.0f, 1.0f / 1048575.0f,
-		1.0f / 2097151.0f, 1.0f / 4194303.0f, 1.0f / 8388607.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f };
-
-	// Inclusive prefix sum over the 64 lanes of a wave, every lane active: four row_shr steps inside the rows of 16 lanes, then
-	// row_bcast:15 / row_bcast:31 carry the row totals across (DPP, no LDS). This is how per sub-track bit widths become bit offsets.
-	__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t value)
-	{
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x111, 0xF, 0xF, true));		// row_shr:1, lanes shifted in from outside a row read 0
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x112, 0xF, 0xF, true));		// row_shr:2
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x114, 0xF, 0xF, true));		// row_shr:4
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x118, 0xF, 0xF, true));		// row_shr:8
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x142, 0xA, 0xF, false));		// row_bcast:15 into rows 1 and 3
-		value += uint32_t(__builtin_amdgcn_update_dpp(0, int(value), 0x143, 0xC, 0xF, false));		// row_bcast:31 into rows 2 and 3
-		return value;
-	}
-
-	// What a lane knows about one key of its animated sub-track once the plan entry is expanded
-	struct sub_track_key
-	{
-		uint32_t num_bits;			// 0 (constant in the segment), 1..23, 32 (raw)
-		uint32_t bit_offset;		// of the sub-track's first bit, from the start of the key's data source (keyframe offset included)
-		float inv_max_value;
-		float range_min[3];			// segment range as floats; constant in the segment: the sample itself, extent 0
-		float range_extent[3];
-	};
-
-	// plan_entry -> widths and float ranges, the reference's own conversions: float(u8) * (1 / 255) for ranges
-	// (animated_track_cache.transform.h:188-196), float(u16) * (1 / 65535) for a sample that is constant in its segment (:552-588).
-	// has_segment_ranges is wave uniform: single segment clips carry no segment range data and decode as v * 1 + 0 (exact for v >= +0).
-	__device__ __forceinline__ void expand_plan_entry(const plan_entry& entry, bool has_segment_ranges, sub_track_key& out)
-	{
-		const uint32_t lo = entry.width_and_range_lo, hi = entry.range_hi;
-		out.num_bits = lo & 0xFFu;
-		if (!has_segment_ranges)
-		{
-			#pragma unroll
-			for (uint32_t c = 0; c < 3; ++c)
-			{
-				out.range_min[c] = 0.0f;
-				out.range_extent[c] = 1.0f;
-			}
-			return;
-		}
-
-		const bool is_constant = out.num_bits == 0;
-		// bytes 1..3 of lo, 0..2 of hi (v_cvt_f32_ubyteN); the constant sample: bits [8, 24) of lo, [24, 40) of hi:lo, [8, 24) of hi
-		const float min8[3] = { float((lo >> 8) & 0xFFu), float((lo >> 16) & 0xFFu), float(lo >> 24) };
-		const float extent8[3] = { float(hi & 0xFFu), float((hi >> 8) & 0xFFu), float((hi >> 16) & 0xFFu) };
-		const float sample16[3] = { float(__builtin_amdgcn_ubfe(lo, 8, 16)), float(__builtin_amdgcn_alignbit(hi, lo, 24) & 0xFFFFu), float(__builtin_amdgcn_ubfe(hi, 8, 16)) };
-		const float min_scale = is_constant ? 1.0f / 65535.0f : 1.0f / 255.0f;
-		const float extent_scale = is_constant ? 0.0f : 1.0f / 255.0f;
-		#pragma unroll
-		for (uint32_t c = 0; c < 3; ++c)
-		{
-			out.range_min[c] = (is_constant ? sample16[c] : min8[c]) * min_scale;
-			out.range_extent[c] = extent8[c] * extent_scale;
-		}
-	}
-
 	// Both keyframes of one animated sub-track, range expanded: the bit unpack of math/vector4_packing.h:921-1035 (quantized) and
 	// :479-599 (raw), then the segment and clip range expansion of animated_track_cache.transform.h:302-350,391-466,930-960.
 	// All four bitstream loads are issued before any of them is used. kHasRaw = false compiles the raw fix-up out.
 	template<bool kHasRaw>
-	__device__ __forceinline__ void unpack_animated_samples(const seek_state& state, const sub_track_key& key0, const sub_track_key& key1,
+	__device__ __forceinline__ void unpack_animated_samples(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, float out_v0[3], float out_v1[3])
 	{
 		const ACLHIP_CONSTANT uint8_t* data0 = as_constant(state.animated_track_data[0]);
 		const ACLHIP_CONSTANT uint8_t* data1 = as_constant(state.animated_track_data[1]);
 
-		const uint32_t num_bits0 = key0.num_bits;
-		const uint32_t num_bits1 = key1.num_bits;
-		const uint32_t bit_offset0 = key0.bit_offset;
-		const uint32_t bit_offset1 = key1.bit_offset;
+		const uint32_t num_bits0 = plan0.bit_offset_and_width >> 24;
+		const uint32_t num_bits1 = plan1.bit_offset_and_width >> 24;
+		const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + (plan0.bit_offset_and_width & 0x00FFFFFFu);
+		const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + (plan1.bit_offset_and_width & 0x00FFFFFFu);
 		const uint32_t bit_offset_z0 = bit_offset0 + 2u * num_bits0;
 		const uint32_t bit_offset_z1 = bit_offset1 + 2u * num_bits1;
 
@@ -458,7 +400,7 @@ namespace aclhip
 			const uint32_t num_bits = key == 0 ? num_bits0 : num_bits1;
 			const uint32_t shift_xy = (key == 0 ? bit_offset0 : bit_offset1) & 7u;
 			const uint32_t shift_z = (key == 0 ? bit_offset_z0 : bit_offset_z1) & 7u;
-			const sub_track_key& plan = key == 0 ? key0 : key1;
+			const plan_entry& plan = key == 0 ? plan0 : plan1;
 
 			const uint32_t hi = __builtin_bswap32(uint32_t(window_xy));
 			const uint32_t lo = __builtin_bswap32(uint32_t(window_xy >> 32));
@@ -557,7 +499,7 @@ namespace aclhip
 	// `lerp_alpha` the alpha handed to the interpolation.
 	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
 	template<bool kHasRaw, bool kPolicies>
-	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const sub_track_key& plan0, const sub_track_key& plan1,
+	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
 		float v0[3], v1[3];

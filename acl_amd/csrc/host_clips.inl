@@ -205,7 +205,6 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	std::vector<clip_range_entry> clip_ranges(std::max<uint32_t>(num_animated, 1));
 	std::vector<sample_record> samples(std::max<uint32_t>(num_samples, 1));
 	std::vector<plan_entry> plan(std::max<size_t>(size_t(num_segments) * num_animated, 1));
-	std::vector<uint32_t> plan_bit_offsets(plan.size(), 0u);		// [segment][sub-track] bit offset inside a keyframe of that segment
 	std::memset(clip_ranges.data(), 0, clip_ranges.size() * sizeof(clip_range_entry));
 	std::memset(samples.data(), 0, samples.size() * sizeof(sample_record));
 	std::memset(plan.data(), 0, plan.size() * sizeof(plan_entry));
@@ -366,15 +365,19 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 				plan_entry& entry = plan[size_t(si) * num_animated + a];
 				const uint32_t num_bits = is_raw ? 32u : stored_bits;
-				plan_bit_offsets[size_t(si) * num_animated + a] = bit_offset;
+				entry.bit_offset_and_width = bit_offset | (num_bits << 24);
+				entry.inv_max_value = num_bits == 0 ? 0.0f : (is_raw ? 1.0f : 1.0f / float((1u << num_bits) - 1u));
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					entry.range_min[c] = 0.0f;
+					entry.range_extent[c] = 1.0f;
+				}
 				has_raw = has_raw || is_raw;
 
-				// the six segment range bytes as the blob holds them (min.xyz, extent.xyz); a sub-track that is constant in the segment
-				// keeps its 16 bit sample there instead, stored as x | y << 16 | z << 32 whatever the kind (expand_plan_entry)
-				uint8_t bytes[6] = { 0, 0, 0, 0, 0, 0 };
 				if (multi_segment && !is_raw)
 				{
-					// rotations SOA in padded groups of 4, translations / scales AOS (write_range_data.h:209-341)
+					// six bytes per sub-track: rotations SOA in padded groups of 4, translations / scales AOS (write_range_data.h:209-341)
+					uint8_t bytes[6];
 					if (is_rotation)
 					{
 						const uint8_t* group = range_data + size_t(a / 4) * 24 + (a % 4);
@@ -386,20 +389,24 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 					if (num_bits == 0)
 					{
-						// hi/lo split across the SOA rows for rotations (animated_track_cache.transform.h:552-588), little endian u16 for
-						// vectors (math/vector4_packing.h:628-653)
-						uint8_t canonical[6];
+						// constant in this segment: a 16 bit sample lives in the range bytes, hi/lo split across the SOA rows for rotations
+						// (animated_track_cache.transform.h:552-588), little endian u16 for vectors (math/vector4_packing.h:628-653)
 						for (uint32_t c = 0; c < 3; ++c)
 						{
 							const uint32_t sample = is_rotation ? ((uint32_t(bytes[c * 2]) << 8) | bytes[c * 2 + 1]) : ((uint32_t(bytes[c * 2 + 1]) << 8) | bytes[c * 2]);
-							canonical[c * 2] = uint8_t(sample & 0xFFu);
-							canonical[c * 2 + 1] = uint8_t(sample >> 8);
+							entry.range_min[c] = float(sample) * (1.0f / 65535.0f);
+							entry.range_extent[c] = 0.0f;
 						}
-						std::memcpy(bytes, canonical, 6);
+					}
+					else
+					{
+						for (uint32_t c = 0; c < 3; ++c)
+						{
+							entry.range_min[c] = float(bytes[c]) * (1.0f / 255.0f);
+							entry.range_extent[c] = float(bytes[3 + c]) * (1.0f / 255.0f);
+						}
 					}
 				}
-				entry.width_and_range_lo = num_bits | (uint32_t(bytes[0]) << 8) | (uint32_t(bytes[1]) << 16) | (uint32_t(bytes[2]) << 24);
-				entry.range_hi = uint32_t(bytes[3]) | (uint32_t(bytes[4]) << 8) | (uint32_t(bytes[5]) << 16);
 
 				bit_offset += num_bits * 3;
 			}
@@ -409,45 +416,40 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 	}
 
-	// ---- animated sub-tracks by pose WINDOW ----
-	// The tables above follow the bitstream (rotations, translations, scales; by track). A wave builds one window of
-	// k_image_chunk_quads consecutive quads, so the tables are reordered by destination window, keeping the bitstream order inside a
-	// window: the sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are a contiguous range of ordinals,
-	// image_chunks[c] .. image_chunks[c + 1], and their bit offsets inside a keyframe are a prefix sum over their widths plus one
-	// constant per (segment, window, kind) -- window_adjust, all zero (and left out) for poses of a single window.
+	// ---- animated sub-tracks in POSE order ----
+	// The tables above follow the bitstream (rotations, translations, scales); lanes do not care which sub-track they get, so the
+	// tables are reordered by destination window (and by kind inside a window). The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
+	// a contiguous range of ordinals, image_chunks[c] .. image_chunks[c + 1]: the pose kernel can build a pose of any size through
+	// a fixed LDS window.
 	const uint32_t num_image_chunks = std::max<uint32_t>((num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
 	std::vector<uint32_t> image_chunks(align_to_u32(num_image_chunks + 1, 4), num_animated);
-	std::vector<uint32_t> window_adjust;
 	if (num_animated != 0)
 	{
 		std::vector<uint32_t> order(num_animated);		// new ordinal -> bitstream ordinal
 		for (uint32_t a = 0; a < num_animated; ++a)
 			order[a] = a;
+		// inside a window rotations come first: the rotation math (two square roots, a division) is most of a lane's work and every
+		// pass that holds a rotation pays for it, so rotations are packed into as few passes as possible
 		const auto sort_key = [&](uint32_t ordinal)
 		{
 			const uint32_t quad = clip_ranges[ordinal].quad_index;
 			const uint64_t window = quad / k_image_chunk_quads;
-			const uint64_t kind = quad - clip_ranges[ordinal].track_index * 3;
-			return (window << 34) | (kind << 32) | quad;
+			const uint64_t is_vector = quad != clip_ranges[ordinal].track_index * 3 ? 1 : 0;
+			return (window << 33) | (is_vector << 32) | quad;
 		};
 		std::sort(order.begin(), order.end(), [&](uint32_t lhs, uint32_t rhs) { return sort_key(lhs) < sort_key(rhs); });
 
 		std::vector<clip_range_entry> ordered_ranges(num_animated);
 		std::vector<plan_entry> ordered_plan(plan.size());
-		std::vector<uint32_t> ordered_offsets(plan.size());
 		for (uint32_t a = 0; a < num_animated; ++a)
 		{
 			ordered_ranges[a] = clip_ranges[order[a]];
 			for (uint32_t si = 0; si < num_segments; ++si)
-			{
 				ordered_plan[size_t(si) * num_animated + a] = plan[size_t(si) * num_animated + order[a]];
-				ordered_offsets[size_t(si) * num_animated + a] = plan_bit_offsets[size_t(si) * num_animated + order[a]];
-			}
 			reinterpret_cast<uint32_t*>(base_pose.data())[size_t(ordered_ranges[a].quad_index) * 4 + 3] = k_quad_special | k_quad_animated | a;
 		}
 		std::memcpy(clip_ranges.data(), ordered_ranges.data(), size_t(num_animated) * sizeof(clip_range_entry));
 		plan.swap(ordered_plan);
-		plan_bit_offsets.swap(ordered_offsets);
 
 		uint32_t next = 0;
 		for (uint32_t chunk = 0; chunk < num_image_chunks; ++chunk)
@@ -456,40 +458,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 				next++;
 			image_chunks[chunk] = next;
 		}
-
-		// what a window local prefix sum of widths lacks: offset of the kind's first sub-track of the window minus the bits of the
-		// window's sub-tracks before it. Checked for every sub-track: the kernels trust it.
-		if (num_image_chunks > 1)
-			window_adjust.assign(size_t(num_segments) * num_image_chunks * 4, 0u);
-		for (uint32_t si = 0; si < num_segments; ++si)
-		{
-			for (uint32_t chunk = 0; chunk < num_image_chunks; ++chunk)
-			{
-				uint32_t prefix = 0;
-				uint32_t adjust[3] = { 0, 0, 0 };
-				bool seen[3] = { false, false, false };
-				for (uint32_t a = image_chunks[chunk]; a < image_chunks[chunk + 1]; ++a)
-				{
-					const uint32_t kind = clip_ranges[a].quad_index - clip_ranges[a].track_index * 3;
-					const uint32_t offset = plan_bit_offsets[size_t(si) * num_animated + a];
-					if (!seen[kind])
-					{
-						seen[kind] = true;
-						adjust[kind] = offset - prefix;
-					}
-					if (prefix + adjust[kind] != offset || (num_image_chunks == 1 && adjust[kind] != 0))
-						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: sub-track widths do not add up to the bit offsets", si);
-					prefix += (plan[size_t(si) * num_animated + a].width_and_range_lo & 0xFFu) * 3;
-				}
-				if (num_image_chunks > 1)
-					std::memcpy(&window_adjust[(size_t(si) * num_image_chunks + chunk) * 4], adjust, sizeof(adjust));
-			}
-		}
 	}
 	else
 		std::fill(image_chunks.begin(), image_chunks.end(), 0u);
-	if (window_adjust.empty() && num_image_chunks > 1)
-		window_adjust.assign(size_t(std::max<uint32_t>(num_segments, 1)) * num_image_chunks * 4, 0u);
 
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
@@ -506,11 +477,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	const uint64_t resolved_pose_offset = base_pose_offset + uint64_t(num_quads) * 16;
 	const uint64_t samples_offset = (resolved_pose_offset + uint64_t(num_quads) * 16 + 31) & ~uint64_t(31);
 	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
-	const uint64_t plan_bit_offsets_offset = plan_offset + plan.size() * sizeof(plan_entry);		// directly behind the plan: the kernels find it there
-	const uint64_t clip_ranges_offset = (plan_bit_offsets_offset + plan_bit_offsets.size() * sizeof(uint32_t) + 15) & ~uint64_t(15);
+	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
-	const uint64_t window_adjust_offset = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);		// directly behind the (padded) window table
-	const uint64_t total_bytes = window_adjust_offset + window_adjust.size() * sizeof(uint32_t) + 16;
+	const uint64_t total_bytes = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);
 	if (total_bytes > 0xFFFFFFFFull)
 		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "clip tables beyond 4 GiB are not supported");
 
@@ -522,11 +491,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
 	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
-	std::memcpy(staging.data() + plan_bit_offsets_offset, plan_bit_offsets.data(), plan_bit_offsets.size() * sizeof(uint32_t));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
 	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
-	if (!window_adjust.empty())
-		std::memcpy(staging.data() + window_adjust_offset, window_adjust.data(), window_adjust.size() * sizeof(uint32_t));
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
@@ -669,9 +635,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.info.has_stripped_keyframes = num_tracks != 0 && header.has_stripped_keyframes() ? 1 : 0;
 	entry.info.track_type = k_track_type_qvvf;
 	entry.info.num_components = 12;
-	// bytes a batch may read from this clip: the blob itself plus the registration time tables (the bit offset table only serves
-	// single track requests: the pose kernels never touch it)
-	entry.touched_bytes = total_bytes - 64 - 16 - plan_bit_offsets.size() * sizeof(uint32_t);
+	// bytes a batch may read from this clip: the blob itself plus the registration time tables
+	entry.touched_bytes = total_bytes - 64;
 	entry.pose_quads = num_quads;
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
 

@@ -22,7 +22,7 @@
 		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
 
 		if (num_quads <= k_image_chunk_quads)
-			decode_window_sub_tracks<false>(window_tables_of(clip, 0), state, params, rounding_policy, params.normalization, 0, clip.num_animated, 0, lane, image);
+			decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, 0, lane, image);
 		else
 		{
 			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
@@ -30,7 +30,7 @@
 			{
 				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
 				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
-				decode_window_sub_tracks<false>(window_tables_of(clip, window), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, 0, lane, image);
+				decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, 0, lane, image);
 			}
 		}
 	}

@@ -74,47 +74,34 @@
 		return default_quad(params, kind, track_index, value, out_store);
 	}
 
-	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-	__device__ __forceinline__ plan_entry load_plan_entry(const plan_entry* row, uint32_t ordinal)
-	{
-		const u32x2 raw = ((const ACLHIP_CONSTANT u32x2*)row)[ordinal];
-		return plan_entry{ raw.x, raw.y };
-	}
-
-	// Where the tables of a pose window's animated sub-tracks are and how its bit offsets start
+	// Where the tables of a pose window's animated sub-tracks are
 	struct window_tables
 	{
 		const plan_entry* plan;					// [num_segments][num_animated]
 		const clip_range_entry* clip_ranges;	// [num_animated]
-		const uint32_t* window_adjust;			// [num_segments][num_windows][4] or null (single window poses: a window local prefix sum IS the bit offset)
 		uint32_t num_animated;
-		uint32_t num_windows;
-		uint32_t window;
-		bool has_segment_ranges;				// num_segments > 1
 	};
 
-	__device__ __forceinline__ window_tables window_tables_of(const device_clip& clip, uint32_t window)
+	__device__ __forceinline__ window_tables window_tables_of(const device_clip& clip)
 	{
 		window_tables tables;
 		tables.plan = clip.plan;
 		tables.clip_ranges = clip.clip_ranges;
 		tables.num_animated = clip.num_animated;
-		tables.num_windows = (clip.num_tracks * 3u + k_image_chunk_quads - 1) / k_image_chunk_quads;
-		tables.window_adjust = tables.num_windows > 1 ? clip.image_chunks + ((tables.num_windows + 1 + 3) & ~3u) : nullptr;
-		tables.window = window;
-		tables.has_segment_ranges = clip.num_segments > 1;
 		return tables;
 	}
 
+#if !defined(ACLHIP_PREFETCH_TABLES)
+	#define ACLHIP_PREFETCH_TABLES 0
+#endif
+
 	// Lanes <-> the animated sub-tracks [first_ordinal, end_ordinal) of one pose window, decoded into their quads of the window's LDS
 	// image (image[0] = quad first_quad of the pose), 64 per pass. A pass:
-	//   1. every lane fetches its 8 byte plan entry (two when the keys straddle two segments -- most sample times fall between two
-	//      keyframes of ONE segment and its row is fetched once) and its clip range; the NEXT pass's entries are requested before this
-	//      pass's arithmetic starts, so a window of several passes pays one memory round trip for them, not one per pass;
-	//   2. bit offsets: a wavefront prefix sum over the widths (3 * num_bits bits per sub-track; the window's sub-tracks are in
-	//      bitstream order), carried from pass to pass in an SGPR, plus -- poses of several windows -- the window's per kind constant;
-	//   3. the keyframe bits of both keys (four loads in flight), 1 / (2^w - 1) from the table, unpack, ranges, W, lerp, normalize.
+	//   1. every lane fetches its 32 byte plan entry (two when the keys straddle two segments -- most sample times fall between two
+	//      keyframes of ONE segment and its row is fetched once: a third less table traffic through the texture unit) and its clip
+	//      range; the NEXT pass's entries are requested before this pass's arithmetic starts, so a window of several passes pays one
+	//      memory round trip for them, not one per pass;
+	//   2. the keyframe bits of both keys (four loads in flight), unpack, ranges, W, lerp, normalize.
 	template<bool kPolicies>
 	__device__ __forceinline__ void decode_window_sub_tracks_with(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
@@ -128,70 +115,29 @@
 		const plan_entry* plan_row0 = tables.plan + size_t(state.segment_index[0]) * tables.num_animated;
 		const plan_entry* plan_row1 = tables.plan + size_t(state.segment_index[1]) * tables.num_animated;
 
-		// poses of several windows: what a window local prefix sum lacks, per sub-track kind, for each key's segment (scalar loads)
-		u32x4 adjust0 = { 0, 0, 0, 0 }, adjust1 = { 0, 0, 0, 0 };
-		const bool multi_window = tables.window_adjust != nullptr;
-		if (multi_window)
-		{
-			const ACLHIP_CONSTANT u32x4* adjust = (const ACLHIP_CONSTANT u32x4*)tables.window_adjust;
-			adjust0 = adjust[size_t(state.segment_index[0]) * tables.num_windows + tables.window];
-			adjust1 = adjust[size_t(state.segment_index[1]) * tables.num_windows + tables.window];
-		}
-
-		uint32_t carry0 = 0, carry1 = 0;		// bits of the window's sub-tracks before this pass (wave uniform)
-
 		uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
-		plan_entry entry0 = load_plan_entry(plan_row0, ordinal);
-		plan_entry entry1 = single_segment ? entry0 : load_plan_entry(plan_row1, ordinal);
+		plan_entry entry0 = load_entry(plan_row0, ordinal);
+		plan_entry entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
 		clip_range_entry clip_range = load_entry(tables.clip_ranges, ordinal);
 
 		for (uint32_t base = first_ordinal; base < end_ordinal; base += k_wave_size)
 		{
 			const bool valid = base + lane < end_ordinal;
-			const plan_entry current0 = entry0, current1 = entry1;
+			const plan_entry plan0 = entry0, plan1 = entry1;
 			const clip_range_entry current_range = clip_range;
 
+#if ACLHIP_PREFETCH_TABLES
 			// the next pass's table entries travel while this pass computes
 			if (base + k_wave_size < end_ordinal)
 			{
 				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
-				entry0 = load_plan_entry(plan_row0, ordinal);
-				entry1 = single_segment ? entry0 : load_plan_entry(plan_row1, ordinal);
+				entry0 = load_entry(plan_row0, ordinal);
+				entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
 				clip_range = load_entry(tables.clip_ranges, ordinal);
 			}
+#endif
 
 			const bool is_rotation = is_rotation_entry(current_range);
-			const uint32_t kind = current_range.quad_index - current_range.track_index * 3u;
-
-			sub_track_key key0, key1;
-			expand_plan_entry(current0, tables.has_segment_ranges, key0);
-			if (single_segment)
-				key1 = key0;
-			else
-				expand_plan_entry(current1, tables.has_segment_ranges, key1);
-
-			// bit offsets: prefix sum of the widths (raw = 96 bits, constant in the segment = none)
-			const uint32_t bits0 = valid ? key0.num_bits * 3u : 0u;
-			const uint32_t inclusive0 = wave_inclusive_scan(bits0);
-			uint32_t relative0 = carry0 + (inclusive0 - bits0);
-			carry0 += __builtin_amdgcn_readlane(inclusive0, 63);
-			uint32_t relative1 = relative0;
-			if (!single_segment)
-			{
-				const uint32_t bits1 = valid ? key1.num_bits * 3u : 0u;
-				const uint32_t inclusive1 = wave_inclusive_scan(bits1);
-				relative1 = carry1 + (inclusive1 - bits1);
-				carry1 += __builtin_amdgcn_readlane(inclusive1, 63);
-			}
-			if (multi_window)
-			{
-				relative0 += kind == 0 ? adjust0.x : (kind == 1 ? adjust0.y : adjust0.z);
-				relative1 += kind == 0 ? adjust1.x : (kind == 1 ? adjust1.y : adjust1.z);
-			}
-			key0.bit_offset = state.key_frame_bit_offsets[0] + relative0;
-			key1.bit_offset = state.key_frame_bit_offsets[1] + relative1;
-			key0.inv_max_value = ((const ACLHIP_CONSTANT float*)k_inv_max_value)[key0.num_bits];
-			key1.inv_max_value = single_segment ? key0.inv_max_value : ((const ACLHIP_CONSTANT float*)k_inv_max_value)[key1.num_bits];
 
 			uint32_t policy = k_round_none;
 			if (kPolicies)
@@ -203,17 +149,27 @@
 			}
 
 			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
-			const bool has_raw = __any(int(key0.num_bits == 32u || key1.num_bits == 32u)) != 0;
+			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
 
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, kPolicies>(state, key0, key1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<false, kPolicies>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 			else
-				value = decode_animated_sub_track<true, kPolicies>(state, key0, key1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<true, kPolicies>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)
 				image[current_range.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
+
+#if !ACLHIP_PREFETCH_TABLES
+			if (base + k_wave_size < end_ordinal)
+			{
+				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
+				entry0 = load_entry(plan_row0, ordinal);
+				entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
+				clip_range = load_entry(tables.clip_ranges, ordinal);
+			}
+#endif
 		}
 	}
 
@@ -335,7 +291,7 @@
 		}
 
 		// lanes <-> animated sub-tracks of this window
-		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip, window), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);

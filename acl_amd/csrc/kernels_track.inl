@@ -42,22 +42,13 @@
 
 		// The reference sums the widths of every preceding animated sub-track to find this one's bits
 		// (skip_*_groups + count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192,1664-1707): O(track index).
-		// Registration left that prefix sum behind the plan: bit_offsets[segment][ordinal].
-		const uint32_t* bit_offsets = reinterpret_cast<const uint32_t*>(clip.plan + size_t(clip.num_segments) * clip.num_animated);
-		const bool has_segment_ranges = clip.num_segments > 1;
+		// The registration time plan already holds that prefix sum.
 		const auto animated_lookup = [&](uint32_t ordinal)
 		{
-			sub_track_key key0, key1;
-			const size_t row0 = size_t(state.segment_index[0]) * clip.num_animated + ordinal;
-			const size_t row1 = size_t(state.segment_index[1]) * clip.num_animated + ordinal;
-			expand_plan_entry(load_plan_entry(clip.plan, uint32_t(row0)), has_segment_ranges, key0);
-			expand_plan_entry(load_plan_entry(clip.plan, uint32_t(row1)), has_segment_ranges, key1);
-			key0.bit_offset = state.key_frame_bit_offsets[0] + bit_offsets[row0];
-			key1.bit_offset = state.key_frame_bit_offsets[1] + bit_offsets[row1];
-			key0.inv_max_value = k_inv_max_value[key0.num_bits];
-			key1.inv_max_value = k_inv_max_value[key1.num_bits];
+			const plan_entry plan0 = load_entry(clip.plan + size_t(state.segment_index[0]) * clip.num_animated, ordinal);
+			const plan_entry plan1 = load_entry(clip.plan + size_t(state.segment_index[1]) * clip.num_animated, ordinal);
 			const clip_range_entry clip_range = load_entry(clip.clip_ranges, ordinal);
-			return decode_animated_sub_track<true, false>(state, key0, key1, clip_range, is_rotation_entry(clip_range),
+			return decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
 				k_round_none, lerp_alpha, params.normalization, false);
 		};
 
