@@ -20,7 +20,12 @@ namespace
 		// the common case (track_writer defaults, no per track rounding, normalization != always) copies a resolved pose image
 		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
 		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
-		const size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
+		size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
+		{
+			// measurement aid: ACLHIP_EXTRA_LDS_BYTES inflates a workgroup's LDS so that fewer workgroups fit a CU (occupancy experiments)
+			static const size_t extra_lds = []() { const char* value = std::getenv("ACLHIP_EXTRA_LDS_BYTES"); return value != nullptr ? size_t(std::atol(value)) : size_t(0); }();
+			lds_bytes += extra_lds;
+		}
 		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
 		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0;
 		const auto kernel = any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)

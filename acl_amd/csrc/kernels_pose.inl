@@ -255,9 +255,11 @@
 			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
 			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
+#if !defined(ACLHIP_EXP_NO_DMA)
 				if (base + lane < window_quads)
 					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+#endif
 			}
 		}
 
@@ -291,7 +293,9 @@
 		}
 
 		// lanes <-> animated sub-tracks of this window
+#if !defined(ACLHIP_EXP_NO_DECODE)
 		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+#endif
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);

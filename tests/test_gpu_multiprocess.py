@@ -62,6 +62,7 @@ def _peer_worker(rank, world_size, port, result_dir):
                 expected = ob.oracle_decompress_tracks_batch([clip.blob], np.zeros(num_instances, dtype=np.uint32), times, clip.num_tracks)
                 assert np.array_equal(gathered.view(np.uint32), expected.view(np.uint32))
                 gather.gathered.zero_()
+                torch.cuda.synchronize(device)       # the clear must have happened before the other ranks push again
             dist.barrier()
         gather.close()
         context.unregister_clip(handle)
