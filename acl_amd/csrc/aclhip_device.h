@@ -194,9 +194,6 @@ namespace aclhip
 
 	__device__ __forceinline__ void store_streaming(void* address, f32x4_store value)
 	{
-#if defined(ACLHIP_EXP_NO_STORE)
-		if (value.x != 12345.678f) return;
-#endif
 		asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(value) : "memory");
 	}
 

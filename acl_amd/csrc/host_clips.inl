@@ -475,7 +475,19 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	}
 
 	const uint64_t resolved_pose_offset = base_pose_offset + uint64_t(num_quads) * 16;
-	const uint64_t samples_offset = (resolved_pose_offset + uint64_t(num_quads) * 16 + 31) & ~uint64_t(31);
+	// the resolved pose once more as 10 packed floats per track (rotation xyzw | translation xyz | scale xyz), directly behind the first:
+	// what the QVV40 output layout starts from (kernels_pose.inl)
+	const uint64_t resolved_qvv40_offset = resolved_pose_offset + uint64_t(num_quads) * 16;
+	std::vector<float> resolved_qvv40((size_t(num_tracks) * 10 + 3) / 4 * 4 + 4, 0.0f);
+	for (uint32_t track = 0; track < num_tracks; ++track)
+	{
+		const float* record = &resolved_pose[size_t(track) * 12];
+		float* packed = &resolved_qvv40[size_t(track) * 10];
+		std::memcpy(packed, record, 16);
+		std::memcpy(packed + 4, record + 4, 12);
+		std::memcpy(packed + 7, record + 8, 12);
+	}
+	const uint64_t samples_offset = (resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31);
 	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
@@ -489,6 +501,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(staging.data() + base_pose_offset, base_pose.data(), size_t(num_quads) * 16);
 	if (num_quads != 0)
 		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
+	std::memcpy(staging.data() + resolved_qvv40_offset, resolved_qvv40.data(), resolved_qvv40.size() * sizeof(float));
 	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));

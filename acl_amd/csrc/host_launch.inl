@@ -28,7 +28,10 @@ namespace
 		}
 		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
 		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0;
-		const auto kernel = any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)
+		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
+		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0;
+		const auto kernel = native_layout ? (params.layout == ACLHIP_LAYOUT_QV32 ? decompress_tracks_qv32_kernel : decompress_tracks_qvv40_kernel)
+			: any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)
 			: (compact ? decompress_tracks_compact_kernel : decompress_tracks_kernel);
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,

@@ -91,20 +91,25 @@
 		return tables;
 	}
 
-#if !defined(ACLHIP_PREFETCH_TABLES)
-	#define ACLHIP_PREFETCH_TABLES 0
-#endif
-
 	// Lanes <-> the animated sub-tracks [first_ordinal, end_ordinal) of one pose window, decoded into their quads of the window's LDS
 	// image (image[0] = quad first_quad of the pose), 64 per pass. A pass:
 	//   1. every lane fetches its 32 byte plan entry (two when the keys straddle two segments -- most sample times fall between two
-	//      keyframes of ONE segment and its row is fetched once: a third less table traffic through the texture unit) and its clip
-	//      range; the NEXT pass's entries are requested before this pass's arithmetic starts, so a window of several passes pays one
-	//      memory round trip for them, not one per pass;
+	//      keyframes of ONE segment and its row is fetched once: a third less table traffic through the texture unit) and its clip range;
 	//   2. the keyframe bits of both keys (four loads in flight), unpack, ranges, W, lerp, normalize.
-	template<bool kPolicies>
-	__device__ __forceinline__ void decode_window_sub_tracks_with(const window_tables& tables, const seek_state& state, const decode_params& params,
-		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+	// Where a decoded sub-track goes in the window's LDS image: the QVV48 image holds the pose's quads as they are
+	struct qvv48_image_writer
+	{
+		f32x4* image;
+		uint32_t first_quad;
+		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
+		{
+			image[entry.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
+		}
+	};
+
+	template<bool kPolicies, class image_writer_type>
+	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image)
 	{
 		if (first_ordinal >= end_ordinal)
 			return;
@@ -125,17 +130,6 @@
 			const bool valid = base + lane < end_ordinal;
 			const plan_entry plan0 = entry0, plan1 = entry1;
 			const clip_range_entry current_range = clip_range;
-
-#if ACLHIP_PREFETCH_TABLES
-			// the next pass's table entries travel while this pass computes
-			if (base + k_wave_size < end_ordinal)
-			{
-				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
-				entry0 = load_entry(plan_row0, ordinal);
-				entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
-				clip_range = load_entry(tables.clip_ranges, ordinal);
-			}
-#endif
 
 			const bool is_rotation = is_rotation_entry(current_range);
 
@@ -159,9 +153,9 @@
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)
-				image[current_range.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
+				write_to_image(current_range, value);
 
-#if !ACLHIP_PREFETCH_TABLES
+			// (requesting the next pass's entries BEFORE this pass's arithmetic was measured: 24 more live registers spill, 2 x slower)
 			if (base + k_wave_size < end_ordinal)
 			{
 				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
@@ -169,7 +163,6 @@
 				entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
 				clip_range = load_entry(tables.clip_ranges, ordinal);
 			}
-#endif
 		}
 	}
 
@@ -177,10 +170,11 @@
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
 	{
+		const qvv48_image_writer writer = { image, first_quad };
 		if (kAnySettings && params.per_track_rounding != 0)
-			decode_window_sub_tracks_with<true>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			decode_window_sub_tracks_into<true>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 		else
-			decode_window_sub_tracks_with<false>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			decode_window_sub_tracks_into<false>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -255,11 +249,9 @@
 			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
 			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
-#if !defined(ACLHIP_EXP_NO_DMA)
 				if (base + lane < window_quads)
 					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
-#endif
 			}
 		}
 
@@ -293,9 +285,9 @@
 		}
 
 		// lanes <-> animated sub-tracks of this window
-#if !defined(ACLHIP_EXP_NO_DECODE)
+		// (decoded quads are written after the DMA has delivered their slots: a wave's memory operations return in order, and the
+		// keyframe loads every decoded value waits for were issued after the DMA)
 		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
-#endif
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -452,6 +444,155 @@
 		}
 	}
 
+	// ---- compact output layouts, the fast path -----------------------------------------------------------------------------------------
+	// aclhip_output_desc layouts QVV40 / QV32 with the reference defaults and nothing else skipped: the window's LDS image is built in
+	// the OUTPUT layout from the start, so the way out is the same plain copy as for QVV48 -- 1 KiB of contiguous HBM per store
+	// instruction -- with a third (QV32) or a sixth (QVV40) fewer bytes:
+	//   QV32   rotation xyzw | translation xyz 0: the base pose DMA gathers quads 3t, 3t + 1 of the clip's resolved pose (global_load_lds
+	//          takes a per lane source address), scale sub-tracks are decoded by nobody;
+	//   QVV40  10 packed floats per track: the DMA source is a second resolved pose image registration lays out in that form behind the
+	//          first (40 bytes per track); a decoded sub-track is written at float 10 t + {0, 4, 7} (8 byte aligned pieces).
+	// Every other combination (skipped kinds, the other default modes, per track rounding) takes the generic compact kernels below.
+	template<uint32_t kLayout>
+	struct compact_image_writer
+	{
+		float* image;
+		uint32_t first_track;
+		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
+		{
+			typedef float f32x2 __attribute__((ext_vector_type(2)));
+			const uint32_t kind = entry.quad_index - entry.track_index * 3u;
+			const uint32_t track = entry.track_index - first_track;
+			if (kLayout == ACLHIP_LAYOUT_QV32)
+			{
+				if (kind != 2)
+					reinterpret_cast<f32x4*>(image)[track * 2u + kind] = f32x4{ value.x, value.y, value.z, value.w };
+				return;
+			}
+			float* record = image + track * 10u;		// 40 bytes per track: 8 byte aligned
+			if (kind == 0)
+			{
+				*reinterpret_cast<f32x2*>(record) = f32x2{ value.x, value.y };
+				*reinterpret_cast<f32x2*>(record + 2) = f32x2{ value.z, value.w };
+			}
+			else if (kind == 1)
+			{
+				*reinterpret_cast<f32x2*>(record + 4) = f32x2{ value.x, value.y };
+				record[6] = value.z;
+			}
+			else
+			{
+				record[7] = value.x;
+				*reinterpret_cast<f32x2*>(record + 8) = f32x2{ value.y, value.z };
+			}
+		}
+	};
+
+	template<uint32_t kLayout>
+	__device__ __forceinline__ void decompress_tracks_compact_window(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
+		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
+		unsigned long long* __restrict__ rejected_count)
+	{
+		static_assert(kLayout == ACLHIP_LAYOUT_QV32 || kLayout == ACLHIP_LAYOUT_QVV40, "compact layouts");
+		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+		constexpr uint32_t k_window_tracks = k_image_chunk_quads / 3u;
+		constexpr uint32_t k_track_bytes = kLayout == ACLHIP_LAYOUT_QV32 ? 32u : 40u;
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
+		uint32_t instance = work_item;
+		uint32_t window = 0;
+		if (windows_per_instance != 1)
+		{
+			instance = work_item / windows_per_instance;
+			window = work_item - instance * windows_per_instance;
+		}
+		if (instance >= num_instances)
+			return;
+
+		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		const float sample_time = as_constant(sample_times)[instance];
+		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
+		{
+			if (lane == 0 && window == 0)
+				atomicAdd(rejected_count, 1ull);
+			return;
+		}
+
+		const uint32_t first_track = window * k_window_tracks;
+		if (first_track >= clip.num_tracks)
+			return;
+		const uint32_t window_tracks = min(clip.num_tracks - first_track, k_window_tracks);
+		const uint32_t window_bytes = window_tracks * k_track_bytes;
+		const uint32_t window_pieces = (window_bytes + 15u) / 16u;		// QVV40 with an odd number of tracks ends on half a piece
+
+		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
+		if (clip.num_tracks > k_window_tracks)
+		{
+			first_ordinal = as_constant(clip.image_chunks)[window];
+			end_ordinal = as_constant(clip.image_chunks)[window + 1];
+		}
+
+		f32x4* image = reinterpret_cast<f32x4*>(dynamic_lds) + size_t(wave_in_block) * lds_quads_per_wave;
+
+		// base pose -> LDS image, already in the output layout
+		for (uint32_t base = 0; base < window_pieces; base += k_wave_size)
+		{
+			const uint32_t piece = base + lane;
+			if (piece < window_pieces)
+			{
+				const ACLHIP_CONSTANT f32x4* source;
+				if (kLayout == ACLHIP_LAYOUT_QV32)
+					source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose + (first_track + (piece >> 1)) * 3u + (piece & 1u);
+				else
+					source = (const ACLHIP_CONSTANT f32x4*)((const ACLHIP_CONSTANT uint8_t*)(clip.resolved_pose + size_t(clip.num_tracks) * 3u) + size_t(first_track) * 40u) + piece;
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)source, (__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+			}
+		}
+
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
+			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
+			: uint32_t(params.rounding_policy);
+
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		// the base pose must be in the image before decoded sub-tracks take their places in it (the QVV40 pieces of a decoded sub-track
+		// and of its constant neighbours share 16 byte units: DMA first, then the decode's own writes)
+		const compact_image_writer<kLayout> writer = { reinterpret_cast<float*>(image), first_track };
+		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer);
+
+		__builtin_amdgcn_s_waitcnt(0);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		constexpr uint32_t k_rows = (k_window_tracks * k_track_bytes / 16u + k_wave_size - 1) / k_wave_size;
+		f32x4 staged[k_rows];
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+			staged[r] = image[min(r * k_wave_size + lane, window_pieces - 1)];
+
+		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
+		uint8_t* out = poses + uint64_t(row) * pose_stride_bytes + size_t(first_track) * k_track_bytes;
+		const uint32_t whole_pieces = window_bytes / 16u;
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+		{
+			const uint32_t piece = r * k_wave_size + lane;
+			if (piece < whole_pieces)
+				store_streaming(out + size_t(piece) * 16, staged[r]);
+			else if (kLayout == ACLHIP_LAYOUT_QVV40 && piece < window_pieces)
+			{
+				const float half[2] = { staged[r].x, staged[r].y };
+				store_streaming_floats<2>(reinterpret_cast<float*>(out + size_t(piece) * 16), half);
+			}
+		}
+	}
+
 	#define ACLHIP_POSE_KERNEL_ARGUMENTS const device_clip* __restrict__ clips, uint32_t num_clips, \
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance, \
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count
@@ -466,6 +607,16 @@
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_qv32_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_compact_window<ACLHIP_LAYOUT_QV32>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_qvv40_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_compact_window<ACLHIP_LAYOUT_QVV40>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// 8 waves per SIMD (64 VGPRs) matter more to this variant than the few instructions the allocator saves with 65

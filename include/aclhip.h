@@ -248,7 +248,9 @@ aclhip_status aclhip_decompress_tracks_batch_rows(aclhip_context* context, const
 
 /* aclhip_decompress_tracks_batch with an output descriptor (NULL = QVV48, nothing skipped, row i): the pose of instance i starts at
  * (char*)poses + row * pose_stride_bytes and holds num_tracks records of 48 / 40 / 32 bytes in the chosen layout;
- * pose_stride_bytes must be a multiple of 16 and at least that size. Same values as the QVV48 decode, compared through the layout. */
+ * pose_stride_bytes must be a multiple of 16 and at least that size -- and should be a multiple of 64 (the HBM access granule): with
+ * rows that start between granules every 1 KiB store of every other pose straddles them (QVV40, 100 bones: 4000 byte rows 82 us per
+ * 64k poses, 4032 byte rows 44 us). Same values as the QVV48 decode, compared through the layout. */
 aclhip_status aclhip_decompress_tracks_batch_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes, void* stream);
 
