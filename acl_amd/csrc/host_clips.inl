@@ -87,6 +87,7 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	device_guard guard(context->device);
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+	collect_retired(context, false);
 
 	uint32_t slot;
 	if (!context->free_slots.empty())
@@ -128,13 +129,15 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	record.flags = k_clip_valid | k_clip_is_scalar | (num_components << k_clip_components_shift);
 	record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
 
-	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
-		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	size_t staging_used = 0;
+	if (!stage_upload(context, d_memory, staging.data(), total_bytes, staging_used)
+		|| !stage_upload(context, context->d_clips + slot, &record, sizeof(record), staging_used) || !finish_uploads(context))
 	{
 		free_clip_memory(context, d_memory);
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
 	}
+	context->clips_registered++;
 
 	host_clip& entry = context->clips[slot];
 	entry.in_use = true;
@@ -513,6 +516,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	device_guard guard(context->device);
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
+	collect_retired(context, false);
 
 	uint32_t slot;
 	if (!context->free_slots.empty())
@@ -620,13 +624,15 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.db_bulk_data[1] = db.d_bulk_data[1];
 	}
 
-	if (hipMemcpy(d_memory, staging.data(), total_bytes, hipMemcpyHostToDevice) != hipSuccess
-		|| hipMemcpy(context->d_clips + slot, &record, sizeof(record), hipMemcpyHostToDevice) != hipSuccess)
+	size_t staging_used = 0;
+	if (!stage_upload(context, d_memory, staging.data(), total_bytes, staging_used)
+		|| !stage_upload(context, context->d_clips + slot, &record, sizeof(record), staging_used) || !finish_uploads(context))
 	{
 		free_clip_memory(context, d_memory);
 		context->free_slots.push_back(slot);
 		return fail(context, ACLHIP_ERROR_DEVICE, "uploading the clip failed");
 	}
+	context->clips_registered++;
 	if (database != ACLHIP_INVALID_HANDLE)
 		context->databases[database].num_bound_clips++;
 
@@ -694,19 +700,29 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 
 	device_guard guard(context->device);
+	collect_retired(context, false);
+
+	// The record is cleared now (launches enqueued from here on refuse the handle); the clip's memory, its share of a hierarchy image and
+	// the handle itself are given back once everything already enqueued on the streams this context launched on has completed --
+	// nobody waits for that here. Callers still owe the reference's contract: no decode of a clip after its unregistration.
 	device_clip cleared;
 	std::memset(&cleared, 0, sizeof(cleared));
-	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
-	ACLHIP_CHECK_HIP(context, hipMemcpy(context->d_clips + clip, &cleared, sizeof(cleared), hipMemcpyHostToDevice));
-	free_clip_memory(context, context->clips[clip].device_memory);
-	if (context->clips[clip].d_hierarchy != nullptr)
-		release_hierarchy(context, context->clips[clip].d_hierarchy);
+	size_t staging_used = 0;
+	if (!stage_upload(context, context->d_clips + clip, &cleared, sizeof(cleared), staging_used) || !finish_uploads(context))
+		return fail(context, ACLHIP_ERROR_DEVICE, "clearing the clip record failed");
+	{
+		aclhip_context::retired_item item;
+		item.clip_memory = context->clips[clip].device_memory;
+		item.hierarchy = context->clips[clip].d_hierarchy;
+		item.slot = clip;
+		retire(context, std::move(item));
+	}
+	context->clips_unregistered++;
 	const uint32_t bound_database = context->clips[clip].database;
 	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
 		context->databases[bound_database].num_bound_clips--;
 	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
-	context->free_slots.push_back(clip);
 	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
 		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))
 		recompute_launch_maxima(context);

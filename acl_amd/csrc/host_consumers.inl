@@ -183,24 +183,26 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			if (candidate.parents == canonical)
 				shared = &candidate;
 
+		collect_retired(context, false);
 		uint32_t* d_hierarchy = shared != nullptr ? shared->d_image : nullptr;
-		hipError_t hip_status = hipSuccess;
+		size_t staging_used = 0;
+		bool uploaded = true;
 		if (shared == nullptr)
 		{
-			if (hipMalloc(reinterpret_cast<void**>(&d_hierarchy), image.size() * sizeof(uint32_t)) != hipSuccess)
-				return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of %zu bytes failed", image.size() * sizeof(uint32_t));
-			hip_status = hipMemcpy(d_hierarchy, image.data(), image.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+			// (a piece of a clip slab, uploaded on the context's copy stream: no allocation call and no copy that would stall the device)
+			d_hierarchy = reinterpret_cast<uint32_t*>(allocate_clip_memory(context, image.size() * sizeof(uint32_t)));
+			if (d_hierarchy == nullptr)
+				return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "allocating %zu bytes for the hierarchy failed", image.size() * sizeof(uint32_t));
+			uploaded = stage_upload(context, d_hierarchy, image.data(), image.size() * sizeof(uint32_t), staging_used);
 		}
-		// launches in flight may still walk the hierarchy that is being replaced
-		if (hip_status == hipSuccess)
-			hip_status = hipDeviceSynchronize();
-		if (hip_status == hipSuccess)
-			hip_status = hipMemcpy(reinterpret_cast<uint8_t*>(context->d_clips + clip) + offsetof(device_clip, hierarchy), &d_hierarchy, sizeof(d_hierarchy), hipMemcpyHostToDevice);
-		if (hip_status != hipSuccess)
+		// launches in flight may still walk the hierarchy that is being replaced: it is retired, not freed (see retire())
+		uploaded = uploaded && stage_upload(context, reinterpret_cast<uint8_t*>(context->d_clips + clip) + offsetof(device_clip, hierarchy), &d_hierarchy, sizeof(d_hierarchy), staging_used)
+			&& finish_uploads(context);
+		if (!uploaded)
 		{
 			if (shared == nullptr)
-				(void)hipFree(d_hierarchy);
-			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the hierarchy failed: %s", hipGetErrorString(hip_status));
+				free_clip_memory(context, d_hierarchy);
+			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the hierarchy failed");
 		}
 		if (shared != nullptr)
 			shared->num_users++;
@@ -213,7 +215,11 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			context->hierarchies.push_back(std::move(created));
 		}
 		if (entry.d_hierarchy != nullptr)
-			release_hierarchy(context, entry.d_hierarchy);
+		{
+			aclhip_context::retired_item item;
+			item.hierarchy = entry.d_hierarchy;
+			retire(context, std::move(item));
+		}
 		entry.d_hierarchy = d_hierarchy;
 		const bool held_maximum = entry.hierarchy_words != 0 && entry.hierarchy_words == context->max_hierarchy_words;
 		entry.hierarchy_words = max_schedule_words;
@@ -242,6 +248,7 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding, normalization != always");
 
 		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+		note_launch_stream(context, stream);
 
 		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
 		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
@@ -334,6 +341,9 @@ namespace
 		if (!single_track && out_row_bytes == 0)
 			out_row_bytes = uint64_t(max_tracks) * bytes_per_track;
 
+		// (the host convenience calls are synchronous by contract and stage through temporary device buffers on the default stream;
+		// callers that must not disturb work in flight use the device pointer entry points)
+		hipStream_t work_stream = nullptr;
 		std::vector<void*> allocations;
 		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
 		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
@@ -415,16 +425,16 @@ namespace
 
 		aclhip_status status;
 		if (single_track)
-			status = aclhip_decompress_track_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks), num_instances, &local, d_out, nullptr);
+			status = aclhip_decompress_track_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks), num_instances, &local, d_out, work_stream);
 		else if (consumers != nullptr)
-			status = aclhip_decompress_poses_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, &local_consumers, d_out, device_stride, nullptr);
+			status = aclhip_decompress_poses_batch(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local, &local_consumers, d_out, device_stride, work_stream);
 		else
 			status = aclhip_decompress_tracks_batch_out(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), num_instances, &local,
-				output != nullptr ? &local_output : nullptr, d_out, device_stride, nullptr);
+				output != nullptr ? &local_output : nullptr, d_out, device_stride, work_stream);
 
 		if (status == ACLHIP_OK)
 		{
-			hipError_t copy_status = hipDeviceSynchronize();
+			hipError_t copy_status = hipStreamSynchronize(work_stream);
 			if (copy_status == hipSuccess)
 				copy_status = hipMemcpy2D(out, out_stride_bytes, d_out, device_stride, std::min<uint64_t>(out_row_bytes, device_stride), num_instances, hipMemcpyDeviceToHost);
 			if (copy_status != hipSuccess)

@@ -63,6 +63,38 @@ struct aclhip_context
 	struct hierarchy_image { std::vector<uint32_t> parents; uint32_t* d_image = nullptr; uint32_t num_users = 0; };
 	std::vector<hierarchy_image> hierarchies;
 
+	// ---- stream ordered clip lifetime --------------------------------------------------------------------------------------------
+	// Registering, replacing and unregistering clips never stalls the device: uploads go through a pinned staging buffer on the
+	// context's own NON-BLOCKING copy stream (only the calling thread waits for its copy), and what an unregistration retires is freed
+	// once an event recorded on every stream this context has launched on has completed -- polled by later calls, never waited for
+	// (except in aclhip_destroy). The clip table never moves: its address range is reserved up front and backed page by page.
+	hipStream_t copy_stream = nullptr;
+	uint8_t* pinned_staging = nullptr;
+	size_t pinned_staging_bytes = 0;
+	std::vector<hipStream_t> launch_streams;		// every stream work was enqueued on (nullptr = the default stream)
+	std::vector<hipEvent_t> event_pool;
+	struct retired_item
+	{
+		std::vector<hipEvent_t> events;				// one per launch stream, recorded when the item was retired
+		void* clip_memory = nullptr;				// a piece of a slab
+		uint32_t* hierarchy = nullptr;				// a walk schedule image (shared images are reference counted)
+		uint32_t slot = ACLHIP_INVALID_HANDLE;		// clip handle that becomes reusable
+		uint8_t* database_memory[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };		// hipMalloc'ed pieces of a database
+		uint8_t* database_pinned[2] = { nullptr, nullptr };
+	};
+	std::vector<retired_item> retired;
+	uint64_t clips_registered = 0;					// statistics (aclhip_get_lifetime_stats)
+	uint64_t clips_unregistered = 0;
+	uint64_t deferred_frees_completed = 0;
+
+	// the clip table: reserved address range, mapped in `table_granularity` steps (virtual memory management API); when the device does
+	// not offer that, one fixed allocation of k_fixed_table_entries records
+	bool table_is_virtual = false;
+	size_t table_reserved_bytes = 0;
+	size_t table_mapped_bytes = 0;
+	size_t table_granularity = 0;
+	std::vector<hipMemGenericAllocationHandle_t> table_handles;
+
 	// buffers of other processes mapped by aclhip_peer_open_buffer: the pointer handed out and the allocation it lies in
 	struct peer_mapping { void* buffer; void* base; };
 	std::vector<peer_mapping> peer_mappings;
@@ -144,6 +176,8 @@ namespace
 		}
 	}
 
+	void free_clip_memory(aclhip_context* context, void* memory);
+
 	void release_hierarchy(aclhip_context* context, const uint32_t* d_image)
 	{
 		for (size_t i = 0; i < context->hierarchies.size(); ++i)
@@ -152,7 +186,7 @@ namespace
 				continue;
 			if (--context->hierarchies[i].num_users == 0)
 			{
-				(void)hipFree(context->hierarchies[i].d_image);
+				free_clip_memory(context, context->hierarchies[i].d_image);		// (a piece of a clip slab: no hipFree, which would synchronize the device)
 				context->hierarchies.erase(context->hierarchies.begin() + ptrdiff_t(i));
 			}
 			return;
@@ -192,6 +226,140 @@ namespace
 				slab.used = 0;
 			return;
 		}
+	}
+}
+
+namespace
+{
+	constexpr uint32_t k_reserved_table_entries = 1u << 22;		// 4 M clips = 512 MiB of address space, backed on demand
+	constexpr uint32_t k_fixed_table_entries = 1u << 18;		// without virtual memory management: 32 MiB, allocated once
+
+	// Streams the context enqueued work on: what a retired clip must outlive. (Callers that destroy a stream they decoded on: an event
+	// record on it fails from then on and the stream is dropped from the list.)
+	void note_launch_stream(aclhip_context* context, hipStream_t stream)
+	{
+		for (hipStream_t known : context->launch_streams)
+			if (known == stream)
+				return;
+		context->launch_streams.push_back(stream);
+	}
+
+	hipEvent_t take_event(aclhip_context* context)
+	{
+		if (!context->event_pool.empty())
+		{
+			hipEvent_t event = context->event_pool.back();
+			context->event_pool.pop_back();
+			return event;
+		}
+		hipEvent_t event = nullptr;
+		if (hipEventCreateWithFlags(&event, hipEventDisableTiming) != hipSuccess)
+			return nullptr;
+		return event;
+	}
+
+	// Records "everything enqueued so far" on every launch stream into the item and queues it; nothing is freed here
+	void retire(aclhip_context* context, aclhip_context::retired_item&& item)
+	{
+		for (size_t i = 0; i < context->launch_streams.size();)
+		{
+			hipEvent_t event = take_event(context);
+			if (event != nullptr && hipEventRecord(event, context->launch_streams[i]) == hipSuccess)
+			{
+				item.events.push_back(event);
+				++i;
+				continue;
+			}
+			// the caller destroyed this stream: its work is over
+			(void)hipGetLastError();
+			if (event != nullptr)
+				context->event_pool.push_back(event);
+			context->launch_streams.erase(context->launch_streams.begin() + ptrdiff_t(i));
+		}
+		context->retired.push_back(std::move(item));
+	}
+
+	void release_hierarchy(aclhip_context* context, const uint32_t* d_image);
+	void free_clip_memory(aclhip_context* context, void* memory);
+
+	// Frees what retired items held once their events have completed; `wait` = block for them (aclhip_destroy)
+	void collect_retired(aclhip_context* context, bool wait)
+	{
+		for (size_t i = 0; i < context->retired.size();)
+		{
+			aclhip_context::retired_item& item = context->retired[i];
+			bool done = true;
+			for (hipEvent_t event : item.events)
+			{
+				const hipError_t status = wait ? hipEventSynchronize(event) : hipEventQuery(event);
+				if (status == hipErrorNotReady)
+				{
+					done = false;
+					break;
+				}
+				if (status != hipSuccess)
+					(void)hipGetLastError();		// a stream that died with its event: nothing left to wait for
+			}
+			if (!done)
+			{
+				++i;
+				continue;
+			}
+			for (hipEvent_t event : item.events)
+				context->event_pool.push_back(event);
+			if (item.clip_memory != nullptr)
+				free_clip_memory(context, item.clip_memory);
+			if (item.hierarchy != nullptr)
+				release_hierarchy(context, item.hierarchy);
+			if (item.slot != ACLHIP_INVALID_HANDLE)
+				context->free_slots.push_back(item.slot);
+			for (uint8_t* memory : item.database_memory)
+				if (memory != nullptr)
+					(void)hipFree(memory);
+			for (uint8_t* memory : item.database_pinned)
+				if (memory != nullptr)
+					(void)hipHostFree(memory);
+			context->deferred_frees_completed++;
+			context->retired[i] = std::move(context->retired.back());
+			context->retired.pop_back();
+		}
+	}
+
+	// Host bytes -> device memory without touching the caller's streams: staged in pinned memory, copied on the context's copy
+	// stream. The copies of one call are waited for together (finish_uploads): only the calling thread blocks.
+	bool stage_upload(aclhip_context* context, void* device_destination, const void* host_source, size_t bytes, size_t& staging_used)
+	{
+		if (bytes == 0)
+			return true;
+		const size_t needed = staging_used + ((bytes + 255) & ~size_t(255));
+		if (needed > context->pinned_staging_bytes)
+		{
+			// grow: earlier pieces of this call are still being copied from the old buffer
+			if (staging_used != 0 && hipStreamSynchronize(context->copy_stream) != hipSuccess)
+				return false;
+			staging_used = 0;
+			const size_t capacity = std::max<size_t>((bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1), size_t(4) << 20);
+			if (capacity > context->pinned_staging_bytes)
+			{
+				if (context->pinned_staging != nullptr)
+					(void)hipHostFree(context->pinned_staging);
+				context->pinned_staging = nullptr;
+				context->pinned_staging_bytes = 0;
+				if (hipHostMalloc(reinterpret_cast<void**>(&context->pinned_staging), capacity, hipHostMallocDefault) != hipSuccess)
+					return false;
+				context->pinned_staging_bytes = capacity;
+			}
+		}
+		std::memcpy(context->pinned_staging + staging_used, host_source, bytes);
+		if (hipMemcpyAsync(device_destination, context->pinned_staging + staging_used, bytes, hipMemcpyHostToDevice, context->copy_stream) != hipSuccess)
+			return false;
+		staging_used += (bytes + 255) & ~size_t(255);
+		return true;
+	}
+
+	bool finish_uploads(aclhip_context* context)
+	{
+		return hipStreamSynchronize(context->copy_stream) == hipSuccess;
 	}
 }
 
@@ -368,27 +536,74 @@ namespace
 		return (types[track_index / 16] >> ((15 - (track_index % 16)) * 2)) & 3u;
 	}
 
+	// The clip table never moves (launches in flight and captured hipGraphs hold its address): records are added by backing more of
+	// the reserved address range. Called under the registry lock.
 	aclhip_status grow_clip_table(aclhip_context* context, uint32_t needed)
 	{
 		if (needed <= context->d_clips_capacity)
 			return ACLHIP_OK;
 
-		// 16384 records = 2 MiB: the table only moves (and captured hipGraphs that hold its address only go stale) past that many clips
-		uint32_t capacity = std::max<uint32_t>(context->d_clips_capacity * 2, 16384);
-		while (capacity < needed)
-			capacity *= 2;
-
-		device_clip* d_new = nullptr;
-		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&d_new), sizeof(device_clip) * capacity));
-		ACLHIP_CHECK_HIP(context, hipMemset(d_new, 0, sizeof(device_clip) * capacity));
-		if (context->d_clips != nullptr)
+		if (context->d_clips == nullptr)
 		{
-			ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
-			ACLHIP_CHECK_HIP(context, hipMemcpy(d_new, context->d_clips, sizeof(device_clip) * context->d_clips_capacity, hipMemcpyDeviceToDevice));
-			ACLHIP_CHECK_HIP(context, hipFree(context->d_clips));
+			// first call (aclhip_create): reserve the range, or fall back to one fixed allocation
+			hipMemAllocationProp properties = {};
+			properties.type = hipMemAllocationTypePinned;
+			properties.location.type = hipMemLocationTypeDevice;
+			properties.location.id = context->device;
+			size_t granularity = 0;
+			void* range = nullptr;
+			static const bool allow_virtual = []() { const char* value = std::getenv("ACLHIP_VIRTUAL_CLIP_TABLE"); return value == nullptr || value[0] != '0'; }();
+			if (allow_virtual && hipMemGetAllocationGranularity(&granularity, &properties, hipMemAllocationGranularityRecommended) == hipSuccess && granularity != 0
+				&& hipMemAddressReserve(&range, size_t(k_reserved_table_entries) * sizeof(device_clip), granularity, nullptr, 0) == hipSuccess && range != nullptr)
+			{
+				context->table_is_virtual = true;
+				context->table_granularity = granularity;
+				context->table_reserved_bytes = size_t(k_reserved_table_entries) * sizeof(device_clip);
+				context->d_clips = static_cast<device_clip*>(range);
+			}
+			else
+			{
+				(void)hipGetLastError();
+				device_clip* table = nullptr;
+				ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&table), sizeof(device_clip) * k_fixed_table_entries));
+				ACLHIP_CHECK_HIP(context, hipMemsetAsync(table, 0, sizeof(device_clip) * k_fixed_table_entries, context->copy_stream));
+				ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
+				context->d_clips = table;
+				context->d_clips_capacity = k_fixed_table_entries;
+				return needed <= k_fixed_table_entries ? ACLHIP_OK : fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "the clip table holds %u clips", k_fixed_table_entries);
+			}
 		}
-		context->d_clips = d_new;
-		context->d_clips_capacity = capacity;
+
+		if (!context->table_is_virtual)
+			return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "the clip table holds %u clips", context->d_clips_capacity);
+		if (size_t(needed) * sizeof(device_clip) > context->table_reserved_bytes)
+			return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "the clip table holds %u clips", k_reserved_table_entries);
+
+		// back [mapped, mapped + step): at least 16384 records (2 MiB) at a time
+		const size_t wanted = std::max<size_t>(size_t(needed) * sizeof(device_clip), context->table_mapped_bytes + (size_t(16384) * sizeof(device_clip)));
+		const size_t new_mapped = std::min((wanted + context->table_granularity - 1) / context->table_granularity * context->table_granularity, context->table_reserved_bytes);
+		const size_t step = new_mapped - context->table_mapped_bytes;
+		hipMemAllocationProp properties = {};
+		properties.type = hipMemAllocationTypePinned;
+		properties.location.type = hipMemLocationTypeDevice;
+		properties.location.id = context->device;
+		hipMemGenericAllocationHandle_t handle;
+		ACLHIP_CHECK_HIP(context, hipMemCreate(&handle, step, &properties, 0));
+		uint8_t* address = reinterpret_cast<uint8_t*>(context->d_clips) + context->table_mapped_bytes;
+		hipMemAccessDesc access = {};
+		access.location.type = hipMemLocationTypeDevice;
+		access.location.id = context->device;
+		access.flags = hipMemAccessFlagsProtReadWrite;
+		if (hipMemMap(address, step, 0, handle, 0) != hipSuccess || hipMemSetAccess(address, step, &access, 1) != hipSuccess)
+		{
+			(void)hipMemRelease(handle);
+			return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "backing %zu more bytes of the clip table failed", step);
+		}
+		context->table_handles.push_back(handle);
+		ACLHIP_CHECK_HIP(context, hipMemsetAsync(address, 0, step, context->copy_stream));
+		ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
+		context->table_mapped_bytes = new_mapped;
+		context->d_clips_capacity = uint32_t(new_mapped / sizeof(device_clip));
 		return ACLHIP_OK;
 	}
 
@@ -493,9 +708,13 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	}
 
 	device_guard guard(device_index);
-	if (!guard.ok || hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
-		|| hipMemset(context->d_rejected, 0, sizeof(unsigned long long)) != hipSuccess)
+	if (!guard.ok || hipStreamCreateWithFlags(&context->copy_stream, hipStreamNonBlocking) != hipSuccess
+		|| hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
+		|| hipMemsetAsync(context->d_rejected, 0, sizeof(unsigned long long), context->copy_stream) != hipSuccess
+		|| hipStreamSynchronize(context->copy_stream) != hipSuccess)
 	{
+		if (context->copy_stream != nullptr)
+			(void)hipStreamDestroy(context->copy_stream);
 		delete context;
 		return ACLHIP_ERROR_DEVICE;
 	}
@@ -504,6 +723,7 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	if (status != ACLHIP_OK)
 	{
 		(void)hipFree(context->d_rejected);
+		(void)hipStreamDestroy(context->copy_stream);
 		delete context;
 		return status;
 	}
@@ -519,10 +739,15 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 	{
 		device_guard guard(context->device);
 		(void)hipDeviceSynchronize();
+		collect_retired(context, true);
+		for (hipEvent_t event : context->event_pool)
+			(void)hipEventDestroy(event);
+		if (context->pinned_staging != nullptr)
+			(void)hipHostFree(context->pinned_staging);
+		if (context->copy_stream != nullptr)
+			(void)hipStreamDestroy(context->copy_stream);
 		for (aclhip_context::clip_slab& slab : context->slabs)
 			(void)hipFree(slab.base);
-		for (aclhip_context::hierarchy_image& hierarchy : context->hierarchies)
-			(void)hipFree(hierarchy.d_image);
 		for (host_database& db : context->databases)
 		{
 			if (!db.in_use)
@@ -536,7 +761,15 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 					(void)hipHostFree(db.pinned_bulk_data[tier]);
 			}
 		}
-		if (context->d_clips != nullptr)
+		if (context->d_clips != nullptr && context->table_is_virtual)
+		{
+			if (context->table_mapped_bytes != 0)
+				(void)hipMemUnmap(context->d_clips, context->table_mapped_bytes);
+			for (hipMemGenericAllocationHandle_t handle : context->table_handles)
+				(void)hipMemRelease(handle);
+			(void)hipMemAddressFree(context->d_clips, context->table_reserved_bytes);
+		}
+		else if (context->d_clips != nullptr)
 			(void)hipFree(context->d_clips);
 		if (context->d_rejected != nullptr)
 			(void)hipFree(context->d_rejected);

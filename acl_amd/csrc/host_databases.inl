@@ -138,17 +138,20 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
 
+	// (uploads on the context's copy stream: registering a database does not stall decodes in flight)
+	collect_retired(context, false);
+	size_t staging_used = 0;
 	bool ok = hipMalloc(reinterpret_cast<void**>(&db.d_runtime_headers), runtime.size()) == hipSuccess
-		&& hipMemcpy(db.d_runtime_headers, runtime.data(), runtime.size(), hipMemcpyHostToDevice) == hipSuccess;
+		&& stage_upload(context, db.d_runtime_headers, runtime.data(), runtime.size(), staging_used);
 	for (int tier = 0; tier < 2 && ok; ++tier)
 	{
 		// +64: keyframe windows of up to 16 bytes are read past the last sample, the reference reserves 15 (compress.database.impl.h:910)
 		const size_t bulk_bytes = size_t(header.bulk_data_size[tier]) + 64;
 		ok = hipMalloc(reinterpret_cast<void**>(&db.d_bulk_data[tier]), bulk_bytes) == hipSuccess
-			&& hipMemset(db.d_bulk_data[tier], 0xCD, bulk_bytes) == hipSuccess		// like debug_database_streamer: not-resident memory is poison
+			&& hipMemsetAsync(db.d_bulk_data[tier], 0xCD, bulk_bytes, context->copy_stream) == hipSuccess		// like debug_database_streamer: not-resident memory is poison
 			&& hipMalloc(reinterpret_cast<void**>(&db.d_patches[tier]), std::max<size_t>(patches[tier].size(), 1) * sizeof(tier_patch)) == hipSuccess;
 		if (ok && !patches[tier].empty())
-			ok = hipMemcpy(db.d_patches[tier], patches[tier].data(), patches[tier].size() * sizeof(tier_patch), hipMemcpyHostToDevice) == hipSuccess;
+			ok = stage_upload(context, db.d_patches[tier], patches[tier].data(), patches[tier].size() * sizeof(tier_patch), staging_used);
 		if (ok && header.bulk_data_size[tier] != 0)
 		{
 			ok = hipHostMalloc(reinterpret_cast<void**>(&db.pinned_bulk_data[tier]), header.bulk_data_size[tier], hipHostMallocDefault) == hipSuccess;
@@ -156,6 +159,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 				std::memcpy(db.pinned_bulk_data[tier], bulk_sources[tier], header.bulk_data_size[tier]);
 		}
 	}
+	ok = ok && finish_uploads(context);
 	if (!ok)
 	{
 		release_database(db);
@@ -302,8 +306,19 @@ extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, acl
 	if (context->databases[database].num_bound_clips != 0)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "%u clips are still bound to this database", context->databases[database].num_bound_clips);
 	device_guard guard(context->device);
-	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
-	release_database(context->databases[database]);
+	collect_retired(context, false);
+	// retired, not freed: stream-in copies and decodes already enqueued may still touch the tiers (freed once they have completed)
+	host_database& db = context->databases[database];
+	aclhip_context::retired_item item;
+	item.database_memory[0] = db.d_runtime_headers;
+	for (int tier = 0; tier < 2; ++tier)
+	{
+		item.database_memory[1 + tier] = db.d_bulk_data[tier];
+		item.database_memory[3 + tier] = reinterpret_cast<uint8_t*>(db.d_patches[tier]);
+		item.database_pinned[tier] = db.pinned_bulk_data[tier];
+	}
+	retire(context, std::move(item));
+	db = host_database();
 	return ACLHIP_OK;
 }
 
@@ -374,6 +389,7 @@ namespace
 
 		device_guard guard(context->device);
 		hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+		note_launch_stream(context, hip_stream);
 		const uint32_t first_patch = db.chunk_first_patch[tier_index][first_chunk_index];
 		const uint32_t num_patches = db.chunk_first_patch[tier_index][last_chunk_index + 1] - first_patch;
 

@@ -6,9 +6,9 @@ namespace
 	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
-		// launches read the clip table's address and the registry's maxima: enqueue under the registry lock, so that a registration
-		// that moves the table (it synchronizes the device first) never frees it under a launch that is being prepared
+		// launches read the registry's maxima and are noted (note_launch_stream) under the registry lock; the clip table itself never moves
 		std::lock_guard<std::mutex> lock(context->mutex);
+		note_launch_stream(context, stream);
 
 		// one wave per (instance, pose window); instances of clips with fewer windows than the largest registered clip leave waves idle
 		const uint32_t windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
@@ -247,6 +247,7 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 
 	std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
 	device_guard guard(context->device);
+	note_launch_stream(context, static_cast<hipStream_t>(stream));
 	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
 	hipLaunchKernelGGL(decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
 		context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,

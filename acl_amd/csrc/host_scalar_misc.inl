@@ -24,6 +24,7 @@ namespace
 
 		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
 		device_guard guard(context->device);
+		note_launch_stream(context, static_cast<hipStream_t>(stream));
 		if (track_indices != nullptr)
 		{
 			const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
@@ -96,6 +97,9 @@ namespace
 		}
 
 		device_guard guard(context->device);
+		// (the host convenience calls are synchronous by contract and stage through temporary device buffers on the default stream;
+		// callers that must not disturb work in flight use the device pointer entry points)
+		hipStream_t work_stream = nullptr;
 		std::vector<void*> allocations;
 		auto release = [&]() { for (void* p : allocations) (void)hipFree(p); };
 		auto upload = [&](const void* host, size_t bytes, void** out_device) -> bool
@@ -131,10 +135,10 @@ namespace
 		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
 
 		aclhip_status status = launch_scalar(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks),
-			num_instances, &local, d_out, out_stride_bytes, nullptr);
+			num_instances, &local, d_out, out_stride_bytes, work_stream);
 		if (status == ACLHIP_OK)
 		{
-			hipError_t copy_status = hipDeviceSynchronize();
+			hipError_t copy_status = hipStreamSynchronize(work_stream);
 			if (copy_status == hipSuccess)
 				copy_status = hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
 			if (copy_status != hipSuccess)
@@ -336,6 +340,24 @@ extern "C" aclhip_status aclhip_push_poses_to_peer(aclhip_context* context, void
 	device_guard guard(context->device);
 	// unified addressing: the runtime sees a peer mapped destination and drives the copy over the link between the two GPUs (SDMA)
 	ACLHIP_CHECK_HIP(context, hipMemcpyAsync(static_cast<uint8_t*>(peer_buffer) + offset_bytes, shard_poses, shard_bytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_get_lifetime_stats(aclhip_context* context, uint64_t* out_stats)
+{
+	if (context == nullptr || out_stats == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	device_guard guard(context->device);
+	collect_retired(context, false);
+	out_stats[0] = context->clips_registered;
+	out_stats[1] = context->clips_unregistered;
+	out_stats[2] = context->deferred_frees_completed;
+	out_stats[3] = context->retired.size();
+	out_stats[4] = context->d_clips_capacity;
+	out_stats[5] = context->table_is_virtual ? 1 : 0;
+	out_stats[6] = reinterpret_cast<uintptr_t>(context->d_clips);
+	out_stats[7] = context->launch_streams.size();
 	return ACLHIP_OK;
 }
 

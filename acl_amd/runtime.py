@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
-    "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
+    "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
@@ -183,6 +183,7 @@ def load_library():
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
     poutput = ctypes.POINTER(OutputDesc)
+    lib.aclhip_get_lifetime_stats.argtypes = [vp, ctypes.POINTER(u64)]
     lib.aclhip_peer_export_buffer.argtypes = [vp, vp, vp]
     lib.aclhip_peer_open_buffer.argtypes = [vp, vp, ctypes.POINTER(vp)]
     lib.aclhip_peer_close_buffer.argtypes = [vp, vp]
@@ -556,6 +557,13 @@ class Context:
 
     def push_poses_to_peer(self, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream=None):
         self._check(self._lib.aclhip_push_poses_to_peer(self._handle, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream))
+
+    def lifetime_stats(self):
+        """aclhip_get_lifetime_stats as a dict"""
+        values = (ctypes.c_uint64 * 8)()
+        self._check(self._lib.aclhip_get_lifetime_stats(self._handle, values))
+        names = ("registered", "unregistered", "recycled", "pending", "table_capacity", "table_is_virtual", "table_address", "launch_streams")
+        return dict(zip(names, (int(v) for v in values)))
 
     def rejected_instance_count(self):
         count = ctypes.c_uint64(0)

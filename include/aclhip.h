@@ -163,8 +163,18 @@ void aclhip_default_params(aclhip_decompress_params* out_params);
  * `compressed_tracks` is a HOST pointer to `size` bytes; the caller may free it as soon as the call returns. */
 aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip);
 
-/* Replaces decompression_context::reset() / the end of the blob's lifetime. Stream ordered work using the clip must have completed. */
+/* Replaces decompression_context::reset() / the end of the blob's lifetime. Like every call that registers, replaces or retires
+ * something (clips, hierarchies, databases) it never synchronizes the device: the clip's record is cleared at once -- launches made
+ * from here on refuse the handle -- and its memory and its handle are recycled when everything that was enqueued before the call,
+ * on any stream this context has launched on, has completed. The caller's side of the contract is the reference's: do not decode a
+ * clip after its unregistration. */
 aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip);
+
+/* Counters of the stream ordered lifetime management, for tests and tools: out_stats[0] clips registered, [1] clips unregistered,
+ * [2] retired items whose memory has been recycled, [3] retired items still waiting for work in flight, [4] capacity of the clip
+ * table in records, [5] 1 when the table grows inside a reserved address range (it never moves either way), [6] its device
+ * address, [7] streams the context has launched on. out_stats holds 8 values. */
+aclhip_status aclhip_get_lifetime_stats(aclhip_context* context, uint64_t* out_stats);
 
 aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info);
 
@@ -338,7 +348,8 @@ typedef enum aclhip_additive_format
 /* Parent of every transform of a registered transform clip (track_desc_transformf::parent_index, core/track_desc.h), copied.
  * parent_indices[i] < i for every transform but the roots (sorted parent first, as local_to_object_space assumes); transform 0
  * is a root whatever parent_indices[0] says (the reference never reads it), ACLHIP_NO_PARENT marks further roots.
- * num_tracks must be the clip's. Replaces a previous hierarchy of the clip; synchronizes the device. */
+ * num_tracks must be the clip's. Replaces a previous hierarchy of the clip (stream ordered like aclhip_unregister_clip: the old walk
+ * schedule is recycled once the launches already enqueued have completed). */
 aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks);
 
 /* Host only (no GPU work): how aclhip_set_clip_hierarchy schedules the object space walk of a hierarchy when up to

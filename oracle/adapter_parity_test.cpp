@@ -115,6 +115,12 @@ namespace
 					if (std::memcmp(cpu_pose.data(), gpu_pose.data(), cpu_pose.size() * sizeof(float)) != 0)
 					{
 						std::fprintf(stderr, "pose mismatch: looping %d rounding %u time %f\n", looping, r, double(sample_time));
+						for (size_t k = 0, shown = 0; k < cpu_pose.size() && shown < 8; ++k)
+							if (std::memcmp(&cpu_pose[k], &gpu_pose[k], sizeof(float)) != 0)
+							{
+								std::fprintf(stderr, "  float %zu (track %zu, lane %zu): reference %.9g, gpu %.9g\n", k, k / 12, k % 12, double(cpu_pose[k]), double(gpu_pose[k]));
+								shown++;
+							}
 						return 3;
 					}
 				}

@@ -157,6 +157,7 @@ def test_stream_in_is_ordered_with_decodes_on_the_same_stream(context):
     d_clips = torch.full((times.size,), clips[clip_index], dtype=torch.int32, device="cuda")
     d_times = torch.from_numpy(times).cuda()
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())         # d_clips / d_times were uploaded on the current stream
     snapshots = []
     with torch.cuda.stream(stream):
         for tier in (None, 1, 2):

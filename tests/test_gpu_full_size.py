@@ -28,6 +28,7 @@ def _decode(ctx, torch, device, handles, which, times, max_tracks, params=None, 
     d_times = torch.from_numpy(times).to(device)
     d_poses = torch.zeros((times.size, max_tracks, 12), dtype=torch.float32, device=device)
     stream = stream or torch.cuda.current_stream(device)
+    stream.wait_stream(torch.cuda.current_stream(device))       # the uploads and the zero fill above ran on the current stream (side streams do not wait for it on their own)
     ctx.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), times.size, d_poses.data_ptr(), max_tracks * 48, params=params, stream=stream.cuda_stream)
     stream.synchronize()
     return d_poses

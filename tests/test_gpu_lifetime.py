@@ -1,0 +1,152 @@
+"""Stream ordered clip lifetime: registering, replacing and unregistering clips while decodes are in flight never stalls or corrupts
+them. The reference's contexts bind and reset in nanoseconds on the CPU (decompress.impl.h:66-83); an engine streams clips in and
+out every frame, so the GPU side must not pay a device-wide synchronization for it. Needs a GPU."""
+import os
+import re
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_no_device_wide_synchronization_in_the_lifetime_paths():
+    """source check: hipDeviceSynchronize / hipFree / default stream copies only where a call is synchronous by contract"""
+    allowed = {"host_context.inl": ["aclhip_destroy"], "host_scalar_misc.inl": ["aclhip_get_rejected_instance_count"]}
+    for name in ("host_clips.inl", "host_context.inl", "host_databases.inl", "host_consumers.inl", "host_launch.inl", "host_scalar_misc.inl"):
+        text = open(os.path.join(ROOT, "acl_amd", "csrc", name)).read()
+        count = len(re.findall(r"hipDeviceSynchronize\(", text))
+        assert count == len(allowed.get(name, [])), (name, count)
+        if name in ("host_clips.inl", "host_context.inl", "host_databases.inl", "host_launch.inl"):      # (the *_host convenience calls are synchronous by contract)
+            assert not re.findall(r"\bhipMemcpy\(", text), name
+
+
+def test_register_and_unregister_10000_clips_while_another_thread_decodes():
+    rng = np.random.default_rng(0)
+    resident = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)
+    churn = [synth.build_clip(seed=700 + i, num_tracks=int(rng.integers(3, 130)), num_samples=int(rng.integers(2, 120)), has_scale=int(i % 3 == 0)) for i in range(64)]
+    with runtime.Context(0) as context:
+        handle = context.register_clip(resident.blob)
+        device = torch.device("cuda", 0)
+        n = 8192
+        times = rng.uniform(0.0, resident.duration, size=n).astype(np.float32)
+        expected = ob.oracle_decompress_tracks_batch([resident.blob], np.zeros(n, dtype=np.uint32), times, 100)
+        d_clips = torch.full((n,), handle, dtype=torch.int32, device=device)
+        d_times = torch.from_numpy(times).to(device)
+        stats_before = context.lifetime_stats()
+
+        stop = threading.Event()
+        failures = []
+        decoded_batches = [0]
+
+        def decode_loop():
+            stream = torch.cuda.Stream(device)
+            with torch.cuda.stream(stream):
+                d_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+            stream.wait_stream(torch.cuda.current_stream(device))       # d_clips / d_times were uploaded on the current stream
+            while not stop.is_set():
+                for _ in range(8):
+                    context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, stream=stream.cuda_stream)
+                stream.synchronize()
+                poses = d_poses.cpu().numpy()
+                if not np.array_equal(poses.view(np.uint32), expected.view(np.uint32)):
+                    failures.append("pose mismatch while clips were registered / unregistered")
+                    return
+                decoded_batches[0] += 8
+                with torch.cuda.stream(stream):
+                    d_poses.zero_()
+
+        worker = threading.Thread(target=decode_loop)
+        worker.start()
+        t0 = time.perf_counter()
+        total = 10000
+        live = []
+        for i in range(total):
+            live.append(context.register_clip(churn[i % len(churn)].blob, check_hash=False))
+            if len(live) >= 48:
+                # unregister in a scrambled order: slab pieces are freed out of order
+                victims = sorted(rng.choice(len(live), size=32, replace=False), reverse=True)
+                for index in victims:
+                    context.unregister_clip(live.pop(int(index)))
+        for clip in live:
+            context.unregister_clip(clip)
+        elapsed = time.perf_counter() - t0
+        stop.set()
+        worker.join()
+        assert not failures, failures
+        assert decoded_batches[0] > 0
+
+        torch.cuda.synchronize(device)
+        stats = context.lifetime_stats()
+        assert stats["registered"] - stats_before["registered"] == total
+        assert stats["unregistered"] - stats_before["unregistered"] == total
+        assert stats["pending"] == 0 and stats["recycled"] >= total         # everything retired has been recycled (no leak)
+        assert stats["table_address"] == stats_before["table_address"]      # the clip table did not move
+        print(f"\n{total} clips registered + unregistered in {elapsed:.2f} s = {total / elapsed:.0f} clips/s next to {decoded_batches[0]} decoded batches "
+              f"(virtual clip table: {stats['table_is_virtual']})")
+
+        # the resident clip still decodes, and a fresh registration reuses recycled handles
+        poses = context.decompress_tracks(np.full(16, handle), times[:16])
+        assert helpers.exact(poses, expected[:16])
+        again = context.register_clip(churn[0].blob)
+        assert again < 200
+        context.unregister_clip(again)
+        context.unregister_clip(handle)
+
+
+def test_clip_table_grows_in_place_past_its_first_pages():
+    """20000 live clips: more than the 16384 records first backed; the table keeps its address (captured hipGraphs stay valid)"""
+    clip = synth.build_clip(seed=5, num_tracks=3, num_samples=2)
+    with runtime.Context(0) as context:
+        first = context.register_clip(clip.blob)
+        address = context.lifetime_stats()["table_address"]
+        handles = [context.register_clip(clip.blob, check_hash=False) for _ in range(20000)]
+        stats = context.lifetime_stats()
+        assert stats["table_address"] == address
+        assert stats["table_capacity"] >= 20001
+        times = np.array([0.0, clip.duration], dtype=np.float32)
+        a = context.decompress_tracks(np.full(2, first), times)
+        b = context.decompress_tracks(np.full(2, handles[-1]), times)
+        assert helpers.exact(a, b)
+        for handle in handles[::-1]:
+            context.unregister_clip(handle)
+        context.unregister_clip(first)
+
+
+def test_replacing_a_hierarchy_under_launches_in_flight():
+    clip = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)
+    with runtime.Context(0) as context:
+        handle = context.register_clip(clip.blob)
+        device = torch.device("cuda", 0)
+        n = 4096
+        rng = np.random.default_rng(3)
+        times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+        d_clips = torch.full((n,), handle, dtype=torch.int32, device=device)
+        d_times = torch.from_numpy(times).to(device)
+        d_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+        consumers = runtime.PoseConsumers()
+        consumers.object_space = 1
+        stream = torch.cuda.Stream(device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        hierarchies = [synth.humanoid_hierarchy(100), np.concatenate([[runtime.NO_PARENT], np.arange(99)]).astype(np.uint32)]       # a humanoid, a chain
+        local = ob.oracle_decompress_tracks_batch([clip.blob], np.zeros(n, dtype=np.uint32), times, 100)
+        for round_index in range(6):
+            parents = hierarchies[round_index % 2]
+            context.set_clip_hierarchy(handle, parents)          # replaces the previous one while the last round's launches may still run
+            for _ in range(4):
+                context.decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, consumers, stream=stream.cuda_stream)
+        stream.synchronize()
+        poses = d_poses.cpu().numpy()
+        for i in rng.choice(n, size=16, replace=False):
+            assert helpers.exact(poses[i], ob.oracle_local_to_object_space(hierarchies[1], local[i]))
+        assert context.rejected_instance_count() == 0
+        context.unregister_clip(handle)
