@@ -10,6 +10,7 @@
 #include <acl/core/compressed_tracks.h>
 #include <acl/core/track_writer.h>
 #include <acl/decompression/database/database.h>
+#include <acl/decompression/database/database_streamer.h>
 #include <acl/decompression/decompression_settings.h>
 
 #include "aclhip.hpp"
@@ -85,37 +86,102 @@ namespace acl_gpu
 		};
 	}
 
-	// acl::database_context<settings> (includes/acl/decompression/database/database.h:69-201) on the GPU. The reference pulls bulk data
-	// through two database_streamer objects while it decodes; here the GPU side owns the residency, so what initialize() takes is
-	// the bytes those streamers would serve (what debug_database_streamer is constructed with), and a streaming request is a stream
-	// ordered copy + metadata update: nothing is ever "in progress" for the caller to poll.
+	namespace impl
+	{
+		// what a decompression context needs of the database it is bound to, whatever its settings type
+		struct database_context_base
+		{
+			virtual ~database_context_base() = default;
+			virtual void update() const = 0;		// bring the GPU side up to date with requests the caller's streamers have completed
+		};
+	}
+
+	// acl::database_context<settings> (includes/acl/decompression/database/database.h:69-201) on the GPU, in two forms:
+	//  * initialize(database [, bulk_data_medium, bulk_data_low]): the GPU side owns the residency. What it takes is the bytes the
+	//    reference's streamers would serve (what debug_database_streamer is constructed with); a streaming request is a stream ordered
+	//    copy + metadata update, nothing is ever "in progress" for the caller to poll.
+	//  * initialize(allocator, database, medium_streamer, low_streamer) -- the reference's own signature (database.h:116): the caller's
+	//    acl::database_streamer objects serve the bulk data, synchronously or not. They are driven by the reference's own
+	//    database_context, kept inside (chunk selection, request ids, complete() / cancel(), database_streamer.impl.h:60-172: a streamer
+	//    only befriends that class); every request it reports complete is mirrored on the GPU: the range the streamer filled is copied
+	//    to HBM and the tier metadata published (aclhip_database_stream_in_from / _stream_out). Requests of an asynchronous streamer
+	//    are mirrored when they have completed -- at the latest by the next query, request or decode.
 	template<class database_settings_type>
-	class database_context
+	class database_context final : public impl::database_context_base
 	{
 	public:
 		// reference: initialize(allocator, database) -- bulk data inline (database.h:110)
-		bool initialize(const acl::compressed_database& database) { return m_impl.initialize(device(), &database, database.get_size()); }
-		// reference: initialize(allocator, database, medium_tier_streamer, low_tier_streamer) (database.h:116)
+		bool initialize(const acl::compressed_database& database) { m_streamers[0] = m_streamers[1] = nullptr; return m_impl.initialize(device(), &database, database.get_size()); }
+		// the bytes the reference's streamers would serve
 		bool initialize(const acl::compressed_database& database, const uint8_t* bulk_data_medium, const uint8_t* bulk_data_low)
 		{
+			m_streamers[0] = m_streamers[1] = nullptr;
 			return m_impl.initialize(device(), &database, database.get_size(), bulk_data_medium, bulk_data_low);
 		}
+		// reference: initialize(allocator, database, medium_tier_streamer, low_tier_streamer) (database.h:116)
+		bool initialize(acl::iallocator& allocator, const acl::compressed_database& database, acl::database_streamer& medium_tier_streamer, acl::database_streamer& low_tier_streamer)
+		{
+			reset();
+			if (!m_reference.initialize(allocator, database, medium_tier_streamer, low_tier_streamer))
+				return false;
+			if (!m_impl.initialize_streamed(device(), &database, database.get_size()))
+			{
+				m_reference.reset();
+				return false;
+			}
+			m_streamers[0] = &medium_tier_streamer;
+			m_streamers[1] = &low_tier_streamer;
+			return true;
+		}
 		bool is_initialized() const { return m_impl.is_initialized(); }
-		void reset() { m_impl.reset(); }
+		void reset()
+		{
+			m_impl.reset();
+			if (m_reference.is_initialized())
+				m_reference.reset();
+			m_streamers[0] = m_streamers[1] = nullptr;
+			m_num_pending = 0;
+		}
 		bool is_bound_to(const acl::compressed_database& database) const { return m_impl.is_bound_to(&database); }
 		bool contains(const acl::compressed_tracks& tracks) const { return m_impl.contains(&tracks); }
-		bool is_streamed_in(acl::quality_tier tier) const { return m_impl.is_streamed_in(static_cast<aclhip::quality_tier>(tier)); }
-		bool is_streaming(acl::quality_tier tier) const { return m_impl.is_streaming(static_cast<aclhip::quality_tier>(tier)); }
-		acl::database_stream_request_result stream_in(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U)
+		bool is_streamed_in(acl::quality_tier tier) const { update(); return m_impl.is_streamed_in(static_cast<aclhip::quality_tier>(tier)); }
+		bool is_streaming(acl::quality_tier tier) const
 		{
-			return convert(m_impl.stream_in(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream));
+			update();
+			for (uint32_t i = 0; i < m_num_pending; ++i)
+				if (m_pending[i].tier == tier)
+					return true;
+			return m_impl.is_streaming(static_cast<aclhip::quality_tier>(tier));
 		}
-		acl::database_stream_request_result stream_out(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U)
-		{
-			return convert(m_impl.stream_out(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream));
-		}
+		acl::database_stream_request_result stream_in(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U) { return request(tier, num_chunks_to_stream, true); }
+		acl::database_stream_request_result stream_out(acl::quality_tier tier, uint32_t num_chunks_to_stream = ~0U) { return request(tier, num_chunks_to_stream, false); }
 
 		const aclhip::database_context<aclhip::default_database_settings>& get() const { return m_impl; }
+
+		// Mirrors the requests the caller's streamers have completed since the last call (in request order; a request that is still
+		// in flight holds back the later ones of its tier)
+		void update() const override
+		{
+			uint32_t kept = 0;
+			for (uint32_t i = 0; i < m_num_pending; ++i)
+			{
+				const pending_request request = m_pending[i];
+				bool blocked = m_reference.is_streaming(request.tier);
+				for (uint32_t k = 0; k < kept && !blocked; ++k)
+					blocked = m_pending[k].tier == request.tier;
+				if (blocked)
+				{
+					m_pending[kept++] = request;
+					continue;
+				}
+				const aclhip::quality_tier tier = static_cast<aclhip::quality_tier>(request.tier);
+				if (request.stream_in)
+					(void)m_impl.stream_in_from(tier, request.num_chunks, m_streamers[uint32_t(request.tier) - 1]->get_bulk_data(request.tier));
+				else
+					(void)m_impl.stream_out(tier, request.num_chunks);
+			}
+			m_num_pending = kept;
+		}
 
 	private:
 		static acl::database_stream_request_result convert(aclhip::database_stream_request_result result)
@@ -131,7 +197,32 @@ namespace acl_gpu
 			}
 		}
 
-		aclhip::database_context<aclhip::default_database_settings> m_impl;
+		acl::database_stream_request_result request(acl::quality_tier tier, uint32_t num_chunks_to_stream, bool stream_in)
+		{
+			if (m_streamers[0] == nullptr)
+				return convert(stream_in ? m_impl.stream_in(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream) : m_impl.stream_out(static_cast<aclhip::quality_tier>(tier), num_chunks_to_stream));
+
+			// the caller's streamers: the reference's context decides and drives them, the GPU side follows
+			update();
+			if (m_num_pending == k_max_pending)
+				return acl::database_stream_request_result::no_free_streaming_requests;
+			const acl::database_stream_request_result result = stream_in ? m_reference.stream_in(tier, num_chunks_to_stream) : m_reference.stream_out(tier, num_chunks_to_stream);
+			if (result == acl::database_stream_request_result::dispatched)
+			{
+				m_pending[m_num_pending++] = pending_request{ tier, num_chunks_to_stream, stream_in };
+				update();		// a synchronous streamer has completed already
+			}
+			return result;
+		}
+
+		struct pending_request { acl::quality_tier tier; uint32_t num_chunks; bool stream_in; };
+		static constexpr uint32_t k_max_pending = 8;
+
+		mutable aclhip::database_context<aclhip::default_database_settings> m_impl;
+		acl::database_context<database_settings_type> m_reference;		// bookkeeping for the caller's streamers only: nothing decodes through it
+		acl::database_streamer* m_streamers[2] = { nullptr, nullptr };
+		mutable pending_request m_pending[k_max_pending] = {};
+		mutable uint32_t m_num_pending = 0;
 	};
 
 	template<class settings_type>
@@ -143,10 +234,11 @@ namespace acl_gpu
 		template<class database_settings_type>
 		bool initialize(const acl::compressed_tracks& tracks, const database_context<database_settings_type>& database)
 		{
+			m_database = &database;
 			return m_impl.initialize(&tracks, tracks.get_size(), database.get());
 		}
 		bool is_initialized() const { return m_impl.is_initialized(); }
-		void reset() { m_impl.reset(); }
+		void reset() { m_impl.reset(); m_database = nullptr; }
 		bool relocated(const acl::compressed_tracks& tracks) { return m_impl.relocated(&tracks); }
 		bool is_bound_to(const acl::compressed_tracks& tracks) const { return m_impl.is_bound_to(&tracks); }
 		void set_looping_policy(acl::sample_looping_policy policy) { m_impl.set_looping_policy(static_cast<aclhip::sample_looping_policy>(policy)); }
@@ -154,12 +246,16 @@ namespace acl_gpu
 		void seek(float sample_time, acl::sample_rounding_policy policy) { m_impl.seek(sample_time, static_cast<aclhip::sample_rounding_policy>(policy)); }
 
 		template<class writer_type>
-		void decompress_tracks(writer_type& writer) { impl::writer_adapter<writer_type> adapter(writer); m_impl.decompress_tracks(adapter); }
+		void decompress_tracks(writer_type& writer) { follow_database(); impl::writer_adapter<writer_type> adapter(writer); m_impl.decompress_tracks(adapter); }
 
 		template<class writer_type>
-		void decompress_track(uint32_t track_index, writer_type& writer) { impl::writer_adapter<writer_type> adapter(writer); m_impl.decompress_track(track_index, adapter); }
+		void decompress_track(uint32_t track_index, writer_type& writer) { follow_database(); impl::writer_adapter<writer_type> adapter(writer); m_impl.decompress_track(track_index, adapter); }
 
 	private:
+		// requests the caller's streamers completed since the last decode become visible first
+		void follow_database() const { if (m_database != nullptr) m_database->update(); }
+
 		aclhip::decompression_context<impl::mapped_settings<settings_type>> m_impl;
+		const impl::database_context_base* m_database = nullptr;
 	};
 }

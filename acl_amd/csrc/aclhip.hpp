@@ -200,6 +200,34 @@ namespace aclhip
 			return true;
 		}
 
+		// A database whose bulk data is served by the caller's own streamers (aclhip_register_database_streamed): stream_in_from()
+		// hands the tier's bulk data over with every request
+		bool initialize_streamed(device& gpu, const void* compressed_database, uint64_t size)
+		{
+			reset();
+			if (!gpu.is_valid() || compressed_database == nullptr)
+				return false;
+			aclhip_database handle = ACLHIP_INVALID_HANDLE;
+			if (aclhip_register_database_streamed(gpu.get(), compressed_database, size, 0, &handle) != ACLHIP_OK)
+				return false;
+			m_device = &gpu;
+			m_database = handle;
+			m_compressed_database = compressed_database;
+			return true;
+		}
+
+		database_stream_request_result stream_in_from(quality_tier tier, uint32_t num_chunks_to_stream, const void* tier_bulk_data, void* stream = nullptr)
+		{
+			if (!is_initialized())
+				return database_stream_request_result::context_not_initialized;
+			if (tier == quality_tier::highest_importance)
+				return database_stream_request_result::invalid_database_tier;
+			uint32_t moved = 0;
+			if (aclhip_database_stream_in_from(m_device->get(), m_database, uint32_t(tier), num_chunks_to_stream, tier_bulk_data, stream, &moved) != ACLHIP_OK)
+				return database_stream_request_result::no_free_streaming_requests;
+			return moved != 0 ? database_stream_request_result::dispatched : database_stream_request_result::done;
+		}
+
 		const void* get_compressed_database() const { return m_compressed_database; }
 		bool is_initialized() const { return m_device != nullptr; }
 

@@ -619,6 +619,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			context->free_slots.push_back(slot);
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "the database's keyframes for this clip lie outside of its bulk data");
 		}
+		if (db.streamed)
+			for (uint32_t si = 0; si < num_segments; ++si)
+				db.segment_pose_bits.emplace_back(record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header)), segment_pose_bit_sizes[si]);
 		record.db_headers = db.d_runtime_headers;
 		record.db_bulk_data[0] = db.d_bulk_data[0];
 		record.db_bulk_data[1] = db.d_bulk_data[1];

@@ -34,7 +34,14 @@ namespace
 		std::vector<uint32_t> chunk_first_patch[2];		// num_chunks + 1 entries
 		std::vector<uint32_t> loaded_chunks[2];			// bitset, first chunk in the MSB like core/bitset.h
 		std::vector<database_clip_metadata> clip_metadata;
-		std::vector<tier_patch> patches_by_header[2];	// every chunk segment of the tier, sorted by segment_header_offset (bounds checks when a clip is bound)
+		std::vector<tier_patch> patches_by_header[2];	// every (known) chunk segment of the tier, sorted by segment_header_offset (bounds checks when a clip is bound)
+		// databases whose bulk data arrives through the caller's own streamers (aclhip_register_database_streamed): chunks are parsed
+		// and checked when they first arrive, their patches appended in chunk order
+		bool streamed = false;
+		uint32_t num_parsed_chunks[2] = { 0, 0 };
+		tier_patch* pinned_patches[2] = { nullptr, nullptr };	// host mirror of d_patches the uploads are made from
+		uint32_t patch_capacity[2] = { 0, 0 };
+		std::vector<std::pair<uint32_t, uint32_t>> segment_pose_bits;	// (runtime segment header offset, bits per keyframe) of the bound clips
 	};
 }
 

@@ -21,13 +21,15 @@ namespace
 			(void)hipFree(db.d_patches[tier]);
 			if (db.pinned_bulk_data[tier] != nullptr)
 				(void)hipHostFree(db.pinned_bulk_data[tier]);
+			if (db.pinned_patches[tier] != nullptr)
+				(void)hipHostFree(db.pinned_patches[tier]);
 		}
 		db = host_database();
 	}
 }
 
 static aclhip_status register_database_impl(aclhip_context* context, const void* compressed_database, uint64_t size,
-	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database, bool validate_only)
+	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database, bool validate_only, bool streamed = false)
 {
 	if (context == nullptr || out_database == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -58,7 +60,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 
 	const bool is_inline = (header.misc_packed & 1u) != 0;
 	const uint8_t* bulk_sources[2] = { static_cast<const uint8_t*>(bulk_data_medium), static_cast<const uint8_t*>(bulk_data_low) };
-	for (int tier = 0; tier < 2; ++tier)
+	for (int tier = 0; tier < 2 && !streamed; ++tier)
 	{
 		if (header.bulk_data_size[tier] == 0)
 			continue;
@@ -73,6 +75,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 	}
 
 	host_database db;
+	db.streamed = streamed;
 	db.hash = buffer_header.hash;
 	db.info.num_clips = header.num_clips;
 	db.info.num_segments = header.num_segments;
@@ -108,6 +111,10 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 		for (uint32_t chunk_index = 0; chunk_index < num_chunks; ++chunk_index)
 		{
 			const database_chunk_description& description = tier_descriptions[chunk_index];
+			if (uint64_t(description.offset) + description.size > header.bulk_data_size[tier] || description.size < sizeof(database_chunk_header) || description.size > header.max_chunk_size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d lies outside of the bulk data", chunk_index, tier + 1);
+			if (streamed)
+				continue;		// its header arrives with the chunk (parse_arrived_chunks)
 			db.chunk_first_patch[tier][chunk_index] = uint32_t(patches[tier].size());
 			if (uint64_t(description.offset) + description.size > header.bulk_data_size[tier] || description.size < sizeof(database_chunk_header) || description.size > header.max_chunk_size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d lies outside of the bulk data", chunk_index, tier + 1);
@@ -125,7 +132,11 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 				patches[tier].push_back(tier_patch{ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
 			}
 		}
-		db.chunk_first_patch[tier][num_chunks] = uint32_t(patches[tier].size());
+		if (!streamed)
+		{
+			db.chunk_first_patch[tier][num_chunks] = uint32_t(patches[tier].size());
+			db.num_parsed_chunks[tier] = num_chunks;
+		}
 		db.patches_by_header[tier] = patches[tier];
 		std::sort(db.patches_by_header[tier].begin(), db.patches_by_header[tier].end(),
 			[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; });
@@ -149,13 +160,16 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 		const size_t bulk_bytes = size_t(header.bulk_data_size[tier]) + 64;
 		ok = hipMalloc(reinterpret_cast<void**>(&db.d_bulk_data[tier]), bulk_bytes) == hipSuccess
 			&& hipMemsetAsync(db.d_bulk_data[tier], 0xCD, bulk_bytes, context->copy_stream) == hipSuccess		// like debug_database_streamer: not-resident memory is poison
-			&& hipMalloc(reinterpret_cast<void**>(&db.d_patches[tier]), std::max<size_t>(patches[tier].size(), 1) * sizeof(tier_patch)) == hipSuccess;
+			&& hipMalloc(reinterpret_cast<void**>(&db.d_patches[tier]), std::max<size_t>(streamed ? header.num_segments : patches[tier].size(), 1) * sizeof(tier_patch)) == hipSuccess;
+		db.patch_capacity[tier] = uint32_t(streamed ? header.num_segments : patches[tier].size());		// a segment has at most one entry per tier
 		if (ok && !patches[tier].empty())
 			ok = stage_upload(context, db.d_patches[tier], patches[tier].data(), patches[tier].size() * sizeof(tier_patch), staging_used);
+		if (ok && streamed && header.num_segments != 0 && num_descriptions != 0)
+			ok = hipHostMalloc(reinterpret_cast<void**>(&db.pinned_patches[tier]), size_t(header.num_segments) * sizeof(tier_patch), hipHostMallocDefault) == hipSuccess;
 		if (ok && header.bulk_data_size[tier] != 0)
 		{
 			ok = hipHostMalloc(reinterpret_cast<void**>(&db.pinned_bulk_data[tier]), header.bulk_data_size[tier], hipHostMallocDefault) == hipSuccess;
-			if (ok)
+			if (ok && !streamed)
 				std::memcpy(db.pinned_bulk_data[tier], bulk_sources[tier], header.bulk_data_size[tier]);
 		}
 	}
@@ -181,6 +195,11 @@ extern "C" aclhip_status aclhip_register_database(aclhip_context* context, const
 	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database)
 {
 	return guarded(context, [&]() { return register_database_impl(context, compressed_database, size, bulk_data_medium, bulk_data_low, check_hash, out_database, false); });
+}
+
+extern "C" aclhip_status aclhip_register_database_streamed(aclhip_context* context, const void* compressed_database, uint64_t size, int check_hash, aclhip_database* out_database)
+{
+	return guarded(context, [&]() { return register_database_impl(context, compressed_database, size, nullptr, nullptr, check_hash, out_database, false, true); });
 }
 
 // ---- host only validation (no device needed) ---------------------------------------------------------------------------
@@ -335,7 +354,57 @@ extern "C" aclhip_status aclhip_get_database_info(const aclhip_context* context,
 
 namespace
 {
-	aclhip_status stream_database(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks_to_stream, void* stream, bool stream_in, uint32_t* out_num_chunks)
+	// Streamed databases: chunks [first, last] of `tier_bulk_data` (the tier's bulk data as the caller's streamer holds it) have just
+	// arrived. Chunks seen for the first time are checked and turned into metadata patches -- what registration does up front when it is
+	// given the bulk data (stream_in only ever continues behind the last resident chunk: first arrivals come in chunk order) -- and the
+	// bytes are taken over into the pinned backing store the device copy is made from.
+	aclhip_status take_arrived_chunks(aclhip_context* context, host_database& db, uint32_t tier_index, uint32_t first_chunk_index, uint32_t last_chunk_index,
+		const uint8_t* tier_bulk_data, hipStream_t hip_stream)
+	{
+		const uint32_t bulk_size = db.info.bulk_data_size[tier_index];
+		const uint32_t first_new_patch = db.chunk_first_patch[tier_index][db.num_parsed_chunks[tier_index]];
+		uint32_t next_patch = first_new_patch;
+		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)
+		{
+			const database_chunk_description& description = db.chunks[tier_index][chunk_index];
+			const database_chunk_header& chunk = *reinterpret_cast<const database_chunk_header*>(tier_bulk_data + description.offset);
+			if (chunk.index != chunk_index || chunk.size != description.size
+				|| uint64_t(sizeof(database_chunk_header)) + uint64_t(chunk.num_segments) * sizeof(database_chunk_segment_header) > description.size)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u arrived with an invalid header", chunk_index, tier_index + 1);
+			std::memcpy(db.pinned_bulk_data[tier_index] + description.offset, tier_bulk_data + description.offset, description.size);
+			if (chunk_index < db.num_parsed_chunks[tier_index])
+				continue;		// seen before (streamed out and back in): its patches are on the device already
+			if (chunk_index != db.num_parsed_chunks[tier_index])
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "chunk %u of tier %u arrived before chunk %u", chunk_index, tier_index + 1, db.num_parsed_chunks[tier_index]);
+
+			const database_chunk_segment_header* segments = reinterpret_cast<const database_chunk_segment_header*>(&chunk + 1);
+			if (uint64_t(next_patch) + chunk.num_segments > db.patch_capacity[tier_index])
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u lists more segments than the database has", chunk_index, tier_index + 1);
+			for (uint32_t i = 0; i < chunk.num_segments; ++i)
+			{
+				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > db.runtime_headers_size || segments[i].samples_offset >= bulk_size)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u points outside of the database", chunk_index, tier_index + 1);
+				// keyframes of a clip that is already bound must lie inside the tier (clips bound later are checked when they are bound)
+				for (const std::pair<uint32_t, uint32_t>& bound : db.segment_pose_bits)
+					if (bound.first == segments[i].segment_header_offset
+						&& uint64_t(segments[i].samples_offset) + (uint64_t(__builtin_popcount(segments[i].sample_indices)) * bound.second + 7) / 8 > bulk_size)
+						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u: keyframes lie outside of the bulk data", chunk_index, tier_index + 1);
+				const tier_patch patch = { segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset };
+				db.pinned_patches[tier_index][next_patch++] = patch;
+				db.patches_by_header[tier_index].insert(std::upper_bound(db.patches_by_header[tier_index].begin(), db.patches_by_header[tier_index].end(), patch,
+					[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; }), patch);
+			}
+			db.num_parsed_chunks[tier_index] = chunk_index + 1;
+			db.chunk_first_patch[tier_index][chunk_index + 1] = next_patch;
+		}
+		if (next_patch != first_new_patch)
+			ACLHIP_CHECK_HIP(context, hipMemcpyAsync(db.d_patches[tier_index] + first_new_patch, db.pinned_patches[tier_index] + first_new_patch,
+				size_t(next_patch - first_new_patch) * sizeof(tier_patch), hipMemcpyHostToDevice, hip_stream));
+		return ACLHIP_OK;
+	}
+
+	aclhip_status stream_database(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks_to_stream, void* stream, bool stream_in, uint32_t* out_num_chunks,
+		const void* tier_bulk_data = nullptr)
 	{
 		if (context == nullptr)
 			return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -350,8 +419,10 @@ namespace
 		host_database& db = context->databases[database];
 		const uint32_t tier_index = tier - 1;
 		const uint32_t num_chunks = db.info.num_chunks[tier_index];
+		if (stream_in && db.streamed != (tier_bulk_data != nullptr) && num_chunks != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, db.streamed ? "a streamed database takes its chunks through aclhip_database_stream_in_from" : "this database was registered with its bulk data");
 		num_chunks_to_stream = std::min(num_chunks_to_stream, num_chunks);
-		if (num_chunks == 0 || num_chunks_to_stream == 0)
+		if (num_chunks == 0)
 			return ACLHIP_OK;
 
 		// Which chunks: the first missing ones when streaming in, the first resident ones when streaming out -- the reference's
@@ -383,15 +454,27 @@ namespace
 		if (first_chunk_index == ~0u || first_chunk_index >= num_chunks)
 			return ACLHIP_OK;	// database_stream_request_result::done
 
-		const uint64_t last_chunk_index64 = uint64_t(first_chunk_index) + num_chunks_to_stream - 1;
-		const uint32_t last_chunk_index = last_chunk_index64 >= num_chunks ? num_chunks - 1 : uint32_t(last_chunk_index64);
+		// The reference's own arithmetic (database.impl.h:490-497,571-578), quirk included: a request for 0 chunks computes
+		// first + 0 - 1, which wraps when the first candidate is chunk 0 -- the WHOLE tier moves -- and is first - 1 otherwise: nothing moves
+		const uint64_t last_chunk_index64 = uint64_t(first_chunk_index) + uint64_t(num_chunks_to_stream) - 1;
+		const uint32_t last_chunk_index = last_chunk_index64 >= uint64_t(num_chunks) ? num_chunks - 1 : uint32_t(last_chunk_index64);
 		const uint32_t num_streaming_chunks = last_chunk_index - first_chunk_index + 1;
+		if (num_streaming_chunks == 0)
+			return ACLHIP_OK;	// database_stream_request_result::done
 
 		device_guard guard(context->device);
 		hipStream_t hip_stream = static_cast<hipStream_t>(stream);
 		note_launch_stream(context, hip_stream);
-		const uint32_t first_patch = db.chunk_first_patch[tier_index][first_chunk_index];
-		const uint32_t num_patches = db.chunk_first_patch[tier_index][last_chunk_index + 1] - first_patch;
+		if (stream_in && db.streamed)
+		{
+			const aclhip_status arrived = take_arrived_chunks(context, db, tier_index, first_chunk_index, last_chunk_index, static_cast<const uint8_t*>(tier_bulk_data), hip_stream);
+			if (arrived != ACLHIP_OK)
+				return arrived;
+		}
+		// (a streamed database only knows the chunks that have arrived; none beyond them can be resident)
+		const uint32_t known_end = std::min(last_chunk_index + 1, db.num_parsed_chunks[tier_index]);
+		const uint32_t first_patch = db.chunk_first_patch[tier_index][std::min(first_chunk_index, known_end)];
+		const uint32_t num_patches = db.chunk_first_patch[tier_index][known_end] - first_patch;
 
 		if (stream_in)
 		{
@@ -423,6 +506,14 @@ namespace
 extern "C" aclhip_status aclhip_database_stream_in(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks)
 {
 	return stream_database(context, database, tier, num_chunks, stream, true, out_num_chunks);
+}
+
+extern "C" aclhip_status aclhip_database_stream_in_from(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, const void* tier_bulk_data,
+	void* stream, uint32_t* out_num_chunks)
+{
+	if (tier_bulk_data == nullptr)
+		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null bulk data") : ACLHIP_ERROR_INVALID_ARGUMENT;
+	return stream_database(context, database, tier, num_chunks, stream, true, out_num_chunks, tier_bulk_data);
 }
 
 extern "C" aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks)

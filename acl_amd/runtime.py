@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
-    "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
+    "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
@@ -184,6 +184,8 @@ def load_library():
     pconsumers = ctypes.POINTER(PoseConsumers)
     poutput = ctypes.POINTER(OutputDesc)
     lib.aclhip_get_lifetime_stats.argtypes = [vp, ctypes.POINTER(u64)]
+    lib.aclhip_register_database_streamed.argtypes = [vp, vp, u64, i32, ctypes.POINTER(u32)]
+    lib.aclhip_database_stream_in_from.argtypes = [vp, u32, u32, u32, vp, vp, ctypes.POINTER(u32)]
     lib.aclhip_peer_export_buffer.argtypes = [vp, vp, vp]
     lib.aclhip_peer_open_buffer.argtypes = [vp, vp, ctypes.POINTER(vp)]
     lib.aclhip_peer_close_buffer.argtypes = [vp, vp]
@@ -332,6 +334,17 @@ class Context:
         self._check(self._lib.aclhip_register_database(self._handle, array.ctypes.data, array.size, _host_ptr(medium), _host_ptr(low),
                                                        1 if check_hash else 0, ctypes.byref(handle)))
         return handle.value
+
+    def register_database_streamed(self, database, check_hash=True):
+        """aclhip_register_database_streamed: the bulk data arrives with the stream-in requests (database_stream_in_from)"""
+        handle = ctypes.c_uint32(INVALID_HANDLE)
+        self._check(self._lib.aclhip_register_database_streamed(self._handle, database.ctypes.data, database.size, int(check_hash), ctypes.byref(handle)))
+        return handle.value
+
+    def database_stream_in_from(self, database, tier, tier_bulk_data, num_chunks=0xFFFFFFFF, stream=None):
+        moved = ctypes.c_uint32(0)
+        self._check(self._lib.aclhip_database_stream_in_from(self._handle, database, tier, num_chunks, tier_bulk_data.ctypes.data, stream, ctypes.byref(moved)))
+        return moved.value
 
     def unregister_database(self, database):
         self._check(self._lib.aclhip_unregister_database(self._handle, database))

@@ -226,9 +226,23 @@ aclhip_status aclhip_register_clip_with_database(aclhip_context* context, const 
  * tier 1 = medium importance, 2 = lowest importance. stream_in copies the next `num_chunks` missing chunks from pinned host
  * memory to HBM with hipMemcpyAsync on `stream` and then publishes their segments' tier metadata (stream ordered: decodes enqueued
  * later on the same stream see the new keyframes); stream_out retires the metadata of the first `num_chunks` resident chunks.
- * `out_num_chunks` (optional) receives how many chunks were actually moved (0 = done, like database_stream_request_result::done). */
+ * `out_num_chunks` (optional) receives how many chunks were actually moved (0 = done, like database_stream_request_result::done).
+ * A request for 0 chunks follows the reference's arithmetic to the letter (database.impl.h:490-497,571-578: `first + 0 - 1` wraps
+ * when the first candidate is chunk 0 and the WHOLE tier moves; with any other first candidate nothing does). */
 aclhip_status aclhip_database_stream_in(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
 aclhip_status aclhip_database_stream_out(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, void* stream, uint32_t* out_num_chunks);
+
+/* Databases whose bulk data is served by the CALLER's streamers (acl::database_streamer objects, decompression/database/
+ * database_streamer.h:95-175): only the compressed_database itself is known at registration. A stream-in request then hands over the
+ * tier's bulk data as the streamer holds it (database_streamer::get_bulk_data(tier), HOST pointer; valid for the chunks the request
+ * selects -- the same chunks the reference's database_context selects for the same request, database.impl.h:478-497): chunks seen for
+ * the first time are validated and turned into tier metadata like aclhip_register_database does up front, their bytes are copied and
+ * travel to HBM on `stream`. aclhip_database_stream_out and everything else work as for any database.
+ * acl_gpu::database_context (acl_amd/csrc/acl_gpu_adapter.h) drives the caller's streamers through the reference's own
+ * database_context and mirrors every completed request with these calls. */
+aclhip_status aclhip_register_database_streamed(aclhip_context* context, const void* compressed_database, uint64_t size, int check_hash, aclhip_database* out_database);
+aclhip_status aclhip_database_stream_in_from(aclhip_context* context, aclhip_database database, uint32_t tier, uint32_t num_chunks, const void* tier_bulk_data,
+	void* stream, uint32_t* out_num_chunks);
 
 /* Host only (no GPU work): strip_database_quality_tier (compression/compress.h:124, impl/compress.database.impl.h:1388-1525) --
  * the compressed_database without its medium (tier 1) or low (tier 2) importance tier, byte for byte what the reference builds

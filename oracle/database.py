@@ -136,12 +136,17 @@ class OracleDatabase:
     def _stream(self, tier, num_chunks, stream_in):
         total = self.num_chunks[tier]
         num_chunks = min(num_chunks, total)
-        if total == 0 or num_chunks == 0:
+        if total == 0:
             return 0
         first = self._first_chunk(tier, stream_in)
         if first is None or first >= total:
             return 0
-        last = min(first + num_chunks - 1, total - 1)
+        # database.impl.h:490-497,571-578 in the reference's unsigned 64 bit arithmetic: a request for 0 chunks wraps when the first
+        # candidate is chunk 0 (the whole tier moves) and selects nothing otherwise
+        last64 = (first + num_chunks - 1) & 0xFFFFFFFFFFFFFFFF
+        last = total - 1 if last64 >= total else last64
+        if last - first + 1 == 0:
+            return 0
         self._apply(tier, first, last, stream_in)
         return last - first + 1
 

@@ -121,12 +121,21 @@ int main(int argc, char** argv)
 	if (database.is_valid(true).any())
 		return 102;
 
+	// ACLHIP_ADAPTER_STREAMERS=1: the GPU context is handed streamer OBJECTS like the reference's (its own pair: a streamer serves one
+	// database context), not the bytes they serve
+	const char* streamers_mode = std::getenv("ACLHIP_ADAPTER_STREAMERS");
+	const bool use_streamer_objects = streamers_mode != nullptr && streamers_mode[0] == '1';
+
 	acl::ansi_allocator allocator;
 	acl::debug_database_streamer streamer_medium(allocator, bulk_medium.data, uint32_t(bulk_medium.size));
 	acl::debug_database_streamer streamer_low(allocator, bulk_low.data, uint32_t(bulk_low.size));
+	acl::debug_database_streamer gpu_streamer_medium(allocator, bulk_medium.data, uint32_t(bulk_medium.size));
+	acl::debug_database_streamer gpu_streamer_low(allocator, bulk_low.data, uint32_t(bulk_low.size));
 	acl::database_context<acl::default_database_settings> cpu_database;
 	acl_gpu::database_context<acl::default_database_settings> gpu_database;
-	if (!cpu_database.initialize(allocator, database, streamer_medium, streamer_low) || !gpu_database.initialize(database, bulk_medium.data, bulk_low.data))
+	if (!cpu_database.initialize(allocator, database, streamer_medium, streamer_low))
+		return 103;
+	if (!(use_streamer_objects ? gpu_database.initialize(allocator, database, gpu_streamer_medium, gpu_streamer_low) : gpu_database.initialize(database, bulk_medium.data, bulk_low.data)))
 		return 103;
 	if (!gpu_database.is_bound_to(database))
 		return 104;

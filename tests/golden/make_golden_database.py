@@ -30,6 +30,12 @@ CASES = {
     "two_clips_single_chunk": (
         [(70, 16, 64), (71, 28, 40)], dict(medium_proportion=0.25, low_proportion=0.25, max_chunk_size=64 * 1024),
         [(2, ALL, 1), (1, ALL, 1), (2, ALL, 0), (1, ALL, 0)]),
+    # num_chunks = 0: the reference's `first + 0 - 1` wraps when the first candidate chunk is chunk 0 and the WHOLE tier moves
+    # (database.impl.h:490-492,571-573); with any other first chunk nothing does. (stream_out(tier, 0) while later chunks are NOT resident
+    # walks chunk headers that were never streamed in and crashes the reference: not part of the script.)
+    "zero_chunk_requests": (
+        [(90, 60, 300), (91, 40, 220)], dict(medium_proportion=0.3, low_proportion=0.3, max_chunk_size=4096),
+        [(2, 0, 1), (2, 0, 0), (1, 1, 1), (1, 0, 1), (1, ALL, 1), (1, 0, 0), (2, 2, 1), (2, 0, 1), (2, ALL, 1), (1, ALL, 1)]),
     "medium_tier_only": (
         [(80, 22, 120), (81, 12, 33)], dict(medium_proportion=0.5, low_proportion=0.0, max_chunk_size=4096),
         [(1, 1, 1), (2, ALL, 1), (1, ALL, 1), (1, 1, 0)]),
@@ -43,7 +49,10 @@ def main():
         raise SystemExit("oracle/_ref/libaclref_db.so is missing: run `make -C oracle ref` where /root/reference exists")
     rng = np.random.default_rng(777)
     os.makedirs(os.path.join(HERE, "database"), exist_ok=True)
+    only = sys.argv[1:]
     for name, (raw_specs, build_options, ops) in CASES.items():
+        if only and name not in only:
+            continue
         blobs = []
         for seed, num_tracks, num_samples in raw_specs:
             raw_clip = synth.build_clip(seed=seed, num_tracks=num_tracks, num_samples=num_samples, with_side_data=True)

@@ -45,11 +45,13 @@ DATABASE_BINARY = os.path.join(os.path.dirname(BINARY), "database_adapter_parity
 
 
 @pytest.mark.skipif(not os.path.exists(DATABASE_BINARY), reason="oracle/_ref/database_adapter_parity_test not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("streamer_objects", [False, True], ids=["bulk_bytes", "caller_streamers"])
 @pytest.mark.parametrize("name", helpers.database_golden_cases())
-def test_reference_database_context_and_gpu_adapter_agree_bit_for_bit(tmp_path, name):
+def test_reference_database_context_and_gpu_adapter_agree_bit_for_bit(tmp_path, name, streamer_objects):
     """acl::database_context fed by the reference's debug_database_streamer next to acl_gpu::database_context, one process, the
-    fixture's script of stream_in / stream_out requests (incl. partial tiers and holes): same request results, same poses after
-    every request"""
+    fixture's script of stream_in / stream_out requests (incl. partial tiers, holes and requests for 0 chunks): same request results,
+    same poses after every request. caller_streamers: the GPU context is initialized like the reference's, with acl::database_streamer
+    OBJECTS (initialize(allocator, database, medium_streamer, low_streamer), database.h:116), not with the bytes they serve."""
     case = helpers.load_database_golden(name)
     files = {}
     for key in ("database", "bulk_medium", "bulk_low"):
@@ -63,6 +65,6 @@ def test_reference_database_context_and_gpu_adapter_agree_bit_for_bit(tmp_path, 
         clip.tofile(path)
         clip_paths.append(str(path))
     result = subprocess.run([DATABASE_BINARY, str(files["database"]), str(files["bulk_medium"]), str(files["bulk_low"]), str(ops_path)] + clip_paths,
-                            capture_output=True, text=True, timeout=300)
+                            capture_output=True, text=True, timeout=300, env=dict(os.environ, ACLHIP_ADAPTER_STREAMERS="1" if streamer_objects else "0"))
     assert result.returncode == 0, f"exit code {result.returncode}\n{result.stdout}\n{result.stderr}"
     assert f"{len(case['ops'])} requests, {len(clip_paths)} clips" in result.stdout
