@@ -579,6 +579,15 @@ namespace aclhip
 		return make_float4(result.x, result.y, result.z, 0.0f);
 	}
 
+	// rtm::qvv_mul leaves the quaternion path when any scale component of either side is negative (mirrored rigs) and composes 3x4
+	// matrices instead. That path is not restated: the kernels take the quaternion path for every scale and COUNT the
+	// transforms for which the reference would have done otherwise (aclhip_get_negative_scale_count), so that a caller with mirrored rigs
+	// knows which results follow a different formula.
+	__device__ __forceinline__ bool qvv_mul_takes_matrix_path(const qvv& lhs, const qvv& rhs)
+	{
+		return fminf(fminf(fminf(lhs.scale.x, lhs.scale.y), lhs.scale.z), fminf(fminf(rhs.scale.x, rhs.scale.y), rhs.scale.z)) < 0.0f;
+	}
+
 	// lhs first, then rhs (child, then parent)
 	__device__ __forceinline__ qvv qvv_mul(const qvv& lhs, const qvv& rhs)
 	{

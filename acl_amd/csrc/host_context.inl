@@ -54,7 +54,7 @@ struct aclhip_context
 	std::vector<host_database> databases;
 	device_clip* d_clips = nullptr;
 	uint32_t d_clips_capacity = 0;
-	unsigned long long* d_rejected = nullptr;
+	unsigned long long* d_rejected = nullptr;	// [0] instances the kernels refused, [1] transforms of the pose consumers that met a negative scale
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
 	uint32_t max_hierarchy_words = 0;		// largest walk schedule (aclhip_set_clip_hierarchy) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
@@ -716,8 +716,8 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 
 	device_guard guard(device_index);
 	if (!guard.ok || hipStreamCreateWithFlags(&context->copy_stream, hipStreamNonBlocking) != hipSuccess
-		|| hipMalloc(reinterpret_cast<void**>(&context->d_rejected), sizeof(unsigned long long)) != hipSuccess
-		|| hipMemsetAsync(context->d_rejected, 0, sizeof(unsigned long long), context->copy_stream) != hipSuccess
+		|| hipMalloc(reinterpret_cast<void**>(&context->d_rejected), 2 * sizeof(unsigned long long)) != hipSuccess
+		|| hipMemsetAsync(context->d_rejected, 0, 2 * sizeof(unsigned long long), context->copy_stream) != hipSuccess
 		|| hipStreamSynchronize(context->copy_stream) != hipSuccess)
 	{
 		if (context->copy_stream != nullptr)

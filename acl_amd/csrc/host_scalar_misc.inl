@@ -373,6 +373,18 @@ extern "C" aclhip_status aclhip_get_rejected_instance_count(aclhip_context* cont
 	return ACLHIP_OK;
 }
 
+extern "C" aclhip_status aclhip_get_negative_scale_count(aclhip_context* context, uint64_t* out_count)
+{
+	if (context == nullptr || out_count == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	device_guard guard(context->device);
+	unsigned long long value = 0;
+	ACLHIP_CHECK_HIP(context, hipDeviceSynchronize());
+	ACLHIP_CHECK_HIP(context, hipMemcpy(&value, context->d_rejected + 1, sizeof(value), hipMemcpyDeviceToHost));
+	*out_count = value;
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch)
 {

@@ -166,6 +166,10 @@
 				const qvv additive = load_qvv(image, transform_index);
 				const qvv base = load_qvv(base_source, transform_index);
 				store_qvv(image, transform_index, apply_additive_to_base(consumers.additive_format, base, additive));
+				// additive_clip_format8::relative is a qvv_mul (core/additive_utils.h:128-160)
+				const uint64_t mirrored = __ballot(consumers.additive_format == 1 && qvv_mul_takes_matrix_path(additive, base));
+				if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
+					atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
 			}
 		}
 
@@ -203,7 +207,11 @@
 							if (pair_index < step_end)
 							{
 								const uint32_t pair = pairs[pair_index];		// transform | parent << 16
-								qvv object = qvv_mul(load_qvv(slot_image, pair & 0xFFFFu), load_qvv(slot_image, pair >> 16));
+								const qvv child = load_qvv(slot_image, pair & 0xFFFFu), parent = load_qvv(slot_image, pair >> 16);
+								const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
+								if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
+									atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
+								qvv object = qvv_mul(child, parent);
 								object.rotation = quat_normalize(object.rotation);
 								store_qvv(slot_image, pair & 0xFFFFu, object);
 							}

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
-    "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
+    "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
@@ -184,6 +184,7 @@ def load_library():
     pconsumers = ctypes.POINTER(PoseConsumers)
     poutput = ctypes.POINTER(OutputDesc)
     lib.aclhip_get_lifetime_stats.argtypes = [vp, ctypes.POINTER(u64)]
+    lib.aclhip_get_negative_scale_count.argtypes = [vp, ctypes.POINTER(u64)]
     lib.aclhip_register_database_streamed.argtypes = [vp, vp, u64, i32, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_in_from.argtypes = [vp, u32, u32, u32, vp, vp, ctypes.POINTER(u32)]
     lib.aclhip_peer_export_buffer.argtypes = [vp, vp, vp]
@@ -570,6 +571,11 @@ class Context:
 
     def push_poses_to_peer(self, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream=None):
         self._check(self._lib.aclhip_push_poses_to_peer(self._handle, peer_ptr, offset_bytes, shard_ptr, shard_bytes, stream))
+
+    def negative_scale_count(self):
+        count = ctypes.c_uint64(0)
+        self._check(self._lib.aclhip_get_negative_scale_count(self._handle, ctypes.byref(count)))
+        return count.value
 
     def lifetime_stats(self):
         """aclhip_get_lifetime_stats as a dict"""

@@ -130,6 +130,38 @@ def test_no_consumers_equals_decompress_tracks(context):
     context.unregister_clip(handle)
 
 
+def test_transforms_that_meet_a_negative_scale_are_counted(context):
+    """rtm::qvv_mul composes matrices when a scale component is negative (mirrored rigs); the kernels keep the quaternion formula and
+    count such transforms (aclhip_get_negative_scale_count) -- `relative` additive onto mirrored base poses, then object space"""
+    clip = synth.build_clip(seed=78, num_tracks=24, num_samples=30, has_scale=1)
+    handle = context.register_clip(clip.blob)
+    rng = np.random.default_rng(5)
+    parents = random_hierarchy(rng, 24, 3)
+    context.set_clip_hierarchy(handle, parents)
+    n = 9
+    times = np.linspace(0.0, clip.duration, n, dtype=np.float32)
+    handles = np.full(n, handle, dtype=np.uint32)
+    base = np.zeros((n, 24, 12), dtype=np.float32)
+    base[..., 3] = 1.0
+    base[..., 8:11] = 1.0
+    before = context.negative_scale_count()
+    context.decompress_poses(handles, times, additive_format=runtime.ADDITIVE_RELATIVE, base_poses=base)
+    local = context.decompress_poses(handles, times)
+    assert np.all(local[..., 8:11] > 0.0)                                      # the clip itself holds positive scales
+    assert context.negative_scale_count() == before                             # nothing mirrored: nothing counted
+    mirrored = base.copy()
+    mirrored[2, 5, 8] = -1.0                                                    # one mirrored base transform of one instance ...
+    mirrored[7, :, 9] = -1.0                                                    # ... and a whole mirrored base pose
+    context.decompress_poses(handles, times, additive_format=runtime.ADDITIVE_RELATIVE, base_poses=mirrored)
+    assert context.negative_scale_count() == before + 1 + 24
+    # object space: every transform below a mirrored one multiplies with a negative scale; roots never do
+    before = context.negative_scale_count()
+    context.decompress_poses(handles[:1], times[7:8], additive_format=runtime.ADDITIVE_RELATIVE, base_poses=mirrored[7:8], object_space=True)
+    num_roots = int(np.sum((parents == runtime.NO_PARENT) | (np.arange(24) == 0)))
+    assert context.negative_scale_count() == before + 24 + (24 - num_roots)
+    context.unregister_clip(handle)
+
+
 def test_refused_instances_and_arguments(context):
     rng = np.random.default_rng(3)
     with_hierarchy = synth.build_clip(seed=81, num_tracks=20, num_samples=20)
