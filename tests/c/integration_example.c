@@ -1,4 +1,4 @@
-/* The call sequences INTEGRATION.md shows (sections 1, 3, 4b), as one C99 translation unit that must compile and link against
+/* The call sequences INTEGRATION.md shows (sections 1, 3, 4b, 5), as one C99 translation unit that must compile and link against
  * libaclhip.so with the signatures the document uses. Never run: tests/test_capi_symbols.py only builds it. */
 #include "aclhip.h"
 
@@ -30,12 +30,24 @@ int integration_example(const void* tracks, uint64_t tracks_size, const void* co
 	s = aclhip_decompress_track_batch(gpu, d_clips, d_times, d_bones, num_instances, &params, d_transforms, hip_stream);
 	s = aclhip_order_instances_for_locality(gpu, host_clips, num_instances, order);
 	s = aclhip_decompress_tracks_batch_rows(gpu, d_clips, d_times, d_rows, num_instances, &params, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+	{
+		aclhip_output_desc output = { 0 };
+		output.layout = ACLHIP_LAYOUT_QV32;
+		s = aclhip_decompress_tracks_batch_out(gpu, d_clips, d_times, num_instances, &params, &output, d_poses, (uint64_t)max_tracks * 32, hip_stream);
+	}
 
 	/* section 3 */
 	s = aclhip_register_database(gpu, compressed_db, db_size, bulk_medium, bulk_low, 0, &db);
 	s = aclhip_register_clip_with_database(gpu, tracks, tracks_size, 0, db, &db_clip);
 	s = aclhip_database_stream_in(gpu, db, 1, 4, hip_stream, &moved);
 	s = aclhip_database_stream_out(gpu, db, 2, ~0u, hip_stream, &moved);
+	{
+		/* the engine's own streamers serve the bulk data */
+		aclhip_database streamed_db;
+		s = aclhip_register_database_streamed(gpu, compressed_db, db_size, 0, &streamed_db);
+		s = aclhip_database_stream_in_from(gpu, streamed_db, 1, 2, bulk_medium, hip_stream, &moved);
+		(void)aclhip_unregister_database(gpu, streamed_db);
+	}
 
 	/* section 4b */
 	s = aclhip_set_clip_hierarchy(gpu, clip, parent_indices, num_tracks);
@@ -46,6 +58,16 @@ int integration_example(const void* tracks, uint64_t tracks_size, const void* co
 	consumers.base_poses = NULL;
 	consumers.base_pose_stride_bytes = 0;
 	s = aclhip_decompress_poses_batch(gpu, d_clips, d_times, num_instances, &params, &consumers, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+
+	/* section 5 */
+	{
+		uint8_t handle[ACLHIP_PEER_HANDLE_BYTES];
+		void* peer = NULL;
+		s = aclhip_peer_export_buffer(gpu, d_poses, handle);
+		s = aclhip_peer_open_buffer(gpu, handle, &peer);
+		s = aclhip_push_poses_to_peer(gpu, peer, 0, d_poses, (uint64_t)num_instances * max_tracks * 48, hip_stream);
+		s = aclhip_peer_close_buffer(gpu, peer);
+	}
 
 	(void)aclhip_unregister_clip(gpu, db_clip);
 	(void)aclhip_unregister_database(gpu, db);
