@@ -49,15 +49,24 @@ namespace
 			if (size_t(frame_lds_bytes) * 2 * k_waves_per_block > 40 * 1024 || context->max_scalar_frame_bytes < 192)
 				frame_lds_bytes = 0;
 
-			const dim3 grid(uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block));
-			const size_t lds_bytes = size_t(frame_lds_bytes) * 2 * k_waves_per_block;
+			// groups of k_scalar_group consecutive instances per wave (kernels_scalar.inl) when the frames of a group fit LDS with at least
+			// four workgroups per CU and the batch is large enough to fill the device with a quarter of the waves
+			const bool grouped = frame_lds_bytes != 0 && size_t(frame_lds_bytes) * 2 * k_scalar_group * k_waves_per_block <= 40 * 1024 && num_instances >= 16384;
+			const uint64_t launch_waves = grouped ? uint64_t((num_instances + k_scalar_group - 1) / k_scalar_group) * chunks_per_instance : num_waves;
+			const dim3 grid(uint32_t((launch_waves + k_waves_per_block - 1) / k_waves_per_block));
+			const size_t lds_bytes = size_t(frame_lds_bytes) * 2 * k_waves_per_block * (grouped ? k_scalar_group : 1u);
 			const auto launch = [&](auto kernel)
 			{
 				hipLaunchKernelGGL(kernel, grid, dim3(k_block_size), lds_bytes, static_cast<hipStream_t>(stream), context->d_clips, context->d_clips_capacity, clips, sample_times,
 					num_instances, chunks_per_instance, device_params, static_cast<uint8_t*>(out), out_stride_bytes, frame_lds_bytes, context->d_rejected);
 			};
 			const bool policies = device_params.per_track_rounding != 0;
-			if (frame_lds_bytes != 0)
+			if (grouped)
+			{
+				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_grouped_kernel<1, true>); else launch(decompress_scalar_tracks_grouped_kernel<1, false>); }
+				else { if (policies) launch(decompress_scalar_tracks_grouped_kernel<4, true>); else launch(decompress_scalar_tracks_grouped_kernel<4, false>); }
+			}
+			else if (frame_lds_bytes != 0)
 			{
 				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_kernel<true, 1, true>); else launch(decompress_scalar_tracks_kernel<true, 1, false>); }
 				else { if (policies) launch(decompress_scalar_tracks_kernel<true, 4, true>); else launch(decompress_scalar_tracks_kernel<true, 4, false>); }

@@ -174,3 +174,70 @@ def test_large_batch_on_device_pointers(context):
     lo, hi = clip.keyframes.min(axis=0)[:, 0], clip.keyframes.max(axis=0)[:, 0]
     assert (values >= lo - 1e-3 * (1 + np.abs(lo))).all() and (values <= hi + 1e-3 * (1 + np.abs(hi))).all()
     context.unregister_clip(handle)
+
+
+def _oracle_rows(clips, which, times, policies=None, options=None):
+    rows = []
+    for i in range(len(which)):
+        policy = 0 if policies is None else int(policies[i])
+        rows.append(ob.oracle_scalar_decompress_tracks(clips[which[i]].blob, float(times[i]), policy, options))
+    return rows
+
+
+@pytest.mark.parametrize("spec", [dict(seed=9, track_type=0, num_tracks=256, num_samples=120, sample_rate=60.0, raw_fraction=0.01),      # the bench list
+                                  dict(seed=10, track_type=4, num_tracks=70, num_samples=60, raw_fraction=0.1),
+                                  dict(seed=11, track_type=2, num_tracks=300, num_samples=45, wrap=1)])
+def test_large_batches_take_groups_of_instances_per_wave(context, spec):
+    """from 16 384 instances on a wave decodes 4 consecutive instances (decompress_scalar_tracks_grouped_kernel): groups of one clip
+    share the track tables and their round trips, groups of mixed / refused clips fall back -- every value against the oracle"""
+    clip = synth.build_scalar_clip(**spec)
+    other = synth.build_scalar_clip(seed=spec["seed"] + 50, track_type=spec["track_type"], num_tracks=spec["num_tracks"] - 7, num_samples=33)
+    handles = np.array([context.register_clip(clip.blob), context.register_clip(other.blob)], dtype=np.uint32)
+    clips = [clip, other]
+    rng = np.random.default_rng(spec["seed"])
+    n = 16384 + 3                                                        # the last group is partial
+    which = np.zeros(n, dtype=np.int64)
+    which[5000:5400] = rng.integers(0, 2, size=400)                      # mixed groups in the middle
+    which[9000:9016] = 1                                                 # whole groups of the other clip
+    durations = np.array([c.duration for c in clips], dtype=np.float32)
+    times = (rng.uniform(-0.05, 1.05, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+    values = context.decompress_scalar_tracks(handles[which], times)
+    check = np.unique(np.concatenate([np.arange(0, n, 97), np.arange(4990, 5410), np.arange(8990, 9030), np.arange(n - 9, n)]))
+    expected = _oracle_rows(clips, which[check], times[check])
+    for row, i in enumerate(check):
+        tracks = clips[which[i]].num_tracks
+        assert helpers.exact(values[i, :tracks], expected[row]), f"instance {i}"
+
+    # per instance rounding policies and per track rounding go through the grouped kernel as well
+    instance_rounding = rng.integers(0, 4, size=n).astype(np.uint8)
+    values = context.decompress_scalar_tracks(handles[which], times, instance_rounding=instance_rounding)
+    expected = _oracle_rows(clips, which[check], times[check], policies=instance_rounding[check])
+    for row, i in enumerate(check):
+        assert helpers.exact(values[i, : clips[which[i]].num_tracks], expected[row]), f"instance {i} (instance rounding)"
+    track_rounding = rng.integers(0, 4, size=spec["num_tracks"]).astype(np.uint8)
+    params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+    values = context.decompress_scalar_tracks(handles[which], times, params=params, track_rounding=track_rounding)
+    options = ob.default_options(per_track_rounding=1)
+    options.track_rounding = track_rounding.ctypes.data
+    expected = _oracle_rows(clips, which[check], times[check], policies=np.full(n, ob.ROUND_PER_TRACK)[check], options=options)
+    for row, i in enumerate(check):
+        assert helpers.exact(values[i, : clips[which[i]].num_tracks], expected[row]), f"instance {i} (per track rounding)"
+
+    # an unknown handle inside a group: refused and counted, its neighbours decode (device pointer entry point)
+    import torch
+    before = context.rejected_instance_count()
+    bad = handles[which].copy()
+    bad[8] = 123456
+    components = clip.num_components
+    d_clips = torch.from_numpy(bad.astype(np.int32)).cuda()
+    d_times = torch.from_numpy(times).cuda()
+    d_values = torch.full((n, spec["num_tracks"] * components), 7.0, dtype=torch.float32, device="cuda")
+    context.decompress_scalar_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_values.data_ptr(), spec["num_tracks"] * components * 4)
+    torch.cuda.synchronize()
+    values = d_values.cpu().numpy().reshape(n, spec["num_tracks"], components)
+    assert context.rejected_instance_count() == before + 1
+    assert np.all(values[8] == 7.0)
+    for i in (7, 9, 10, 11):
+        assert helpers.exact(values[i, : clip.num_tracks], ob.oracle_scalar_decompress_tracks(clip.blob, float(times[i])))
+    for handle in handles:
+        context.unregister_clip(int(handle))
