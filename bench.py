@@ -546,26 +546,21 @@ def main():
     for _ in range(args.warmup):
         job.step()
 
-    # HIP events on the launch stream cut the timed region into chunks of launches; (chunk time / launches in it) averaged over the
-    # region is the kernel's mean duration including the (~1 us) launch boundary
-    chunk = max(1, min(100, args.steps // 10))
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps // chunk + 2)]
+    # two HIP events on the launch stream bracket the timed launches: their distance / K is the kernel's mean duration including the
+    # (~1 us) launch boundary (no events in between: every record is one more packet between two launches)
+    start_mark, stop_mark = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     stream_schedule = job.stream_schedule(args.steps)
 
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    num_marks = 0
+    start_mark.record(job.stream)
     for i in range(args.steps):
-        if i % chunk == 0:
-            marks[num_marks].record(job.stream)
-            num_marks += 1
         if i in stream_schedule:
             job.context.database_stream_in(job.database, stream_schedule[i][0], stream_schedule[i][1], stream=job.stream.cuda_stream)
         job.step()
-    marks[num_marks].record(job.stream)
-    num_marks += 1
+    stop_mark.record(job.stream)
     torch.cuda.synchronize(device)
     if distributed:
         dist.barrier()
@@ -577,15 +572,11 @@ def main():
         elapsed = float(elapsed_tensor.item())
 
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
-    kernel_ms = float(marks[0].elapsed_time(marks[num_marks - 1])) / args.steps
+    kernel_ms = float(start_mark.elapsed_time(stop_mark)) / args.steps
     kernel_ms_back_to_back = None if profiling else job.kernel_ms(max(10, min(args.steps, 100)))
     algorithmic_bytes = job.algorithmic_bytes()
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
     fill_gbps = job.context.measure_write_bandwidth(job.d_poses.data_ptr(), job.num_instances * job.pose_stride, repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
-
-    gather = None
-    if distributed and args.gather != "none":
-        gather = measure_gather(job, dist, rank, world_size, args.gather)
 
     kernel_name = job.kernel_name()
     result = None
@@ -634,8 +625,28 @@ def main():
                 "plain_store_stream_gbps": fill_gbps,      # a plain 16 B per lane store sweep over the same pose buffer, for scale (not a ceiling: DESIGN.md 6)
             },
         }
-        if gather is not None:
+    if distributed and args.gather != "none":
+        # The gathers are timed AFTER the decode numbers are final, under a watchdog: the decode line must reach the driver whatever a
+        # collective or a peer mapping does on a node this code has never run on. A gather that does not come back within the limit is
+        # reported as such and the line is printed from the watchdog thread (the main thread may be stuck inside the runtime).
+        import threading
+        gather = {"status": "running"}
+        if rank == 0:
             result["gather"] = gather
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(float(os.environ.get("ACLHIP_BENCH_GATHER_TIMEOUT", "120"))):
+                return
+            if rank == 0:
+                gather["status"] = "timed out"
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        gather.update(measure_gather(job, dist, rank, world_size, args.gather))
+        gather["status"] = "done"
+        finished.set()
 
     headline = (job.clips, job.clip_indices, job.times, job.pose_stride // 4 if job.is_scalar else job.max_tracks, job.is_scalar, job.database is not None, job.consumers is not None)
     job.close()
