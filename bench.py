@@ -248,7 +248,8 @@ class Job:
 
     def kernel_name(self):
         if self.is_scalar:
-            return "decompress_scalar_tracks_kernel"
+            # 4 instances per wave from 16384 instances on (host_scalar_misc.inl); below that one wave per instance
+            return "decompress_scalar_tracks_grouped_kernel" if self.num_instances >= 16384 else "decompress_scalar_tracks_kernel"
         if self.consumers is not None:
             return "decompress_poses_consumer_kernel"
         name = self.context.tracks_kernel_name(self.params)
@@ -354,6 +355,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
+            "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload for all of the workload's clips (setup)
             "launches_timed": repeats,
         }
     finally:
@@ -659,6 +661,10 @@ def main():
             measure_job("256_clips", rank, device_index, order="locality"),
             measure_job("cinematic", rank, device_index, repeats=150),
             measure_job("database", rank, device_index),
+            # scalar track lists and the pose consumers fused into the decode
+            measure_job("scalar", rank, device_index),
+            measure_job("object_space", rank, device_index, repeats=150),
+            measure_job("additive_object_space", rank, device_index, repeats=100),
         ]
         result["footprint_sweep"] = [
             {key: entry[key] for key in ("instances", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}

@@ -24,7 +24,7 @@ run_workload() {      # <name for files> <traffic key> <bench arguments...>
     [ -n "$csv" ] && cp "$csv" gpurun_out/${tag}_${name}_${counter}.csv
   done
   python tools/traffic_from_pmc.py "$key" gpurun_out/${tag}_${name}_FETCH_SIZE.csv gpurun_out/${tag}_${name}_WRITE_SIZE.csv gpurun_out/traffic.json > /dev/null
-  python tools/pmc_summary.py decompress gpurun_out/${tag}_${name}_FETCH_SIZE.csv gpurun_out/${tag}_${name}_WRITE_SIZE.csv | sed "s#^.*csv: ##" > gpurun_out/${tag}_${name}_pmc_hbm.txt
+  python tools/pmc_summary.py "${PMC_KERNEL_FILTER:-decompress}" gpurun_out/${tag}_${name}_FETCH_SIZE.csv gpurun_out/${tag}_${name}_WRITE_SIZE.csv | sed "s#^.*csv: ##" > gpurun_out/${tag}_${name}_pmc_hbm.txt
   rm -f gpurun_out/${tag}_${name}_FETCH_SIZE.csv gpurun_out/${tag}_${name}_WRITE_SIZE.csv
 }
 run_workload one_clip "one_clip" --workload one_clip
@@ -34,6 +34,9 @@ run_workload cinematic "cinematic" --workload cinematic
 run_workload database "database" --workload database
 run_workload one_clip_qv32 "one_clip, qv32" --workload one_clip --layout qv32
 run_workload one_clip_qvv40 "one_clip, qvv40" --workload one_clip --layout qvv40
+run_workload scalar "scalar" --workload scalar
+run_workload object_space "object_space" --workload object_space
+run_workload additive_object_space "additive_object_space" --workload additive_object_space
 cp gpurun_out/traffic.json profiles/traffic.json      # the default run below reads the traffic it reports from profiles/traffic.json
 ( time python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python - <<PY

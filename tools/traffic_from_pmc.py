@@ -8,12 +8,12 @@ import os
 import sys
 
 
-def mean_counter(path, counter, match="decompress_tracks"):
+def mean_counter(path, counter, match="decompress_"):
     values, name = [], None
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter and match in row["Kernel_Name"]:
             values.append(float(row["Counter_Value"]))
-            name = row["Kernel_Name"].split("(")[0].split("::")[-1]
+            name = row["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]
     return sum(values) / len(values), len(values), name
 
 
