@@ -88,8 +88,17 @@ struct aclhip_context
 		uint32_t slot = ACLHIP_INVALID_HANDLE;		// clip handle that becomes reusable
 		uint8_t* database_memory[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };		// hipMalloc'ed pieces of a database
 		uint8_t* database_pinned[2] = { nullptr, nullptr };
+		void* device_memory = nullptr;				// any other hipMalloc'ed piece
 	};
 	std::vector<retired_item> retired;
+	// aclhip_order_instances_device: per stream, the per clip counters (zero between calls) followed by the per clip cursors
+	struct order_scratch
+	{
+		hipStream_t stream = nullptr;
+		uint32_t* bins = nullptr;
+		size_t capacity = 0;						// bins per half
+	};
+	std::vector<order_scratch> order_scratches;
 	uint64_t clips_registered = 0;					// statistics (aclhip_get_lifetime_stats)
 	uint64_t clips_unregistered = 0;
 	uint64_t deferred_frees_completed = 0;
@@ -326,6 +335,8 @@ namespace
 			for (uint8_t* memory : item.database_pinned)
 				if (memory != nullptr)
 					(void)hipHostFree(memory);
+			if (item.device_memory != nullptr)
+				(void)hipFree(item.device_memory);
 			context->deferred_frees_completed++;
 			context->retired[i] = std::move(context->retired.back());
 			context->retired.pop_back();
@@ -780,6 +791,8 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 			(void)hipFree(context->d_clips);
 		if (context->d_rejected != nullptr)
 			(void)hipFree(context->d_rejected);
+		for (const aclhip_context::order_scratch& scratch : context->order_scratches)
+			(void)hipFree(scratch.bins);
 	}
 	delete context;
 }

@@ -133,28 +133,79 @@ extern "C" aclhip_status aclhip_decompress_tracks_batch_out(aclhip_context* cont
 }
 
 // Work order for batches that draw on many clips. Workgroup b of a launch runs on XCD b % 8 (each XCD has its own 4 MB L2) and
-// holds k_waves_per_block consecutive (instance, pose window) work items: dealing the instances out so that every clip is only
-// ever decoded on ONE XCD, next to its other instances, leaves each L2 with an eighth of the clips to keep.
+// holds k_waves_per_block consecutive (instance, pose window) work items: bucketing the instances by clip and giving every XCD one
+// contiguous range of that sequence, served through the slots whose waves start on that XCD, leaves each L2 with an eighth of the
+// clips to keep (order_layout, kernels_misc.inl).
+namespace
+{
+	uint32_t windows_per_instance_of(aclhip_context* context)
+	{
+		if (context == nullptr)
+			return 1;
+		std::lock_guard<std::mutex> lock(context->mutex);
+		return std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+	}
+
+	order_layout make_order_layout(uint32_t num_instances, uint32_t windows_per_instance)
+	{
+		order_layout layout;
+		std::memset(&layout, 0, sizeof(layout));
+		uint32_t period = 32;		// 8 workgroups x k_waves_per_block waves, in slots: the smallest p with p * windows a multiple of 32
+		for (uint32_t p = 1; p <= 32; ++p)
+			if ((uint64_t(p) * windows_per_instance) % (k_num_xcds * k_waves_per_block) == 0)
+			{
+				period = p;
+				break;
+			}
+		const auto fill = [&](uint32_t slots_per_period, auto&& xcd_of_slot)
+		{
+			std::memset(layout.per_xcd, 0, sizeof(layout.per_xcd));
+			layout.period = slots_per_period;
+			for (uint32_t slot = 0; slot < slots_per_period; ++slot)
+			{
+				const uint32_t xcd = xcd_of_slot(slot);
+				layout.slots[xcd][layout.per_xcd[xcd]++] = uint8_t(slot);
+			}
+		};
+		fill(period, [&](uint32_t slot) { return uint32_t((uint64_t(slot) * windows_per_instance / k_waves_per_block) % k_num_xcds); });
+		bool every_xcd_starts_poses = true;
+		for (uint32_t x = 0; x < k_num_xcds; ++x)
+			every_xcd_starts_poses = every_xcd_starts_poses && layout.per_xcd[x] != 0;
+		if (!every_xcd_starts_poses)
+			fill(k_num_xcds, [](uint32_t slot) { return slot; });		// poses of 8+ windows span the XCDs anyway: plain bucketing by clip
+
+		const uint32_t whole_periods = num_instances / layout.period;
+		const uint32_t tail = num_instances % layout.period;
+		for (uint32_t x = 0; x < k_num_xcds; ++x)
+		{
+			uint32_t served = whole_periods * layout.per_xcd[x];
+			for (uint32_t k = 0; k < layout.per_xcd[x]; ++k)
+				served += layout.slots[x][k] < tail ? 1u : 0u;
+			layout.range_begin[x + 1] = layout.range_begin[x] + served;
+		}
+		return layout;
+	}
+}
+
 extern "C" aclhip_status aclhip_order_instances_for_locality(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order)
+{
+	return aclhip_order_instances_for_pose_windows(windows_per_instance_of(const_cast<aclhip_context*>(context)), clips, num_instances, out_order);
+}
+
+extern "C" aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_instance, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order)
 {
 	if ((clips == nullptr || out_order == nullptr) && num_instances != 0)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (windows_per_instance == 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (num_instances == 0)
+		return ACLHIP_OK;
 
-	constexpr uint32_t k_num_xcds = 8;
-	uint32_t windows_per_instance = 1;
-	if (context != nullptr)
+	const order_layout layout = make_order_layout(num_instances, windows_per_instance);
+	return guarded(static_cast<aclhip_context*>(nullptr), [&]() -> aclhip_status
 	{
-		std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
-		windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
-	}
-	// instances per workgroup; poses of several windows fill whole workgroups on their own, only the clip order matters then
-	const uint32_t group = std::max<uint32_t>(k_waves_per_block / windows_per_instance, 1);
-
-	return guarded(const_cast<aclhip_context*>(context), [&]() -> aclhip_status
-	{
-		// per XCD: its instances, bucketed by clip (stable: instances of a clip keep their relative order). A counting sort when the
-		// handles are small numbers (they are slots of the registry), a comparison sort for arbitrary values
-		std::vector<uint32_t> sorted(num_instances);
+		// the instances bucketed by clip (stable: instances of a clip keep their relative order). A counting sort when the handles
+		// are small numbers (they are slots of the registry), a comparison sort for arbitrary values
 		uint32_t max_clip = 0;
 		for (uint32_t i = 0; i < num_instances; ++i)
 			max_clip = std::max(max_clip, clips[i]);
@@ -162,71 +213,79 @@ extern "C" aclhip_status aclhip_order_instances_for_locality(const aclhip_contex
 		{
 			std::vector<uint32_t> position(size_t(max_clip) + 2, 0);
 			for (uint32_t i = 0; i < num_instances; ++i)
-				position[clips[i]]++;
-			// first position of every clip in (clip % 8, clip) order
-			uint32_t next = 0;
-			for (uint32_t xcd = 0; xcd < k_num_xcds; ++xcd)
-				for (uint64_t clip = xcd; clip <= max_clip; clip += k_num_xcds)
-				{
-					const uint32_t count = position[clip];
-					position[clip] = next;
-					next += count;
-				}
+				position[size_t(clips[i]) + 1]++;
+			for (size_t clip = 0; clip <= max_clip; ++clip)
+				position[clip + 1] += position[clip];
 			for (uint32_t i = 0; i < num_instances; ++i)
-				sorted[position[clips[i]]++] = i;
+				out_order[order_slot_of(layout, position[clips[i]]++)] = i;
 		}
 		else
 		{
+			std::vector<uint32_t> sorted(num_instances);
 			for (uint32_t i = 0; i < num_instances; ++i)
 				sorted[i] = i;
-			std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b)
-			{
-				const uint32_t xcd_a = clips[a] % k_num_xcds, xcd_b = clips[b] % k_num_xcds;
-				return xcd_a != xcd_b ? xcd_a < xcd_b : clips[a] < clips[b];
-			});
-		}
-		uint32_t list_begin[k_num_xcds + 1] = {};
-		for (uint32_t i = 0; i < num_instances; ++i)
-			list_begin[clips[sorted[i]] % k_num_xcds + 1]++;
-		for (uint32_t x = 0; x < k_num_xcds; ++x)
-			list_begin[x + 1] += list_begin[x];
-
-		// deal whole workgroups out round robin; an XCD whose list runs dry takes from the longest remaining list
-		uint32_t cursor[k_num_xcds];
-		for (uint32_t x = 0; x < k_num_xcds; ++x)
-			cursor[x] = list_begin[x];
-		uint32_t written = 0;
-		for (uint32_t workgroup = 0; written < num_instances; ++workgroup)
-		{
-			uint32_t source = workgroup % k_num_xcds;
-			if (cursor[source] == list_begin[source + 1])
-			{
-				uint32_t longest = 0;
-				for (uint32_t x = 0; x < k_num_xcds; ++x)
-					if (list_begin[x + 1] - cursor[x] > longest)
-					{
-						longest = list_begin[x + 1] - cursor[x];
-						source = x;
-					}
-			}
-			const uint32_t take = std::min<uint32_t>(group, list_begin[source + 1] - cursor[source]);
-			for (uint32_t k = 0; k < take; ++k)
-				out_order[written++] = sorted[cursor[source]++];
-			// a short tail would shift every later workgroup's XCD: pad it from the longest list
-			for (uint32_t k = take; k < group && written < num_instances; ++k)
-			{
-				uint32_t longest = 0, from = 0;
-				for (uint32_t x = 0; x < k_num_xcds; ++x)
-					if (list_begin[x + 1] - cursor[x] > longest)
-					{
-						longest = list_begin[x + 1] - cursor[x];
-						from = x;
-					}
-				out_order[written++] = sorted[cursor[from]++];
-			}
+			std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return clips[a] < clips[b]; });
+			for (uint32_t position = 0; position < num_instances; ++position)
+				out_order[order_slot_of(layout, position)] = sorted[position];
 		}
 		return ACLHIP_OK;
 	});
+}
+
+// The same order computed on the device, stream ordered: count per clip, scan, scatter (three small kernels on `stream`, counters
+// kept per stream by the context). Which instance of a clip takes which of the clip's slots is decided by atomics: a valid order,
+// not a reproducible one.
+extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream_handle)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (num_instances == 0)
+		return ACLHIP_OK;
+	if (clips == nullptr || out_order == nullptr || (out_sample_times != nullptr && sample_times == nullptr))
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or order buffer");
+
+	hipStream_t stream = static_cast<hipStream_t>(stream_handle);
+	const order_layout layout = make_order_layout(num_instances, windows_per_instance_of(context));
+
+	device_guard guard(context->device);
+	std::lock_guard<std::mutex> lock(context->mutex);		// the scratch of a stream is handed to one call at a time, in stream order
+	const uint32_t num_bins = uint32_t(context->clips.size()) + 1;		// handles are slots of the registry; the last bin takes everything else
+	const size_t padded_bins = (size_t(num_bins) + 4095) / 4096 * 4096;
+	note_launch_stream(context, stream);
+	aclhip_context::order_scratch* scratch = nullptr;
+	for (aclhip_context::order_scratch& known : context->order_scratches)
+		if (known.stream == stream)
+			scratch = &known;
+	if (scratch == nullptr)
+	{
+		context->order_scratches.emplace_back();
+		scratch = &context->order_scratches.back();
+		scratch->stream = stream;
+	}
+	if (scratch->capacity < padded_bins)
+	{
+		if (scratch->bins != nullptr)
+		{
+			aclhip_context::retired_item item;
+			item.device_memory = scratch->bins;
+			retire(context, std::move(item));
+			scratch->bins = nullptr;
+			scratch->capacity = 0;
+		}
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->bins), padded_bins * 2 * sizeof(uint32_t)));
+		scratch->capacity = padded_bins;
+		ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->bins, 0, padded_bins * sizeof(uint32_t), stream));		// once: the scan leaves the counters at zero
+	}
+	uint32_t* counters = scratch->bins;
+	uint32_t* cursors = scratch->bins + scratch->capacity;
+
+	const uint32_t num_blocks = (num_instances + k_order_instances_per_block - 1) / k_order_instances_per_block;
+	hipLaunchKernelGGL(order_count_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, num_instances, num_bins, counters);
+	hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counters, cursors, num_bins);
+	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times);
+	ACLHIP_CHECK_HIP(context, hipGetLastError());
+	return ACLHIP_OK;
 }
 
 extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,

@@ -1,5 +1,5 @@
 // kernels_misc.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
-// Small kernels: the sample list of convert_track_list, database tier metadata, the write bandwidth probe.
+// Small kernels: the sample list of convert_track_list, database tier metadata, the device side locality order, the write bandwidth probe.
 
 	// The instance list of convert_track_list's sampling loop (compression/impl/convert.impl.h:161-166): one instance per sample at
 	// min(float(i) / sample_rate, duration), with the correctly rounded fp32 division the host code performs.
@@ -43,4 +43,166 @@
 		const float4 value = make_float4(seed, seed + 1.0f, seed + 2.0f, seed + 3.0f);
 		for (uint64_t quad = uint64_t(blockIdx.x) * k_block_size + threadIdx.x; quad < num_quads; quad += stride)
 			destination[quad] = value;
+	}
+
+	// ---- decode order for batches that draw on many clips (aclhip_order_instances_device; host twin in host_launch.inl) ----
+	// Slot j of a launch (the j-th instance of the list) starts at wave j * windows_per_instance, workgroup b holds k_waves_per_block
+	// consecutive waves and runs on XCD b % 8: which slots an XCD serves repeats with a period of at most 32 slots. The instances are
+	// bucketed by clip into one sequence; XCD x serves positions [range_begin[x], range_begin[x + 1]) of it, through its own slots in
+	// ascending order -- every clip is decoded on one XCD (two where a range boundary cuts it), next to its other instances.
+	constexpr uint32_t k_num_xcds = 8;
+	struct order_layout
+	{
+		uint32_t period;							// slots per period
+		uint32_t per_xcd[k_num_xcds];				// slots of XCD x in a period
+		uint32_t range_begin[k_num_xcds + 1];		// positions of the bucketed sequence served by XCD x
+		uint8_t slots[k_num_xcds][32];				// XCD x's slots within a period, ascending
+	};
+
+	__host__ __device__ inline uint32_t order_slot_of(const order_layout& layout, uint32_t position)
+	{
+		uint32_t xcd = 0;
+		for (uint32_t x = 1; x < k_num_xcds; ++x)
+			xcd += position >= layout.range_begin[x] ? 1u : 0u;
+		const uint32_t rank = position - layout.range_begin[xcd];
+		const uint32_t per_period = layout.per_xcd[xcd];
+		return (rank / per_period) * layout.period + layout.slots[xcd][rank % per_period];
+	}
+
+	// Device scope atomics on a handful of addresses (one per clip) run at the memory fabric's pace, serialized per address: a
+	// workgroup first gathers its 2048 instances per clip in an LDS hash table (LDS atomics), then touches each of its clips' bins once.
+	constexpr uint32_t k_order_block_size = 1024;
+	#if !defined(ACLHIP_ORDER_INSTANCES_PER_THREAD)
+#define ACLHIP_ORDER_INSTANCES_PER_THREAD 2
+#endif
+	constexpr uint32_t k_order_instances_per_thread = ACLHIP_ORDER_INSTANCES_PER_THREAD;
+	constexpr uint32_t k_order_instances_per_block = k_order_block_size * k_order_instances_per_thread;
+	constexpr uint32_t k_order_table_size = 2 * k_order_instances_per_block;		// load factor <= 0.5
+	constexpr uint32_t k_order_empty_key = 0xFFFFFFFFu;								// never a bin: bins are clamped to num_bins - 1
+
+	struct order_table
+	{
+		uint32_t keys[k_order_table_size];
+		uint32_t counts[k_order_table_size];
+	};
+
+	__device__ inline void order_table_clear(order_table& table)
+	{
+		for (uint32_t slot = threadIdx.x; slot < k_order_table_size; slot += k_order_block_size)
+		{
+			table.keys[slot] = k_order_empty_key;
+			table.counts[slot] = 0;
+		}
+		__syncthreads();
+	}
+
+	// the slot of `bin` in the workgroup's table and the instance's rank among the workgroup's instances of that bin
+	__device__ inline uint32_t order_table_insert(order_table& table, uint32_t bin, uint32_t& rank)
+	{
+		uint32_t slot = ((bin * 2654435761u) >> 16) & (k_order_table_size - 1);
+		for (;;)
+		{
+			const uint32_t found = atomicCAS(&table.keys[slot], k_order_empty_key, bin);
+			if (found == k_order_empty_key || found == bin)
+				break;
+			slot = (slot + 1) & (k_order_table_size - 1);
+		}
+		rank = atomicAdd(&table.counts[slot], 1u);
+		return slot;
+	}
+
+	// instances per clip; handles past the registry (the decode rejects them) share the last bin
+	__global__ __launch_bounds__(k_order_block_size) void order_count_kernel(const uint32_t* __restrict__ clip_ids, uint32_t num_instances, uint32_t num_bins, uint32_t* __restrict__ bins)
+	{
+		__shared__ order_table table;
+		order_table_clear(table);
+		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		{
+			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
+			uint32_t rank;
+			if (instance < num_instances)
+				order_table_insert(table, min(clip_ids[instance], num_bins - 1), rank);
+		}
+		__syncthreads();
+		for (uint32_t slot = threadIdx.x; slot < k_order_table_size; slot += k_order_block_size)
+			if (table.keys[slot] != k_order_empty_key)
+				atomicAdd(&bins[table.keys[slot]], table.counts[slot]);
+	}
+
+	// counts -> first position of every clip (the cursors of the scatter); leaves the counters at zero for the next call. One
+	// workgroup, 4096 bins per iteration (the arrays are padded to that)
+	__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t* __restrict__ counters, uint32_t* __restrict__ cursors, uint32_t num_bins)
+	{
+		__shared__ uint32_t wave_totals[16];
+		__shared__ uint32_t carry;
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave = threadIdx.x / k_wave_size;
+		if (threadIdx.x == 0)
+			carry = 0;
+		__syncthreads();
+		for (uint32_t base = 0; base < num_bins; base += 4096)
+		{
+			uint4* quad = reinterpret_cast<uint4*>(counters + base) + threadIdx.x;
+			const uint4 counts = *quad;
+			*quad = uint4{ 0, 0, 0, 0 };
+			const uint32_t sum = counts.x + counts.y + counts.z + counts.w;
+			uint32_t inclusive = sum;
+			for (uint32_t step = 1; step < k_wave_size; step *= 2)
+			{
+				const uint32_t below = __shfl_up(inclusive, step);
+				if (lane >= step)
+					inclusive += below;
+			}
+			if (lane == k_wave_size - 1)
+				wave_totals[wave] = inclusive;
+			__syncthreads();
+			uint32_t first = carry + inclusive - sum;
+			for (uint32_t w = 0; w < wave; ++w)
+				first += wave_totals[w];
+			reinterpret_cast<uint4*>(cursors + base)[threadIdx.x] = uint4{ first, first + counts.x, first + counts.x + counts.y, first + counts.x + counts.y + counts.z };
+			__syncthreads();
+			if (threadIdx.x == 1023)
+				carry = first + sum;
+			__syncthreads();
+		}
+	}
+
+	// every instance takes the next position of its clip and lands in the slot that position maps to
+	__global__ __launch_bounds__(k_order_block_size) void order_scatter_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		uint32_t num_bins, uint32_t* __restrict__ bins, order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times)
+	{
+		__shared__ order_table table;
+		__shared__ order_layout layout;
+		if (threadIdx.x < sizeof(order_layout) / 4)
+			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
+		order_table_clear(table);
+
+		uint32_t clip_id[k_order_instances_per_thread], slot[k_order_instances_per_thread], rank[k_order_instances_per_thread];
+		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		{
+			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
+			if (instance < num_instances)
+			{
+				clip_id[k] = clip_ids[instance];
+				slot[k] = order_table_insert(table, min(clip_id[k], num_bins - 1), rank[k]);
+			}
+		}
+		__syncthreads();
+		// the workgroup's instances of a clip take consecutive positions: counts[] becomes the first of them
+		for (uint32_t entry = threadIdx.x; entry < k_order_table_size; entry += k_order_block_size)
+			if (table.keys[entry] != k_order_empty_key)
+				table.counts[entry] = atomicAdd(&bins[table.keys[entry]], table.counts[entry]);
+		__syncthreads();
+		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		{
+			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
+			if (instance >= num_instances)
+				continue;
+			const uint32_t destination = order_slot_of(layout, table.counts[slot[k]] + rank[k]);
+			out_order[destination] = instance;
+			if (out_clip_ids != nullptr)
+				out_clip_ids[destination] = clip_id[k];
+			if (out_sample_times != nullptr)
+				out_sample_times[destination] = sample_times[instance];
+		}
 	}

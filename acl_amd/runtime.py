@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_database_stream_in", "aclhip_database_stream_out",
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
-    "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality",
+    "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
@@ -181,6 +181,8 @@ def load_library():
     lib.aclhip_decompress_scalar_track_host.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64]
     lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
+    lib.aclhip_order_instances_for_pose_windows.argtypes = [u32, vp, u32, vp]
+    lib.aclhip_order_instances_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
     poutput = ctypes.POINTER(OutputDesc)
     lib.aclhip_get_lifetime_stats.argtypes = [vp, ctypes.POINTER(u64)]
@@ -222,13 +224,13 @@ def check_database(database, bulk_data_medium=None, bulk_data_low=None, check_ha
     return status, message.value.decode()
 
 
-def order_instances_for_locality(clips):
-    """aclhip_order_instances_for_locality without a context (poses of one wavefront): host only, no GPU needed."""
+def order_instances_for_locality(clips, windows_per_instance=1):
+    """aclhip_order_instances_for_pose_windows (no context: the caller says how many wavefronts a pose takes): host only, no GPU needed."""
     clips = np.ascontiguousarray(clips, dtype=np.uint32)
     order = np.empty(clips.size, dtype=np.uint32)
-    status = load_library().aclhip_order_instances_for_locality(None, clips.ctypes.data, clips.size, order.ctypes.data)
+    status = load_library().aclhip_order_instances_for_pose_windows(windows_per_instance, clips.ctypes.data, clips.size, order.ctypes.data)
     if status != 0:
-        raise AclHipError(status, "aclhip_order_instances_for_locality failed")
+        raise AclHipError(status, "aclhip_order_instances_for_pose_windows failed")
     return order
 
 
@@ -394,6 +396,10 @@ class Context:
         order = np.empty(clips.size, dtype=np.uint32)
         self._check(self._lib.aclhip_order_instances_for_locality(self._handle, clips.ctypes.data, clips.size, order.ctypes.data))
         return order
+
+    def order_instances_device(self, clips_ptr, times_ptr, num_instances, order_ptr, out_clips_ptr=None, out_times_ptr=None, stream=None):
+        """aclhip_order_instances_device: the locality order of a DEVICE instance list, stream ordered (device pointers)."""
+        self._check(self._lib.aclhip_order_instances_device(self._handle, clips_ptr, times_ptr, num_instances, order_ptr, out_clips_ptr, out_times_ptr, stream))
 
     def decompress_track_batch(self, clips_ptr, times_ptr, tracks_ptr, num_instances, out_ptr, params=None, stream=None):
         params = params if params is not None else default_params()

@@ -133,7 +133,8 @@ def load_database_fixture():
 
 class Job:
     """Registered clips, instance list and pose buffer of one workload in HBM, and the launch through the C ABI.
-    order: "random" (as drawn), "by_clip" (host bucketed), "locality" (aclhip_order_instances_for_locality on the host).
+    order: "random" (as drawn), "by_clip" (host bucketed), "locality" (aclhip_order_instances_for_locality on the host, setup),
+    "device" (aclhip_order_instances_device in front of EVERY launch, on the launch stream: the ordering is part of the step).
     layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
     def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48"):
@@ -184,6 +185,13 @@ class Job:
 
         self.d_clips = torch.from_numpy(self.handles[clip_indices].astype(np.int32)).to(self.device)
         self.d_times = torch.from_numpy(times).to(self.device)
+        self._order_args = None
+        if order == "device":
+            # the caller's lists stay as drawn; every step orders them into the lists the decode reads
+            self.d_source_clips, self.d_source_times = self.d_clips.clone(), self.d_times.clone()
+            self.d_order = torch.zeros((self.num_instances,), dtype=torch.int32, device=self.device)
+            if keep_rows:
+                self.d_rows = self.d_order
         self.d_poses = torch.empty((self.num_instances, self.pose_stride // 4), dtype=torch.float32, device=self.device)
         self.stream = torch.cuda.current_stream(self.device)
         self.params = runtime.default_params()
@@ -219,7 +227,17 @@ class Job:
         else:
             self._launch, self._args = self.lib.aclhip_decompress_tracks_batch, (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), poses_ptr, self.pose_stride, stream_ptr)
 
+        if order == "device":
+            self._order_args = (handle, self.d_source_clips.data_ptr(), self.d_source_times.data_ptr(), n, self.d_order.data_ptr(), clips_ptr, times_ptr, stream_ptr)
+
+    def order_step(self):
+        status = self.lib.aclhip_order_instances_device(*self._order_args)
+        if status != 0:
+            raise SystemExit(f"the device side ordering failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
+
     def step(self):
+        if self._order_args is not None:
+            self.order_step()
         status = self._launch(*self._args)
         if status != 0:
             raise SystemExit(f"the batch launch failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
@@ -335,6 +353,18 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             kernel_ms = float(start.elapsed_time(stop)) / repeats
         else:
             kernel_ms = job.kernel_ms(repeats)
+        ordering_ms_device = decode_ms_order_reused = None
+        if job.order == "device":
+            start, stop = job.torch.cuda.Event(enable_timing=True), job.torch.cuda.Event(enable_timing=True)
+            start.record(job.stream)
+            for _ in range(repeats):
+                job.order_step()
+            stop.record(job.stream)
+            stop.synchronize()
+            ordering_ms_device = float(start.elapsed_time(stop)) / repeats
+            order_arguments, job._order_args = job._order_args, None          # the instance list outlives the frame: ordered once, decoded again and again
+            decode_ms_order_reused = job.kernel_ms(repeats)
+            job._order_args = order_arguments
         algorithmic = job.algorithmic_bytes()
         achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
         kernel = job.kernel_name()
@@ -355,6 +385,8 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "frac": achieved / HBM_PEAK_GBPS,
             "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
+            "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
+            "kernel_ms_order_reused": decode_ms_order_reused,  # the decode alone in that order (an instance list ordered once, sample times refreshed per frame)
             "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload for all of the workload's clips (setup)
             "launches_timed": repeats,
         }
@@ -497,8 +529,9 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=sorted(WORKLOAD_TEXT))
     parser.add_argument("--instances", type=int, default=INSTANCES_PER_GPU, help="instances per GPU")
-    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality"],
-                        help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup)")
+    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device"],
+                        help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup); "
+                             "aclhip_order_instances_device in front of every launch (part of the step)")
     parser.add_argument("--keep-rows", action="store_true", help="with --order locality: store every pose in its instance's ORIGINAL row")
     parser.add_argument("--layout", default="qvv48", choices=["qvv48", "qvv40", "qv32"], help="output layout (aclhip_output_desc)")
     parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
@@ -586,7 +619,8 @@ def main():
         total_poses = job.num_instances * world_size * args.steps
         workload_text = WORKLOAD_TEXT[args.workload]
         if args.order != "random":
-            workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order"}[args.order]
+            workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order",
+                              "device": ", ordered by aclhip_order_instances_device in front of every launch (inside the step)"}[args.order]
             workload_text += ", poses scattered back to their original rows" if args.keep_rows else ""
         result = {
             "metric": "poses/sec (whole node), 64k clip instances x 100 bones per GPU, seek + decompress_tracks",
@@ -659,6 +693,7 @@ def main():
         result["workloads"] = [
             measure_job("256_clips", rank, device_index),
             measure_job("256_clips", rank, device_index, order="locality"),
+            measure_job("256_clips", rank, device_index, order="device"),          # ordered on the GPU in front of every launch: the ordering is in kernel_ms
             measure_job("cinematic", rank, device_index, repeats=150),
             measure_job("database", rank, device_index),
             # scalar track lists and the pose consumers fused into the decode

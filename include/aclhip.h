@@ -283,11 +283,26 @@ uint32_t aclhip_layout_bytes_per_track(uint32_t layout);
 
 /* Host only (no GPU work): a decode order for a batch that draws on many clips -- a permutation of [0, num_instances) for the
  * instance list `clips` (HOST array) under which every clip is decoded on ONE XCD (workgroup b of a launch runs on XCD b % 8,
- * each XCD has its own L2), next to its other instances. Use: clips'[k] = clips[out_order[k]], sample_times'[k] =
- * sample_times[out_order[k]], pose k of the launch belongs to instance out_order[k]. 64k instances over 256 clips: 61 -> 50 us,
- * the time of a single-clip batch; a batch of one clip is unaffected. `context` tells how many wavefronts a pose of the largest
- * registered clip takes (may be NULL: one). Stable: instances of one clip keep their relative order. */
+ * each XCD has its own L2; a clip that straddles the boundary between two XCDs' shares is decoded on both), next to its other
+ * instances. Use: clips'[k] = clips[out_order[k]], sample_times'[k] = sample_times[out_order[k]], pose k of the launch belongs
+ * to instance out_order[k]. 64k instances over 256 clips: 61 -> 50 us, the time of a single-clip batch; a batch of one clip is
+ * unaffected. `context` tells how many wavefronts a pose of the largest registered clip takes (may be NULL: one).
+ * Stable: instances of one clip keep their relative order. */
 aclhip_status aclhip_order_instances_for_locality(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order);
+
+/* aclhip_order_instances_for_locality for a caller that knows the pose size instead of holding a context: windows_per_instance =
+ * ceil(3 * num_tracks of the largest clip / ACLHIP_WINDOW_QUADS) wavefronts per pose (1 up to 104 tracks). Host only. */
+aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_instance, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order);
+
+/* The same order computed on the GPU for instance lists that live there (all pointers DEVICE pointers, stream ordered: three small
+ * kernels on `stream`, counters kept per stream by the context, no host synchronization). Writes the permutation to out_order and,
+ * when the pointers are not NULL, the permuted lists out_clips[k] = clips[out_order[k]], out_sample_times[k] =
+ * sample_times[out_order[k]] (the arguments of the decode that follows on the same stream; rows = out_order puts the poses back
+ * in the caller's rows). Which instance of a clip takes which of the clip's slots is decided by atomics: every call returns a valid
+ * order, not the same one. An instance list usually outlives a frame (which character plays which clip changes rarely, the
+ * sample times every frame): order once, keep the lists in that order. */
+aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);
 
 /* Replaces seek() + decompress_track(track_indices[i], writer) (decompress.h:172; decompress_track_v0 :1753-2050):
  * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers. */

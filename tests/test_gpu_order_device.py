@@ -1,0 +1,114 @@
+"""aclhip_order_instances_device: the locality order of an instance list that lives on the GPU (count per clip, scan, scatter on the
+caller's stream). Same structure as the host order (tests/test_order_instances.py) except that the atomics decide which instance of
+a clip takes which of the clip's slots; the decode that follows gives the oracle's poses. Needs a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+import helpers
+from test_order_instances import check_order
+
+pytestmark = pytest.mark.gpu
+
+
+def _order_on_device(context, device, handles_of_instances, times, stream=None):
+    n = handles_of_instances.size
+    d_clips = torch.from_numpy(handles_of_instances.astype(np.int32)).to(device)
+    d_times = torch.from_numpy(times).to(device)
+    d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+    d_out_clips = torch.full((n,), -1, dtype=torch.int32, device=device)
+    d_out_times = torch.zeros((n,), dtype=torch.float32, device=device)
+    torch.cuda.synchronize(device)
+    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr(), d_out_times.data_ptr(),
+                                   stream=None if stream is None else stream.cuda_stream)
+    return d_clips, d_times, d_order, d_out_clips, d_out_times
+
+
+@pytest.mark.parametrize("num_instances,num_clips,big_rig_tracks", [(1, 1, 0), (37, 3, 0), (10000, 20, 0), (65536, 64, 0), (6000, 9, 300), (3000, 5, 700)])
+def test_device_order_and_the_decode_that_follows(num_instances, num_clips, big_rig_tracks):
+    rng = np.random.default_rng(num_instances)
+    clips = [synth.build_clip(seed=300 + i, num_tracks=int(rng.integers(2, 104)), num_samples=int(rng.integers(2, 90)), has_scale=int(i % 4 == 0)) for i in range(num_clips)]
+    if big_rig_tracks:
+        clips[0] = synth.build_clip(seed=299, num_tracks=big_rig_tracks, num_samples=40, has_scale=1)      # poses of 3 / 7 wavefronts
+    max_tracks = max(c.num_tracks for c in clips)
+    windows = -(-max_tracks * 3 // 312)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        which = rng.integers(0, num_clips, size=num_instances)
+        times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+        stream = torch.cuda.Stream(device)
+        d_clips, d_times, d_order, d_out_clips, d_out_times = _order_on_device(context, device, handles[which], times, stream)
+
+        # the decode that follows on the same stream: poses in decode order, then put back into the caller's rows
+        stride = max_tracks * 48
+        d_poses = torch.zeros((num_instances, max_tracks, 12), dtype=torch.float32, device=device)
+        d_rows = torch.zeros((num_instances, max_tracks, 12), dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        context.decompress_tracks_batch(d_out_clips.data_ptr(), d_out_times.data_ptr(), num_instances, d_poses.data_ptr(), stride, stream=stream.cuda_stream)
+        context.decompress_tracks_batch_rows(d_out_clips.data_ptr(), d_out_times.data_ptr(), d_order.data_ptr(), num_instances, d_rows.data_ptr(), stride, stream=stream.cuda_stream)
+        stream.synchronize()
+
+        order = d_order.cpu().numpy().astype(np.uint32)
+        check_order(handles[which], order, windows, stable=False)
+        assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), handles[which][order])
+        assert np.array_equal(d_out_times.cpu().numpy().view(np.uint32), times[order].view(np.uint32))
+
+        expected = ob.oracle_decompress_tracks_batch([c.blob for c in clips], which.astype(np.uint32), times, max_tracks)
+        in_rows = d_rows.cpu().numpy()
+        in_decode_order = d_poses.cpu().numpy()
+        for i in range(num_instances) if num_instances <= 64 else rng.choice(num_instances, size=64, replace=False):
+            tracks = clips[which[i]].num_tracks
+            assert helpers.exact(in_rows[i, :tracks], expected[i, :tracks])
+        position = np.empty(num_instances, dtype=np.int64)
+        position[order] = np.arange(num_instances)
+        # every instance, through the permutation (rows past a clip's own tracks are not written: compare per clip)
+        for w in range(num_clips):
+            mine = np.nonzero(which == w)[0]
+            tracks = clips[w].num_tracks
+            assert np.array_equal(in_decode_order[position[mine], :tracks].view(np.uint32), expected[mine, :tracks].view(np.uint32))
+            assert np.array_equal(in_rows[mine, :tracks].view(np.uint32), expected[mine, :tracks].view(np.uint32))
+        assert context.rejected_instance_count() == 0
+        for handle in handles:
+            context.unregister_clip(int(handle))
+
+
+def test_unknown_handles_are_ordered_too_and_rejected_by_the_decode():
+    clip = synth.build_clip(seed=5, num_tracks=10, num_samples=8)
+    with runtime.Context(0) as context:
+        handle = context.register_clip(clip.blob)
+        device = torch.device("cuda", 0)
+        n = 500
+        rng = np.random.default_rng(0)
+        instance_clips = np.where(rng.uniform(size=n) < 0.1, 0x7FFFFFF0, handle).astype(np.uint32)
+        times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+        _, _, d_order, d_out_clips, d_out_times = _order_on_device(context, device, instance_clips, times)
+        torch.cuda.synchronize(device)
+        order = d_order.cpu().numpy().astype(np.uint32)
+        assert np.array_equal(np.sort(order), np.arange(n))
+        assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), instance_clips[order])
+        d_poses = torch.zeros((n, 10, 12), dtype=torch.float32, device=device)
+        context.decompress_tracks_batch(d_out_clips.data_ptr(), d_out_times.data_ptr(), n, d_poses.data_ptr(), 480)
+        torch.cuda.synchronize(device)
+        assert context.rejected_instance_count() == int((instance_clips != handle).sum())
+        context.unregister_clip(handle)
+
+
+def test_a_registry_of_20000_clips_scans_in_several_rounds():
+    """more bins than one round of the scan kernel holds (4096)"""
+    clip = synth.build_clip(seed=5, num_tracks=3, num_samples=2)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(clip.blob, check_hash=False) for _ in range(9000)], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        rng = np.random.default_rng(4)
+        instance_clips = handles[rng.integers(0, handles.size, size=30000)]
+        times = np.zeros(30000, dtype=np.float32)
+        _, _, d_order, d_out_clips, _ = _order_on_device(context, device, instance_clips, times)
+        torch.cuda.synchronize(device)
+        order = d_order.cpu().numpy().astype(np.uint32)
+        check_order(instance_clips, order, 1, stable=False)
+        assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), instance_clips[order])
+        for handle in handles[::-1]:
+            context.unregister_clip(int(handle))
