@@ -7,7 +7,7 @@
 int integration_example(const void* tracks, uint64_t tracks_size, const void* compressed_db, uint64_t db_size, const void* bulk_medium, const void* bulk_low,
 	const aclhip_clip* d_clips, const float* d_times, const uint32_t* d_bones, uint32_t num_instances, void* d_poses, void* d_transforms, uint32_t max_tracks,
 	const uint32_t* parent_indices, uint32_t num_tracks, const aclhip_clip* d_base_clips, const float* d_base_times,
-	const aclhip_clip* host_clips, uint32_t* order, const uint32_t* d_rows, void* hip_stream)
+	const aclhip_clip* host_clips, uint32_t* order, uint32_t* d_rows, aclhip_clip* d_ordered_clips, float* d_ordered_times, void* hip_stream)
 {
 	aclhip_context* gpu = NULL;
 	aclhip_clip clip, db_clip;
@@ -29,6 +29,9 @@ int integration_example(const void* tracks, uint64_t tracks_size, const void* co
 	s = aclhip_decompress_tracks_batch(gpu, d_clips, d_times, num_instances, &params, d_poses, (uint64_t)max_tracks * 48, hip_stream);
 	s = aclhip_decompress_track_batch(gpu, d_clips, d_times, d_bones, num_instances, &params, d_transforms, hip_stream);
 	s = aclhip_order_instances_for_locality(gpu, host_clips, num_instances, order);
+	s = aclhip_order_instances_for_pose_windows(1, host_clips, num_instances, order);
+	s = aclhip_order_instances_device(gpu, d_clips, d_times, num_instances, d_rows, d_ordered_clips, d_ordered_times, hip_stream);
+	s = aclhip_decompress_tracks_batch(gpu, d_ordered_clips, d_ordered_times, num_instances, NULL, d_poses, (uint64_t)max_tracks * 48, hip_stream);
 	s = aclhip_decompress_tracks_batch_rows(gpu, d_clips, d_times, d_rows, num_instances, &params, d_poses, (uint64_t)max_tracks * 48, hip_stream);
 	{
 		aclhip_output_desc output = { 0 };
