@@ -167,6 +167,7 @@ namespace aclhip
 		uint64_t base_pose_stride_bytes;
 		uint32_t additive_format;			// acl::additive_clip_format8; 0 = no base
 		uint32_t object_space;				// 1: local -> object space with the clip's hierarchy
+		uint32_t fused_base;				// 1: base clips are decoded by the instance's own wave, the additive clip onto them (additive0 / additive1)
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)

@@ -253,7 +253,11 @@ namespace
 		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
 		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
 		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
-		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (base_is_clip ? 2 : 1);
+		// additive0 / additive1 combine sub-track with sub-track: the base clip is decoded into the instance's image and the additive clip
+		// onto it by one wave; the relative format (a qvv_mul) needs both poses whole: a second wave, a second image
+		const bool fused_base = base_is_clip && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
+		const bool two_waves = base_is_clip && !fused_base;
+		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1);
 		const size_t lds_schedule_bytes = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0;
 		constexpr size_t k_lds_bytes = 160 * 1024 - 128;		// the kernel's few static words
 		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
@@ -264,7 +268,7 @@ namespace
 		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) + lds_schedule_bytes > k_lds_bytes / 3)
 			log2_instances_per_block--;
 		const uint32_t instances_per_block = 1u << log2_instances_per_block;
-		const uint32_t waves_per_block = instances_per_block * (base_is_clip ? 2 : 1);
+		const uint32_t waves_per_block = instances_per_block * (two_waves ? 2 : 1);
 		const uint32_t num_blocks = (num_instances + instances_per_block - 1) / instances_per_block;
 		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block + lds_schedule_bytes;
 		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
@@ -277,6 +281,7 @@ namespace
 		device_consumers.base_pose_stride_bytes = consumers.base_pose_stride_bytes;
 		device_consumers.additive_format = consumers.additive_format;
 		device_consumers.object_space = consumers.object_space != 0 ? 1 : 0;
+		device_consumers.fused_base = fused_base ? 1 : 0;
 
 		hipLaunchKernelGGL(decompress_poses_consumer_kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
@@ -475,3 +480,11 @@ extern "C" aclhip_status aclhip_decompress_track_host(aclhip_context* context, c
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null track index list") : ACLHIP_ERROR_INVALID_ARGUMENT;
 	return decompress_host(context, clips, sample_times, track_indices, num_instances, params, default_values_count, transforms, 48, 48);
 }
+
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+// measurement aid, see kernels_consumers.inl
+extern "C" int aclhip_debug_read_phase_times(unsigned long long* out, uint32_t count)
+{
+	return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(aclhip::phase_times), size_t(count) * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost));
+}
+#endif

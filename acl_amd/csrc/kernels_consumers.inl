@@ -4,6 +4,28 @@
 	// ---- pose consumers -----------------------------------------------------------------------------------------------
 	// Decodes the whole local pose of one clip instance into an LDS image (image[0] = quad 0), window by window like the pose kernels
 	// but in ONE wave, because what follows needs every transform of the pose. Common-case settings only (see launch_consumers).
+	template<class image_writer_type>
+	__device__ __forceinline__ void decode_animated_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		uint32_t lane, image_writer_type write_to_image)
+	{
+		seek_state state;
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		if (num_quads <= k_image_chunk_quads)
+			decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, lane, write_to_image);
+		else
+		{
+			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
+			for (uint32_t window = 0; window < num_windows; ++window)
+			{
+				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
+				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
+				decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, write_to_image);
+			}
+		}
+	}
+
 	__device__ __forceinline__ void decode_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
 		uint32_t lane, f32x4* image)
 	{
@@ -17,22 +39,56 @@
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
 		}
+		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0 });
+	}
 
-		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
-
-		if (num_quads <= k_image_chunk_quads)
-			decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, 0, lane, image);
-		else
+	// transform_add0 / transform_add1 (core/additive_utils.h:128-142) one sub-track at a time: unlike the relative format (a qvv_mul)
+	// they combine rotation with rotation, translation with translation and scale with scale. kind: 0 rotation, 1 translation, 2 scale
+	__device__ __forceinline__ f32x4 apply_additive_sub_track(uint32_t additive_format, uint32_t kind, float4 additive, f32x4 base)
+	{
+		if (kind == 0)
 		{
-			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
-			for (uint32_t window = 0; window < num_windows; ++window)
-			{
-				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
-				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
-				decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, 0, lane, image);
-			}
+			const float4 rotation = quat_mul(additive, make_float4(base.x, base.y, base.z, base.w));
+			return f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
 		}
+		if (kind == 1)
+			return f32x4{ additive.x + base.x, additive.y + base.y, additive.z + base.z, 0.0f };
+		if (additive_format == 2)
+			return f32x4{ additive.x * base.x, additive.y * base.y, additive.z * base.z, 0.0f };
+		return f32x4{ (1.0f + additive.x) * base.x, (1.0f + additive.y) * base.y, (1.0f + additive.z) * base.z, 0.0f };
+	}
+
+	// A decoded sub-track of an additive clip goes ONTO the base pose the image already holds
+	struct additive_image_writer
+	{
+		f32x4* image;
+		uint32_t additive_format;
+		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
+		{
+			const uint32_t quad = entry.quad_index;
+			image[quad] = apply_additive_sub_track(additive_format, quad - (quad / 3u) * 3u, value, image[quad]);
+		}
+	};
+
+	// The additive clip applied onto the base pose in `image`, sub-track by sub-track: the constant and default ones from the clip's
+	// base pose table (defaults are the track_writer's own: what the pose consumers require), the animated ones as they are decoded.
+	__device__ __forceinline__ void apply_additive_clip_onto_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		uint32_t additive_format, uint32_t lane, f32x4* image)
+	{
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+		{
+			float4 value = load_quad(clip.base_pose, quad);
+			const uint32_t marker = __float_as_uint(value.w);
+			if (int32_t(marker) < 0)
+			{
+				if ((marker & k_quad_animated) != 0)
+					continue;
+				value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+			}
+			image[quad] = apply_additive_sub_track(additive_format, quad - (quad / 3u) * 3u, value, image[quad]);
+		}
+		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, additive_image_writer{ image, additive_format });
 	}
 
 	__device__ __forceinline__ void wave_lds_barrier()
@@ -69,6 +125,13 @@
 	// waves left in LDS next to their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
 	// HBM happens on the image the decode already holds.
 	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
+	// Measurement aid (-DACLHIP_EXP_PHASE_TIMES, tools/phase_times.py): wall clock stamps of a workgroup's phases
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+	__device__ unsigned long long phase_times[16384 * 4];
+#define ACLHIP_PHASE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define ACLHIP_PHASE_STAMP(k) do { } while (0)
+#endif
 	constexpr uint32_t k_consumer_max_instances = 8;
 	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
 
@@ -83,14 +146,19 @@
 
 		const bool has_base = consumers.additive_format != 0;
 		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
+		// a base clip under additive0 / additive1: ONE wave decodes the base into the instance's image and the additive clip onto it
+		// (half the LDS per instance, half the waves: twice the poses a CU holds); otherwise a second wave decodes the base into its own image
+		const bool fused_base = base_is_clip && consumers.fused_base != 0;
+		const bool two_waves = base_is_clip && !fused_base;
 		const bool object_space = consumers.object_space != 0;
+		ACLHIP_PHASE_STAMP(0);
 
 		// wave -> (instance slot of the workgroup, role): role 1 waves (base clips only) decode the slot's base
 		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
 		const uint32_t slot = wave_in_block & ((1u << log2_instances_per_block) - 1u);
 		const uint32_t role = wave_in_block >> log2_instances_per_block;
-		const uint32_t waves_per_instance = base_is_clip ? 2u : 1u;
+		const uint32_t waves_per_instance = two_waves ? 2u : 1u;
 		const uint32_t instance = (blockIdx.x << log2_instances_per_block) + slot;
 
 		uint8_t* instance_lds = dynamic_lds + size_t(slot) * lds_bytes_per_instance;
@@ -117,12 +185,13 @@
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
 				: uint32_t(params.rounding_policy);
 
+			device_clip base_clip = clip;
 			if (base_is_clip)
 			{
 				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
-				const device_clip base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
+				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks;
-				if (!refused && role == 1 && clip.num_tracks != 0)
+				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
 					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}
 
@@ -136,7 +205,14 @@
 				num_tracks = clip.num_tracks;
 				if (role == 0)
 				{
-					decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+					if (fused_base)
+					{
+						decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, image);
+						wave_lds_barrier();		// the base pose is complete (its DMA has landed)
+						apply_additive_clip_onto_image(clip, as_constant(sample_times)[instance], rounding_policy, params, consumers.additive_format, lane, image);
+					}
+					else
+						decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					if (object_space)
 					{
 						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
@@ -153,12 +229,12 @@
 		}
 
 		// both images of every instance are complete
-		if (base_is_clip)
+		if (two_waves)
 			__syncthreads();
 		else
 			wave_lds_barrier();
 
-		if (has_base)
+		if (has_base && !fused_base)
 		{
 			const f32x4* base_source = base_is_clip ? base_image : reinterpret_cast<const f32x4*>(consumers.base_poses + uint64_t(instance) * consumers.base_pose_stride_bytes);
 			for (uint32_t transform_index = role * k_wave_size + lane; transform_index < num_tracks; transform_index += waves_per_instance * k_wave_size)
@@ -181,6 +257,7 @@
 				walk_schedules[slot] = schedule;
 			}
 			__syncthreads();
+			ACLHIP_PHASE_STAMP(1);
 
 			// the walking wave rotates with the workgroup index: waves land on SIMDs by their index inside the workgroup, and walks that
 			// all ran on a CU's first SIMD would queue there
@@ -239,8 +316,9 @@
 				__builtin_amdgcn_s_setprio(0);
 			}
 			__syncthreads();
+			ACLHIP_PHASE_STAMP(2);
 		}
-		else if (base_is_clip)
+		else if (two_waves)
 			__syncthreads();
 		else
 			wave_lds_barrier();
@@ -249,4 +327,5 @@
 		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes);
 		for (uint32_t quad = role * k_wave_size + lane; quad < num_quads; quad += waves_per_instance * k_wave_size)
 			store_streaming(&pose[quad], image[quad]);
+		ACLHIP_PHASE_STAMP(3);
 	}
