@@ -50,7 +50,7 @@
 
 	// One track of a scalar track list, C components: unpack both key frames, expand, lerp, store C packed floats.
 	template<uint32_t C, bool kFromLds>
-	__device__ __forceinline__ void decode_scalar_track(const scalar_frames& frames, const scalar_track_tables<C>& tables, float alpha, float* destination)
+	__device__ __forceinline__ void decode_scalar_track_values(const scalar_frames& frames, const scalar_track_tables<C>& tables, float alpha, float* value)
 	{
 		const scalar_track_header& header = tables.header;
 		const float* range = tables.range;
@@ -66,7 +66,6 @@
 		const uint32_t field_bits = is_raw ? 0u : num_bits;
 		const bool wave_has_raw = !kFromLds && __any(int(is_raw)) != 0;
 
-		float value[C];
 		#pragma unroll
 		for (uint32_t c = 0; c < C; ++c)
 		{
@@ -114,8 +113,92 @@
 			const float lerped = (value1 * alpha) + (value0 - (value0 * alpha));
 			value[c] = is_constant ? range[c] : lerped;
 		}
+	}
 
+	template<uint32_t C, bool kFromLds>
+	__device__ __forceinline__ void decode_scalar_track(const scalar_frames& frames, const scalar_track_tables<C>& tables, float alpha, float* destination)
+	{
+		float value[C];
+		decode_scalar_track_values<C, kFromLds>(frames, tables, alpha, value);
 		store_streaming_floats<C>(destination, value);
+	}
+
+	// Which tracks a lane of a track list wave takes: kRows of them. Rows of one or two floats per track are written 16 bytes per lane
+	// -- 4 / C CONSECUTIVE tracks per lane, one dwordx4 store (1 KiB per store instruction instead of 256 / 512 bytes) -- when the wave
+	// takes 4 tracks per lane; otherwise (and for 3 / 4 floats per track, whose rows already are 12 / 16 bytes per lane) 64 apart.
+	template<uint32_t C, uint32_t kRows>
+	struct scalar_lane_tracks
+	{
+		static constexpr uint32_t k_run = (C <= 2 && kRows * C >= 4) ? 4 / C : 1;		// consecutive tracks per lane
+		static __device__ __forceinline__ uint32_t track_of(uint32_t first_track, uint32_t j, uint32_t lane)
+		{
+			return first_track + (j / k_run) * (k_wave_size * k_run) + lane * k_run + (j % k_run);
+		}
+	};
+
+	// Decodes a lane's tracks of ONE instance and stores them; rounding: per track policy source (null: the alpha as it is)
+	template<uint32_t C, uint32_t kRows, bool kFromLds, bool kPolicies>
+	__device__ __forceinline__ void decode_and_store_lane_tracks(const scalar_frames& frames, const scalar_track_tables<C> (&tables)[kRows], float seek_alpha,
+		uint32_t rounding_policy, const uint8_t* track_rounding_policies, uint32_t first_track, uint32_t num_tracks, uint32_t lane, float* row)
+	{
+		typedef scalar_lane_tracks<C, kRows> lane_tracks;
+		constexpr uint32_t k_run = lane_tracks::k_run;
+		#pragma unroll
+		for (uint32_t j0 = 0; j0 < kRows; j0 += k_run)
+		{
+			float values[k_run * C];
+			#pragma unroll
+			for (uint32_t r = 0; r < k_run; ++r)
+			{
+				const uint32_t track_index = lane_tracks::track_of(first_track, j0 + r, lane);
+				if (track_index < num_tracks)
+				{
+					float alpha = seek_alpha;
+					if (kPolicies)
+					{
+						// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
+						uint32_t policy = rounding_policy;
+						if (rounding_policy == k_round_per_track)
+							policy = track_rounding_policies != nullptr ? track_rounding_policies[track_index] : k_round_none;
+						alpha = apply_rounding_policy(alpha, policy);
+					}
+					decode_scalar_track_values<C, kFromLds>(frames, tables[j0 + r], alpha, values + r * C);
+				}
+			}
+			const uint32_t first_of_run = lane_tracks::track_of(first_track, j0, lane);
+			if constexpr (k_run == 1)
+			{
+				if (first_of_run < num_tracks)
+				{
+					float value[C];
+					#pragma unroll
+					for (uint32_t c = 0; c < C; ++c)
+						value[c] = values[c];
+					store_streaming_floats<C>(row + first_of_run * C, value);
+				}
+			}
+			else
+			{
+				if (first_of_run + k_run <= num_tracks)
+				{
+					const float value[4] = { values[0], values[1], values[2], values[3] };
+					store_streaming_floats<4>(row + first_of_run * C, value);		// (rows are 16 byte aligned, runs start at multiples of 4 floats)
+				}
+				else
+				{
+					#pragma unroll
+					for (uint32_t r = 0; r < k_run; ++r)
+						if (first_of_run + r < num_tracks)
+						{
+							float value[C];
+							#pragma unroll
+							for (uint32_t c = 0; c < C; ++c)
+								value[c] = values[r * C + c];
+							store_streaming_floats<C>(row + (first_of_run + r) * C, value);
+						}
+				}
+			}
+		}
 	}
 
 	__device__ __forceinline__ void decode_scalar_track_any(uint32_t num_components, const uint8_t* blob, const scalar_track_header* headers, const float* ranges,
@@ -225,7 +308,7 @@
 			scalar_track_tables<C> tables[kRows];
 			#pragma unroll
 			for (uint32_t j = 0; j < kRows; ++j)
-				tables[j] = load_scalar_track_tables<C>(headers, ranges, min(first_track + j * k_wave_size + lane, num_tracks - 1));
+				tables[j] = load_scalar_track_tables<C>(headers, ranges, min(scalar_lane_tracks<C, kRows>::track_of(first_track, j, lane), num_tracks - 1));
 
 			if (kFromLds)
 			{
@@ -236,24 +319,7 @@
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			}
 
-			#pragma unroll
-			for (uint32_t j = 0; j < kRows; ++j)
-			{
-				const uint32_t track_index = first_track + j * k_wave_size + lane;
-				if (track_index < num_tracks)
-				{
-					float alpha = seek_alpha;
-					if (kPolicies)
-					{
-						// track_writer::get_rounding_policy, applied to the alpha the seek left behind (:246-258,273-279)
-						uint32_t policy = rounding_policy;
-						if (rounding_policy == k_round_per_track)
-							policy = track_rounding_policies != nullptr ? track_rounding_policies[track_index] : k_round_none;
-						alpha = apply_rounding_policy(alpha, policy);
-					}
-					decode_scalar_track<C, kFromLds>(frames, tables[j], alpha, row + track_index * C);
-				}
-			}
+			decode_and_store_lane_tracks<C, kRows, kFromLds, kPolicies>(frames, tables, seek_alpha, rounding_policy, track_rounding_policies, first_track, num_tracks, lane, row);
 		};
 		switch (num_components)
 		{
@@ -291,8 +357,9 @@
 	// k_scalar_group CONSECUTIVE instances: when they are of one clip (the usual shape of an instance list: sorted, or one list for
 	// all characters) the tables are fetched once and stay in registers, the seeks run back to back on the scalar unit, all the key
 	// frames are DMA'd into LDS together, and the wave pays its round trips once per group instead of once per instance
-	// (28.0 -> 25.8 us for 64k x 256 float1f curves: what remains is the decode's own arithmetic, about 140 VALU instructions per
-	// instance and 256 curves, and the 1 KiB rows). Groups of mixed clips fall back to one instance after the other.
+	// (28.0 -> 25.8 us for 64k x 256 float1f curves, 25.0 with 16 byte stores: what remains is the decode's own arithmetic, about 140
+	// VALU instructions per instance and 256 curves = 17 us of issue per SIMD; groups of 2 / 8: 28.4 / 32.6 us; capping the registers
+	// for 6 / 8 waves per SIMD: 22.7 / 42 us on this shape, slower on 1024 curves). Groups of mixed clips fall back to one instance after the other.
 	constexpr uint32_t k_scalar_group = 4;
 
 	template<uint32_t kRows, bool kPolicies>
@@ -396,7 +463,7 @@
 			scalar_track_tables<C> tables[kRows];
 			#pragma unroll
 			for (uint32_t j = 0; j < kRows; ++j)
-				tables[j] = load_scalar_track_tables<C>(headers, ranges, min(first_track + j * k_wave_size + lane, num_tracks - 1));
+				tables[j] = load_scalar_track_tables<C>(headers, ranges, min(scalar_lane_tracks<C, kRows>::track_of(first_track, j, lane), num_tracks - 1));
 			wave_lds_barrier();		// every frame copy has landed
 
 			#pragma unroll
@@ -405,23 +472,7 @@
 				if (k >= count)
 					break;
 				float* row = reinterpret_cast<float*>(out + uint64_t(first_instance + k) * out_stride_bytes);
-				#pragma unroll
-				for (uint32_t j = 0; j < kRows; ++j)
-				{
-					const uint32_t track_index = first_track + j * k_wave_size + lane;
-					if (track_index < num_tracks)
-					{
-						float alpha = alphas[k];
-						if (kPolicies)
-						{
-							uint32_t policy = rounding_policies[k];
-							if (policy == k_round_per_track)
-								policy = track_rounding_policies != nullptr ? track_rounding_policies[track_index] : k_round_none;
-							alpha = apply_rounding_policy(alpha, policy);
-						}
-						decode_scalar_track<C, true>(frames[k], tables[j], alpha, row + track_index * C);
-					}
-				}
+				decode_and_store_lane_tracks<C, kRows, true, kPolicies>(frames[k], tables, alphas[k], rounding_policies[k], track_rounding_policies, first_track, num_tracks, lane, row);
 			}
 		};
 		switch (num_components)
