@@ -128,7 +128,7 @@
 	// Measurement aid (-DACLHIP_EXP_PHASE_TIMES, tools/phase_times.py): wall clock stamps of a workgroup's phases
 #if defined(ACLHIP_EXP_PHASE_TIMES)
 	__device__ unsigned long long phase_times[16384 * 4];
-#define ACLHIP_PHASE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#define ACLHIP_PHASE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
 #else
 #define ACLHIP_PHASE_STAMP(k) do { } while (0)
 #endif
@@ -143,6 +143,7 @@
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
 		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do
 		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
+		__shared__ uint32_t walk_tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
 
 		const bool has_base = consumers.additive_format != 0;
 		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
@@ -255,13 +256,17 @@
 			{
 				walk_levels[slot] = num_levels;
 				walk_schedules[slot] = schedule;
+				walk_tracks[slot] = num_tracks;
 			}
 			__syncthreads();
 			ACLHIP_PHASE_STAMP(1);
 
-			// the walking wave rotates with the workgroup index: waves land on SIMDs by their index inside the workgroup, and walks that
-			// all ran on a CU's first SIMD would queue there
-			if (wave_in_block == (blockIdx.x & ((blockDim.x / k_wave_size) - 1u)))
+			// ONE wave walks and then stores the workgroup's poses; the others are done and give their wave slots and registers back (a
+			// pose waits in LDS for the walk about as long as its decode took: with every wave parked at a barrier the wave slots, not the
+			// LDS, decided how many poses a CU holds). The walking wave rotates with the workgroup index: waves land on SIMDs by their
+			// index inside the workgroup, and walks that all ran on a CU's first SIMD would queue there.
+			if (wave_in_block != (blockIdx.x & ((blockDim.x / k_wave_size) - 1u)))
+				return;
 			{
 				// lanes <-> (instance slot, transform of the current step): slot = lane % instances, lane / instances picks the slot's
 				// transform inside the step. A transform's parent was scheduled in an earlier step: final by the time it is read.
@@ -315,8 +320,20 @@
 				}
 				__builtin_amdgcn_s_setprio(0);
 			}
-			__syncthreads();
+			wave_lds_barrier();
 			ACLHIP_PHASE_STAMP(2);
+
+			const uint32_t instances_per_block = 1u << log2_instances_per_block;
+			for (uint32_t store_slot = 0; store_slot < instances_per_block; ++store_slot)
+			{
+				const uint32_t slot_quads = walk_tracks[store_slot] * 3u;
+				const f32x4* slot_image = reinterpret_cast<const f32x4*>(dynamic_lds + size_t(store_slot) * lds_bytes_per_instance);
+				f32x4* slot_pose = reinterpret_cast<f32x4*>(poses + uint64_t((blockIdx.x << log2_instances_per_block) + store_slot) * pose_stride_bytes);
+				for (uint32_t quad = lane; quad < slot_quads; quad += k_wave_size)
+					store_streaming(&slot_pose[quad], slot_image[quad]);
+			}
+			ACLHIP_PHASE_STAMP(3);
+			return;
 		}
 		else if (two_waves)
 			__syncthreads();
