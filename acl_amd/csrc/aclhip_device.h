@@ -133,6 +133,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_wraps = 1u << 3;					// compressed_tracks::get_looping_policy() == wrap
 	constexpr uint32_t k_clip_has_raw = 1u << 4;				// some (segment, sub-track) uses the raw bit rate
 	constexpr uint32_t k_clip_is_scalar = 1u << 5;				// scalar track list: only the scalar kernel accepts it
+	constexpr uint32_t k_clip_scaled = 1u << 6;					// scale sub-tracks, or a default scale other than 1: some scale of a pose may differ from 1
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
@@ -167,7 +168,6 @@ namespace aclhip
 		uint64_t base_pose_stride_bytes;
 		uint32_t additive_format;			// acl::additive_clip_format8; 0 = no base
 		uint32_t object_space;				// 1: local -> object space with the clip's hierarchy
-		uint32_t fused_base;				// 1: base clips are decoded by the instance's own wave, the additive clip onto them (additive0 / additive1)
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)

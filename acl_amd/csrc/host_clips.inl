@@ -562,6 +562,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	if (num_tracks != 0)
 	{
 		record.flags |= has_scale ? k_clip_has_scale : 0u;
+		record.flags |= (has_scale || float(header.default_scale()) != 1.0f) ? k_clip_scaled : 0u;
 		record.flags |= stripped ? k_clip_has_stripped_keyframes : 0u;
 		record.flags |= header.has_database() ? k_clip_has_database : 0u;
 		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
@@ -661,6 +662,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.touched_bytes = total_bytes - 64;
 	entry.pose_quads = num_quads;
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
+	entry.scaled = num_tracks != 0 && (has_scale || float(header.default_scale()) != 1.0f);
+	context->num_scaled_clips += entry.scaled ? 1u : 0u;
 
 	*out_clip = slot;
 	return ACLHIP_OK;
@@ -726,6 +729,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 		context->databases[bound_database].num_bound_clips--;
 	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
+	context->num_scaled_clips -= removed.scaled ? 1u : 0u;
 	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
 		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))
 		recompute_launch_maxima(context);

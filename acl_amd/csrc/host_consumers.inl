@@ -252,7 +252,12 @@ namespace
 
 		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
 		// most 8, 4 unless told otherwise: measured best) as leave room for three workgroups per CU: the object space walk packs its lanes with instances of one workgroup
-		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(context->max_pose_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
+		// No clip with a scale other than 1 registered, no base to combine with: every scale of every pose is 1, in local and in object
+		// space -- the LDS images hold rotation | translation (32 of a transform's 48 bytes: half as many poses again per CU) and the
+		// scales are written on the way out
+		const bool unit_scale = !has_base && consumers.object_space != 0 && context->num_scaled_clips == 0 && std::getenv("ACLHIP_CONSUMER_KEEP_SCALE") == nullptr;
+		const uint32_t image_quads = unit_scale ? context->max_pose_quads / 3 * 2 : context->max_pose_quads;
+		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(image_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
 		// additive0 / additive1 combine sub-track with sub-track: the base clip is decoded into the instance's image and the additive clip
 		// onto it by one wave; the relative format (a qvv_mul) needs both poses whole: a second wave, a second image
 		const bool fused_base = base_is_clip && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
@@ -271,8 +276,6 @@ namespace
 		const uint32_t waves_per_block = instances_per_block * (two_waves ? 2 : 1);
 		const uint32_t num_blocks = (num_instances + instances_per_block - 1) / instances_per_block;
 		const size_t lds_bytes = lds_bytes_per_instance * instances_per_block + lds_schedule_bytes;
-		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
-			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(decompress_poses_consumer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
 
 		consumer_params device_consumers;
 		device_consumers.base_clip_ids = base_is_clip ? consumers.base_clips : nullptr;
@@ -281,9 +284,21 @@ namespace
 		device_consumers.base_pose_stride_bytes = consumers.base_pose_stride_bytes;
 		device_consumers.additive_format = consumers.additive_format;
 		device_consumers.object_space = consumers.object_space != 0 ? 1 : 0;
-		device_consumers.fused_base = fused_base ? 1 : 0;
 
-		hipLaunchKernelGGL(decompress_poses_consumer_kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
+		// one instantiation per (object space, kind of base, rotation | translation images)
+		const uint32_t base_kind = !has_base ? k_consumer_base_none : (!base_is_clip ? k_consumer_base_buffer : (fused_base ? k_consumer_base_fused : k_consumer_base_second_wave));
+		typedef void (*consumer_kernel)(const device_clip*, uint32_t, const uint32_t*, const float*, uint32_t, decode_params, consumer_params, uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, unsigned long long*);
+		static const consumer_kernel kernels[2][4] =
+		{
+			{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false>,
+			  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false>, decompress_poses_consumer_kernel<false, k_consumer_base_fused, false> },
+			{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false>,
+			  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false> },
+		};
+		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true> : kernels[consumers.object_space != 0 ? 1 : 0][base_kind];
+		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
+			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
+		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, uint32_t(lds_bytes_per_instance), log2_instances_per_block, context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());

@@ -42,6 +42,22 @@
 		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0 });
 	}
 
+	// The pose without its scales (every one of them is 1): rotation | translation, 32 bytes per transform, like the QV32 output layout
+	__device__ __forceinline__ void decode_unit_scale_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		uint32_t lane, f32x4* image)
+	{
+		const uint32_t num_pieces = clip.num_tracks * 2u;
+		const ACLHIP_CONSTANT f32x4* resolved = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose;
+		for (uint32_t base = 0; base < num_pieces; base += k_wave_size)
+		{
+			const uint32_t piece = base + lane;
+			if (piece < num_pieces)
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resolved + (piece >> 1) * 3u + (piece & 1u)),
+					(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
+		}
+		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, compact_image_writer<ACLHIP_LAYOUT_QV32>{ reinterpret_cast<float*>(image), 0 });
+	}
+
 	// transform_add0 / transform_add1 (core/additive_utils.h:128-142) one sub-track at a time: unlike the relative format (a qvv_mul)
 	// they combine rotation with rotation, translation with translation and scale with scale. kind: 0 rotation, 1 translation, 2 scale
 	__device__ __forceinline__ f32x4 apply_additive_sub_track(uint32_t additive_format, uint32_t kind, float4 additive, f32x4 base)
@@ -135,6 +151,15 @@
 	constexpr uint32_t k_consumer_max_instances = 8;
 	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
 
+	// Launch wide facts are template arguments (each instantiation keeps only its own path: registers, code size):
+	//   kObjectSpace   local -> object space with the clips' hierarchies
+	//   kBase          k_consumer_base_*: no base | a pose buffer in HBM | a clip decoded by a second wave into a second image (the relative
+	//                  format) | a clip decoded by the instance's own wave, the additive clip onto it (additive0 / additive1)
+	//   kUnitScale     object space without a base while no registered clip has a scale other than 1: the images hold rotation |
+	//                  translation only (32 of a transform's 48 bytes)
+	constexpr uint32_t k_consumer_base_none = 0, k_consumer_base_buffer = 1, k_consumer_base_second_wave = 2, k_consumer_base_fused = 3;
+
+	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale>
 	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
 		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t log2_instances_per_block,
@@ -145,13 +170,15 @@
 		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
 		__shared__ uint32_t walk_tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
 
-		const bool has_base = consumers.additive_format != 0;
-		const bool base_is_clip = has_base && consumers.base_clip_ids != nullptr;
+		static_assert(!kUnitScale || (kObjectSpace && kBase == k_consumer_base_none), "rotation | translation images: object space without a base");
+		constexpr bool has_base = kBase != k_consumer_base_none;
+		constexpr bool base_is_clip = kBase == k_consumer_base_second_wave || kBase == k_consumer_base_fused;
 		// a base clip under additive0 / additive1: ONE wave decodes the base into the instance's image and the additive clip onto it
 		// (half the LDS per instance, half the waves: twice the poses a CU holds); otherwise a second wave decodes the base into its own image
-		const bool fused_base = base_is_clip && consumers.fused_base != 0;
-		const bool two_waves = base_is_clip && !fused_base;
-		const bool object_space = consumers.object_space != 0;
+		constexpr bool fused_base = kBase == k_consumer_base_fused;
+		constexpr bool two_waves = kBase == k_consumer_base_second_wave;
+		constexpr bool object_space = kObjectSpace;
+		constexpr bool unit_scale = kUnitScale;
 		ACLHIP_PHASE_STAMP(0);
 
 		// wave -> (instance slot of the workgroup, role): role 1 waves (base clips only) decode the slot's base
@@ -180,7 +207,8 @@
 			// refused: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images, bases that
 			// are unknown or describe another number of transforms (the reference asserts matching track counts where it combines them).
 			// Both waves of an instance come to the same verdict; the first one reports it.
-			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr) || clip.num_tracks * 3u > lds_quads_per_image;
+			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr)
+				|| clip.num_tracks * (unit_scale ? 2u : 3u) > lds_quads_per_image || (unit_scale && (clip.flags & k_clip_scaled) != 0);
 
 			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
@@ -212,6 +240,8 @@
 						wave_lds_barrier();		// the base pose is complete (its DMA has landed)
 						apply_additive_clip_onto_image(clip, as_constant(sample_times)[instance], rounding_policy, params, consumers.additive_format, lane, image);
 					}
+					else if (unit_scale)
+						decode_unit_scale_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					else
 						decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					if (object_space)
@@ -276,8 +306,9 @@
 				const uint32_t slot_steps = walk_levels[walk_slot];
 				const uint32_t* slot_schedule = walk_schedules[walk_slot];
 
-				const auto walk = [&](const auto* schedule_words)
+				const auto walk = [&](const auto* schedule_words, auto scale_is_one)
 				{
+					constexpr bool k_unit_scale = decltype(scale_is_one)::value;
 					const auto* pairs = schedule_words + 2u + slot_steps;
 					uint32_t step_start = 0;
 					for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
@@ -289,13 +320,28 @@
 							if (pair_index < step_end)
 							{
 								const uint32_t pair = pairs[pair_index];		// transform | parent << 16
-								const qvv child = load_qvv(slot_image, pair & 0xFFFFu), parent = load_qvv(slot_image, pair >> 16);
-								const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
-								if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
-									atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
-								qvv object = qvv_mul(child, parent);
-								object.rotation = quat_normalize(object.rotation);
-								store_qvv(slot_image, pair & 0xFFFFu, object);
+								if constexpr (k_unit_scale)
+								{
+									// rotation | translation images; qvv_mul with both scales 1: translation * 1 is the translation itself
+									const uint32_t child_quad = (pair & 0xFFFFu) * 2u, parent_quad = (pair >> 16) * 2u;
+									const f32x4 child_rotation = slot_image[child_quad], child_translation = slot_image[child_quad + 1];
+									const f32x4 parent_rotation = slot_image[parent_quad], parent_translation = slot_image[parent_quad + 1];
+									const float4 parent_quat = make_float4(parent_rotation.x, parent_rotation.y, parent_rotation.z, parent_rotation.w);
+									const float4 rotation = quat_normalize(quat_mul(make_float4(child_rotation.x, child_rotation.y, child_rotation.z, child_rotation.w), parent_quat));
+									const float4 rotated = quat_mul_vector3(make_float4(child_translation.x, child_translation.y, child_translation.z, 0.0f), parent_quat);
+									slot_image[child_quad] = f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
+									slot_image[child_quad + 1] = f32x4{ rotated.x + parent_translation.x, rotated.y + parent_translation.y, rotated.z + parent_translation.z, 0.0f };
+								}
+								else
+								{
+									const qvv child = load_qvv(slot_image, pair & 0xFFFFu), parent = load_qvv(slot_image, pair >> 16);
+									const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
+									if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
+										atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
+									qvv object = qvv_mul(child, parent);
+									object.rotation = quat_normalize(object.rotation);
+									store_qvv(slot_image, pair & 0xFFFFu, object);
+								}
 							}
 							step_start = step_end;
 						}
@@ -313,10 +359,18 @@
 					const uint32_t leader = uint32_t(__builtin_ctzll(walkers));
 					const uint64_t mine = reinterpret_cast<uint64_t>(slot_schedule);
 					const uint64_t first_schedule = (uint64_t(__shfl(uint32_t(mine >> 32), int(leader))) << 32) | __shfl(uint32_t(mine), int(leader));
-					if (__all(int(slot_steps == 0 || mine == first_schedule)) != 0)
-						walk(static_cast<const uint32_t*>(shared_schedule));
+					const bool shared_copy = __all(int(slot_steps == 0 || mine == first_schedule)) != 0;
+					if (unit_scale)
+					{
+						if (shared_copy)
+							walk(static_cast<const uint32_t*>(shared_schedule), std::true_type());
+						else
+							walk(as_constant(slot_schedule), std::true_type());
+					}
+					else if (shared_copy)
+						walk(static_cast<const uint32_t*>(shared_schedule), std::false_type());
 					else
-						walk(as_constant(slot_schedule));
+						walk(as_constant(slot_schedule), std::false_type());
 				}
 				__builtin_amdgcn_s_setprio(0);
 			}
@@ -329,8 +383,20 @@
 				const uint32_t slot_quads = walk_tracks[store_slot] * 3u;
 				const f32x4* slot_image = reinterpret_cast<const f32x4*>(dynamic_lds + size_t(store_slot) * lds_bytes_per_instance);
 				f32x4* slot_pose = reinterpret_cast<f32x4*>(poses + uint64_t((blockIdx.x << log2_instances_per_block) + store_slot) * pose_stride_bytes);
-				for (uint32_t quad = lane; quad < slot_quads; quad += k_wave_size)
-					store_streaming(&slot_pose[quad], slot_image[quad]);
+				if (unit_scale)
+				{
+					// rotation | translation in LDS, rotation | translation | scale (1, 1, 1) in the pose
+					for (uint32_t quad = lane; quad < slot_quads; quad += k_wave_size)
+					{
+						const uint32_t track = quad / 3u;
+						const uint32_t kind = quad - track * 3u;
+						const f32x4 value = kind == 2 ? f32x4{ 1.0f, 1.0f, 1.0f, 0.0f } : slot_image[track * 2u + min(kind, 1u)];
+						store_streaming(&slot_pose[quad], value);
+					}
+				}
+				else
+					for (uint32_t quad = lane; quad < slot_quads; quad += k_wave_size)
+						store_streaming(&slot_pose[quad], slot_image[quad]);
 			}
 			ACLHIP_PHASE_STAMP(3);
 			return;

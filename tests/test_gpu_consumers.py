@@ -326,3 +326,49 @@ def test_mixed_skeletons_inside_one_workgroup():
         got = context.decompress_poses(np.full(8, handles[3], dtype=np.uint32), times[:8] * 0.0, object_space=True, num_tracks=50)
         assert helpers.exact(got[0], ob.oracle_local_to_object_space(parents[3], ob.oracle_decompress_tracks(clips[3].blob, 0.0)))
         assert context.rejected_instance_count() == 0
+
+
+@pytest.mark.parametrize("num_tracks", [1, 7, 100, 104, 105, 333])
+def test_poses_without_scale_keep_no_scale_in_lds(num_tracks):
+    """no registered clip has a scale other than 1: the object space images hold rotation | translation only (half as many poses again
+    per CU). Same bits as the oracle and as the three-quad images (ACLHIP_CONSUMER_KEEP_SCALE); a clip WITH scale in the registry
+    switches the launch back, and mixes of both kinds decode together."""
+    import os
+    rng = np.random.default_rng(num_tracks)
+    clips = [synth.build_clip(seed=800 + num_tracks + k, num_tracks=num_tracks, num_samples=30 + 11 * k) for k in range(2)]
+    parents = random_hierarchy(rng, num_tracks, parent_span=max(1, num_tracks // 6), extra_roots=1 if num_tracks > 4 else 0)
+    with runtime.Context(0) as context:
+        handles = [context.register_clip(c.blob) for c in clips]
+        for handle in handles:
+            context.set_clip_hierarchy(handle, parents)
+        n = 37
+        which = rng.integers(0, 2, size=n)
+        times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+        clip_handles = np.array([handles[w] for w in which], dtype=np.uint32)
+        expected = np.stack([ob.oracle_local_to_object_space(parents, ob.oracle_decompress_tracks(clips[w].blob, float(t))) for w, t in zip(which, times)])
+
+        two_quads = context.decompress_poses(clip_handles, times, object_space=True)
+        assert helpers.exact(two_quads, expected)
+        assert np.array_equal(two_quads[:, :, 8:12], np.broadcast_to(np.array([1.0, 1.0, 1.0, 0.0], dtype=np.float32), (n, num_tracks, 4)))
+        os.environ["ACLHIP_CONSUMER_KEEP_SCALE"] = "1"
+        try:
+            three_quads = context.decompress_poses(clip_handles, times, object_space=True)
+        finally:
+            del os.environ["ACLHIP_CONSUMER_KEEP_SCALE"]
+        assert helpers.exact(three_quads, two_quads)
+
+        # a clip with scale joins the registry: launches keep the scales again, for every clip
+        scaled = synth.build_clip(seed=900 + num_tracks, num_tracks=num_tracks, num_samples=20, has_scale=1)
+        scaled_handle = context.register_clip(scaled.blob)
+        context.set_clip_hierarchy(scaled_handle, parents)
+        mixed_handles = np.concatenate([clip_handles, np.full(5, scaled_handle, dtype=np.uint32)])
+        mixed_times = np.concatenate([times, rng.uniform(0.0, scaled.duration, size=5).astype(np.float32)])
+        mixed = context.decompress_poses(mixed_handles, mixed_times, object_space=True)
+        assert helpers.exact(mixed[:n], expected)
+        for i in range(5):
+            local = ob.oracle_decompress_tracks(scaled.blob, float(mixed_times[n + i]))
+            assert helpers.exact(mixed[n + i], ob.oracle_local_to_object_space(parents, local))
+        # ... and leaves it again
+        context.unregister_clip(scaled_handle)
+        assert helpers.exact(context.decompress_poses(clip_handles, times, object_space=True), expected)
+        assert context.rejected_instance_count() == 0
