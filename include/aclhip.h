@@ -299,7 +299,8 @@ aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_insta
  * when the pointers are not NULL, the permuted lists out_clips[k] = clips[out_order[k]], out_sample_times[k] =
  * sample_times[out_order[k]] (the arguments of the decode that follows on the same stream; rows = out_order puts the poses back
  * in the caller's rows). Which instance of a clip takes which of the clip's slots is decided by atomics: every call returns a valid
- * order, not the same one. An instance list usually outlives a frame (which character plays which clip changes rarely, the
+ * order, not the same one. The first call on a stream allocates that stream's counters: make it before capturing the stream into a
+ * hipGraph. An instance list usually outlives a frame (which character plays which clip changes rarely, the
  * sample times every frame): order once, keep the lists in that order. */
 aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);

@@ -225,10 +225,23 @@ def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
     d_rows = torch.from_numpy(rows).to(device)
     d_scattered = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
 
+    # ... and a decode in the order aclhip_order_instances_device gives, computed inside the graph (its per stream counters are allocated
+    # by the first call on a stream: one call before the capture)
+    d_order = torch.zeros(n, dtype=torch.int32, device=device)
+    d_ordered_clips = torch.zeros(n, dtype=torch.int32, device=device)
+    d_ordered_times = torch.zeros(n, dtype=torch.float32, device=device)
+    d_ordered_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+
     graph = torch.cuda.CUDAGraph()
     capture_stream = torch.cuda.Stream(device)
+    torch.cuda.synchronize(device)
+    ctx.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_ordered_clips.data_ptr(), d_ordered_times.data_ptr(), stream=capture_stream.cuda_stream)
+    capture_stream.synchronize()
     with torch.cuda.graph(graph, stream=capture_stream):
         stream_handle = torch.cuda.current_stream(device).cuda_stream
+        assert stream_handle == capture_stream.cuda_stream
+        ctx.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_ordered_clips.data_ptr(), d_ordered_times.data_ptr(), stream=stream_handle)
+        ctx.decompress_tracks_batch(d_ordered_clips.data_ptr(), d_ordered_times.data_ptr(), n, d_ordered_poses.data_ptr(), 4800, stream=stream_handle)
         ctx.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, stream=stream_handle)
         ctx.decompress_scalar_tracks_batch(d_curve_clips.data_ptr(), d_times.data_ptr(), n, d_values.data_ptr(), 256, stream=stream_handle)
         ctx.decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_object_poses.data_ptr(), 4800, consumers, stream=stream_handle)
@@ -245,6 +258,9 @@ def test_batch_launches_can_be_captured_into_a_hip_graph(setup):
             assert helpers.exact(values[i], ob.oracle_scalar_decompress_tracks(curves.blob, float(times[i]))[:, 0])
         object_poses, scattered = d_object_poses.cpu().numpy(), d_scattered.cpu().numpy()
         assert helpers.exact(scattered[rows], poses)
+        order = d_order.cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(n))
+        assert helpers.exact(d_ordered_poses.cpu().numpy(), poses[order])
         for i in rng.choice(n, size=8, replace=False):
             assert helpers.exact(object_poses[i], ob.oracle_local_to_object_space(parents, ob.oracle_decompress_tracks(clip.blob, float(times[i]))))
     assert ctx.rejected_instance_count() == 0
