@@ -141,13 +141,6 @@
 	// waves left in LDS next to their poses; then the finished poses stream out. What a caller would otherwise do in further passes over the pose buffer in
 	// HBM happens on the image the decode already holds.
 	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
-	// Measurement aid (-DACLHIP_EXP_PHASE_TIMES, tools/phase_times.py): wall clock stamps of a workgroup's phases
-#if defined(ACLHIP_EXP_PHASE_TIMES)
-	__device__ unsigned long long phase_times[16384 * 4];
-#define ACLHIP_PHASE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
-#else
-#define ACLHIP_PHASE_STAMP(k) do { } while (0)
-#endif
 	constexpr uint32_t k_consumer_max_instances = 8;
 	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
 

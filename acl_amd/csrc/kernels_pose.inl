@@ -2,6 +2,20 @@
 // The pose kernels: decompress_tracks_kernel, decompress_tracks_any_settings_kernel (one wave64 per instance and pose window).
 
 	constexpr uint32_t k_wave_size = 64;
+
+	// Measurement aid (-DACLHIP_EXP_PHASE_TIMES, tools/phase_times.py): wall clock stamps of the phases of a workgroup (pose consumers) / of a workgroup's first wave (pose kernel)
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+	__device__ unsigned long long phase_times[16384 * 4];
+#define ACLHIP_PHASE_STAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define ACLHIP_PHASE_STAMP(k) do { } while (0)
+#endif
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+#define ACLHIP_WAVE0_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) phase_times[blockIdx.x * 4 + (k)] = wall_clock64(); } while (0)
+#else
+#define ACLHIP_WAVE0_STAMP(k) do { } while (0)
+#endif
+
 #if !defined(ACLHIP_WAVES_PER_BLOCK)
 	#define ACLHIP_WAVES_PER_BLOCK 4
 #endif
@@ -198,6 +212,7 @@
 		unsigned long long* __restrict__ rejected_count)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+		ACLHIP_WAVE0_STAMP(0);
 
 		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
@@ -262,6 +277,10 @@
 
 		seek_state state;
 		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+		asm volatile("" :: "s"(state.key_frame_bit_offsets[0]), "s"(state.key_frame_bit_offsets[1]));		// the seek's loads have arrived
+		ACLHIP_WAVE0_STAMP(1);
+#endif
 
 		if (kAnySettings && normalization == ACLHIP_NORMALIZE_ALWAYS)
 		{
@@ -294,6 +313,7 @@
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		ACLHIP_WAVE0_STAMP(2);
 
 		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults)
 		{
@@ -442,6 +462,7 @@
 			if (kAnySettings || kCompactOutput)
 				kind = kind == 2 ? 0u : kind + 1u;
 		}
+		ACLHIP_WAVE0_STAMP(3);
 	}
 
 	// ---- compact output layouts, the fast path -----------------------------------------------------------------------------------------
