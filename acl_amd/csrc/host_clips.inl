@@ -158,6 +158,8 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	entry.scalar_frame_bytes = (num_bits_per_frame + 7) / 8;
 	context->max_scalar_tracks = std::max(context->max_scalar_tracks, entry.scalar_tracks);
 	context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, entry.scalar_frame_bytes);
+	entry.wide_scalar = num_components != 1;
+	context->num_wide_scalar_clips += entry.wide_scalar ? 1u : 0u;
 
 	*out_clip = slot;
 	return ACLHIP_OK;
@@ -730,6 +732,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
 	context->num_scaled_clips -= removed.scaled ? 1u : 0u;
+	context->num_wide_scalar_clips -= removed.wide_scalar ? 1u : 0u;
 	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
 		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))
 		recompute_launch_maxima(context);

@@ -61,10 +61,17 @@ namespace
 					num_instances, chunks_per_instance, device_params, static_cast<uint8_t*>(out), out_stride_bytes, frame_lds_bytes, context->d_rejected);
 			};
 			const bool policies = device_params.per_track_rounding != 0;
-			if (grouped)
+			if (grouped && context->num_wide_scalar_clips == 0)
 			{
-				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_grouped_kernel<1, true>); else launch(decompress_scalar_tracks_grouped_kernel<1, false>); }
-				else { if (policies) launch(decompress_scalar_tracks_grouped_kernel<4, true>); else launch(decompress_scalar_tracks_grouped_kernel<4, false>); }
+				// every registered list is float1f (blend shape weights, curves): the kernel compiled for one float per track only
+				// (47 instead of 109 registers: twice the waves per SIMD)
+				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_grouped_kernel<1, true, 1>); else launch(decompress_scalar_tracks_grouped_kernel<1, false, 1>); }
+				else { if (policies) launch(decompress_scalar_tracks_grouped_kernel<4, true, 1>); else launch(decompress_scalar_tracks_grouped_kernel<4, false, 1>); }
+			}
+			else if (grouped)
+			{
+				if (rows == 1) { if (policies) launch(decompress_scalar_tracks_grouped_kernel<1, true, 0>); else launch(decompress_scalar_tracks_grouped_kernel<1, false, 0>); }
+				else { if (policies) launch(decompress_scalar_tracks_grouped_kernel<4, true, 0>); else launch(decompress_scalar_tracks_grouped_kernel<4, false, 0>); }
 			}
 			else if (frame_lds_bytes != 0)
 			{

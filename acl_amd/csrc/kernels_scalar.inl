@@ -228,7 +228,8 @@
 	// through the texture unit, dependent on the table read. frame_lds_bytes == 0 (a registered list's frame does not fit): global reads.
 	// kRows: tracks per lane (1 when no registered list has more than 64 tracks, else 4); kPolicies: per track rounding -- launch wide
 	// facts, compiled as separate kernels so that each stays small.
-	template<bool kFromLds, uint32_t kRows, bool kPolicies>
+	// kComponents: 0 = lists of any track type; 1 = every registered list is float1f (launch wide, host_scalar_misc.inl): one code path
+	template<bool kFromLds, uint32_t kRows, bool kPolicies, uint32_t kComponents = 0>
 	__device__ __forceinline__ void decompress_scalar_tracks_instance(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t instance, uint32_t chunk,
 		const decode_params& params, uint8_t* __restrict__ out, uint64_t out_stride_bytes, uint32_t frame_lds_bytes, uint8_t* wave_lds, uint32_t lane,
@@ -321,12 +322,22 @@
 
 			decode_and_store_lane_tracks<C, kRows, kFromLds, kPolicies>(frames, tables, seek_alpha, rounding_policy, track_rounding_policies, first_track, num_tracks, lane, row);
 		};
-		switch (num_components)
+		if constexpr (kComponents == 1)
 		{
-		case 1: decode_tracks(std::integral_constant<uint32_t, 1>()); break;
-		case 2: decode_tracks(std::integral_constant<uint32_t, 2>()); break;
-		case 3: decode_tracks(std::integral_constant<uint32_t, 3>()); break;
-		default: decode_tracks(std::integral_constant<uint32_t, 4>()); break;
+			if (num_components == 1)
+				decode_tracks(std::integral_constant<uint32_t, 1>());
+			else if (lane == 0 && chunk == 0)
+				atomicAdd(rejected_count, 1ull);		// (a wider list registered behind the launch's back)
+		}
+		else
+		{
+			switch (num_components)
+			{
+			case 1: decode_tracks(std::integral_constant<uint32_t, 1>()); break;
+			case 2: decode_tracks(std::integral_constant<uint32_t, 2>()); break;
+			case 3: decode_tracks(std::integral_constant<uint32_t, 3>()); break;
+			default: decode_tracks(std::integral_constant<uint32_t, 4>()); break;
+			}
 		}
 	}
 
@@ -362,7 +373,7 @@
 	// for 6 / 8 waves per SIMD: 22.7 / 42 us on this shape, slower on 1024 curves). Groups of mixed clips fall back to one instance after the other.
 	constexpr uint32_t k_scalar_group = 4;
 
-	template<uint32_t kRows, bool kPolicies>
+	template<uint32_t kRows, bool kPolicies, uint32_t kComponents>
 	__global__ __launch_bounds__(k_block_size) void decompress_scalar_tracks_grouped_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t chunks_per_instance,
 		decode_params params, uint8_t* __restrict__ out, uint64_t out_stride_bytes, uint32_t frame_lds_bytes, unsigned long long* __restrict__ rejected_count)
@@ -406,7 +417,7 @@
 			// mixed, refused or empty: one instance after the other through the first frame slots (each call waits for its own LDS reads)
 			for (uint32_t k = 0; k < count; ++k)
 			{
-				decompress_scalar_tracks_instance<true, kRows, kPolicies>(clips, num_clips, clip_ids, sample_times, first_instance + k, chunk, params, out, out_stride_bytes,
+				decompress_scalar_tracks_instance<true, kRows, kPolicies, kComponents>(clips, num_clips, clip_ids, sample_times, first_instance + k, chunk, params, out, out_stride_bytes,
 					frame_lds_bytes, wave_lds, lane, rejected_count);
 				wave_lds_barrier();
 			}
@@ -475,12 +486,22 @@
 				decode_and_store_lane_tracks<C, kRows, true, kPolicies>(frames[k], tables, alphas[k], rounding_policies[k], track_rounding_policies, first_track, num_tracks, lane, row);
 			}
 		};
-		switch (num_components)
+		if constexpr (kComponents == 1)
 		{
-		case 1: decode_tracks(std::integral_constant<uint32_t, 1>()); break;
-		case 2: decode_tracks(std::integral_constant<uint32_t, 2>()); break;
-		case 3: decode_tracks(std::integral_constant<uint32_t, 3>()); break;
-		default: decode_tracks(std::integral_constant<uint32_t, 4>()); break;
+			if (num_components == 1)
+				decode_tracks(std::integral_constant<uint32_t, 1>());
+			else if (lane == 0 && chunk == 0)
+				atomicAdd(rejected_count, (unsigned long long)count);
+		}
+		else
+		{
+			switch (num_components)
+			{
+			case 1: decode_tracks(std::integral_constant<uint32_t, 1>()); break;
+			case 2: decode_tracks(std::integral_constant<uint32_t, 2>()); break;
+			case 3: decode_tracks(std::integral_constant<uint32_t, 3>()); break;
+			default: decode_tracks(std::integral_constant<uint32_t, 4>()); break;
+			}
 		}
 	}
 

@@ -241,3 +241,38 @@ def test_large_batches_take_groups_of_instances_per_wave(context, spec):
         assert helpers.exact(values[i, : clip.num_tracks], ob.oracle_scalar_decompress_tracks(clip.blob, float(times[i])))
     for handle in handles:
         context.unregister_clip(int(handle))
+
+
+def test_float1f_only_registries_take_the_one_float_kernel():
+    """while every registered list is float1f the grouped kernel compiled for one float per track runs (half the registers); a wider list
+    in the registry switches launches to the kernel for any track type, and back when it leaves -- same values throughout"""
+    curves = [synth.build_scalar_clip(seed=60 + k, track_type=0, num_tracks=256 - 31 * k, num_samples=50 + 9 * k, raw_fraction=0.02) for k in range(2)]
+    wide = synth.build_scalar_clip(seed=70, track_type=2, num_tracks=40, num_samples=30)
+    rng = np.random.default_rng(60)
+    n = 16384 + 5
+    with runtime.Context(0) as ctx:
+        handles = np.array([ctx.register_clip(c.blob) for c in curves], dtype=np.uint32)
+        which = (rng.uniform(size=n) < 0.3).astype(np.int64)
+        which[4000:8000] = 0
+        durations = np.array([c.duration for c in curves], dtype=np.float32)
+        times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+        check = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(3990, 4010), np.arange(n - 7, n)]))
+        expected = _oracle_rows(curves, which[check], times[check])
+
+        def run_and_compare():
+            values = ctx.decompress_scalar_tracks(handles[which], times)
+            for row, i in enumerate(check):
+                assert helpers.exact(values[i, : curves[which[i]].num_tracks], expected[row]), f"instance {i}"
+
+        run_and_compare()                                   # float1f only
+        wide_handle = ctx.register_clip(wide.blob)
+        run_and_compare()                                   # a float3f list is registered: the kernel for any track type
+        mixed_handles = np.concatenate([handles[which[:16380]], np.full(20, wide_handle, dtype=np.uint32)])
+        mixed_times = np.concatenate([times[:16380], rng.uniform(0.0, wide.duration, size=20).astype(np.float32)])
+        device_values = ctx.decompress_scalar_tracks(mixed_handles, mixed_times)
+        for i in range(16380, 16400):
+            got = device_values[i].reshape(-1)[: wide.num_tracks * 3].reshape(wide.num_tracks, 3)
+            assert helpers.exact(got, ob.oracle_scalar_decompress_tracks(wide.blob, float(mixed_times[i])))
+        ctx.unregister_clip(wide_handle)
+        run_and_compare()                                   # float1f only again
+        assert ctx.rejected_instance_count() == 0
