@@ -1,9 +1,12 @@
 #!/bin/bash
 # Evidence for profiles/ (round 2): for every north-star workload the bench line, the rocprofv3 --kernel-trace --stats summary of the same
 # command, and FETCH_SIZE / WRITE_SIZE in their own --pmc passes (-> traffic.json); then the default bench.py run (all workloads, footprint
-# sweep, layouts, CPU thread sweep). usage (on the GPU box): tools/profile_round2.sh <tag>   -> gpurun_out/<tag>_*
+# sweep, layouts, CPU thread sweep). usage (on the GPU box): tools/profile_round2.sh <tag> [workload file names ...]   -> gpurun_out/<tag>_*
+# (with names, e.g. "scalar object_space": only those workloads are re-measured, the other lines and the default run are left alone)
 set -u
 tag=${1:-r02}
+shift
+only="$*"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rm -f gpurun_out/traffic.json
@@ -12,6 +15,7 @@ lines=gpurun_out/${tag}_workloads_bench.jsonl
 : > $lines
 run_workload() {      # <name for files> <traffic key> <bench arguments...>
   name=$1; key=$2; shift 2
+  if [ -n "$only" ] && ! echo " $only " | grep -q " $name "; then return; fi
   python bench.py --no-cpu-baseline --no-extras "$@" 2> /dev/null | tail -1 >> $lines
   rm -rf /tmp/prof_trace
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o trace -- python bench.py --no-cpu-baseline --no-extras "$@" > /dev/null 2> /tmp/trace.log
@@ -38,6 +42,7 @@ run_workload scalar "scalar" --workload scalar
 run_workload object_space "object_space" --workload object_space
 run_workload additive_object_space "additive_object_space" --workload additive_object_space
 cp gpurun_out/traffic.json profiles/traffic.json      # the default run below reads the traffic it reports from profiles/traffic.json
+if [ -n "$only" ]; then cat $lines; exit 0; fi
 ( time python bench.py ) > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 python - <<PY
 import json
