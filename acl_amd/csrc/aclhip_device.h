@@ -213,6 +213,21 @@ namespace aclhip
 			asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(f32x4_store{ value[0], value[1], value[2], value[3] }) : "memory");
 	}
 
+	// The same stores from a wave uniform base (SGPR pair) + a 32 bit byte offset per lane: no 64 bit address arithmetic per store
+	template<uint32_t C>
+	__device__ __forceinline__ void store_streaming_floats_at(float* uniform_base, uint32_t byte_offset, const float (&value)[C])
+	{
+		static_assert(C >= 1 && C <= 4, "1 to 4 floats");
+		if constexpr (C == 1)
+			asm volatile("global_store_dword %0, %1, %2 sc0 sc1 nt" :: "v"(byte_offset), "v"(value[0]), "s"(uniform_base) : "memory");
+		else if constexpr (C == 2)
+			asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1 nt" :: "v"(byte_offset), "v"(f32x2_store{ value[0], value[1] }), "s"(uniform_base) : "memory");
+		else if constexpr (C == 3)
+			asm volatile("global_store_dwordx3 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" :: "v"(byte_offset), "v"(f32x3_store{ value[0], value[1], value[2] }), "s"(uniform_base) : "memory");
+		else
+			asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" :: "v"(byte_offset), "v"(f32x4_store{ value[0], value[1], value[2], value[3] }), "s"(uniform_base) : "memory");
+	}
+
 	// One 16 byte sample record in a single (scalar, when the index is wave uniform) load
 	typedef uint32_t u32x4_record __attribute__((ext_vector_type(4)));
 	__device__ __forceinline__ sample_record load_sample_record(const sample_record* table, uint32_t index)

@@ -136,7 +136,7 @@
 		}
 	};
 
-	// Decodes a lane's tracks of ONE instance and stores them; rounding: per track policy source (null: the alpha as it is)
+	// Decodes a lane's tracks of ONE instance and stores them (row: wave uniform); rounding: per track policy source (null: the alpha as it is)
 	template<uint32_t C, uint32_t kRows, bool kFromLds, bool kPolicies>
 	__device__ __forceinline__ void decode_and_store_lane_tracks(const scalar_frames& frames, const scalar_track_tables<C> (&tables)[kRows], float seek_alpha,
 		uint32_t rounding_policy, const uint8_t* track_rounding_policies, uint32_t first_track, uint32_t num_tracks, uint32_t lane, float* row)
@@ -174,7 +174,7 @@
 					#pragma unroll
 					for (uint32_t c = 0; c < C; ++c)
 						value[c] = values[c];
-					store_streaming_floats<C>(row + first_of_run * C, value);
+					store_streaming_floats_at<C>(row, first_of_run * C * 4u, value);
 				}
 			}
 			else
@@ -182,7 +182,7 @@
 				if (first_of_run + k_run <= num_tracks)
 				{
 					const float value[4] = { values[0], values[1], values[2], values[3] };
-					store_streaming_floats<4>(row + first_of_run * C, value);		// (rows are 16 byte aligned, runs start at multiples of 4 floats)
+					store_streaming_floats_at<4>(row, first_of_run * C * 4u, value);		// (rows are 16 byte aligned, runs start at multiples of 4 floats)
 				}
 				else
 				{
@@ -194,7 +194,7 @@
 							#pragma unroll
 							for (uint32_t c = 0; c < C; ++c)
 								value[c] = values[r * C + c];
-							store_streaming_floats<C>(row + (first_of_run + r) * C, value);
+							store_streaming_floats_at<C>(row, (first_of_run + r) * C * 4u, value);
 						}
 				}
 			}
