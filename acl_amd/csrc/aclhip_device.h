@@ -595,16 +595,117 @@ namespace aclhip
 		return make_float4(result.x, result.y, result.z, 0.0f);
 	}
 
-	// rtm::qvv_mul leaves the quaternion path when any scale component of either side is negative (mirrored rigs) and composes 3x4
-	// matrices instead. That path is not restated: the kernels take the quaternion path for every scale and COUNT the
-	// transforms for which the reference would have done otherwise (aclhip_get_negative_scale_count), so that a caller with mirrored rigs
-	// knows which results follow a different formula.
+	// rtm::qvv_mul leaves the quaternion path when any scale component of either side is negative (mirrored rigs: a quaternion cannot
+	// carry a reflection) and composes 3x4 matrices instead. The kernels do the same (qvv_mul_through_matrices below) for exactly
+	// those transforms, and keep COUNTING them (aclhip_get_negative_scale_count).
 	__device__ __forceinline__ bool qvv_mul_takes_matrix_path(const qvv& lhs, const qvv& rhs)
 	{
 		return fminf(fminf(fminf(lhs.scale.x, lhs.scale.y), lhs.scale.z), fminf(fminf(rhs.scale.x, rhs.scale.y), rhs.scale.z)) < 0.0f;
 	}
 
-	// lhs first, then rhs (child, then parent)
+	// RTM 2.x's route for negative scales, restated operation by operation (the reciprocal square roots are the correctly rounded
+	// 1 / sqrt like everywhere else in this file; pinned by tests/test_gpu_consumers.py against an fp64 matrix chain):
+	//   matrix_from_qvv(lhs) * matrix_from_qvv(rhs)   row vectors, lhs first; every row ((x * X + y * Y) + z * Z) [+ W]
+	//   matrix_remove_scale                            every axis normalized by its own length (left alone below a squared length of 1e-8)
+	//   axis * sign(lhs.scale * rhs.scale)             +1 / -1 per axis (+1 for zero)
+	//   rotation = quat_from_matrix(axes), normalized; translation = the product's W row; scale = lhs.scale * rhs.scale
+	// Rare (mirrored rigs only): kept out of line so that the walk's registers are those of the quaternion path.
+	struct matrix3x3_rows { float m[3][3]; };
+
+	__device__ __forceinline__ matrix3x3_rows rotation_scale_matrix_of(const qvv& t)
+	{
+		const float x = t.rotation.x, y = t.rotation.y, z = t.rotation.z, w = t.rotation.w;
+		const float x2 = x + x, y2 = y + y, z2 = z + z;
+		const float xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2, wx = w * x2, wy = w * y2, wz = w * z2;
+		matrix3x3_rows r;
+		r.m[0][0] = (1.0f - (yy + zz)) * t.scale.x; r.m[0][1] = (xy + wz) * t.scale.x; r.m[0][2] = (xz - wy) * t.scale.x;
+		r.m[1][0] = (xy - wz) * t.scale.y; r.m[1][1] = (1.0f - (xx + zz)) * t.scale.y; r.m[1][2] = (yz + wx) * t.scale.y;
+		r.m[2][0] = (xz + wy) * t.scale.z; r.m[2][1] = (yz - wx) * t.scale.z; r.m[2][2] = (1.0f - (xx + yy)) * t.scale.z;
+		return r;
+	}
+
+	__device__ __forceinline__ qvv qvv_mul_through_matrices(const qvv& lhs, const qvv& rhs)
+	{
+		const matrix3x3_rows l = rotation_scale_matrix_of(lhs);
+		const matrix3x3_rows r = rotation_scale_matrix_of(rhs);
+		const float rhs_translation[3] = { rhs.translation.x, rhs.translation.y, rhs.translation.z };
+		const float lhs_translation[3] = { lhs.translation.x, lhs.translation.y, lhs.translation.z };
+		const float scale[3] = { lhs.scale.x * rhs.scale.x, lhs.scale.y * rhs.scale.y, lhs.scale.z * rhs.scale.z };
+
+		float axes[3][3], translation[3];
+		#pragma unroll
+		for (uint32_t c = 0; c < 3; ++c)
+			translation[c] = rhs_translation[c] + (((lhs_translation[0] * r.m[0][c]) + (lhs_translation[1] * r.m[1][c])) + (lhs_translation[2] * r.m[2][c]));
+		#pragma unroll
+		for (uint32_t row = 0; row < 3; ++row)
+		{
+			float axis[3];
+			#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c)
+				axis[c] = ((l.m[row][0] * r.m[0][c]) + (l.m[row][1] * r.m[1][c])) + (l.m[row][2] * r.m[2][c]);
+			const float length_squared = ((axis[0] * axis[0]) + (axis[1] * axis[1])) + (axis[2] * axis[2]);
+			const float inv_length = length_squared >= 1.0e-8f ? 1.0f / sqrtf(length_squared) : 1.0f;
+			const float sign = scale[row] >= 0.0f ? 1.0f : -1.0f;
+			#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c)
+				axes[row][c] = (length_squared >= 1.0e-8f ? axis[c] * inv_length : axis[c]) * sign;
+		}
+
+		// rtm::quat_from_matrix
+		float q[4];
+		const float trace = (axes[0][0] + axes[1][1]) + axes[2][2];
+		if (trace > 0.0f)
+		{
+			const float inv_trace = 1.0f / sqrtf(trace + 1.0f);
+			const float half_inv_trace = inv_trace * 0.5f;
+			q[0] = (axes[1][2] - axes[2][1]) * half_inv_trace;
+			q[1] = (axes[2][0] - axes[0][2]) * half_inv_trace;
+			q[2] = (axes[0][1] - axes[1][0]) * half_inv_trace;
+			q[3] = (1.0f / inv_trace) * 0.5f;
+		}
+		else
+		{
+			// the largest diagonal element leads; written per case so that every index is a constant (no scratch memory)
+			const bool y_leads = axes[1][1] > axes[0][0];
+			const bool z_leads = axes[2][2] > (y_leads ? axes[1][1] : axes[0][0]);
+			const uint32_t best = z_leads ? 2u : (y_leads ? 1u : 0u);
+			float best_best, next_next, last_last, best_next, next_best, best_last, last_best, next_last, last_next;
+			if (best == 0)
+			{
+				best_best = axes[0][0]; next_next = axes[1][1]; last_last = axes[2][2];
+				best_next = axes[0][1]; next_best = axes[1][0]; best_last = axes[0][2]; last_best = axes[2][0]; next_last = axes[1][2]; last_next = axes[2][1];
+			}
+			else if (best == 1)
+			{
+				best_best = axes[1][1]; next_next = axes[2][2]; last_last = axes[0][0];
+				best_next = axes[1][2]; next_best = axes[2][1]; best_last = axes[1][0]; last_best = axes[0][1]; next_last = axes[2][0]; last_next = axes[0][2];
+			}
+			else
+			{
+				best_best = axes[2][2]; next_next = axes[0][0]; last_last = axes[1][1];
+				best_next = axes[2][0]; next_best = axes[0][2]; best_last = axes[2][1]; last_best = axes[1][2]; next_last = axes[0][1]; last_next = axes[1][0];
+			}
+			const float pseudo_trace = ((1.0f + best_best) - next_next) - last_last;
+			const float inv_pseudo_trace = 1.0f / sqrtf(pseudo_trace);
+			const float half_inv_pseudo_trace = inv_pseudo_trace * 0.5f;
+			const float q_best = (1.0f / inv_pseudo_trace) * 0.5f;
+			const float q_next = half_inv_pseudo_trace * (best_next + next_best);
+			const float q_last = half_inv_pseudo_trace * (best_last + last_best);
+			q[3] = half_inv_pseudo_trace * (next_last - last_next);
+			q[0] = best == 0 ? q_best : (best == 1 ? q_last : q_next);
+			q[1] = best == 0 ? q_next : (best == 1 ? q_best : q_last);
+			q[2] = best == 0 ? q_last : (best == 1 ? q_next : q_best);
+		}
+
+		qvv result;
+		result.rotation = quat_normalize(make_float4(q[0], q[1], q[2], q[3]));
+		result.translation = make_float4(translation[0], translation[1], translation[2], 0.0f);
+		result.scale = make_float4(scale[0], scale[1], scale[2], 0.0f);
+		return result;
+	}
+
+	// lhs first, then rhs (child, then parent); the quaternion path: callers route qvv_mul_takes_matrix_path() transforms through
+	// qvv_mul_through_matrices
 	__device__ __forceinline__ qvv qvv_mul(const qvv& lhs, const qvv& rhs)
 	{
 		qvv result;
@@ -616,11 +717,19 @@ namespace aclhip
 		return result;
 	}
 
-	// apply_additive_to_base (core/additive_utils.h:150-160); format: acl::additive_clip_format8
+	// apply_additive_to_base (core/additive_utils.h:150-160); format: acl::additive_clip_format8.
+	// kMirrored = false compiles the matrix route of qvv_mul out (launches whose clips cannot produce a negative scale: its registers
+	// would cost every launch a wave per SIMD).
+	template<bool kMirrored>
 	__device__ __forceinline__ qvv apply_additive_to_base(uint32_t additive_format, const qvv& base, const qvv& additive)
 	{
 		if (additive_format == 1)
-			return qvv_mul(additive, base);
+		{
+			qvv result = qvv_mul(additive, base);
+			if (kMirrored && qvv_mul_takes_matrix_path(additive, base))
+				result = qvv_mul_through_matrices(additive, base);
+			return result;
+		}
 		if (additive_format == 2 || additive_format == 3)
 		{
 			// transform_add0 / transform_add1 (:128-142)

@@ -189,6 +189,11 @@ namespace
 					double base[3];
 					for (int c = 0; c < 3; ++c) base[c] = centre + rng.range(-0.6, 0.6) * extent;
 					const double swing = rng.range(0.05, 0.35) * extent;
+					// mirrored rigs: whole components of a scale sub-track are negative (drawn only when asked for: older seeds keep their clips)
+					double mirror[3] = { 1.0, 1.0, 1.0 };
+					if (kind == k_scale && spec.mirrored_scale_fraction > 0.0f)
+						for (int c = 0; c < 3; ++c)
+							mirror[c] = rng.uniform() < double(spec.mirrored_scale_fraction) ? -1.0 : 1.0;
 
 					for (uint32_t s = 0; s < count; ++s)
 					{
@@ -201,7 +206,7 @@ namespace
 								v[c] += swing * amp[c][k] * 0.5 * std::sin(freq[c][k] * time + phase[c][k]);
 							v[c] = std::min(std::max(v[c], centre - extent), centre + extent);
 						}
-						st.raw[s] = { float(v[0]), float(v[1]), float(v[2]) };
+						st.raw[s] = { float(mirror[0] * v[0]), float(mirror[1] * v[1]), float(mirror[2] * v[2]) };
 					}
 				}
 			}
@@ -362,6 +367,7 @@ extern "C" void aclsynth_default_spec(aclsynth_spec* spec)
 	spec->translation_extent = 2.0f;
 	spec->ideal_segment_samples = 16;
 	spec->max_segment_samples = 31;
+	spec->mirrored_scale_fraction = 0.0f;
 }
 
 extern "C" uint32_t aclsynth_build_clip(const aclsynth_spec* spec_, void* out, uint32_t capacity,

@@ -42,6 +42,7 @@ typedef struct aclsynth_spec
 	float translation_extent;		// translations live in [-extent, extent]
 	uint32_t ideal_segment_samples;	// 16
 	uint32_t max_segment_samples;	// 31
+	float mirrored_scale_fraction;	// probability that a component of a constant / animated scale sub-track is NEGATIVE (mirrored rigs); 0 by default
 } aclsynth_spec;
 
 // Fills 'spec' with the CMU-shaped defaults of SURVEY.md section 8(d): 100 bones, 301 samples @ 30 Hz,

@@ -467,6 +467,36 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	else
 		std::fill(image_chunks.begin(), image_chunks.end(), 0u);
 
+	// ---- can a scale of this clip come out negative? ----
+	// rtm::qvv_mul composes matrices instead of quaternions when a scale component of either operand is negative; the pose consumers
+	// compile that route in only while a registered clip can get there (kernels_consumers.inl: kMirrored). Conservative: a constant or
+	// default scale below zero (or not a number), an animated scale whose clip range reaches below zero -- a decoded value is
+	// clip_min + clip_extent * [0, 1] --, or one that is stored raw in some segment (raw samples bypass the ranges).
+	bool negative_scale_possible = false;
+	if (num_tracks != 0)
+	{
+		const auto may_be_negative = [](float value) { return !(value >= 0.0f); };
+		if (!has_scale)
+			negative_scale_possible = may_be_negative(float(header.default_scale()));
+		for (uint32_t track = 0; has_scale && track < num_tracks; ++track)
+		{
+			const float* value = &base_pose[size_t(track * 3 + 2) * 4];
+			const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
+			if (int32_t(marker) >= 0 || (marker & k_quad_animated) == 0)		// constant, or default (the base pose holds the default's xyz)
+				negative_scale_possible = negative_scale_possible || may_be_negative(value[0]) || may_be_negative(value[1]) || may_be_negative(value[2]);
+		}
+		for (uint32_t a = 0; a < num_animated; ++a)
+		{
+			const clip_range_entry& range = clip_ranges[a];
+			if (range.quad_index != range.track_index * 3 + 2)
+				continue;
+			for (uint32_t c = 0; c < 3; ++c)
+				negative_scale_possible = negative_scale_possible || may_be_negative(range.range_min[c]) || may_be_negative(range.range_min[c] + std::min(range.range_extent[c], 0.0f) * 1.01f);
+			for (uint32_t si = 0; si < num_segments; ++si)
+				negative_scale_possible = negative_scale_possible || (plan[size_t(si) * num_animated + a].bit_offset_and_width >> 24) == 32u;
+		}
+	}
+
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
@@ -666,6 +696,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
 	entry.scaled = num_tracks != 0 && (has_scale || float(header.default_scale()) != 1.0f);
 	context->num_scaled_clips += entry.scaled ? 1u : 0u;
+	entry.negative_scale = negative_scale_possible;
+	context->num_negative_scale_clips += entry.negative_scale ? 1u : 0u;
 
 	*out_clip = slot;
 	return ACLHIP_OK;
@@ -732,6 +764,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
 	context->num_scaled_clips -= removed.scaled ? 1u : 0u;
+	context->num_negative_scale_clips -= removed.negative_scale ? 1u : 0u;
 	context->num_wide_scalar_clips -= removed.wide_scalar ? 1u : 0u;
 	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
 		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))

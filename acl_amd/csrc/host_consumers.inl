@@ -288,14 +288,26 @@ namespace
 		// one instantiation per (object space, kind of base, rotation | translation images)
 		const uint32_t base_kind = !has_base ? k_consumer_base_none : (!base_is_clip ? k_consumer_base_buffer : (fused_base ? k_consumer_base_fused : k_consumer_base_second_wave));
 		typedef void (*consumer_kernel)(const device_clip*, uint32_t, const uint32_t*, const float*, uint32_t, decode_params, consumer_params, uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, unsigned long long*);
-		static const consumer_kernel kernels[2][4] =
+		// rtm::qvv_mul's matrix route (negative scales) is compiled into the launches that can meet one: a registered clip whose scale
+		// sub-tracks may decode below zero, or a base the library knows nothing about (a caller's pose buffer)
+		const bool mirrored = context->num_negative_scale_clips != 0 || (has_base && !base_is_clip);
+		static const consumer_kernel kernels[2][2][4] =
 		{
-			{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false>,
-			  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false>, decompress_poses_consumer_kernel<false, k_consumer_base_fused, false> },
-			{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false>,
-			  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false> },
+			{
+				{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false, false>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false, false>,
+				  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false, false>, decompress_poses_consumer_kernel<false, k_consumer_base_fused, false, false> },
+				{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, false>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, false>,
+				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, false>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false, false> },
+			},
+			{
+				// (no object space: only the relative format multiplies transforms -- a base buffer or a second wave's image)
+				{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false, false>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false, true>,
+				  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false, true>, decompress_poses_consumer_kernel<false, k_consumer_base_fused, false, false> },
+				{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, true>,
+				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false, true> },
+			},
 		};
-		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true> : kernels[consumers.object_space != 0 ? 1 : 0][base_kind];
+		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false> : kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind];
 		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
 			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,

@@ -15,6 +15,7 @@ namespace
 		// what this clip asks of a launch (the context keeps the maxima over its live clips)
 		uint32_t pose_quads = 0, hierarchy_words = 0, scalar_tracks = 0, scalar_frame_bytes = 0;
 		bool scaled = false;				// qvvf clip with scale sub-tracks, or whose default scale is not 1
+		bool negative_scale = false;		// some scale sub-track may decode a negative component (mirrored rigs): rtm::qvv_mul then goes through matrices
 		bool wide_scalar = false;			// scalar track list of more than one float per track
 	};
 }
@@ -60,6 +61,7 @@ struct aclhip_context
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
 	uint32_t num_wide_scalar_clips = 0;		// live scalar track lists of 2 - 4 floats per track (while 0 the grouped scalar kernel is compiled for float1f only)
 	uint32_t num_scaled_clips = 0;			// live clips whose scale is not 1 everywhere (the pose consumers keep no scale in LDS while this is 0)
+	uint32_t num_negative_scale_clips = 0;	// live clips that may decode a negative scale (while 0 the pose consumers are compiled without rtm::qvv_mul's matrix route)
 	uint32_t max_hierarchy_words = 0;		// largest walk schedule (aclhip_set_clip_hierarchy) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips

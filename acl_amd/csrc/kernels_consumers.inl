@@ -150,9 +150,11 @@
 	//                  format) | a clip decoded by the instance's own wave, the additive clip onto it (additive0 / additive1)
 	//   kUnitScale     object space without a base while no registered clip has a scale other than 1: the images hold rotation |
 	//                  translation only (32 of a transform's 48 bytes)
+	//   kMirrored      some registered clip may decode a NEGATIVE scale (or the base is a caller's pose buffer): rtm::qvv_mul's matrix
+	//                  route is compiled in (10 more registers: one wave per SIMD less). Transforms that would take it are counted either way.
 	constexpr uint32_t k_consumer_base_none = 0, k_consumer_base_buffer = 1, k_consumer_base_second_wave = 2, k_consumer_base_fused = 3;
 
-	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale>
+	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored>
 	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
 		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t log2_instances_per_block,
@@ -265,7 +267,7 @@
 			{
 				const qvv additive = load_qvv(image, transform_index);
 				const qvv base = load_qvv(base_source, transform_index);
-				store_qvv(image, transform_index, apply_additive_to_base(consumers.additive_format, base, additive));
+				store_qvv(image, transform_index, apply_additive_to_base<kMirrored>(consumers.additive_format, base, additive));
 				// additive_clip_format8::relative is a qvv_mul (core/additive_utils.h:128-160)
 				const uint64_t mirrored = __ballot(consumers.additive_format == 1 && qvv_mul_takes_matrix_path(additive, base));
 				if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
@@ -332,6 +334,8 @@
 									if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
 										atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
 									qvv object = qvv_mul(child, parent);
+									if (kMirrored && mirrored != 0 && qvv_mul_takes_matrix_path(child, parent))
+										object = qvv_mul_through_matrices(child, parent);
 									object.rotation = quat_normalize(object.rotation);
 									store_qvv(slot_image, pair & 0xFFFFu, object);
 								}

@@ -23,6 +23,7 @@ class ClipSpec(ctypes.Structure):
         ("scale_default", ctypes.c_float), ("scale_constant", ctypes.c_float),
         ("min_bits", ctypes.c_uint32), ("max_bits", ctypes.c_uint32), ("width0_fraction", ctypes.c_float), ("raw_fraction", ctypes.c_float),
         ("translation_extent", ctypes.c_float), ("ideal_segment_samples", ctypes.c_uint32), ("max_segment_samples", ctypes.c_uint32),
+        ("mirrored_scale_fraction", ctypes.c_float),
     ]
 
 

@@ -1177,7 +1177,7 @@ uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_n
  *   - quat_mul: per lane (a*rw + b*rx) + (c*ry + d*rz), signs folded into the products;
  *   - quat_mul_vector3(v, q) = quat_mul(quat_mul(conjugate(q), (v.xyz, 0)), q);
  *   - qvv_mul(lhs, rhs): rotation = quat_mul(lhs.r, rhs.r); translation = quat_mul_vector3(lhs.t * rhs.s, rhs.r) + rhs.t;
- *     scale = lhs.s * rhs.s. RTM routes NEGATIVE scales through a matrix decomposition instead: not restated;
+ *     scale = lhs.s * rhs.s. NEGATIVE scales go through 3x4 matrices instead (qvv_mul_through_matrices below);
  *   - qvv_normalize normalizes the rotation. RTM's x86 quat_normalize starts from the hardware reciprocal square root ESTIMATE
  *     (not reproducible between CPU vendors); restated with the reference's own deterministic normalize (quat_normalize above,
  *     acl/math/quatf.h:200-222 arithmetic). Agreement with an x86 build of the reference is therefore to a few ulp per level of
@@ -1204,10 +1204,116 @@ static void quat_mul_vector3(const float vector[3], const float rotation[4], flo
 	out[0] = result[0]; out[1] = result[1]; out[2] = result[2];
 }
 
+/* rtm::qvv_mul's route for NEGATIVE scales (mirrored rigs): when any scale component of either operand is negative a quaternion
+ * cannot carry the reflection, and RTM 2.x composes 3x4 matrices instead --
+ *   matrix_from_qvv(lhs) * matrix_from_qvv(rhs)            (row vectors: lhs first; every row ((x * X + y * Y) + z * Z) [+ W])
+ *   matrix_remove_scale: every axis normalized by its own length (left alone below a squared length of 1e-8)
+ *   each axis multiplied by the sign (+1 / -1, +1 for zero) of the matching component of scale = lhs.scale * rhs.scale
+ *   rotation = quat_from_matrix (trace > 0, or the largest diagonal element), normalized; translation = the product's W row.
+ * Restated from RTM's documented algorithm (rtm/qvvf.h qvv_mul, rtm/matrix3x4f.h, rtm/quatf.h quat_from_matrix); like everywhere
+ * else in this file the reciprocal square roots are the correctly rounded 1 / sqrt (RTM's x86 form refines the RSQRTSS estimate).
+ * Pinned independently of any reading of RTM by tests/test_pose_consumers_oracle.py: object-space transforms of mirrored
+ * hierarchies against an fp64 matrix chain of the same local transforms. */
+static int qvv_mul_takes_matrix_path(const float lhs[12], const float rhs[12])
+{
+	/* vector_any_less_than3(vector_min(lhs.scale, rhs.scale), zero) */
+	uint32_t c;
+	for (c = 0; c < 3; ++c)
+		if ((lhs[8 + c] < rhs[8 + c] ? lhs[8 + c] : rhs[8 + c]) < 0.0f)
+			return 1;
+	return 0;
+}
+
+static void matrix_from_qvv(const float t[12], float m[4][3])
+{
+	const float x = t[0], y = t[1], z = t[2], w = t[3];
+	const float x2 = x + x, y2 = y + y, z2 = z + z;
+	const float xx = x * x2, xy = x * y2, xz = x * z2, yy = y * y2, yz = y * z2, zz = z * z2, wx = w * x2, wy = w * y2, wz = w * z2;
+	m[0][0] = (1.0f - (yy + zz)) * t[8]; m[0][1] = (xy + wz) * t[8]; m[0][2] = (xz - wy) * t[8];
+	m[1][0] = (xy - wz) * t[9]; m[1][1] = (1.0f - (xx + zz)) * t[9]; m[1][2] = (yz + wx) * t[9];
+	m[2][0] = (xz + wy) * t[10]; m[2][1] = (yz - wx) * t[10]; m[2][2] = (1.0f - (xx + yy)) * t[10];
+	m[3][0] = t[4]; m[3][1] = t[5]; m[3][2] = t[6];
+}
+
+static void quat_from_matrix(float m[4][3], float out[4])
+{
+	const float trace = (m[0][0] + m[1][1]) + m[2][2];
+	if (trace > 0.0f)
+	{
+		const float inv_trace = 1.0f / sqrtf(trace + 1.0f);
+		const float half_inv_trace = inv_trace * 0.5f;
+		out[0] = (m[1][2] - m[2][1]) * half_inv_trace;
+		out[1] = (m[2][0] - m[0][2]) * half_inv_trace;
+		out[2] = (m[0][1] - m[1][0]) * half_inv_trace;
+		out[3] = (1.0f / inv_trace) * 0.5f;
+	}
+	else
+	{
+		uint32_t best = 0, next, last;
+		float pseudo_trace, inv_pseudo_trace, half_inv_pseudo_trace;
+		if (m[1][1] > m[0][0])
+			best = 1;
+		if (m[2][2] > m[best][best])
+			best = 2;
+		next = (best + 1) % 3;
+		last = (next + 1) % 3;
+		pseudo_trace = ((1.0f + m[best][best]) - m[next][next]) - m[last][last];
+		inv_pseudo_trace = 1.0f / sqrtf(pseudo_trace);
+		half_inv_pseudo_trace = inv_pseudo_trace * 0.5f;
+		out[best] = (1.0f / inv_pseudo_trace) * 0.5f;
+		out[next] = half_inv_pseudo_trace * (m[best][next] + m[next][best]);
+		out[last] = half_inv_pseudo_trace * (m[best][last] + m[last][best]);
+		out[3] = half_inv_pseudo_trace * (m[next][last] - m[last][next]);
+	}
+	quat_normalize(out);
+}
+
+static void qvv_mul_through_matrices(const float lhs[12], const float rhs[12], float out[12])
+{
+	float l[4][3], r[4][3], product[4][3];
+	uint32_t row, c;
+	matrix_from_qvv(lhs, l);
+	matrix_from_qvv(rhs, r);
+	for (row = 0; row < 4; ++row)
+		for (c = 0; c < 3; ++c)
+		{
+			float value = ((l[row][0] * r[0][c]) + (l[row][1] * r[1][c])) + (l[row][2] * r[2][c]);
+			if (row == 3)
+				value = r[3][c] + value;
+			product[row][c] = value;
+		}
+	for (row = 0; row < 3; ++row)
+	{
+		const float scale = lhs[8 + row] * rhs[8 + row];
+		const float sign = scale >= 0.0f ? 1.0f : -1.0f;
+		const float length_squared = ((product[row][0] * product[row][0]) + (product[row][1] * product[row][1])) + (product[row][2] * product[row][2]);
+		if (length_squared >= 1.0e-8f)
+		{
+			const float inv_length = 1.0f / sqrtf(length_squared);
+			for (c = 0; c < 3; ++c)
+				product[row][c] = product[row][c] * inv_length;
+		}
+		for (c = 0; c < 3; ++c)
+			product[row][c] = product[row][c] * sign;
+		out[8 + row] = scale;
+	}
+	quat_from_matrix(product, out + 0);
+	out[4] = product[3][0]; out[5] = product[3][1]; out[6] = product[3][2];
+	out[7] = 0.0f;
+	out[11] = 0.0f;
+}
+
 void aclo_qvv_mul(const float lhs[12], const float rhs[12], float out[12])
 {
 	float rotation[4], scaled[3], rotated[3];
 	uint32_t c;
+	if (qvv_mul_takes_matrix_path(lhs, rhs))
+	{
+		float result[12];
+		qvv_mul_through_matrices(lhs, rhs, result);
+		memcpy(out, result, sizeof(result));
+		return;
+	}
 	aclo_quat_mul(lhs + 0, rhs + 0, rotation);
 	for (c = 0; c < 3; ++c)
 		scaled[c] = lhs[4 + c] * rhs[8 + c];

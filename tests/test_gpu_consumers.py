@@ -8,7 +8,7 @@ import pytest
 from acl_amd import runtime, synth
 from oracle import bindings as ob
 import helpers
-from test_pose_consumers_oracle import assert_object_space_close
+from test_pose_consumers_oracle import assert_object_space_close, assert_same_affine_maps
 
 pytestmark = pytest.mark.gpu
 
@@ -131,8 +131,8 @@ def test_no_consumers_equals_decompress_tracks(context):
 
 
 def test_transforms_that_meet_a_negative_scale_are_counted(context):
-    """rtm::qvv_mul composes matrices when a scale component is negative (mirrored rigs); the kernels keep the quaternion formula and
-    count such transforms (aclhip_get_negative_scale_count) -- `relative` additive onto mirrored base poses, then object space"""
+    """rtm::qvv_mul composes matrices when a scale component is negative (mirrored rigs); the kernels do the same and count such
+    transforms (aclhip_get_negative_scale_count) -- `relative` additive onto mirrored base poses, then object space"""
     clip = synth.build_clip(seed=78, num_tracks=24, num_samples=30, has_scale=1)
     handle = context.register_clip(clip.blob)
     rng = np.random.default_rng(5)
@@ -160,6 +160,86 @@ def test_transforms_that_meet_a_negative_scale_are_counted(context):
     num_roots = int(np.sum((parents == runtime.NO_PARENT) | (np.arange(24) == 0)))
     assert context.negative_scale_count() == before + 24 + (24 - num_roots)
     context.unregister_clip(handle)
+
+
+def test_mirrored_rig_in_object_space_is_the_fp64_matrix_chain(context):
+    """A mirrored 100-bone rig: negative scales take rtm::qvv_mul's route through 3x4 matrices (aclhip_device.h:
+    qvv_mul_through_matrices). Bit for bit the oracle, and -- independently of any reading of RTM -- the same affine map per bone as
+    the fp64 product of the local matrices down its chain of parents (scales of one magnitude per bone keep the chain free of shear)."""
+    clip = synth.build_clip(seed=91, num_tracks=100, num_samples=61)                      # no scale sub-tracks: every local scale is 1
+    handle = context.register_clip(clip.blob)
+    parents = synth.humanoid_hierarchy(100)
+    context.set_clip_hierarchy(handle, parents)
+    rng = np.random.default_rng(91)
+    n = 64
+    times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+    handles = np.full(n, handle, dtype=np.uint32)
+    # additive0 onto a base of identity rotations, zero translations and scales of +-m: the local pose is the clip's with mirrored scales
+    base = np.zeros((n, 100, 12), dtype=np.float32)
+    base[..., 3] = 1.0
+    magnitude = rng.uniform(0.8, 1.25, size=(n, 100, 1))
+    base[..., 8:11] = (magnitude * np.where(rng.uniform(size=(n, 100, 3)) < 0.25, -1.0, 1.0)).astype(np.float32)
+    before = context.negative_scale_count()
+    got = context.decompress_poses(handles, times, additive_format=runtime.ADDITIVE_ADDITIVE0, base_poses=base, object_space=True)
+    assert context.negative_scale_count() > before
+    for i in range(n):
+        local = ob.oracle_apply_additive_to_base(runtime.ADDITIVE_ADDITIVE0, base[i], ob.oracle_decompress_tracks(clip.blob, float(times[i])))
+        assert (local[:, 8:11] < 0.0).any()
+        assert helpers.bit_equal(got[i], ob.oracle_local_to_object_space(parents, local)), i
+        assert_same_affine_maps(got[i], parents, local)
+    # the `relative` format is a qvv_mul too: mirrored additive onto mirrored base, per transform, against the fp64 matrix product
+    relative = context.decompress_poses(handles, times, additive_format=runtime.ADDITIVE_RELATIVE, base_poses=base)
+    for i in range(0, n, 7):
+        additive = ob.oracle_decompress_tracks(clip.blob, float(times[i]))
+        assert helpers.bit_equal(relative[i], ob.oracle_apply_additive_to_base(runtime.ADDITIVE_RELATIVE, base[i], additive)), i
+    context.unregister_clip(handle)
+
+
+def test_registered_clips_with_negative_scales():
+    """Clips whose OWN scale sub-tracks are negative (constant and animated): registration notices (the pose consumers then run with
+    the matrix route compiled in), every consumer path stays bit exact against the oracle, transforms are counted; a context without
+    such clips counts nothing."""
+    context = runtime.Context(0)
+    try:
+        mirrored = synth.build_clip(seed=92, num_tracks=100, num_samples=45, has_scale=1, scale_default=0.3, scale_constant=0.3, mirrored_scale_fraction=0.3)
+        plain = synth.build_clip(seed=93, num_tracks=100, num_samples=45, has_scale=1)
+        parents = synth.humanoid_hierarchy(100)
+        rng = np.random.default_rng(92)
+        n = 48
+        times = rng.uniform(0.0, mirrored.duration, size=n).astype(np.float32)
+
+        plain_handle = context.register_clip(plain.blob)
+        context.set_clip_hierarchy(plain_handle, parents)
+        context.decompress_poses(np.full(n, plain_handle, dtype=np.uint32), times, object_space=True)
+        assert context.negative_scale_count() == 0
+
+        handle = context.register_clip(mirrored.blob)
+        context.set_clip_hierarchy(handle, parents)
+        handles = np.full(n, handle, dtype=np.uint32)
+        local = oracle_poses([mirrored.blob], np.zeros(n, dtype=np.int64), times)
+        assert (local[..., 8:11] < 0.0).any()
+        got = context.decompress_poses(handles, times, object_space=True)
+        assert context.negative_scale_count() > 0
+        for i in range(n):
+            assert helpers.bit_equal(got[i], ob.oracle_local_to_object_space(parents, local[i])), i
+        # a mirrored clip as the BASE of a relative additive clip (second wave, second image), then object space
+        base_times = rng.uniform(0.0, mirrored.duration, size=n).astype(np.float32)
+        got = context.decompress_poses(np.full(n, plain_handle, dtype=np.uint32), times, additive_format=runtime.ADDITIVE_RELATIVE,
+                                       base_clips=handles, base_sample_times=base_times, object_space=True)
+        additive = oracle_poses([plain.blob], np.zeros(n, dtype=np.int64), times)
+        base = oracle_poses([mirrored.blob], np.zeros(n, dtype=np.int64), base_times)
+        for i in range(n):
+            combined = ob.oracle_apply_additive_to_base(runtime.ADDITIVE_RELATIVE, base[i], additive[i])
+            assert helpers.bit_equal(got[i], ob.oracle_local_to_object_space(parents, combined)), i
+        # additive1 onto the mirrored base by the instance's own wave (the fused path), then object space
+        got = context.decompress_poses(np.full(n, plain_handle, dtype=np.uint32), times, additive_format=runtime.ADDITIVE_ADDITIVE1,
+                                       base_clips=handles, base_sample_times=base_times, object_space=True)
+        for i in range(n):
+            combined = ob.oracle_apply_additive_to_base(runtime.ADDITIVE_ADDITIVE1, base[i], additive[i])
+            assert helpers.bit_equal(got[i], ob.oracle_local_to_object_space(parents, combined)), i
+        assert context.rejected_instance_count() == 0
+    finally:
+        context.close()
 
 
 def test_refused_instances_and_arguments(context):

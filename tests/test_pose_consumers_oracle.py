@@ -60,7 +60,15 @@ def test_additive_apply_is_bit_exact_against_the_reference(seed):
     for additive_format in range(4):
         ours = ob.oracle_apply_additive_to_base(additive_format, base, additive)
         theirs = ob.ref_apply_additive_to_base(additive_format, base, additive)
-        assert helpers.bit_equal(ours, theirs), additive_format
+        if additive_format == 1 and (additive[:, 8:11] < 0.0).any():
+            # relative = rtm::qvv_mul, which composes matrices for negative scales: reciprocal square roots inside (the shim's follow
+            # RTM's RSQRTSS + Newton form, the oracle's are correctly rounded) -- close, not bit equal; the transforms that stayed
+            # on the quaternion path still are
+            mirrored = (np.minimum(additive[:, 8:11], base[:, 8:11]) < 0.0).any(axis=1)
+            assert helpers.bit_equal(ours[~mirrored], zero_w(theirs)[~mirrored])
+            assert np.abs(ours[mirrored] - zero_w(theirs)[mirrored]).max() <= 1.0e-5
+        else:
+            assert helpers.bit_equal(ours, theirs), additive_format
 
 
 @pytest.mark.skipif(not ob.have_ref_pose(), reason="oracle/_ref/libaclref_pose.so not built (no /root/reference)")
@@ -106,3 +114,94 @@ def test_object_space_roots_and_aliasing():
     # a second root's subtree is what the single-root walk makes of it on its own
     sub = ob.oracle_local_to_object_space(np.array([0, 0, 1], dtype=np.uint32), local[[2, 3, 5]])
     assert helpers.exact(out[[2, 3, 5]], sub)
+
+
+# ---- negative scales (mirrored rigs): rtm::qvv_mul goes through 3x4 matrices ---------------------------------------------------------
+# Pinned independently of any reading of RTM: the object space transform of every bone must be the same AFFINE MAP as the fp64
+# product of the local matrices down its chain of parents. (Scales of one magnitude per bone, signs free: the products stay free
+# of shear, which no rotation | translation | scale triple can hold.)
+
+def matrix_of(transform):
+    """4x4 row-vector matrix (point * M) of a rotation | translation | scale record, in fp64"""
+    x, y, z, w = (float(v) for v in transform[0:4])
+    rotation = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)],
+                         [2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)],
+                         [2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+    matrix = np.eye(4, dtype=np.float64)
+    matrix[0:3, 0:3] = rotation * np.asarray(transform[8:11], dtype=np.float64)[:, None]
+    matrix[3, 0:3] = np.asarray(transform[4:7], dtype=np.float64)
+    return matrix
+
+
+def mirrored_pose(rng, num_transforms, mirrored_share=0.3):
+    pose = random_pose(rng, num_transforms)
+    magnitude = rng.uniform(0.8, 1.25, size=(num_transforms, 1))
+    signs = np.where(rng.uniform(size=(num_transforms, 3)) < mirrored_share, -1.0, 1.0)
+    pose[:, 8:11] = (magnitude * signs).astype(np.float32)
+    return pose
+
+
+def assert_same_affine_maps(object_space, parents, local, tolerance=1.0e-5):
+    """every bone's object space record against the fp64 chain of its local matrices, as matrices (entries within `tolerance` of
+    the chain's extent) -- the same thing as pushing the unit points through both"""
+    chain = [None] * local.shape[0]
+    worst = 0.0
+    for bone in range(local.shape[0]):
+        matrix = matrix_of(local[bone])
+        if bone != 0 and parents[bone] != ob.INVALID_PARENT:
+            matrix = matrix @ chain[parents[bone]]
+        chain[bone] = matrix
+        extent = max(1.0, float(np.abs(matrix).max()))
+        worst = max(worst, float(np.abs(matrix_of(object_space[bone]) - matrix).max()) / extent)
+    assert worst <= tolerance, worst
+
+
+@pytest.mark.parametrize("num_transforms,parent_span", [(2, 1), (100, 4), (100, 100), (300, 12)])
+def test_object_space_of_mirrored_rigs_is_the_fp64_matrix_chain(num_transforms, parent_span):
+    rng = np.random.default_rng(1000 + num_transforms + parent_span)
+    parents = np.array([0] + [rng.integers(max(0, i - parent_span), i) for i in range(1, num_transforms)], dtype=np.uint32)
+    local = mirrored_pose(rng, num_transforms)
+    object_space = ob.oracle_local_to_object_space(parents, local)
+    assert (object_space[:, 8:11] < 0.0).any()
+    assert_same_affine_maps(object_space, parents, local)
+    # unit rotations, scales are the plain products of the chain
+    assert np.abs(np.linalg.norm(object_space[:, 0:4].astype(np.float64), axis=1) - 1.0).max() <= 1.0e-6
+    # the quaternion path alone (what rounds 1 and 2 shipped) does NOT pass this check: the test has teeth
+    quaternion_only = local.copy()
+    for bone in range(1, num_transforms):
+        parent = quaternion_only[parents[bone]]
+        child = local[bone]
+        rotation = ob.oracle_quat_mul(child[0:4], parent[0:4])
+        scaled = (child[4:7] * parent[8:11]).astype(np.float32)
+        rotated = ob.oracle_quat_mul(ob.oracle_quat_mul(parent[0:4] * np.array([-1, -1, -1, 1], dtype=np.float32), np.append(scaled, np.float32(0))), parent[0:4])[0:3]
+        quaternion_only[bone, 0:4] = rotation / np.linalg.norm(rotation)
+        quaternion_only[bone, 4:7] = rotated + parent[4:7]
+        quaternion_only[bone, 8:11] = child[8:11] * parent[8:11]
+    with pytest.raises(AssertionError):
+        assert_same_affine_maps(quaternion_only, parents, local)
+
+
+def test_relative_additive_onto_a_mirrored_base_is_the_fp64_matrix_product():
+    rng = np.random.default_rng(77)
+    base, additive = mirrored_pose(rng, 200), mirrored_pose(rng, 200, mirrored_share=0.2)
+    combined = ob.oracle_apply_additive_to_base(1, base, additive)        # relative: qvv_mul(additive, base)
+    worst = 0.0
+    for bone in range(200):
+        expected = matrix_of(additive[bone]) @ matrix_of(base[bone])
+        worst = max(worst, float(np.abs(matrix_of(combined[bone]) - expected).max()) / max(1.0, float(np.abs(expected).max())))
+    assert worst <= 1.0e-5, worst
+    # non-negative scales keep the quaternion path, bit for bit what it always was
+    plain_base, plain_additive = random_pose(rng, 50), random_pose(rng, 50)
+    rotation = np.stack([ob.oracle_quat_mul(plain_additive[i, 0:4], plain_base[i, 0:4]) for i in range(50)])
+    assert helpers.exact(ob.oracle_apply_additive_to_base(1, plain_base, plain_additive)[:, 0:4], rotation)
+
+
+@pytest.mark.skipif(not ob.have_ref_pose(), reason="oracle/_ref/libaclref_pose.so not built (no /root/reference)")
+def test_mirrored_object_space_against_the_reference_functions():
+    """the reference's own local_to_object_space, compiled here against the shim's reading of rtm::qvv_mul (matrix route included)"""
+    rng = np.random.default_rng(4242)
+    parents = np.array([0] + [rng.integers(max(0, i - 6), i) for i in range(1, 150)], dtype=np.uint32)
+    local = mirrored_pose(rng, 150)
+    ours, theirs = ob.oracle_local_to_object_space(parents, local), zero_w(ob.ref_local_to_object_space(parents, local))
+    assert_object_space_close(ours, theirs)
+    assert_same_affine_maps(theirs, parents, local)
