@@ -45,6 +45,9 @@
 namespace aclhip
 {
 #include "kernels_pose.inl"
+#if defined(ACLHIP_EXPERIMENTS)
+#include "kernels_experiments.inl"		// round 3's slower variants (profiles/r03_experiments.md); not part of a default build
+#endif
 #include "kernels_consumers.inl"
 #include "kernels_misc.inl"
 #include "kernels_scalar.inl"
@@ -59,6 +62,9 @@ using namespace aclhip;
 #include "host_context.inl"
 #include "host_clips.inl"
 #include "host_databases.inl"
+#if defined(ACLHIP_EXPERIMENTS)
+#include "host_experiments.inl"
+#endif
 #include "host_launch.inl"
 #include "host_consumers.inl"
 #include "host_scalar_misc.inl"

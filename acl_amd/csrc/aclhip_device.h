@@ -79,6 +79,19 @@ namespace aclhip
 		float inv_max_value;			// math/scalar_packing.h:117-123
 	};
 
+	// One per (segment, pose window), 32 bytes, read through the scalar cache: where inside a keyframe of that segment the bits of the
+	// window's animated sub-tracks sit. The bitstream orders a keyframe by kind (all rotations, all translations, all scales), each
+	// in track order, so a window's sub-tracks form ONE contiguous run of bits per kind: [first_bit[k], end_bit[k]) from the start of
+	// the keyframe (both 0 for a kind without bits in the window). The staged kernel copies these runs into LDS with coalesced 16 byte
+	// reads and lanes pick their fields there, instead of 64 scattered unaligned loads per instruction from the bitstream itself.
+	struct alignas(32) window_span_entry
+	{
+		uint32_t first_bit[3];
+		uint32_t end_bit[3];
+		uint32_t reserved[2];
+	};
+	static_assert(sizeof(window_span_entry) == 32, "layout");
+
 	static_assert(sizeof(scalar_track_header) == 8, "layout");
 	static_assert(sizeof(sample_record) == 16, "layout");
 	static_assert(sizeof(plan_entry) == 32, "layout");
@@ -86,12 +99,14 @@ namespace aclhip
 
 	// Animated sub-tracks are numbered by destination, not in bitstream order: the ones that land in a window of
 	// k_image_chunk_quads consecutive quads form a contiguous range of ordinals, rotations first.
-	// 318 = 106 whole tracks: a window never splits a track, and its first track is even -- what the compact output layouts
-	// need for windows that start 16 byte aligned (kernels_pose.inl)
+	// 312 = 104 whole tracks: a window never splits a track, and it holds an EVEN number of them -- what the compact output layouts
+	// (32 / 40 bytes per track) and the re-tiling path need for windows that start 16 byte aligned (kernels_pose.inl); 4 992 bytes
+	// also keep every 1 KiB store of a window on whole 64 byte granules of the write path (318 quads cost the rig 43 %)
 #if !defined(ACLHIP_WINDOW_QUADS)
 	#define ACLHIP_WINDOW_QUADS 312
 #endif
 	constexpr uint32_t k_image_chunk_quads = ACLHIP_WINDOW_QUADS;
+	static_assert(k_image_chunk_quads % 6 == 0, "windows hold an even number of whole tracks (compact layouts: 16 byte aligned window starts)");
 
 	__device__ __forceinline__ bool is_rotation_entry(const clip_range_entry& entry) { return entry.quad_index == entry.track_index * 3u; }
 
@@ -121,7 +136,8 @@ namespace aclhip
 		uint32_t num_segments;
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
 		uint32_t db_clip_header_offset;			// into db_headers
-		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window
+		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window; behind it,
+												// at the next multiple of 32 bytes: window_span_entry[num_segments][num_windows] (window_spans_of)
 		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: walk schedules for 1 / 2 / 4 / 8 instances per workgroup; or null
 	};
 
@@ -136,6 +152,19 @@ namespace aclhip
 	constexpr uint32_t k_clip_scaled = 1u << 6;					// scale sub-tracks, or a default scale other than 1: some scale of a pose may differ from 1
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_valid = 1u << 31;
+
+	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)
+	__host__ __device__ __forceinline__ uint32_t num_pose_windows(uint32_t num_tracks)
+	{
+		const uint32_t windows = (num_tracks * 3u + k_image_chunk_quads - 1u) / k_image_chunk_quads;
+		return windows != 0 ? windows : 1u;
+	}
+	__host__ __device__ __forceinline__ uint32_t window_spans_word_offset(uint32_t num_windows) { return (num_windows + 1u + 7u) & ~7u; }
+
+	// LDS bytes that staging a run of `bits` keyframe bits takes: whole 16 byte pieces of the bitstream from the piece that holds the
+	// run's first bit (the keyframe may start at any bit of any byte) to the piece that holds its last one, plus one piece of slack for
+	// the 64 bit windows lanes read
+	__host__ __device__ __forceinline__ uint32_t staged_run_bytes(uint32_t bits) { return ((bits + 126u) / 128u + 2u) * 16u; }
 
 	// The transform kernels take valid transform clips, the scalar kernel valid scalar clips
 	__device__ __forceinline__ bool is_transform_clip(uint32_t flags) { return (flags & (k_clip_valid | k_clip_is_scalar)) == k_clip_valid; }
@@ -157,6 +186,7 @@ namespace aclhip
 		uint8_t standard_default_modes;	// 1 when default sub-tracks take the track_writer defaults, whatever the normalization policy
 		uint8_t layout;					// aclhip_pose_layout (aclhip_output_desc)
 		uint8_t skip_mask;				// bit k: sub-tracks of kind k (rotation / translation / scale) are not stored
+		uint8_t items_per_wave;			// decompress_tracks_in_turn_kernel: work items a wave takes in turn
 	};
 
 	// What happens to a decoded (local space) pose before it is stored (aclhip_pose_consumers resolved to device pointers)
@@ -471,6 +501,183 @@ namespace aclhip
 		}
 	}
 
+	// The same unpack with ONE 16 byte load per key, from the DWORD that holds the sub-track's first bit: three components of up to 23
+	// bits start at most 31 bits into it (100 bits), three raw floats end at bit 127. Round 3 measured what the texture unit makes of a
+	// lane's reads of the bitstream: the 8 + 4 byte windows from the BYTE that holds the first bit (unpack_animated_samples above: two
+	// requests per key at any byte address) cost the 300-bone rig 8 % of its launch against one dword aligned request per key, and the
+	// texture unit is what that launch waits for (busy 83 - 93 %); the extraction costs ~30 more instructions and 8 more registers
+	// per pass, which the one-window workloads -- bound by their write stream -- do not get back (64k x 100 bones: 49.6 -> 53.1 us). So:
+	// the kernels of multi-window poses read this way (kWideKeyLoads), everything else as before. profiles/r03_experiments.md
+	typedef uint32_t key_window __attribute__((ext_vector_type(4)));
+
+	// the 32 bits that start `shift` (0..31) bits into the big endian pair hi:lo
+	__device__ __forceinline__ uint32_t bits_from(uint32_t hi, uint32_t lo, uint32_t shift) { return __funnelshift_l(lo, hi, shift); }
+
+	template<bool kHasRaw>
+	__device__ __forceinline__ void unpack_animated_samples_wide(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
+		const clip_range_entry& clip_range, bool is_rotation, float out_v0[3], float out_v1[3])
+	{
+		const uint32_t num_bits0 = plan0.bit_offset_and_width >> 24;
+		const uint32_t num_bits1 = plan1.bit_offset_and_width >> 24;
+		const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + (plan0.bit_offset_and_width & 0x00FFFFFFu);
+		const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + (plan1.bit_offset_and_width & 0x00FFFFFFu);
+
+		// (the keyframe data is 4 byte aligned inside a blob -- compressed_headers.h:309-324 -- but a database tier's need not be: the dword is
+		// found from the address itself)
+		const uintptr_t byte_address0 = reinterpret_cast<uintptr_t>(state.animated_track_data[0]) + (bit_offset0 >> 3);
+		const uintptr_t byte_address1 = reinterpret_cast<uintptr_t>(state.animated_track_data[1]) + (bit_offset1 >> 3);
+		const key_window loaded0 = *reinterpret_cast<const ACLHIP_CONSTANT key_window*>(byte_address0 & ~uintptr_t(3));
+		const key_window loaded1 = *reinterpret_cast<const ACLHIP_CONSTANT key_window*>(byte_address1 & ~uintptr_t(3));
+
+		float v[2][3];
+		#pragma unroll
+		for (uint32_t key = 0; key < 2; ++key)
+		{
+			const key_window loaded = key == 0 ? loaded0 : loaded1;
+			const uint32_t num_bits = key == 0 ? num_bits0 : num_bits1;
+			const uint32_t shift_x = ((uint32_t(key == 0 ? byte_address0 : byte_address1) & 3u) << 3) | ((key == 0 ? bit_offset0 : bit_offset1) & 7u);		// 0..31
+			const plan_entry& plan = key == 0 ? plan0 : plan1;
+
+			// big endian dwords of the bitstream
+			const uint32_t w0 = __builtin_bswap32(loaded.x), w1 = __builtin_bswap32(loaded.y), w2 = __builtin_bswap32(loaded.z), w3 = __builtin_bswap32(loaded.w);
+			const uint32_t shift_y = shift_x + num_bits;			// 1..54: y starts in dword 0 or 1
+			const uint32_t shift_z = shift_y + num_bits;			// 2..77: z starts in dword 0, 1 or 2
+			const bool y_in_1 = shift_y >= 32u;
+			const bool z_in_1 = shift_z >= 32u, z_in_2 = shift_z >= 64u;
+			const uint32_t window_x = bits_from(w0, w1, shift_x);
+			const uint32_t window_y = bits_from(y_in_1 ? w1 : w0, y_in_1 ? w2 : w1, shift_y & 31u);
+			const uint32_t window_z = bits_from(z_in_2 ? w2 : (z_in_1 ? w1 : w0), z_in_2 ? w3 : (z_in_1 ? w2 : w1), shift_z & 31u);
+
+			// v_bfe_u32: (source >> offset) & ((1 << width) - 1), and 0 for width 0 (a sub-track that is constant in its segment)
+			const uint32_t x = __builtin_amdgcn_ubfe(window_x, 32u - num_bits, num_bits);
+			const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
+			const uint32_t z = __builtin_amdgcn_ubfe(window_z, 32u - num_bits, num_bits);
+
+			const float quantized[3] = { float(x) * plan.inv_max_value, float(y) * plan.inv_max_value, float(z) * plan.inv_max_value };
+
+			// v = v * segment_extent + segment_min, then v = v * clip_extent + clip_min (multiply, then add: never fused).
+			// Constant-in-segment sub-tracks arrive here as 0 * 0 + sample; single segment clips as v * 1 + 0: exact for v >= +0.
+			#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c)
+			{
+				const float segment_value = (quantized[c] * plan.range_extent[c]) + plan.range_min[c];
+				v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
+			}
+
+			if (kHasRaw && num_bits == 32u)
+			{
+				// Raw (fp32) keyframes: three big endian floats starting at an arbitrary bit (math/vector4_packing.h:479-599) -- the same
+				// four dwords. What the code above computed for them is discarded. Raw samples skip both range expansions; in the
+				// reference's SOA rotation path the ignored lanes still see value * 1 + 0 twice
+				// (animated_track_cache.transform.h:316-349,420-465), which only matters for a -0.0.
+				const float raw[3] = { __uint_as_float(bits_from(w0, w1, shift_x)), __uint_as_float(bits_from(w1, w2, shift_x)), __uint_as_float(bits_from(w2, w3, shift_x)) };
+				#pragma unroll
+				for (uint32_t c = 0; c < 3; ++c)
+					v[key][c] = is_rotation ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
+			}
+		}
+
+		#pragma unroll
+		for (uint32_t c = 0; c < 3; ++c)
+		{
+			out_v0[c] = v[0][c];
+			out_v1[c] = v[1][c];
+		}
+	}
+
+#if defined(ACLHIP_EXPERIMENTS)
+	// ---- the same unpack from keyframe bits STAGED IN LDS (the staged kernel, kernels_pose.inl) --------------------------------------------
+	// A wave copies the runs of keyframe bits its window needs into LDS with coalesced 16 byte reads (window_span_entry); a lane then
+	// finds its sub-track at bit `position` of its key's staging buffer, MSB first like the bitstream, and reads the same two windows
+	// as unpack_animated_samples does from memory -- 8 bytes from the byte that holds the first bit for x and y, 4 bytes for z -- out of
+	// LDS (gfx950 serves ds_read_b64 / b32 at any byte address), followed by the same instructions.
+	typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
+
+	__device__ __forceinline__ uint32_t load_be32(lds_bytes p)
+	{
+		uint32_t v;
+		__builtin_memcpy(&v, (const __attribute__((address_space(3))) void*)p, 4);
+		return __builtin_bswap32(v);
+	}
+
+	__device__ __forceinline__ uint64_t load_u64(lds_bytes p)
+	{
+		uint64_t v;
+		__builtin_memcpy(&v, (const __attribute__((address_space(3))) void*)p, 8);
+		return v;
+	}
+
+	// position0 / position1: bit position of the sub-track's first bit inside key_bytes0 / key_bytes1 (anything valid for a width of 0)
+	template<bool kHasRaw>
+	__device__ __forceinline__ void unpack_staged_samples(lds_bytes key_bytes0, lds_bytes key_bytes1, uint32_t position0, uint32_t position1,
+		const plan_entry& plan0, const plan_entry& plan1, const clip_range_entry& clip_range, bool is_rotation, float out_v0[3], float out_v1[3])
+	{
+		const uint32_t num_bits0 = plan0.bit_offset_and_width >> 24;
+		const uint32_t num_bits1 = plan1.bit_offset_and_width >> 24;
+		const uint32_t position_z0 = position0 + 2u * num_bits0;
+		const uint32_t position_z1 = position1 + 2u * num_bits1;
+
+		const uint64_t window_xy0 = load_u64(key_bytes0 + (position0 >> 3));
+		const uint32_t window_z0 = load_be32(key_bytes0 + (position_z0 >> 3));
+		const uint64_t window_xy1 = load_u64(key_bytes1 + (position1 >> 3));
+		const uint32_t window_z1 = load_be32(key_bytes1 + (position_z1 >> 3));
+
+		float v[2][3];
+		#pragma unroll
+		for (uint32_t key = 0; key < 2; ++key)
+		{
+			const uint64_t window_xy = key == 0 ? window_xy0 : window_xy1;
+			const uint32_t hi_z = key == 0 ? window_z0 : window_z1;
+			const uint32_t num_bits = key == 0 ? num_bits0 : num_bits1;
+			const uint32_t shift_xy = (key == 0 ? position0 : position1) & 7u;
+			const uint32_t shift_z = (key == 0 ? position_z0 : position_z1) & 7u;
+			const plan_entry& plan = key == 0 ? plan0 : plan1;
+
+			const uint32_t hi = __builtin_bswap32(uint32_t(window_xy));
+			const uint32_t lo = __builtin_bswap32(uint32_t(window_xy >> 32));
+			const uint32_t x = __builtin_amdgcn_ubfe(hi, 32u - shift_xy - num_bits, num_bits);
+			const uint32_t window_y = __builtin_amdgcn_alignbit(hi, lo, 32u - (shift_xy + num_bits));
+			const uint32_t y = __builtin_amdgcn_ubfe(window_y, 32u - num_bits, num_bits);
+			const uint32_t z = __builtin_amdgcn_ubfe(hi_z, 32u - shift_z - num_bits, num_bits);
+
+			const float quantized[3] = { float(x) * plan.inv_max_value, float(y) * plan.inv_max_value, float(z) * plan.inv_max_value };
+			#pragma unroll
+			for (uint32_t c = 0; c < 3; ++c)
+			{
+				const float segment_value = (quantized[c] * plan.range_extent[c]) + plan.range_min[c];
+				v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
+			}
+		}
+
+		if (kHasRaw)
+		{
+			// raw fp32 keyframes (unpack_animated_samples): three big endian floats from an arbitrary bit on; no range expansion
+			#pragma unroll
+			for (uint32_t key = 0; key < 2; ++key)
+			{
+				if ((key == 0 ? num_bits0 : num_bits1) == 32u)
+				{
+					const uint32_t position = key == 0 ? position0 : position1;
+					lds_bytes bytes = (key == 0 ? key_bytes0 : key_bytes1) + (position >> 3);
+					const uint32_t shift = position & 7u;
+					const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
+					float raw[3] = { __uint_as_float(__funnelshift_l(w1, w0, shift)), __uint_as_float(__funnelshift_l(w2, w1, shift)), __uint_as_float(__funnelshift_l(w3, w2, shift)) };
+					#pragma unroll
+					for (uint32_t c = 0; c < 3; ++c)
+						v[key][c] = is_rotation ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
+				}
+			}
+		}
+
+		#pragma unroll
+		for (uint32_t c = 0; c < 3; ++c)
+		{
+			out_v0[c] = v[0][c];
+			out_v1[c] = v[1][c];
+		}
+	}
+#endif
+
 	// math/quatf.h:135-147
 	__device__ __forceinline__ float quat_from_positive_w(float x, float y, float z)
 	{
@@ -514,14 +721,30 @@ namespace aclhip
 	// `policy` is the effective rounding policy of the track (none unless per track rounding is enabled);
 	// `lerp_alpha` the alpha handed to the interpolation.
 	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
-	template<bool kHasRaw, bool kPolicies>
+	template<bool kPolicies>
+	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
+		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples);
+
+	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false>
 	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
 		float v0[3], v1[3];
-		unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+		if constexpr (kWideKeyLoads)
+			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+		else
+			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+		return interpolate_animated_samples<kPolicies>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples);
+	}
 
-		if (is_rotation)
+	// What follows the unpack: W reconstruction, interpolation, normalization (rotations) / the stable lerp (translations, scales)
+	template<bool kPolicies>
+	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
+		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+	{
+		// (the rotation arithmetic -- three square roots and a division, ~90 instructions -- sits behind a branch the WAVE takes: the
+		// compiler otherwise turns `if (is_rotation)` into selects, and a pass of translations and scales pays for rotations it does not have)
+		if (is_rotation && __builtin_amdgcn_ballot_w64(is_rotation) != 0)
 		{
 			float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w(v0[0], v0[1], v0[2]));
 			float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w(v1[0], v1[1], v1[2]));

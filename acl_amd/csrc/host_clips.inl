@@ -426,8 +426,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	// tables are reordered by destination window (and by kind inside a window). The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
 	// a contiguous range of ordinals, image_chunks[c] .. image_chunks[c + 1]: the pose kernel can build a pose of any size through
 	// a fixed LDS window.
-	const uint32_t num_image_chunks = std::max<uint32_t>((num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
-	std::vector<uint32_t> image_chunks(align_to_u32(num_image_chunks + 1, 4), num_animated);
+	const uint32_t num_image_chunks = num_pose_windows(num_tracks);
+	std::vector<uint32_t> image_chunks(window_spans_word_offset(num_image_chunks), num_animated);
 	if (num_animated != 0)
 	{
 		std::vector<uint32_t> order(num_animated);		// new ordinal -> bitstream ordinal
@@ -466,6 +466,44 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	}
 	else
 		std::fill(image_chunks.begin(), image_chunks.end(), 0u);
+
+#if defined(ACLHIP_EXPERIMENTS)
+	// ---- where a window's bits sit inside a keyframe (the staged kernel of kernels_experiments.inl) ----
+	// Per (segment, window) and kind: the run of keyframe bits its animated sub-tracks cover (window_span_entry); per clip, what a
+	// wave needs in LDS to stage one keyframe's runs (16 byte pieces, any alignment of the keyframe) and to keep a window's decoded
+	// sub-tracks.
+	std::vector<window_span_entry> window_spans(std::max<size_t>(size_t(num_segments) * num_image_chunks, 1));
+	std::memset(window_spans.data(), 0, window_spans.size() * sizeof(window_span_entry));
+	uint32_t window_animated_max = 0, window_key_bytes_max = 0;
+	for (uint32_t chunk = 0; chunk < num_image_chunks && num_animated != 0; ++chunk)
+	{
+		const uint32_t first = image_chunks[chunk], end = chunk + 1 < num_image_chunks ? image_chunks[chunk + 1] : num_animated;
+		window_animated_max = std::max(window_animated_max, end - first);
+		for (uint32_t si = 0; si < num_segments; ++si)
+		{
+			window_span_entry& span = window_spans[size_t(si) * num_image_chunks + chunk];
+			bool seen[3] = { false, false, false };
+			for (uint32_t a = first; a < end; ++a)
+			{
+				const plan_entry& entry = plan[size_t(si) * num_animated + a];
+				const uint32_t width = entry.bit_offset_and_width >> 24;
+				if (width == 0)
+					continue;		// constant in this segment: nothing is read
+				const uint32_t kind = clip_ranges[a].quad_index - clip_ranges[a].track_index * 3;
+				const uint32_t bit = entry.bit_offset_and_width & 0x00FFFFFFu;
+				span.first_bit[kind] = seen[kind] ? std::min(span.first_bit[kind], bit) : bit;
+				span.end_bit[kind] = seen[kind] ? std::max(span.end_bit[kind], bit + width * 3) : bit + width * 3;
+				seen[kind] = true;
+			}
+			uint32_t key_bytes = 0;
+			for (uint32_t kind = 0; kind < 3; ++kind)
+				if (seen[kind])
+					key_bytes += staged_run_bytes(span.end_bit[kind] - span.first_bit[kind]);
+			window_key_bytes_max = std::max(window_key_bytes_max, key_bytes);
+		}
+	}
+
+#endif
 
 	// ---- can a scale of this clip come out negative? ----
 	// rtm::qvv_mul composes matrices instead of quaternions when a scale component of either operand is negative; the pose consumers
@@ -523,10 +561,15 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(packed + 7, record + 8, 12);
 	}
 	const uint64_t samples_offset = (resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31);
-	const uint64_t plan_offset = samples_offset + samples.size() * sizeof(sample_record);
+	const uint64_t plan_offset = (samples_offset + samples.size() * sizeof(sample_record) + 31) & ~uint64_t(31);		// 32 byte entries from here on
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
+#if defined(ACLHIP_EXPERIMENTS)
+	const uint64_t window_spans_offset = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);		// (image_chunks_offset is a multiple of 32: whole 32 byte entries before it)
+	const uint64_t total_bytes = window_spans_offset + window_spans.size() * sizeof(window_span_entry);
+#else
 	const uint64_t total_bytes = image_chunks_offset + image_chunks.size() * sizeof(uint32_t);
+#endif
 	if (total_bytes > 0xFFFFFFFFull)
 		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "clip tables beyond 4 GiB are not supported");
 
@@ -541,6 +584,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
 	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
+#if defined(ACLHIP_EXPERIMENTS)
+	std::memcpy(staging.data() + window_spans_offset, window_spans.data(), window_spans.size() * sizeof(window_span_entry));
+#endif
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
@@ -694,6 +740,12 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.touched_bytes = total_bytes - 64;
 	entry.pose_quads = num_quads;
 	context->max_pose_quads = std::max(context->max_pose_quads, num_quads);
+#if defined(ACLHIP_EXPERIMENTS)
+	entry.window_animated = window_animated_max;
+	entry.window_key_bytes = window_key_bytes_max;
+	context->max_window_animated = std::max(context->max_window_animated, window_animated_max);
+	context->max_window_key_bytes = std::max(context->max_window_key_bytes, window_key_bytes_max);
+#endif
 	entry.scaled = num_tracks != 0 && (has_scale || float(header.default_scale()) != 1.0f);
 	context->num_scaled_clips += entry.scaled ? 1u : 0u;
 	entry.negative_scale = negative_scale_possible;
@@ -767,6 +819,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	context->num_negative_scale_clips -= removed.negative_scale ? 1u : 0u;
 	context->num_wide_scalar_clips -= removed.wide_scalar ? 1u : 0u;
 	if ((removed.pose_quads != 0 && removed.pose_quads == context->max_pose_quads) || (removed.hierarchy_words != 0 && removed.hierarchy_words == context->max_hierarchy_words)
+		|| (removed.window_animated != 0 && removed.window_animated == context->max_window_animated) || (removed.window_key_bytes != 0 && removed.window_key_bytes == context->max_window_key_bytes)
 		|| (removed.scalar_tracks != 0 && removed.scalar_tracks == context->max_scalar_tracks) || (removed.scalar_frame_bytes != 0 && removed.scalar_frame_bytes == context->max_scalar_frame_bytes))
 		recompute_launch_maxima(context);
 	return ACLHIP_OK;

@@ -14,6 +14,7 @@ namespace
 		uint64_t touched_bytes = 0;			// bytes of the blob + tables a decode may read
 		// what this clip asks of a launch (the context keeps the maxima over its live clips)
 		uint32_t pose_quads = 0, hierarchy_words = 0, scalar_tracks = 0, scalar_frame_bytes = 0;
+		uint32_t window_animated = 0, window_key_bytes = 0;		// staged kernel: animated sub-tracks of the fullest pose window, LDS bytes to stage one keyframe's runs
 		bool scaled = false;				// qvvf clip with scale sub-tracks, or whose default scale is not 1
 		bool negative_scale = false;		// some scale sub-track may decode a negative component (mirrored rigs): rtm::qvv_mul then goes through matrices
 		bool wide_scalar = false;			// scalar track list of more than one float per track
@@ -59,12 +60,15 @@ struct aclhip_context
 	uint32_t d_clips_capacity = 0;
 	unsigned long long* d_rejected = nullptr;	// [0] instances the kernels refused, [1] transforms of the pose consumers that met a negative scale
 	uint32_t max_pose_quads = 0;			// largest pose (3 * num_tracks) among registered clips
+	uint32_t max_window_animated = 0;		// most animated sub-tracks in one pose window among registered clips
+	uint32_t max_window_key_bytes = 0;		// most LDS bytes staging one keyframe's runs of a window takes, among registered clips
 	uint32_t num_wide_scalar_clips = 0;		// live scalar track lists of 2 - 4 floats per track (while 0 the grouped scalar kernel is compiled for float1f only)
 	uint32_t num_scaled_clips = 0;			// live clips whose scale is not 1 everywhere (the pose consumers keep no scale in LDS while this is 0)
 	uint32_t num_negative_scale_clips = 0;	// live clips that may decode a negative scale (while 0 the pose consumers are compiled without rtm::qvv_mul's matrix route)
 	uint32_t max_hierarchy_words = 0;		// largest walk schedule (aclhip_set_clip_hierarchy) among registered clips
 	uint32_t max_scalar_tracks = 0;			// largest scalar track list among registered clips
 	uint32_t max_scalar_frame_bytes = 0;	// largest frame (one sample of every track) among registered scalar clips
+	uint32_t num_compute_units = 256;		// of the device (MI355X: 256): the persistent kernels fill it once
 	bool force_generic_kernel = false;		// testing aid (ACLHIP_FORCE_GENERIC_KERNEL=1): always launch the any-settings kernel
 
 	// Clips live in a few large HBM slabs instead of one hipMalloc each: a batch that draws on hundreds of clips then touches a
@@ -187,11 +191,14 @@ namespace
 	void recompute_launch_maxima(aclhip_context* context)
 	{
 		context->max_pose_quads = context->max_hierarchy_words = context->max_scalar_tracks = context->max_scalar_frame_bytes = 0;
+		context->max_window_animated = context->max_window_key_bytes = 0;
 		for (const host_clip& clip : context->clips)
 		{
 			if (!clip.in_use)
 				continue;
 			context->max_pose_quads = std::max(context->max_pose_quads, clip.pose_quads);
+			context->max_window_animated = std::max(context->max_window_animated, clip.window_animated);
+			context->max_window_key_bytes = std::max(context->max_window_key_bytes, clip.window_key_bytes);
 			context->max_hierarchy_words = std::max(context->max_hierarchy_words, clip.hierarchy_words);
 			context->max_scalar_tracks = std::max(context->max_scalar_tracks, clip.scalar_tracks);
 			context->max_scalar_frame_bytes = std::max(context->max_scalar_frame_bytes, clip.scalar_frame_bytes);
@@ -656,6 +663,7 @@ namespace
 		out.instance_rows = nullptr;
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;
+		out.items_per_wave = 1;
 		out.rounding_policy = params->rounding_policy;
 		out.looping_policy = params->looping_policy;
 		out.normalization = params->normalization;
@@ -732,6 +740,11 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	}
 
 	device_guard guard(device_index);
+	{
+		int compute_units = 0;
+		if (guard.ok && hipDeviceGetAttribute(&compute_units, hipDeviceAttributeMultiprocessorCount, device_index) == hipSuccess && compute_units > 0)
+			context->num_compute_units = uint32_t(compute_units);
+	}
 	if (!guard.ok || hipStreamCreateWithFlags(&context->copy_stream, hipStreamNonBlocking) != hipSuccess
 		|| hipMalloc(reinterpret_cast<void**>(&context->d_rejected), 2 * sizeof(unsigned long long)) != hipSuccess
 		|| hipMemsetAsync(context->d_rejected, 0, 2 * sizeof(unsigned long long), context->copy_stream) != hipSuccess

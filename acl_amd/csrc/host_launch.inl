@@ -30,50 +30,22 @@ namespace
 		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0;
 		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
 		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0;
-		// poses of several windows, common case, QVV48: decode waves hand their finished windows to one store wave per workgroup
-		// (measurement aid: ACLHIP_HANDOFF_DECODERS = decode waves per workgroup, 0 = off; ACLHIP_HANDOFF_ALWAYS=1 also for one-window poses)
-		static const uint32_t handoff_decoders = []() { const char* value = std::getenv("ACLHIP_HANDOFF_DECODERS"); return value != nullptr ? uint32_t(std::atol(value)) : k_handoff_default_decoders; }();
-		static const bool handoff_always = []() { const char* value = std::getenv("ACLHIP_HANDOFF_ALWAYS"); return value != nullptr && value[0] == '1'; }();
-		static const bool handoff_last_arriver = []() { const char* value = std::getenv("ACLHIP_HANDOFF_LAST_ARRIVER"); return value != nullptr && value[0] == '1'; }();
-		if (handoff_decoders != 0 && !any_settings && !compact && (windows_per_instance > 1 || handoff_always))
+#if defined(ACLHIP_EXPERIMENTS)
 		{
-			void (*handoff_kernel)(ACLHIP_POSE_KERNEL_ARGUMENTS) = nullptr;
-			if (!handoff_last_arriver)
-				switch (handoff_decoders)
-				{
-				case 3: handoff_kernel = decompress_tracks_handoff_kernel<3>; break;
-				case 4: handoff_kernel = decompress_tracks_handoff_kernel<4>; break;
-				case 6: handoff_kernel = decompress_tracks_handoff_kernel<6>; break;
-				case 7: handoff_kernel = decompress_tracks_handoff_kernel<7>; break;
-				case 8: handoff_kernel = decompress_tracks_handoff_kernel<8>; break;
-				case 15: handoff_kernel = decompress_tracks_handoff_kernel<15>; break;
-				default: break;
-				}
-			else
-				switch (handoff_decoders)
-				{
-				case 2: handoff_kernel = decompress_tracks_last_arriver_kernel<2>; break;
-				case 3: handoff_kernel = decompress_tracks_last_arriver_kernel<3>; break;
-				case 4: handoff_kernel = decompress_tracks_last_arriver_kernel<4>; break;
-				case 6: handoff_kernel = decompress_tracks_last_arriver_kernel<6>; break;
-				case 8: handoff_kernel = decompress_tracks_last_arriver_kernel<8>; break;
-				default: break;
-				}
-			if (handoff_kernel == nullptr)
-				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "ACLHIP_HANDOFF_DECODERS: no such kernel shape");
-			const uint32_t handoff_blocks = uint32_t((num_waves + handoff_decoders - 1) / handoff_decoders);
-			const size_t handoff_lds = 256 + size_t(lds_quads_per_wave) * 16 * handoff_decoders + (lds_bytes - size_t(lds_quads_per_wave) * 16 * k_waves_per_block);
-			if (handoff_lds > 48 * 1024)
-				ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(handoff_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(handoff_lds)));
-			hipLaunchKernelGGL(handoff_kernel, dim3(handoff_blocks), dim3((handoff_decoders + (handoff_last_arriver ? 0 : 1)) * k_wave_size), handoff_lds, stream,
-				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
-				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
-			ACLHIP_CHECK_HIP(context, hipGetLastError());
-			return ACLHIP_OK;
+			// round 3's slower kernel variants, selected by environment knobs (host_experiments.inl)
+			bool launched = false;
+			const aclhip_status experiment_status = launch_experimental_tracks(context, clips, sample_times, num_instances, params, poses, pose_stride_bytes, stream,
+				windows_per_instance, num_waves, num_blocks, any_settings, compact, lds_quads_per_wave, lds_bytes, launched);
+			if (launched || experiment_status != ACLHIP_OK)
+				return experiment_status;
 		}
+#endif
+		// poses of several windows read the bitstream with one aligned request per key (kernels_pose.inl); ACLHIP_WIDE_KEY_LOADS=0 / 1 overrides
+		static const int wide_override = []() { const char* value = std::getenv("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
+		const bool wide_key_loads = wide_override >= 0 ? wide_override != 0 : windows_per_instance > 1;
 		const auto kernel = native_layout ? (params.layout == ACLHIP_LAYOUT_QV32 ? decompress_tracks_qv32_kernel : decompress_tracks_qvv40_kernel)
 			: any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)
-			: (compact ? decompress_tracks_compact_kernel : decompress_tracks_kernel);
+			: (compact ? decompress_tracks_compact_kernel : (wide_key_loads ? decompress_tracks_wide_loads_kernel : decompress_tracks_kernel));
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);

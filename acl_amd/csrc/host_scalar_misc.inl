@@ -474,7 +474,9 @@ extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, 
 	if (status != ACLHIP_OK)
 		return status;
 	const bool any_settings = device_params.standard_defaults == 0 || device_params.per_track_rounding != 0 || context->force_generic_kernel;
-	std::snprintf(out_name, capacity, "%s", any_settings ? "decompress_tracks_any_settings_kernel" : "decompress_tracks_kernel");
+	// (poses of several windows take the common case kernel that reads the bitstream one aligned request per key: launch_tracks)
+	const bool several_windows = context->max_pose_quads > k_image_chunk_quads;
+	std::snprintf(out_name, capacity, "%s", any_settings ? "decompress_tracks_any_settings_kernel" : (several_windows ? "decompress_tracks_wide_loads_kernel" : "decompress_tracks_kernel"));
 	return ACLHIP_OK;
 }
 

@@ -67,33 +67,6 @@
 		return entry;
 	}
 
-	// Measurement aids (wrong results, timing only): -DACLHIP_EXP_HALF_TABLES fetches only the half of a table entry that holds the
-	// bit offset / the quad index and makes the other half up (what would the texture unit's time be with half the table bytes?)
-#if defined(ACLHIP_EXP_HALF_TABLES)
-	__device__ __forceinline__ plan_entry load_entry_exp(const plan_entry* table, uint32_t index)
-	{
-		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(table + index);
-		const u32x4 lo = source[0];
-		plan_entry entry;
-		entry.bit_offset_and_width = lo.x; entry.inv_max_value = __uint_as_float(lo.y); entry.range_min[0] = __uint_as_float(lo.z); entry.range_min[1] = __uint_as_float(lo.w);
-		entry.range_min[2] = __uint_as_float(lo.z); entry.range_extent[0] = __uint_as_float(lo.w); entry.range_extent[1] = __uint_as_float(lo.y); entry.range_extent[2] = __uint_as_float(lo.z);
-		return entry;
-	}
-	__device__ __forceinline__ clip_range_entry load_entry_exp(const clip_range_entry* table, uint32_t index)
-	{
-		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(table + index);
-		const u32x4 hi = source[1];
-		clip_range_entry entry;
-		entry.range_extent[0] = __uint_as_float(hi.x); entry.range_extent[1] = __uint_as_float(hi.y); entry.range_extent[2] = __uint_as_float(hi.z); entry.quad_index = hi.w;
-		entry.range_min[0] = __uint_as_float(hi.y); entry.range_min[1] = __uint_as_float(hi.z); entry.range_min[2] = __uint_as_float(hi.x);
-		entry.track_index = hi.w % 3u == 0 ? hi.w / 3u : 0xFFFFFFFFu;
-		return entry;
-	}
-#else
-	template<class entry_t>
-	__device__ __forceinline__ entry_t load_entry_exp(const entry_t* table, uint32_t index) { return load_entry(table, index); }
-#endif
-
 	__device__ __forceinline__ float4 load_quad(const float4* table, uint32_t index)
 	{
 		const f32x4 raw = ((const ACLHIP_CONSTANT f32x4*)table)[index];
@@ -148,7 +121,7 @@
 		}
 	};
 
-	template<bool kPolicies, class image_writer_type>
+	template<bool kPolicies, bool kWideKeyLoads = false, class image_writer_type>
 	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image)
 	{
@@ -162,9 +135,9 @@
 		const plan_entry* plan_row1 = tables.plan + size_t(state.segment_index[1]) * tables.num_animated;
 
 		uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
-		plan_entry entry0 = load_entry_exp(plan_row0, ordinal);
-		plan_entry entry1 = single_segment ? entry0 : load_entry_exp(plan_row1, ordinal);
-		clip_range_entry clip_range = load_entry_exp(tables.clip_ranges, ordinal);
+		plan_entry entry0 = load_entry(plan_row0, ordinal);
+		plan_entry entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
+		clip_range_entry clip_range = load_entry(tables.clip_ranges, ordinal);
 
 		for (uint32_t base = first_ordinal; base < end_ordinal; base += k_wave_size)
 		{
@@ -188,9 +161,9 @@
 
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, kPolicies>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 			else
-				value = decode_animated_sub_track<true, kPolicies>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)
@@ -200,22 +173,22 @@
 			if (base + k_wave_size < end_ordinal)
 			{
 				ordinal = min(base + k_wave_size + lane, end_ordinal - 1);
-				entry0 = load_entry_exp(plan_row0, ordinal);
-				entry1 = single_segment ? entry0 : load_entry_exp(plan_row1, ordinal);
-				clip_range = load_entry_exp(tables.clip_ranges, ordinal);
+				entry0 = load_entry(plan_row0, ordinal);
+				entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
+				clip_range = load_entry(tables.clip_ranges, ordinal);
 			}
 		}
 	}
 
-	template<bool kAnySettings>
+	template<bool kAnySettings, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
 	{
 		const qvv48_image_writer writer = { image, first_quad };
 		if (kAnySettings && params.per_track_rounding != 0)
-			decode_window_sub_tracks_into<true>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
+			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 		else
-			decode_window_sub_tracks_into<false>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
+			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -232,18 +205,17 @@
 	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
 	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
 	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
-	template<bool kAnySettings, bool kCompactOutput>
+	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
-		unsigned long long* __restrict__ rejected_count)
+		unsigned long long* __restrict__ rejected_count, uint32_t work_item, uint32_t* image_clip = nullptr)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
 		ACLHIP_WAVE0_STAMP(0);
 
 		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		const uint32_t work_item = blockIdx.x * k_waves_per_block + wave_in_block;
 		uint32_t instance = work_item;
 		uint32_t window = 0;
 		if (windows_per_instance != 1)
@@ -289,16 +261,20 @@
 		// base pose window -> LDS image, asynchronously: lane i of pass p fetches quad first + p * 64 + i into image[p * 64 + i]
 		{
 			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
-#if !defined(ACLHIP_EXP_NO_DMA)
+			// (in-turn kernel: the image still holds this clip's window from the wave's previous item -- every animated quad is about to be
+			// overwritten, the others are this clip's constants already)
+			const bool image_is_current = image_clip != nullptr && *image_clip == clip_id;
+			if (image_clip != nullptr)
+				*image_clip = clip_id;
+			if (!image_is_current)
+			{
 			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
 			{
 				if (base + lane < window_quads)
 					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
-#else
-			asm volatile("" :: "v"(source));
-#endif
+			}
 		}
 
 		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
@@ -337,7 +313,7 @@
 		// lanes <-> animated sub-tracks of this window
 		// (decoded quads are written after the DMA has delivered their slots: a wave's memory operations return in order, and the
 		// keyframe loads every decoded value waits for were issued after the DMA)
-		decode_window_sub_tracks<kAnySettings>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -650,15 +626,28 @@
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count
 	#define ACLHIP_POSE_KERNEL_FORWARD clips, num_clips, clip_ids, sample_times, num_instances, windows_per_instance, params, poses, pose_stride_bytes, lds_quads_per_wave, rejected_count
 
+	// one wave per (instance, pose window): workgroup b holds work items 4 b .. 4 b + 3
+	__device__ __forceinline__ uint32_t one_shot_work_item()
+	{
+		return blockIdx.x * k_waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+	}
+
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false, false>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_window<false, false>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+	}
+
+	// the same for poses of several windows (the 300-bone rig): one dword aligned 16 byte read of the bitstream per key
+	// (unpack_animated_samples_wide, aclhip_device.h)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_wide_loads_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_window<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_qv32_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
@@ -671,214 +660,13 @@
 		decompress_tracks_compact_window<ACLHIP_LAYOUT_QVV40>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
-	// ---- decode waves hand their windows to a store wave ---------------------------------------------------------------------------------
-	// The common-case kernel above for poses of several windows (the 300-bone rig): a workgroup is kDecoders decode waves + ONE store
-	// wave. A decode wave does everything decompress_tracks_window does up to the finished LDS image, publishes it (a descriptor + a
-	// flag in LDS) and ENDS -- its wave slot and registers go to the next workgroup's decoders while its image waits; the store wave
-	// takes finished images in whatever order they complete, LDS -> registers -> HBM, 1 KiB per store instruction as before.
-	// Why: the HBM write path sustains 6.75 TB/s when <= 8 waves of a CU are inside their store phase and 5.5 TB/s with 32;
-	// here at most (resident workgroups) waves of a CU ever issue stores, and no decode wave sits on its slot while its stores drain.
-#if !defined(ACLHIP_HANDOFF_DEFAULT_DECODERS)
-	#define ACLHIP_HANDOFF_DEFAULT_DECODERS 0
-#endif
-	constexpr uint32_t k_handoff_default_decoders = ACLHIP_HANDOFF_DEFAULT_DECODERS;
-
-	struct alignas(16) handoff_descriptor
-	{
-		uint32_t ready;				// 0 until the image is complete (or the wave has nothing to store: window_quads = 0)
-		uint32_t window_quads;
-		uint32_t pose_offset_lo;	// byte offset of the window's first quad from `poses`
-		uint32_t pose_offset_hi;
-	};
-
-	// kDedicatedStoreWave = false is the same hand-over WITHOUT the extra wave: every decoder takes a ticket when its image is done, all but
-	// the last one end, and the LAST ARRIVER stores the workgroup's images -- no wave slot is spent on waiting.
-	template<uint32_t kDecoders, bool kDedicatedStoreWave>
-	__device__ __forceinline__ void decompress_tracks_handoff(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
-		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
-		unsigned long long* __restrict__ rejected_count)
-	{
-		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-		static_assert(kDecoders >= 1 && kDecoders <= 15, "decode waves of a workgroup: their ready flags are gathered by one ballot");
-
-		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
-		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
-		handoff_descriptor* descriptors = reinterpret_cast<handoff_descriptor*>(dynamic_lds);		// [kDecoders]
-		uint32_t* arrivals = reinterpret_cast<uint32_t*>(dynamic_lds + 240);
-		f32x4* images = reinterpret_cast<f32x4*>(dynamic_lds + 256);
-
-		// LDS is not cleared between workgroups: every decoder lowers its own flag, and nobody looks at a flag before this barrier
-		if (wave_in_block < kDecoders && lane == 0)
-			descriptors[wave_in_block].ready = 0;
-		if (!kDedicatedStoreWave && threadIdx.x == 0)
-			*arrivals = 0;
-		__syncthreads();
-
-		constexpr uint32_t k_rows = (k_image_chunk_quads + k_wave_size - 1) / k_wave_size;
-		const auto store_image = [&](uint32_t decoder)
-		{
-			const uint32_t window_quads = __builtin_amdgcn_readfirstlane(descriptors[decoder].window_quads);
-			if (window_quads == 0)
-				return;
-			const uint64_t pose_offset = uint64_t(__builtin_amdgcn_readfirstlane(descriptors[decoder].pose_offset_lo))
-				| (uint64_t(__builtin_amdgcn_readfirstlane(descriptors[decoder].pose_offset_hi)) << 32);
-			const f32x4* image = images + size_t(decoder) * lds_quads_per_wave;
-			const uint32_t full_rows = window_quads / k_wave_size;
-			f32x4 staged[k_rows];
-			#pragma unroll
-			for (uint32_t r = 0; r < k_rows; ++r)
-				staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
-			f32x4* pose = reinterpret_cast<f32x4*>(poses + pose_offset) + lane;
-			#pragma unroll
-			for (uint32_t r = 0; r < k_rows; ++r)
-				if (r < full_rows || (r == full_rows && r * k_wave_size + lane < window_quads))
-					store_streaming(&pose[r * k_wave_size], staged[r]);
-		};
-
-		if (kDedicatedStoreWave && wave_in_block == kDecoders)
-		{
-			// ---- the store wave ----
-			uint32_t pending = (1u << kDecoders) - 1u;
-			while (pending != 0)
-			{
-				// lane w looks at decoder w's flag
-				uint32_t flag = 0;
-				if (lane < kDecoders)
-					flag = __hip_atomic_load(&descriptors[lane].ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				uint32_t ready = uint32_t(__ballot(flag != 0)) & pending;
-				if (ready == 0)
-				{
-					__builtin_amdgcn_s_sleep(4);
-					continue;
-				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				while (ready != 0)
-				{
-					const uint32_t decoder = uint32_t(__builtin_ctz(ready));
-					ready &= ready - 1u;
-					pending &= ~(1u << decoder);
-					store_image(decoder);
-				}
-			}
-			return;
-		}
-
-		// ---- a decode wave ----
-		handoff_descriptor* descriptor = descriptors + wave_in_block;
-		const auto publish = [&](uint32_t window_quads, uint64_t pose_offset)
-		{
-			// DMA and this wave's LDS writes have landed (s_waitcnt 0) before the flag goes up
-			__builtin_amdgcn_s_waitcnt(0);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			uint32_t ticket = 0;
-			if (lane == 0)
-			{
-				descriptor->window_quads = window_quads;
-				descriptor->pose_offset_lo = uint32_t(pose_offset);
-				descriptor->pose_offset_hi = uint32_t(pose_offset >> 32);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-				if (kDedicatedStoreWave)
-					__hip_atomic_store(&descriptor->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-				else
-					ticket = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
-			if (!kDedicatedStoreWave)
-			{
-				// the last arriver stores every image of the workgroup; everybody else is done
-				ticket = __builtin_amdgcn_readfirstlane(ticket);
-				if (ticket != kDecoders - 1u)
-					return;
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-				for (uint32_t decoder = 0; decoder < kDecoders; ++decoder)
-					store_image(decoder);
-			}
-		};
-
-		const uint32_t work_item = blockIdx.x * kDecoders + wave_in_block;
-		uint32_t instance = work_item;
-		uint32_t window = 0;
-		if (windows_per_instance != 1)
-		{
-			instance = work_item / windows_per_instance;
-			window = work_item - instance * windows_per_instance;
-		}
-		if (instance >= num_instances)
-		{
-			publish(0, 0);
-			return;
-		}
-
-		const uint32_t clip_id = as_constant(clip_ids)[instance];
-		const float sample_time = as_constant(sample_times)[instance];
-		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
-		{
-			if (lane == 0 && window == 0)
-				atomicAdd(rejected_count, 1ull);
-			publish(0, 0);
-			return;
-		}
-
-		const uint32_t num_quads = clip.num_tracks * 3u;
-		const uint32_t first_quad = window * k_image_chunk_quads;
-		if (first_quad >= num_quads)
-		{
-			publish(0, 0);
-			return;
-		}
-		const uint32_t window_quads = min(num_quads - first_quad, k_image_chunk_quads);
-
-		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
-		if (num_quads > k_image_chunk_quads)
-		{
-			first_ordinal = as_constant(clip.image_chunks)[window];
-			end_ordinal = as_constant(clip.image_chunks)[window + 1];
-		}
-
-		f32x4* image = images + size_t(wave_in_block) * lds_quads_per_wave;
-		{
-			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)clip.resolved_pose + first_quad;
-			for (uint32_t base = 0; base < window_quads; base += k_wave_size)
-			{
-				if (base + lane < window_quads)
-					__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(source + base + lane),
-						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
-			}
-		}
-
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
-
-		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
-
-		decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, first_quad, lane, image);
-
-		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
-		publish(window_quads, uint64_t(row) * pose_stride_bytes + uint64_t(first_quad) * 16u);
-	}
-
-	template<uint32_t kDecoders>
-	__global__ __launch_bounds__((kDecoders + 1) * k_wave_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_handoff_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
-	{
-		decompress_tracks_handoff<kDecoders, true>(ACLHIP_POSE_KERNEL_FORWARD);
-	}
-
-	template<uint32_t kDecoders>
-	__global__ __launch_bounds__(kDecoders * k_wave_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_last_arriver_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
-	{
-		decompress_tracks_handoff<kDecoders, false>(ACLHIP_POSE_KERNEL_FORWARD);
-	}
-
 	// 8 waves per SIMD (64 VGPRs) matter more to this variant than the few instructions the allocator saves with 65
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<true, false>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_window<true, false>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_any_settings_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<true, true>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_window<true, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3, experiment A: decode -> store wave hand-off on the 300-bone rig (and on the one-window workloads with ACLHIP_HANDOFF_ALWAYS=1)
 cd "$GRAFT_REPO_ROOT"
+export ACLHIP_LIBRARY=${ACLHIP_LIBRARY:-acl_amd/lib/libaclhip_exp.so}   # tools/build_experiments.sh
 mkdir -p gpurun_out
 {
 echo "== correctness under the hand-off kernels"
