@@ -721,6 +721,11 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	host_clip& entry = context->clips[slot];
 	entry.in_use = true;
 	entry.database = database;
+	if (database != ACLHIP_INVALID_HANDLE && context->databases[database].streamed)
+	{
+		entry.db_first_segment_header = record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header));
+		entry.db_num_segments = num_segments;
+	}
 	entry.device_memory = d_memory;
 	entry.info.num_tracks = num_tracks;
 	entry.info.num_samples = header.num_samples;
@@ -794,25 +799,38 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	device_guard guard(context->device);
 	collect_retired(context, false);
 
-	// The record is cleared now (launches enqueued from here on refuse the handle); the clip's memory, its share of a hierarchy image and
-	// the handle itself are given back once everything already enqueued on the streams this context launched on has completed --
-	// nobody waits for that here. Callers still owe the reference's contract: no decode of a clip after its unregistration.
-	device_clip cleared;
-	std::memset(&cleared, 0, sizeof(cleared));
-	size_t staging_used = 0;
-	if (!stage_upload(context, context->d_clips + clip, &cleared, sizeof(cleared), staging_used) || !finish_uploads(context))
-		return fail(context, ACLHIP_ERROR_DEVICE, "clearing the clip record failed");
+	// Everything is stream ordered and nobody waits here. Decodes ALREADY ENQUEUED on the streams this context launched on still
+	// find the clip -- a kernel reads the table record when it executes, so the record is cleared (on the context's own retire stream)
+	// only behind those launches --; launches that execute after that are refused (counted, their poses untouched); the clip's memory,
+	// its share of a hierarchy image and the handle itself are given back once both have happened. Callers still owe the reference's
+	// contract: no decode of a clip is ENQUEUED after its unregistration.
 	{
 		aclhip_context::retired_item item;
 		item.clip_memory = context->clips[clip].device_memory;
 		item.hierarchy = context->clips[clip].d_hierarchy;
 		item.slot = clip;
-		retire(context, std::move(item));
+		retire(context, std::move(item), context->d_clips + clip);
 	}
 	context->clips_unregistered++;
 	const uint32_t bound_database = context->clips[clip].database;
 	if (bound_database != ACLHIP_INVALID_HANDLE && bound_database < context->databases.size() && context->databases[bound_database].num_bound_clips != 0)
-		context->databases[bound_database].num_bound_clips--;
+	{
+		host_database& db = context->databases[bound_database];
+		db.num_bound_clips--;
+		// the clip's runtime segment headers no longer constrain chunks that arrive (streamed databases)
+		const uint32_t first = context->clips[clip].db_first_segment_header, count = context->clips[clip].db_num_segments;
+		for (uint32_t si = 0; si < count; ++si)
+		{
+			const uint32_t offset = first + si * uint32_t(sizeof(database_runtime_segment_header));
+			for (size_t i = 0; i < db.segment_pose_bits.size(); ++i)
+				if (db.segment_pose_bits[i].first == offset)
+				{
+					db.segment_pose_bits[i] = db.segment_pose_bits.back();
+					db.segment_pose_bits.pop_back();
+					break;
+				}
+		}
+	}
 	const host_clip removed = context->clips[clip];
 	context->clips[clip] = host_clip();
 	context->num_scaled_clips -= removed.scaled ? 1u : 0u;

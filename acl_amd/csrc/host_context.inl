@@ -18,6 +18,7 @@ namespace
 		bool scaled = false;				// qvvf clip with scale sub-tracks, or whose default scale is not 1
 		bool negative_scale = false;		// some scale sub-track may decode a negative component (mirrored rigs): rtm::qvv_mul then goes through matrices
 		bool wide_scalar = false;			// scalar track list of more than one float per track
+		uint32_t db_first_segment_header = 0, db_num_segments = 0;	// bound to a streamed database: its runtime segment headers (host_database::segment_pose_bits)
 	};
 }
 
@@ -43,6 +44,7 @@ namespace
 		// and checked when they first arrive, their patches appended in chunk order
 		bool streamed = false;
 		uint32_t num_parsed_chunks[2] = { 0, 0 };
+		uint32_t num_uploaded_patches[2] = { 0, 0 };	// patches of the parsed chunks whose copy to d_patches has been enqueued
 		tier_patch* pinned_patches[2] = { nullptr, nullptr };	// host mirror of d_patches the uploads are made from
 		uint32_t patch_capacity[2] = { 0, 0 };
 		std::vector<std::pair<uint32_t, uint32_t>> segment_pose_bits;	// (runtime segment header offset, bits per keyframe) of the bound clips
@@ -86,6 +88,7 @@ struct aclhip_context
 	// once an event recorded on every stream this context has launched on has completed -- polled by later calls, never waited for
 	// (except in aclhip_destroy). The clip table never moves: its address range is reserved up front and backed page by page.
 	hipStream_t copy_stream = nullptr;
+	hipStream_t retire_stream = nullptr;		// clears the table records of unregistered clips BEHIND the work in flight (retire)
 	uint8_t* pinned_staging = nullptr;
 	size_t pinned_staging_bytes = 0;
 	std::vector<hipStream_t> launch_streams;		// every stream work was enqueued on (nullptr = the default stream)
@@ -97,7 +100,7 @@ struct aclhip_context
 		uint32_t* hierarchy = nullptr;				// a walk schedule image (shared images are reference counted)
 		uint32_t slot = ACLHIP_INVALID_HANDLE;		// clip handle that becomes reusable
 		uint8_t* database_memory[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };		// hipMalloc'ed pieces of a database
-		uint8_t* database_pinned[2] = { nullptr, nullptr };
+		uint8_t* database_pinned[4] = { nullptr, nullptr, nullptr, nullptr };		// bulk data x 2, patch mirrors x 2
 		void* device_memory = nullptr;				// any other hipMalloc'ed piece
 	};
 	std::vector<retired_item> retired;
@@ -287,8 +290,11 @@ namespace
 		return event;
 	}
 
-	// Records "everything enqueued so far" on every launch stream into the item and queues it; nothing is freed here
-	void retire(aclhip_context* context, aclhip_context::retired_item&& item)
+	// Records "everything enqueued so far" on every launch stream into the item and queues it; nothing is freed here.
+	// `record_to_clear` (a clip's record in the device table, or null): cleared on the context's retire stream BEHIND those same points --
+	// launches already enqueued still find the clip (kernels read the record when they execute, not when they are enqueued), launches
+	// that execute later are refused -- and the item is not recycled before the clear has happened. Nobody waits on the host.
+	void retire(aclhip_context* context, aclhip_context::retired_item&& item, device_clip* record_to_clear = nullptr)
 	{
 		for (size_t i = 0; i < context->launch_streams.size();)
 		{
@@ -304,6 +310,27 @@ namespace
 			if (event != nullptr)
 				context->event_pool.push_back(event);
 			context->launch_streams.erase(context->launch_streams.begin() + ptrdiff_t(i));
+		}
+		if (record_to_clear != nullptr)
+		{
+			bool ordered = context->retire_stream != nullptr;
+			for (size_t i = 0; ordered && i < item.events.size(); ++i)
+				ordered = hipStreamWaitEvent(context->retire_stream, item.events[i], 0) == hipSuccess;
+			hipEvent_t cleared = ordered ? take_event(context) : nullptr;
+			ordered = ordered && cleared != nullptr
+				&& hipMemsetAsync(record_to_clear, 0, sizeof(device_clip), context->retire_stream) == hipSuccess
+				&& hipEventRecord(cleared, context->retire_stream) == hipSuccess;
+			if (ordered)
+				item.events.push_back(cleared);
+			else
+			{
+				// (no stream ordered clear possible: fall back to what round 2 did, a clear the host waits for)
+				(void)hipGetLastError();
+				if (cleared != nullptr)
+					context->event_pool.push_back(cleared);
+				(void)hipMemsetAsync(record_to_clear, 0, sizeof(device_clip), context->copy_stream);
+				(void)hipStreamSynchronize(context->copy_stream);
+			}
 		}
 		context->retired.push_back(std::move(item));
 	}
@@ -746,12 +773,15 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 			context->num_compute_units = uint32_t(compute_units);
 	}
 	if (!guard.ok || hipStreamCreateWithFlags(&context->copy_stream, hipStreamNonBlocking) != hipSuccess
+		|| hipStreamCreateWithFlags(&context->retire_stream, hipStreamNonBlocking) != hipSuccess
 		|| hipMalloc(reinterpret_cast<void**>(&context->d_rejected), 2 * sizeof(unsigned long long)) != hipSuccess
 		|| hipMemsetAsync(context->d_rejected, 0, 2 * sizeof(unsigned long long), context->copy_stream) != hipSuccess
 		|| hipStreamSynchronize(context->copy_stream) != hipSuccess)
 	{
 		if (context->copy_stream != nullptr)
 			(void)hipStreamDestroy(context->copy_stream);
+		if (context->retire_stream != nullptr)
+			(void)hipStreamDestroy(context->retire_stream);
 		delete context;
 		return ACLHIP_ERROR_DEVICE;
 	}
@@ -761,6 +791,7 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	{
 		(void)hipFree(context->d_rejected);
 		(void)hipStreamDestroy(context->copy_stream);
+		(void)hipStreamDestroy(context->retire_stream);
 		delete context;
 		return status;
 	}
@@ -783,6 +814,8 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 			(void)hipHostFree(context->pinned_staging);
 		if (context->copy_stream != nullptr)
 			(void)hipStreamDestroy(context->copy_stream);
+		if (context->retire_stream != nullptr)
+			(void)hipStreamDestroy(context->retire_stream);
 		for (aclhip_context::clip_slab& slab : context->slabs)
 			(void)hipFree(slab.base);
 		for (host_database& db : context->databases)
@@ -796,8 +829,12 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 				(void)hipFree(db.d_patches[tier]);
 				if (db.pinned_bulk_data[tier] != nullptr)
 					(void)hipHostFree(db.pinned_bulk_data[tier]);
+				if (db.pinned_patches[tier] != nullptr)
+					(void)hipHostFree(db.pinned_patches[tier]);
 			}
 		}
+		for (const aclhip_context::peer_mapping& mapping : context->peer_mappings)
+			(void)hipIpcCloseMemHandle(mapping.base);		// buffers of other processes the caller never closed (aclhip_peer_close_buffer)
 		if (context->d_clips != nullptr && context->table_is_virtual)
 		{
 			if (context->table_mapped_bytes != 0)

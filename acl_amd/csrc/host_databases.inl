@@ -335,6 +335,7 @@ extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, acl
 		item.database_memory[1 + tier] = db.d_bulk_data[tier];
 		item.database_memory[3 + tier] = reinterpret_cast<uint8_t*>(db.d_patches[tier]);
 		item.database_pinned[tier] = db.pinned_bulk_data[tier];
+		item.database_pinned[2 + tier] = reinterpret_cast<uint8_t*>(db.pinned_patches[tier]);
 	}
 	retire(context, std::move(item));
 	db = host_database();
@@ -361,9 +362,15 @@ namespace
 	aclhip_status take_arrived_chunks(aclhip_context* context, host_database& db, uint32_t tier_index, uint32_t first_chunk_index, uint32_t last_chunk_index,
 		const uint8_t* tier_bulk_data, hipStream_t hip_stream)
 	{
+		// Untrusted input, two phases: every chunk of the request is checked and its patches collected BEFORE anything of the database's
+		// state changes -- a request that fails half way leaves nothing parsed-but-not-uploaded behind (the kernel that applies the
+		// patches would read table entries nobody wrote) --, then the state is committed and the new patches are uploaded; what a failed
+		// copy left behind is uploaded by the next call (num_uploaded_patches).
 		const uint32_t bulk_size = db.info.bulk_data_size[tier_index];
-		const uint32_t first_new_patch = db.chunk_first_patch[tier_index][db.num_parsed_chunks[tier_index]];
-		uint32_t next_patch = first_new_patch;
+		uint32_t next_chunk = db.num_parsed_chunks[tier_index];
+		uint32_t next_patch = db.chunk_first_patch[tier_index][next_chunk];
+		std::vector<tier_patch> new_patches;
+		std::vector<uint32_t> new_chunk_ends;		// patches up to and including every newly parsed chunk
 		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)
 		{
 			const database_chunk_description& description = db.chunks[tier_index][chunk_index];
@@ -371,11 +378,10 @@ namespace
 			if (chunk.index != chunk_index || chunk.size != description.size
 				|| uint64_t(sizeof(database_chunk_header)) + uint64_t(chunk.num_segments) * sizeof(database_chunk_segment_header) > description.size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u arrived with an invalid header", chunk_index, tier_index + 1);
-			std::memcpy(db.pinned_bulk_data[tier_index] + description.offset, tier_bulk_data + description.offset, description.size);
-			if (chunk_index < db.num_parsed_chunks[tier_index])
-				continue;		// seen before (streamed out and back in): its patches are on the device already
-			if (chunk_index != db.num_parsed_chunks[tier_index])
-				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "chunk %u of tier %u arrived before chunk %u", chunk_index, tier_index + 1, db.num_parsed_chunks[tier_index]);
+			if (chunk_index < next_chunk)
+				continue;		// seen before (streamed out and back in): its patches are known
+			if (chunk_index != next_chunk)
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "chunk %u of tier %u arrived before chunk %u", chunk_index, tier_index + 1, next_chunk);
 
 			const database_chunk_segment_header* segments = reinterpret_cast<const database_chunk_segment_header*>(&chunk + 1);
 			if (uint64_t(next_patch) + chunk.num_segments > db.patch_capacity[tier_index])
@@ -389,17 +395,39 @@ namespace
 					if (bound.first == segments[i].segment_header_offset
 						&& uint64_t(segments[i].samples_offset) + (uint64_t(__builtin_popcount(segments[i].sample_indices)) * bound.second + 7) / 8 > bulk_size)
 						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u: keyframes lie outside of the bulk data", chunk_index, tier_index + 1);
-				const tier_patch patch = { segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset };
-				db.pinned_patches[tier_index][next_patch++] = patch;
-				db.patches_by_header[tier_index].insert(std::upper_bound(db.patches_by_header[tier_index].begin(), db.patches_by_header[tier_index].end(), patch,
-					[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; }), patch);
+				new_patches.push_back({ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
 			}
-			db.num_parsed_chunks[tier_index] = chunk_index + 1;
-			db.chunk_first_patch[tier_index][chunk_index + 1] = next_patch;
+			next_patch += chunk.num_segments;
+			next_chunk = chunk_index + 1;
+			new_chunk_ends.push_back(next_patch);
 		}
-		if (next_patch != first_new_patch)
-			ACLHIP_CHECK_HIP(context, hipMemcpyAsync(db.d_patches[tier_index] + first_new_patch, db.pinned_patches[tier_index] + first_new_patch,
-				size_t(next_patch - first_new_patch) * sizeof(tier_patch), hipMemcpyHostToDevice, hip_stream));
+
+		// commit: bytes into the backing store, patches into the mirror and the lookup, chunk bookkeeping
+		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)
+		{
+			const database_chunk_description& description = db.chunks[tier_index][chunk_index];
+			std::memcpy(db.pinned_bulk_data[tier_index] + description.offset, tier_bulk_data + description.offset, description.size);
+		}
+		const uint32_t first_new_patch = db.chunk_first_patch[tier_index][db.num_parsed_chunks[tier_index]];
+		for (size_t i = 0; i < new_patches.size(); ++i)
+		{
+			const tier_patch& patch = new_patches[i];
+			db.pinned_patches[tier_index][first_new_patch + i] = patch;
+			db.patches_by_header[tier_index].insert(std::upper_bound(db.patches_by_header[tier_index].begin(), db.patches_by_header[tier_index].end(), patch,
+				[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; }), patch);
+		}
+		for (uint32_t end : new_chunk_ends)
+			db.chunk_first_patch[tier_index][++db.num_parsed_chunks[tier_index]] = end;
+
+		// upload whatever of the parsed chunks' patches is not on the device yet (this request's, and what an earlier failed copy left)
+		const uint32_t parsed_patches = db.chunk_first_patch[tier_index][db.num_parsed_chunks[tier_index]];
+		if (parsed_patches != db.num_uploaded_patches[tier_index])
+		{
+			const uint32_t first_pending = db.num_uploaded_patches[tier_index];
+			ACLHIP_CHECK_HIP(context, hipMemcpyAsync(db.d_patches[tier_index] + first_pending, db.pinned_patches[tier_index] + first_pending,
+				size_t(parsed_patches - first_pending) * sizeof(tier_patch), hipMemcpyHostToDevice, hip_stream));
+			db.num_uploaded_patches[tier_index] = parsed_patches;
+		}
 		return ACLHIP_OK;
 	}
 

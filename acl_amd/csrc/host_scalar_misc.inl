@@ -359,6 +359,33 @@ extern "C" aclhip_status aclhip_push_poses_to_peer(aclhip_context* context, void
 	return ACLHIP_OK;
 }
 
+extern "C" aclhip_status aclhip_forget_stream(aclhip_context* context, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	device_guard guard(context->device);
+	// (outside the lock: other threads keep registering and launching while this stream drains)
+	ACLHIP_CHECK_HIP(context, hipStreamSynchronize(hip_stream));
+	std::lock_guard<std::mutex> lock(context->mutex);
+	for (size_t i = 0; i < context->launch_streams.size(); ++i)
+		if (context->launch_streams[i] == hip_stream)
+		{
+			context->launch_streams.erase(context->launch_streams.begin() + ptrdiff_t(i));
+			break;
+		}
+	for (size_t i = 0; i < context->order_scratches.size(); ++i)
+		if (context->order_scratches[i].stream == hip_stream)
+		{
+			if (context->order_scratches[i].bins != nullptr)
+				(void)hipFree(context->order_scratches[i].bins);		// the stream is idle: nothing uses its scratch
+			context->order_scratches.erase(context->order_scratches.begin() + ptrdiff_t(i));
+			break;
+		}
+	collect_retired(context, false);
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_get_lifetime_stats(aclhip_context* context, uint64_t* out_stats)
 {
 	if (context == nullptr || out_stats == nullptr)

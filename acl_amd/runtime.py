@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
+    "aclhip_forget_stream",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
@@ -317,6 +318,10 @@ class Context:
 
     def unregister_clip(self, clip):
         self._check(self._lib.aclhip_unregister_clip(self._handle, clip))
+
+    def forget_stream(self, stream):
+        """aclhip_forget_stream: before destroying a stream the context has launched on"""
+        self._check(self._lib.aclhip_forget_stream(self._handle, ctypes.c_void_p(stream)))
 
     def clip_info(self, clip):
         info = ClipInfo()

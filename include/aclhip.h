@@ -164,11 +164,18 @@ void aclhip_default_params(aclhip_decompress_params* out_params);
 aclhip_status aclhip_register_clip(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_clip* out_clip);
 
 /* Replaces decompression_context::reset() / the end of the blob's lifetime. Like every call that registers, replaces or retires
- * something (clips, hierarchies, databases) it never synchronizes the device: the clip's record is cleared at once -- launches made
- * from here on refuse the handle -- and its memory and its handle are recycled when everything that was enqueued before the call,
- * on any stream this context has launched on, has completed. The caller's side of the contract is the reference's: do not decode a
+ * something (clips, hierarchies, databases) it never synchronizes the device and nobody waits: decodes that were ENQUEUED before the
+ * call, on any stream this context has launched on, still decode the clip (its record in the device table is cleared behind them, on
+ * a stream of the context's own); launches that execute later refuse the handle (counted, poses untouched); the clip's memory and its
+ * handle are recycled when both have happened. The caller's side of the contract is the reference's: do not enqueue a decode of a
  * clip after its unregistration. */
 aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_clip clip);
+
+/* The context remembers every stream it has launched on (retired clips, hierarchies and databases wait for the work enqueued on
+ * them). Call this BEFORE destroying a stream the context has launched on: it waits for that stream's work (hipStreamSynchronize)
+ * and forgets the stream. A destroyed stream the context still remembers is detected when its next event cannot be recorded, but
+ * using a stale handle is undefined behaviour by HIP's rules -- this call is the defined way. */
+aclhip_status aclhip_forget_stream(aclhip_context* context, void* stream);
 
 /* Counters of the stream ordered lifetime management, for tests and tools: out_stats[0] clips registered, [1] clips unregistered,
  * [2] retired items whose memory has been recycled, [3] retired items still waiting for work in flight, [4] capacity of the clip

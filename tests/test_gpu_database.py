@@ -174,3 +174,51 @@ def test_stream_in_is_ordered_with_decodes_on_the_same_stream(context):
         for i in range(0, times.size, 17):
             assert helpers.bit_equal(actual[i], oracle_db.decompress_tracks(blob, float(times[i])))
     _release(context, database, clips)
+
+
+def test_a_streamed_request_that_fails_half_way_leaves_nothing_behind():
+    """Caller-supplied streamers hand over bulk data that arrives from outside: untrusted. A request whose LATER chunk is corrupt
+    must leave no chunk parsed-but-not-uploaded (the patches of the chunks in front of it would never reach the device, and the
+    kernel that applies them would read table entries nobody wrote): all of a request's chunks are checked before any state changes,
+    and the same request with good data then streams everything in."""
+    name = "three_clips_4k_chunks"
+    case = helpers.load_database_golden(name)
+    with runtime.Context(0) as context:
+        database = context.register_database_streamed(case["database"])
+        clips = [context.register_clip_with_database(clip, database) for clip in case["clips"]]
+        info = context.database_info(database)
+        oracle_db = OracleDatabase(case["database"], case["bulk_medium"], case["bulk_low"])
+        num_times = case["times"].shape[1]
+        handles = np.repeat(np.array(clips, dtype=np.uint32), num_times)
+        times = case["times"].reshape(-1)
+        max_tracks = case["poses"].shape[4]
+
+        def check():
+            poses = context.decompress_tracks(handles, times, num_tracks=max_tracks)
+            for c, clip in enumerate(case["clips"]):
+                num_tracks = ob.oracle().aclo_num_tracks(clip.ctypes.data)
+                for t in range(num_times):
+                    expected = oracle_db.decompress_tracks(clip, float(case["times"][c, t]))
+                    assert helpers.bit_equal(poses[c * num_times + t, :num_tracks], expected), (c, t)
+
+        for tier, bulk in ((runtime.TIER_MEDIUM_IMPORTANCE, case["bulk_medium"]), (runtime.TIER_LOWEST_IMPORTANCE, case["bulk_low"])):
+            num_chunks = int(info.num_chunks[tier - 1])
+            if num_chunks < 2 or bulk.size == 0:
+                continue
+            # the LAST chunk's header lies about its index: the request for all chunks must fail as a whole
+            corrupt = synth.aligned_bytes(bulk.size)
+            corrupt[:] = bulk
+            offsets = [int(offset) for offset in oracle_db.chunks[tier][:, 1]]
+            corrupt[offsets[-1]: offsets[-1] + 4] = np.frombuffer(np.uint32(0xDEAD).tobytes(), dtype=np.uint8)
+            with pytest.raises(runtime.AclHipError):
+                context.database_stream_in_from(database, tier, corrupt)
+            check()                                                    # nothing became resident
+            good = synth.aligned_bytes(bulk.size)
+            good[:] = bulk
+            assert context.database_stream_in_from(database, tier, good) == num_chunks
+            oracle_db.stream_in(tier, num_chunks)
+            check()
+        assert context.rejected_instance_count() == 0
+        for clip in clips:
+            context.unregister_clip(clip)
+        context.unregister_database(database)

@@ -150,3 +150,46 @@ def test_replacing_a_hierarchy_under_launches_in_flight():
             assert helpers.exact(poses[i], ob.oracle_local_to_object_space(hierarchies[1], local[i]))
         assert context.rejected_instance_count() == 0
         context.unregister_clip(handle)
+
+
+def test_decodes_enqueued_before_an_unregistration_still_decode_the_clip():
+    """A kernel reads the clip table when it EXECUTES. aclhip_unregister_clip therefore clears the clip's record behind the launches
+    already enqueued (round 2 cleared it at once: a decode that had not started yet skipped the clip's instances). A long chain of
+    launches keeps the stream busy, the clip is unregistered while most of them have not run, every pose of every launch is checked."""
+    rng = np.random.default_rng(12)
+    clip = synth.build_clip(seed=801, num_tracks=100, num_samples=120)
+    filler = synth.build_clip(seed=802, num_tracks=300, num_samples=60, has_scale=1)
+    device = torch.device("cuda", 0)
+    with runtime.Context(0) as context:
+        handle = context.register_clip(clip.blob)
+        filler_handle = context.register_clip(filler.blob)
+        n, launches = 4096, 24
+        times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+        expected = ob.oracle_decompress_tracks_batch([clip.blob], np.zeros(n, dtype=np.uint32), times, 100)
+        stream = torch.cuda.Stream(device)
+        d_clips = torch.full((n,), handle, dtype=torch.int32, device=device)
+        d_times = torch.from_numpy(times).to(device)
+        d_filler_clips = torch.full((65536,), filler_handle, dtype=torch.int32, device=device)
+        d_filler_times = torch.zeros((65536,), dtype=torch.float32, device=device)
+        d_filler_poses = torch.empty((65536, 300, 12), dtype=torch.float32, device=device)
+        d_poses = torch.full((launches, n, 300, 12), -7.0, dtype=torch.float32, device=device)      # (rows of the largest registered pose)
+        torch.cuda.synchronize(device)
+        for k in range(launches):
+            # ~0.2 ms of other work in front of every decode of the clip: the stream is far behind the host by the end of the loop
+            context.decompress_tracks_batch(d_filler_clips.data_ptr(), d_filler_times.data_ptr(), 65536, d_filler_poses.data_ptr(), 300 * 48, stream=stream.cuda_stream)
+            context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses[k].data_ptr(), 300 * 48, stream=stream.cuda_stream)
+        context.unregister_clip(handle)                     # returns at once: nothing waits for the stream
+        still_running = not stream.query()
+        stream.synchronize()
+        poses = d_poses.cpu().numpy()
+        for k in range(launches):
+            assert helpers.bit_equal(poses[k, :, :100], expected), k
+        assert context.rejected_instance_count() == 0
+        assert still_running, "the stream had drained before the unregistration: the test did not exercise the ordering"
+        # the handle is refused by launches made once the clear has happened
+        context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses[0].data_ptr(), 300 * 48, stream=stream.cuda_stream)
+        stream.synchronize()
+        assert context.rejected_instance_count() == n
+        context.forget_stream(stream.cuda_stream)
+        assert context.lifetime_stats()["launch_streams"] == 0
+        context.unregister_clip(filler_handle)
