@@ -7,6 +7,7 @@
 #include "acl_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------------
@@ -1117,6 +1118,21 @@ int aclo_scalar_decompress_track(const void* blob, float sample_time, int roundi
 	return decode_scalar_tracks(blob, sample_time, rounding_policy, options, (int)track_index, out_value - (size_t)track_index * num_components);
 }
 
+/* decompress_tracks of a scalar track list for every instance of a batch (full-size GPU batches are compared instance by instance);
+ * instance i's values go to out + i * row_stride_floats, num_tracks * C floats */
+int aclo_scalar_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, float* out, uint64_t row_stride_floats)
+{
+	uint32_t i;
+	for (i = 0; i < count; ++i)
+	{
+		const int result = aclo_scalar_decompress_tracks(blobs[clip_indices[i]], sample_times[i], rounding_policy, options, out + (uint64_t)i * row_stride_floats);
+		if (result != 0)
+			return result;
+	}
+	return 0;
+}
+
 uint32_t aclo_selftest_pack_vector3_uXX(uint32_t first_num_bits, uint32_t last_num_bits)
 {
 	static const uint32_t offsets[] = { 0, 1, 5, 31, 32, 33, 63, 64, 65, 93 };
@@ -1384,6 +1400,42 @@ void aclo_local_to_object_space(const uint32_t* parent_indices, const float* loc
 		result[11] = 0.0f;
 		memcpy(out_object_pose + (uint64_t)i * 12, result, sizeof(result));
 	}
+}
+
+/* The consumers' pipeline for a batch, so that full-size GPU batches are compared instance by instance (the reference validates every
+ * sample: tools/acl_compressor/sources/validate_tracks.cpp:92-260): decompress_tracks of (blobs[clip_indices[i]], sample_times[i]);
+ * with an additive format, decompress_tracks of its base (blobs[base_clip_indices[i]], base_sample_times[i]) and
+ * apply_additive_to_base; with parent_indices, local_to_object_space. All clips of one call have num_transforms tracks. */
+int aclo_decompress_poses_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, int additive_format, const uint32_t* base_clip_indices, const float* base_sample_times,
+	const uint32_t* parent_indices, uint32_t num_transforms, float* out, uint64_t pose_stride_floats)
+{
+	uint32_t i;
+	float* base_pose = additive_format != 0 ? (float*)malloc((size_t)num_transforms * 12 * sizeof(float)) : NULL;
+	int result = 0;
+	if (additive_format != 0 && base_pose == NULL)
+		return -1;
+	for (i = 0; i < count && result == 0; ++i)
+	{
+		float* pose = out + (uint64_t)i * pose_stride_floats;
+		if (aclo_num_tracks(blobs[clip_indices[i]]) != num_transforms)
+			result = -2;
+		if (result == 0)
+			result = aclo_decompress_tracks(blobs[clip_indices[i]], sample_times[i], rounding_policy, options, pose);
+		if (result == 0 && additive_format != 0)
+		{
+			if (aclo_num_tracks(blobs[base_clip_indices[i]]) != num_transforms)
+				result = -2;
+			else
+				result = aclo_decompress_tracks(blobs[base_clip_indices[i]], base_sample_times[i], rounding_policy, options, base_pose);
+			if (result == 0)
+				aclo_apply_additive_to_base(additive_format, base_pose, pose, num_transforms, pose);
+		}
+		if (result == 0 && parent_indices != NULL)
+			aclo_local_to_object_space(parent_indices, pose, num_transforms, pose);
+	}
+	free(base_pose);
+	return result;
 }
 
 /* ---- small utilities the reference's unit tests pin (tests/sources/core/test_time_utils.cpp, test_bit_manip_utils.cpp,

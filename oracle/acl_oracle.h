@@ -120,6 +120,8 @@ int aclo_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_
 uint32_t aclo_scalar_num_components(const void* blob);
 int aclo_scalar_decompress_tracks(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, float* out);
 int aclo_scalar_decompress_track(const void* blob, float sample_time, int rounding_policy, const aclo_options* options, uint32_t track_index, float* out_value);
+int aclo_scalar_decompress_tracks_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, float* out, uint64_t row_stride_floats);
 
 /* Small utilities pinned by the reference's unit tests (tests/sources/core/test_time_utils.cpp:35-57, test_bit_manip_utils.cpp:31-60,
  * tests/sources/math/test_scalar_packing.cpp:44-140); see tests/test_oracle_kats.py */
@@ -143,6 +145,9 @@ void aclo_quat_mul(const float lhs[4], const float rhs[4], float out[4]);
 void aclo_qvv_mul(const float lhs[12], const float rhs[12], float out[12]);
 void aclo_apply_additive_to_base(int additive_format, const float* base_pose, const float* additive_pose, uint32_t num_transforms, float* out_pose);
 void aclo_local_to_object_space(const uint32_t* parent_indices, const float* local_pose, uint32_t num_transforms, float* out_object_pose);
+int aclo_decompress_poses_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, int additive_format, const uint32_t* base_clip_indices, const float* base_sample_times,
+	const uint32_t* parent_indices, uint32_t num_transforms, float* out, uint64_t pose_stride_floats);
 
 #ifdef __cplusplus
 }

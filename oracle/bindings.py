@@ -212,6 +212,76 @@ def oracle_decompress_tracks_batch(blobs, clip_indices, sample_times, max_tracks
     return out
 
 
+def _host_threads(threads):
+    import os
+    if threads is not None:
+        return threads
+    return max(1, min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+
+
+def oracle_decompress_poses_batch(blobs, clip_indices, sample_times, num_transforms, additive_format=0, base_clip_indices=None, base_sample_times=None,
+                                  parent_indices=None, rounding=ROUND_NONE, options=None, threads=None):
+    """decode -> apply_additive_to_base -> local_to_object_space for EVERY instance (aclo_decompress_poses_batch), split over host
+    threads. Returns [count, num_transforms, 12] float32."""
+    import concurrent.futures
+    lib = oracle()
+    lib.aclo_decompress_poses_batch.restype = ctypes.c_int
+    count = int(len(clip_indices))
+    indices = np.ascontiguousarray(clip_indices, dtype=np.uint32)
+    times = np.ascontiguousarray(sample_times, dtype=np.float32)
+    base_indices = np.ascontiguousarray(base_clip_indices if base_clip_indices is not None else np.zeros(count), dtype=np.uint32)
+    base_times = np.ascontiguousarray(base_sample_times if base_sample_times is not None else np.zeros(count), dtype=np.float32)
+    parents = None if parent_indices is None else np.ascontiguousarray(parent_indices, dtype=np.uint32)
+    out = np.zeros((count, num_transforms, 12), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    blob_ptrs = (ctypes.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    threads = _host_threads(threads)
+    piece = max(64, (count + threads - 1) // threads)
+
+    def run(first):
+        n = min(piece, count - first)
+        result = lib.aclo_decompress_poses_batch(blob_ptrs, ctypes.c_void_p(indices[first:].ctypes.data), ctypes.c_void_p(times[first:].ctypes.data), ctypes.c_uint32(n),
+                                                 ctypes.c_int(rounding), ctypes.byref(options), ctypes.c_int(int(additive_format)),
+                                                 ctypes.c_void_p(base_indices[first:].ctypes.data), ctypes.c_void_p(base_times[first:].ctypes.data),
+                                                 ctypes.c_void_p(parents.ctypes.data if parents is not None else None), ctypes.c_uint32(num_transforms),
+                                                 ctypes.c_void_p(out[first:].ctypes.data), ctypes.c_uint64(num_transforms * 12))
+        if result != 0:
+            raise RuntimeError(f"aclo_decompress_poses_batch failed: {result}")
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(run, range(0, count, piece)))
+    return out
+
+
+def oracle_scalar_decompress_tracks_batch(blobs, clip_indices, sample_times, row_floats, rounding=ROUND_NONE, options=None, threads=None):
+    """scalar decompress_tracks for EVERY instance (aclo_scalar_decompress_tracks_batch), split over host threads. Returns
+    [count, row_floats] float32 (num_tracks * C values per instance, the rest of a row zero)."""
+    import concurrent.futures
+    lib = oracle()
+    lib.aclo_scalar_decompress_tracks_batch.restype = ctypes.c_int
+    count = int(len(clip_indices))
+    indices = np.ascontiguousarray(clip_indices, dtype=np.uint32)
+    times = np.ascontiguousarray(sample_times, dtype=np.float32)
+    out = np.zeros((count, row_floats), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    blob_ptrs = (ctypes.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    threads = _host_threads(threads)
+    piece = max(64, (count + threads - 1) // threads)
+
+    def run(first):
+        n = min(piece, count - first)
+        result = lib.aclo_scalar_decompress_tracks_batch(blob_ptrs, ctypes.c_void_p(indices[first:].ctypes.data), ctypes.c_void_p(times[first:].ctypes.data), ctypes.c_uint32(n),
+                                                         ctypes.c_int(rounding), ctypes.byref(options), ctypes.c_void_p(out[first:].ctypes.data), ctypes.c_uint64(row_floats))
+        if result != 0:
+            raise RuntimeError(f"aclo_scalar_decompress_tracks_batch failed: {result}")
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(run, range(0, count, piece)))
+    return out
+
+
 def oracle_decompress_track(blob, sample_time, track_index, rounding=ROUND_NONE, options=None):
     lib = oracle()
     out = np.zeros(12, dtype=np.float32)

@@ -316,9 +316,9 @@ def test_pose_too_large_for_lds():
 
 
 def test_full_size_batch_properties(context):
-    """65 536 instances (BASELINE's batch): the fused kernel equals decode + host-side consumers on a sample of instances, and an
-    identity additive (additive0 with an identity pose buffer as the ADDITIVE side is not expressible; instead: relative onto an
-    identity base) leaves the decode untouched apart from the multiplication by one."""
+    """65 536 instances (BASELINE's batch): EVERY instance of the fused kernel against the oracle's decode -> additive -> object space
+    pipeline (aclo_decompress_poses_batch on all host threads), for object space alone and for additive1 onto a base clip instance +
+    object space -- the two pose consumer workloads bench.py times."""
     import torch
     clip = synth.build_clip(seed=7, num_tracks=100, num_samples=301)
     handle = context.register_clip(clip.blob)
@@ -335,12 +335,28 @@ def test_full_size_batch_properties(context):
     torch.cuda.synchronize()
     got = poses.cpu().numpy()
     host_times = times.cpu().numpy()
-    for i in rng.integers(0, n, size=64):
-        local = ob.oracle_decompress_tracks(clip.blob, float(host_times[i]))
-        assert helpers.exact(got[i], ob.oracle_local_to_object_space(parents, local))
+    expected = ob.oracle_decompress_poses_batch([clip.blob], np.zeros(n, dtype=np.uint32), host_times, 100, parent_indices=parents)
+    assert helpers.bit_equal(got, expected)
     # object space rotations stay normalized, whatever the depth
     lengths = np.linalg.norm(got[:, :, 0:4], axis=2)
     assert np.abs(lengths - 1.0).max() < 1.0e-5
+
+    # additive1 onto a base clip instance decoded by the instance's own wave, then object space: every instance again
+    additive = synth.build_clip(seed=12, num_tracks=100, num_samples=121, rotation_constant=0.5, translation_constant=0.8)
+    additive_handle = context.register_clip(additive.blob)
+    context.set_clip_hierarchy(additive_handle, parents)
+    additive_times = rng.uniform(0.0, additive.duration, size=n).astype(np.float32)
+    consumers.additive_format = runtime.ADDITIVE_ADDITIVE1
+    consumers.base_clips = handles.data_ptr()
+    consumers.base_sample_times = times.data_ptr()
+    d_additive_clips = torch.full((n,), additive_handle, dtype=torch.int32).cuda()
+    d_additive_times = torch.from_numpy(additive_times).cuda()
+    context.decompress_poses_batch(d_additive_clips.data_ptr(), d_additive_times.data_ptr(), n, poses.data_ptr(), 4800, consumers)
+    torch.cuda.synchronize()
+    expected = ob.oracle_decompress_poses_batch([clip.blob, additive.blob], np.ones(n, dtype=np.uint32), additive_times, 100, additive_format=runtime.ADDITIVE_ADDITIVE1,
+                                                base_clip_indices=np.zeros(n, dtype=np.uint32), base_sample_times=host_times, parent_indices=parents)
+    assert helpers.bit_equal(poses.cpu().numpy(), expected)
+    context.unregister_clip(additive_handle)
     context.unregister_clip(handle)
     assert context.rejected_instance_count() >= 0
 
