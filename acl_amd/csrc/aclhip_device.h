@@ -43,6 +43,20 @@ namespace aclhip
 		uint32_t segment_and_local;		// segment index << 5 | index of the sample inside its segment (a segment holds at most 32 samples)
 	};
 
+	// Clips bound to a compressed_database keep 32 bytes per sample: the record above and a COPY of the runtime tier metadata of the
+	// sample's segment -- (samples_offset << 32) | sample_indices for the medium and the lowest importance tier, 0 while a tier is not
+	// resident (database_runtime_segment_header, core/impl/compressed_headers.h:420-439). The seek then needs what it needs for any clip:
+	// one scalar load per key (round 2 read the runtime header itself, whose address is only known once the sample record has arrived:
+	// a fourth dependent load, 3.0 instead of 1.8 us of seek). refresh_database_sample_tiers_kernel rewrites the copies behind every
+	// stream_in / stream_out, stream ordered; each word is written and read whole, so a decode racing on another stream sees the old or
+	// the new state of a tier like the reference's relaxed atomics do (database.impl.h:616-618).
+	struct alignas(32) database_sample_record
+	{
+		sample_record record;
+		uint64_t tier_metadata[2];
+	};
+	static_assert(sizeof(database_sample_record) == 32, "layout");
+
 	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
 	// how to expand them, ready to use. Widths: 1..23 = quantized, 0 = constant in the segment (the 16 bit sample is pre-converted into
 	// range_min, range_extent = 0, nothing is read), 32 = raw fp32 (ranges ignored).
@@ -121,7 +135,7 @@ namespace aclhip
 	{
 		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
-		const sample_record* samples;			// [num_samples]
+		const sample_record* samples;			// [num_samples]; database_sample_record[num_samples] for clips bound to a database (k_clip_database_samples)
 		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
 		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
 		const clip_range_entry* clip_ranges;	// [num_animated]; scalar clips: float[num_tracks][2 * C] range rows
@@ -150,6 +164,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_has_raw = 1u << 4;				// some (segment, sub-track) uses the raw bit rate
 	constexpr uint32_t k_clip_is_scalar = 1u << 5;				// scalar track list: only the scalar kernel accepts it
 	constexpr uint32_t k_clip_scaled = 1u << 6;					// scale sub-tracks, or a default scale other than 1: some scale of a pose may differ from 1
+	constexpr uint32_t k_clip_database_samples = 1u << 7;		// bound to a database: `samples` holds database_sample_record (tier metadata copied per sample)
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
@@ -268,6 +283,15 @@ namespace aclhip
 		return record;
 	}
 
+	typedef uint32_t u32x8_record __attribute__((ext_vector_type(8)));
+	__device__ __forceinline__ database_sample_record load_database_sample_record(const sample_record* table, uint32_t index)
+	{
+		const u32x8_record raw = ((const ACLHIP_CONSTANT u32x8_record*)table)[index];
+		database_sample_record record;
+		__builtin_memcpy(&record, &raw, sizeof(record));
+		return record;
+	}
+
 	// core/impl/interpolation_utils.impl.h:261-278
 	__device__ __forceinline__ float apply_rounding_policy(float alpha, uint32_t policy)
 	{
@@ -327,8 +351,24 @@ namespace aclhip
 		find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_time, rounding_policy, looping_policy,
 			key_frame0, key_frame1, alpha);
 
-		const sample_record segment0 = load_sample_record(clip.samples, key_frame0);
-		const sample_record segment1 = load_sample_record(clip.samples, key_frame1);
+		// one scalar load per key: the sample's record, and for clips bound to a database the tier metadata of its segment with it
+		const bool has_database = (clip.flags & k_clip_database_samples) != 0;
+		sample_record segment0, segment1;
+		uint64_t medium0 = 0, medium1 = 0, low0 = 0, low1 = 0;
+		if (has_database)
+		{
+			const database_sample_record record0 = load_database_sample_record(clip.samples, key_frame0);
+			const database_sample_record record1 = load_database_sample_record(clip.samples, key_frame1);
+			segment0 = record0.record;
+			segment1 = record1.record;
+			medium0 = record0.tier_metadata[0]; low0 = record0.tier_metadata[1];
+			medium1 = record1.tier_metadata[0]; low1 = record1.tier_metadata[1];
+		}
+		else
+		{
+			segment0 = load_sample_record(clip.samples, key_frame0);
+			segment1 = load_sample_record(clip.samples, key_frame1);
+		}
 		const uint32_t segment_index0 = segment0.segment_and_local >> 5;
 		const uint32_t segment_index1 = segment1.segment_and_local >> 5;
 
@@ -346,18 +386,8 @@ namespace aclhip
 			uint32_t sample_indices0 = segment0.sample_indices;
 			uint32_t sample_indices1 = segment1.sample_indices;
 			const float clip_sample_index = alpha + float(key_frame0);
-			const bool has_database = (clip.flags & k_clip_has_database) != 0 && clip.db_headers != nullptr;
-
-			uint64_t medium0 = 0, medium1 = 0, low0 = 0, low1 = 0;
 			if (has_database)
 			{
-				const uint8_t* db_segment_headers = clip.db_headers + clip.db_clip_header_offset + sizeof(database_runtime_clip_header);
-				const uint64_t* tiers0 = reinterpret_cast<const uint64_t*>(db_segment_headers + sizeof(database_runtime_segment_header) * segment_index0);
-				const uint64_t* tiers1 = reinterpret_cast<const uint64_t*>(db_segment_headers + sizeof(database_runtime_segment_header) * segment_index1);
-				medium0 = __hip_atomic_load(tiers0 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				low0 = __hip_atomic_load(tiers0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				medium1 = __hip_atomic_load(tiers1 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				low1 = __hip_atomic_load(tiers1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				sample_indices0 |= uint32_t(medium0) | uint32_t(low0);
 				sample_indices1 |= uint32_t(medium1) | uint32_t(low1);
 			}

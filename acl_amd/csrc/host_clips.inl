@@ -165,6 +165,36 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	return ACLHIP_OK;
 }
 
+namespace
+{
+	// The device copy of a database's list of bound clips (refresh_database_sample_tiers_kernel): rewritten whole, on the copy stream,
+	// the calling thread waits. A list that outgrows its buffer moves to a new one; the old one is retired behind the work in flight.
+	aclhip_status upload_bound_clips(aclhip_context* context, host_database& db)
+	{
+		if (db.bound_clips.size() > db.bound_clips_capacity)
+		{
+			const uint32_t capacity = std::max<uint32_t>(uint32_t(db.bound_clips.size()) * 2, 64);
+			uint32_t* grown = nullptr;
+			if (hipMalloc(reinterpret_cast<void**>(&grown), size_t(capacity) * sizeof(uint32_t)) != hipSuccess)
+				return fail(context, ACLHIP_ERROR_OUT_OF_MEMORY, "hipMalloc of a database's clip list failed");
+			if (db.d_bound_clips != nullptr)
+			{
+				aclhip_context::retired_item item;
+				item.device_memory = db.d_bound_clips;
+				retire(context, std::move(item));
+			}
+			db.d_bound_clips = grown;
+			db.bound_clips_capacity = capacity;
+		}
+		if (db.bound_clips.empty())
+			return ACLHIP_OK;
+		size_t staging_used = 0;
+		if (!stage_upload(context, db.d_bound_clips, db.bound_clips.data(), db.bound_clips.size() * sizeof(uint32_t), staging_used) || !finish_uploads(context))
+			return fail(context, ACLHIP_ERROR_DEVICE, "uploading a database's clip list failed");
+		return ACLHIP_OK;
+	}
+}
+
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
 	bool validate_only = false)
 {
@@ -561,7 +591,11 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(packed + 7, record + 8, 12);
 	}
 	const uint64_t samples_offset = (resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31);
-	const uint64_t plan_offset = (samples_offset + samples.size() * sizeof(sample_record) + 31) & ~uint64_t(31);		// 32 byte entries from here on
+	// clips bound to a database carry a copy of their segments' tier metadata per sample (database_sample_record; zero = not resident
+	// until refresh_database_sample_tiers_kernel has run for the clip, below)
+	const bool database_samples = database != ACLHIP_INVALID_HANDLE && num_tracks != 0 && header.has_database();
+	const size_t sample_record_size = database_samples ? sizeof(database_sample_record) : sizeof(sample_record);
+	const uint64_t plan_offset = (samples_offset + samples.size() * sample_record_size + 31) & ~uint64_t(31);		// 32 byte entries from here on
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
 #if defined(ACLHIP_EXPERIMENTS)
@@ -580,7 +614,11 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	if (num_quads != 0)
 		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
 	std::memcpy(staging.data() + resolved_qvv40_offset, resolved_qvv40.data(), resolved_qvv40.size() * sizeof(float));
-	std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
+	if (database_samples)
+		for (size_t sample = 0; sample < samples.size(); ++sample)
+			std::memcpy(staging.data() + samples_offset + sample * sizeof(database_sample_record), &samples[sample], sizeof(sample_record));		// (tier metadata: the staging bytes are zero)
+	else
+		std::memcpy(staging.data() + samples_offset, samples.data(), samples.size() * sizeof(sample_record));
 	std::memcpy(staging.data() + plan_offset, plan.data(), plan.size() * sizeof(plan_entry));
 	std::memcpy(staging.data() + clip_ranges_offset, clip_ranges.data(), clip_ranges.size() * sizeof(clip_range_entry));
 	std::memcpy(staging.data() + image_chunks_offset, image_chunks.data(), image_chunks.size() * sizeof(uint32_t));
@@ -704,6 +742,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.db_headers = db.d_runtime_headers;
 		record.db_bulk_data[0] = db.d_bulk_data[0];
 		record.db_bulk_data[1] = db.d_bulk_data[1];
+		record.flags |= k_clip_database_samples;
 	}
 
 	size_t staging_used = 0;
@@ -716,7 +755,36 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	}
 	context->clips_registered++;
 	if (database != ACLHIP_INVALID_HANDLE)
-		context->databases[database].num_bound_clips++;
+	{
+		// the database's list of bound clips grows by this one, and the clip's sample records get the tiers' current state: on the copy
+		// stream, BEHIND everything already enqueued on the streams this context launched on (a stream_in that has not executed yet
+		// must not be overtaken: its own refresh ran over a list without this clip). Binding a clip to a database is the one
+		// registration that waits for work in flight.
+		host_database& db = context->databases[database];
+		db.num_bound_clips++;
+		db.bound_clips.push_back(slot);
+		const aclhip_status list_status = upload_bound_clips(context, db);
+		bool refreshed = list_status == ACLHIP_OK && order_stream_behind_launches(context, context->copy_stream);
+		if (refreshed)
+		{
+			hipLaunchKernelGGL(refresh_database_sample_tiers_kernel, dim3(1), dim3(256), 0, context->copy_stream,
+				context->d_clips, context->d_clips_capacity, db.d_bound_clips + (db.bound_clips.size() - 1), 1u, db.d_runtime_headers);
+			refreshed = hipGetLastError() == hipSuccess && finish_uploads(context);
+		}
+		if (!refreshed)
+		{
+			db.bound_clips.pop_back();
+			db.num_bound_clips--;
+			device_clip cleared;
+			std::memset(&cleared, 0, sizeof(cleared));
+			size_t cleared_staging = 0;
+			(void)stage_upload(context, context->d_clips + slot, &cleared, sizeof(cleared), cleared_staging);
+			(void)finish_uploads(context);
+			free_clip_memory(context, d_memory);
+			context->free_slots.push_back(slot);
+			return list_status != ACLHIP_OK ? list_status : fail(context, ACLHIP_ERROR_DEVICE, "binding the clip to the database failed");
+		}
+	}
 
 	host_clip& entry = context->clips[slot];
 	entry.in_use = true;
@@ -817,6 +885,16 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	{
 		host_database& db = context->databases[bound_database];
 		db.num_bound_clips--;
+		// (the device copy of the list keeps the handle until the next bind: refreshes skip entries whose table record is no longer a
+		// clip of this database)
+		for (size_t i = 0; i < db.bound_clips.size(); ++i)
+			if (db.bound_clips[i] == clip)
+			{
+				db.bound_clips[i] = db.bound_clips.back();
+				db.bound_clips.pop_back();
+				break;
+			}
+		(void)upload_bound_clips(context, db);
 		// the clip's runtime segment headers no longer constrain chunks that arrive (streamed databases)
 		const uint32_t first = context->clips[clip].db_first_segment_header, count = context->clips[clip].db_num_segments;
 		for (uint32_t si = 0; si < count; ++si)

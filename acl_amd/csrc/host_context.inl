@@ -48,6 +48,10 @@ namespace
 		tier_patch* pinned_patches[2] = { nullptr, nullptr };	// host mirror of d_patches the uploads are made from
 		uint32_t patch_capacity[2] = { 0, 0 };
 		std::vector<std::pair<uint32_t, uint32_t>> segment_pose_bits;	// (runtime segment header offset, bits per keyframe) of the bound clips
+		// the clips bound to the database, for refresh_database_sample_tiers_kernel: host list and its device copy
+		std::vector<uint32_t> bound_clips;
+		uint32_t* d_bound_clips = nullptr;
+		uint32_t bound_clips_capacity = 0;
 	};
 }
 
@@ -418,6 +422,29 @@ namespace
 	bool finish_uploads(aclhip_context* context)
 	{
 		return hipStreamSynchronize(context->copy_stream) == hipSuccess;
+	}
+
+	// Makes `stream` wait for everything enqueued so far on the streams this context has launched on (events, no host wait)
+	bool order_stream_behind_launches(aclhip_context* context, hipStream_t stream)
+	{
+		for (size_t i = 0; i < context->launch_streams.size();)
+		{
+			hipEvent_t event = take_event(context);
+			if (event != nullptr && hipEventRecord(event, context->launch_streams[i]) == hipSuccess)
+			{
+				const bool waiting = hipStreamWaitEvent(stream, event, 0) == hipSuccess;
+				context->event_pool.push_back(event);		// (the wait holds its own reference to the recorded state)
+				if (!waiting)
+					return false;
+				++i;
+				continue;
+			}
+			(void)hipGetLastError();		// the caller destroyed this stream: its work is over
+			if (event != nullptr)
+				context->event_pool.push_back(event);
+			context->launch_streams.erase(context->launch_streams.begin() + ptrdiff_t(i));
+		}
+		return true;
 	}
 }
 
@@ -823,6 +850,7 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 			if (!db.in_use)
 				continue;
 			(void)hipFree(db.d_runtime_headers);
+			(void)hipFree(db.d_bound_clips);
 			for (int tier = 0; tier < 2; ++tier)
 			{
 				(void)hipFree(db.d_bulk_data[tier]);

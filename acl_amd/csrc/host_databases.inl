@@ -15,6 +15,7 @@ namespace
 	void release_database(host_database& db)
 	{
 		(void)hipFree(db.d_runtime_headers);
+		(void)hipFree(db.d_bound_clips);
 		for (int tier = 0; tier < 2; ++tier)
 		{
 			(void)hipFree(db.d_bulk_data[tier]);
@@ -337,6 +338,7 @@ extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, acl
 		item.database_pinned[tier] = db.pinned_bulk_data[tier];
 		item.database_pinned[2 + tier] = reinterpret_cast<uint8_t*>(db.pinned_patches[tier]);
 	}
+	item.database_memory[5] = reinterpret_cast<uint8_t*>(db.d_bound_clips);
 	retire(context, std::move(item));
 	db = host_database();
 	return ACLHIP_OK;
@@ -517,6 +519,13 @@ namespace
 			hipLaunchKernelGGL(apply_tier_metadata_kernel, dim3((num_patches + 255) / 256), dim3(256), 0, hip_stream,
 				db.d_runtime_headers, db.d_patches[tier_index], first_patch, num_patches, tier_index, stream_in ? 1u : 0u);
 			ACLHIP_CHECK_HIP(context, hipGetLastError());
+			// ... and into the sample records of the clips bound to the database, where the decode reads them (database_sample_record)
+			if (!db.bound_clips.empty())
+			{
+				hipLaunchKernelGGL(refresh_database_sample_tiers_kernel, dim3(uint32_t(db.bound_clips.size())), dim3(256), 0, hip_stream,
+					context->d_clips, context->d_clips_capacity, db.d_bound_clips, uint32_t(db.bound_clips.size()), db.d_runtime_headers);
+				ACLHIP_CHECK_HIP(context, hipGetLastError());
+			}
 		}
 
 		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)

@@ -35,6 +35,36 @@
 		__hip_atomic_store(metadata, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 
+	// Copies the runtime tier metadata of every segment into the sample records of the clips bound to the database
+	// (database_sample_record, aclhip_device.h): one workgroup per bound clip, threads <-> samples. Enqueued behind
+	// apply_tier_metadata_kernel by every stream_in / stream_out, and once for a clip when it is bound. `bound_clips` is the host's
+	// list as of some moment between the call and the execution: an entry is acted on only if its table record (read now) is a
+	// live clip bound to THIS database -- a handle that was unregistered or recycled in between is skipped.
+	__global__ __launch_bounds__(256) void refresh_database_sample_tiers_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ bound_clips, uint32_t num_bound_clips, const uint8_t* __restrict__ runtime_headers)
+	{
+		if (blockIdx.x >= num_bound_clips)
+			return;
+		const uint32_t clip_id = bound_clips[blockIdx.x];
+		if (clip_id >= num_clips)
+			return;
+		const device_clip clip = clips[clip_id];
+		if ((clip.flags & (k_clip_valid | k_clip_database_samples)) != (k_clip_valid | k_clip_database_samples) || clip.db_headers != runtime_headers)
+			return;
+		database_sample_record* samples = reinterpret_cast<database_sample_record*>(const_cast<sample_record*>(clip.samples));
+		const uint8_t* segment_headers = runtime_headers + clip.db_clip_header_offset + sizeof(database_runtime_clip_header);
+		for (uint32_t sample = threadIdx.x; sample < clip.num_samples; sample += blockDim.x)
+		{
+			const uint32_t segment = samples[sample].record.segment_and_local >> 5;
+			const unsigned long long* metadata = reinterpret_cast<const unsigned long long*>(segment_headers + sizeof(database_runtime_segment_header) * segment);
+			for (uint32_t tier = 0; tier < 2; ++tier)
+			{
+				const unsigned long long value = __hip_atomic_load(metadata + tier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(reinterpret_cast<unsigned long long*>(&samples[sample].tier_metadata[tier]), value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+
 	// Measurement aid: streams `num_quads` float4 to HBM, 16 bytes per lane, to find the write bandwidth a pose-shaped store
 	// stream can reach on this device (the decode kernel is a write streamer).
 	__global__ __launch_bounds__(k_block_size) void stream_write_kernel(float4* __restrict__ destination, uint64_t num_quads, float seed)
