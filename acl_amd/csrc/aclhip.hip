@@ -66,5 +66,6 @@ using namespace aclhip;
 #include "host_experiments.inl"
 #endif
 #include "host_launch.inl"
+#include "host_lists.inl"
 #include "host_consumers.inl"
 #include "host_scalar_misc.inl"

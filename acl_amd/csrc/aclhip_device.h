@@ -192,6 +192,7 @@ namespace aclhip
 		const uint8_t* track_rounding_policies;
 		const uint8_t* instance_rounding_policies;
 		const uint32_t* instance_rows;	// pose kernels: row of the pose buffer each instance writes, or null (row = instance index)
+		const uint32_t* time_indices;	// pose kernels: entry of sample_times each instance reads, or null (its own): instance lists kept in decode order
 		uint8_t rounding_policy;
 		uint8_t looping_policy;
 		uint8_t normalization;

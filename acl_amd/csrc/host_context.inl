@@ -113,9 +113,13 @@ struct aclhip_context
 	{
 		hipStream_t stream = nullptr;
 		uint32_t* bins = nullptr;
-		size_t capacity = 0;						// bins per half
+		size_t capacity = 0;						// words allocated
+		size_t zeroed_bins = 0;						// the counters | cursors layout (padded bins per half) the words were zeroed for; 0: not zeroed
 	};
 	std::vector<order_scratch> order_scratches;
+	// aclhip_instance_list_*: instance lists kept in decode order (host_lists.inl)
+	struct instance_list;
+	std::vector<instance_list> instance_lists;
 	uint64_t clips_registered = 0;					// statistics (aclhip_get_lifetime_stats)
 	uint64_t clips_unregistered = 0;
 	uint64_t deferred_frees_completed = 0;
@@ -715,6 +719,7 @@ namespace
 		out.track_rounding_policies = params->track_rounding_policies;
 		out.instance_rounding_policies = params->instance_rounding_policies;
 		out.instance_rows = nullptr;
+		out.time_indices = nullptr;
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;
 		out.items_per_wave = 1;
@@ -827,6 +832,8 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 	return ACLHIP_OK;
 }
 
+void free_instance_lists(aclhip_context* context);		// host_lists.inl
+
 extern "C" void aclhip_destroy(aclhip_context* context)
 {
 	if (context == nullptr)
@@ -835,6 +842,7 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 		device_guard guard(context->device);
 		(void)hipDeviceSynchronize();
 		collect_retired(context, true);
+		free_instance_lists(context);
 		for (hipEvent_t event : context->event_pool)
 			(void)hipEventDestroy(event);
 		if (context->pinned_staging != nullptr)

@@ -248,8 +248,24 @@ extern "C" aclhip_status aclhip_order_instances_for_pose_windows(uint32_t window
 // The same order computed on the device, stream ordered: count per clip, scan, scatter (three small kernels on `stream`, counters
 // kept per stream by the context). Which instance of a clip takes which of the clip's slots is decided by atomics: a valid order,
 // not a reproducible one.
+namespace
+{
+	aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+		uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, uint32_t* out_positions, void* stream_handle);
+}
+
+constexpr size_t order_control_words = 4;		// room behind the counters for the one launch experiment's control words
+
 extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream_handle)
+{
+	return order_instances_on_device(context, clips, sample_times, num_instances, out_order, out_clips, out_sample_times, nullptr, stream_handle);
+}
+
+namespace
+{
+aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, uint32_t* out_positions, void* stream_handle)
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
@@ -264,7 +280,6 @@ extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, 
 	device_guard guard(context->device);
 	std::lock_guard<std::mutex> lock(context->mutex);		// the scratch of a stream is handed to one call at a time, in stream order
 	const uint32_t num_bins = uint32_t(context->clips.size()) + 1;		// handles are slots of the registry; the last bin takes everything else
-	const size_t padded_bins = (size_t(num_bins) + 4095) / 4096 * 4096;
 	note_launch_stream(context, stream);
 	aclhip_context::order_scratch* scratch = nullptr;
 	for (aclhip_context::order_scratch& known : context->order_scratches)
@@ -276,8 +291,10 @@ extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, 
 		scratch = &context->order_scratches.back();
 		scratch->stream = stream;
 	}
-	if (scratch->capacity < padded_bins)
+	const auto reserve = [&](size_t words) -> aclhip_status
 	{
+		if (scratch->capacity >= words)
+			return ACLHIP_OK;
 		if (scratch->bins != nullptr)
 		{
 			aclhip_context::retired_item item;
@@ -286,19 +303,62 @@ extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, 
 			scratch->bins = nullptr;
 			scratch->capacity = 0;
 		}
-		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->bins), padded_bins * 2 * sizeof(uint32_t)));
-		scratch->capacity = padded_bins;
-		ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->bins, 0, padded_bins * sizeof(uint32_t), stream));		// once: the scan leaves the counters at zero
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->bins), words * sizeof(uint32_t)));
+		scratch->capacity = words;
+		scratch->zeroed_bins = 0;
+		return ACLHIP_OK;
+	};
+
+	// ACLHIP_ORDER_LAUNCHES=3 forces the older form (LDS hash tables + device scope atomics), what large clip tables take anyway
+	static const int forced_form = []() { const char* value = std::getenv("ACLHIP_ORDER_LAUNCHES"); return value != nullptr ? int(value[0] - '0') : 0; }();
+	if (num_bins <= k_order_direct_bins && forced_form == 0)
+	{
+		// per workgroup histograms as a [workgroup][bin] matrix: no device scope atomic, nothing to zero between calls
+		// (few, large workgroups: the matrix the middle kernel scans has workgroups x bins entries, and one workgroup scans it)
+		static const uint32_t instances_per_order_block = []() { const char* value = std::getenv("ACLHIP_ORDER_INSTANCES_PER_BLOCK"); return value != nullptr ? uint32_t(std::atol(value)) : 4096u; }();
+		const uint32_t num_blocks = std::min<uint32_t>((num_instances + instances_per_order_block - 1) / instances_per_order_block, std::max<uint32_t>(context->num_compute_units, 1));
+		const uint32_t instances_per_block = (num_instances + num_blocks - 1) / num_blocks;
+		const aclhip_status status = reserve(size_t(num_blocks) * num_bins);
+		if (status != ACLHIP_OK)
+			return status;
+		hipLaunchKernelGGL(order_histogram_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, num_instances, instances_per_block, num_bins, scratch->bins);
+		hipLaunchKernelGGL(order_offsets_kernel, dim3(1), dim3(k_order_direct_block_size), 0, stream, scratch->bins, num_blocks * num_bins);
+		hipLaunchKernelGGL(order_place_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block, num_bins,
+			scratch->bins, layout, out_order, out_clips, out_sample_times, out_positions);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+
+	const size_t padded_bins = (size_t(num_bins) + 4095) / 4096 * 4096;
+	{
+		const aclhip_status status = reserve(padded_bins * 2 + order_control_words);
+		if (status != ACLHIP_OK)
+			return status;
+	}
+	if (scratch->zeroed_bins != padded_bins)
+	{
+		ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->bins, 0, (padded_bins * 2 + order_control_words) * sizeof(uint32_t), stream));		// once: every call leaves the counters at zero
+		scratch->zeroed_bins = padded_bins;
 	}
 	uint32_t* counters = scratch->bins;
-	uint32_t* cursors = scratch->bins + scratch->capacity;
+	uint32_t* cursors = scratch->bins + padded_bins;
 
 	const uint32_t num_blocks = (num_instances + k_order_instances_per_block - 1) / k_order_instances_per_block;
+#if defined(ACLHIP_EXPERIMENTS)
+	if (forced_form == 1 && num_blocks <= context->num_compute_units)
+	{
+		hipLaunchKernelGGL(order_instances_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins,
+			counters, cursors, reinterpret_cast<order_control*>(scratch->bins + padded_bins * 2), layout, out_order, out_clips, out_sample_times, out_positions);
+		ACLHIP_CHECK_HIP(context, hipGetLastError());
+		return ACLHIP_OK;
+	}
+#endif
 	hipLaunchKernelGGL(order_count_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, num_instances, num_bins, counters);
 	hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counters, cursors, num_bins);
-	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times);
+	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times, out_positions);
 	ACLHIP_CHECK_HIP(context, hipGetLastError());
 	return ACLHIP_OK;
+}
 }
 
 extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,

@@ -1,0 +1,207 @@
+// host_lists.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
+// Host side: persistent instance lists (include/aclhip.h: aclhip_instance_list_*). The library owns the decode order of a list whose
+// clip assignment outlives a frame: ordered once (order_instances_on_device), patched in place when a few instances change clip
+// (update_instance_list_kernel), re-ordered before a decode once an eighth of it has changed.
+
+struct aclhip_context::instance_list
+{
+	bool in_use = false;
+	uint32_t num_instances = 0;
+	uint32_t* d_memory = nullptr;			// clips (instance order) | order (slot -> instance) | positions (instance -> slot) | ordered clips (slot order)
+	uint32_t changed_since_ordered = 0;		// instances whose clip changed since the list was last ordered
+	bool ordered = false;
+	uint64_t num_orderings = 0;
+
+	uint32_t* clips() const { return d_memory; }
+	uint32_t* order() const { return d_memory + num_instances; }
+	uint32_t* positions() const { return d_memory + size_t(num_instances) * 2; }
+	uint32_t* ordered_clips() const { return d_memory + size_t(num_instances) * 3; }
+};
+
+void free_instance_lists(aclhip_context* context)
+{
+	for (aclhip_context::instance_list& list : context->instance_lists)
+		if (list.in_use && list.d_memory != nullptr)
+			(void)hipFree(list.d_memory);
+	context->instance_lists.clear();
+}
+
+namespace
+{
+	aclhip_context::instance_list* find_list(aclhip_context* context, aclhip_instance_list list)
+	{
+		return list < context->instance_lists.size() && context->instance_lists[list].in_use ? &context->instance_lists[list] : nullptr;
+	}
+
+	aclhip_status order_list(aclhip_context* context, aclhip_context::instance_list& list, void* stream)
+	{
+		const aclhip_status status = order_instances_on_device(context, list.clips(), nullptr, list.num_instances, list.order(), list.ordered_clips(), nullptr, list.positions(), stream);
+		if (status == ACLHIP_OK)
+		{
+			list.ordered = true;
+			list.changed_since_ordered = 0;
+			list.num_orderings++;
+		}
+		return status;
+	}
+}
+
+extern "C" aclhip_status aclhip_instance_list_create(aclhip_context* context, uint32_t num_instances, aclhip_instance_list* out_list)
+{
+	if (context == nullptr || out_list == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	*out_list = ACLHIP_INVALID_HANDLE;
+	if (num_instances == 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an instance list holds at least one instance");
+	device_guard guard(context->device);
+	uint32_t* memory = nullptr;
+	ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&memory), size_t(num_instances) * 4 * sizeof(uint32_t)));
+
+	std::lock_guard<std::mutex> lock(context->mutex);
+	uint32_t slot = 0;
+	while (slot < context->instance_lists.size() && context->instance_lists[slot].in_use)
+		slot++;
+	if (slot == context->instance_lists.size())
+		context->instance_lists.emplace_back();
+	aclhip_context::instance_list& list = context->instance_lists[slot];
+	list = aclhip_context::instance_list();
+	list.in_use = true;
+	list.num_instances = num_instances;
+	list.d_memory = memory;
+	*out_list = slot;
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_instance_list_destroy(aclhip_context* context, aclhip_instance_list handle)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+	device_guard guard(context->device);
+	// decodes of the list may still be in flight: its memory is retired behind them
+	aclhip_context::retired_item item;
+	item.device_memory = list->d_memory;
+	retire(context, std::move(item));
+	*list = aclhip_context::instance_list();
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context, aclhip_instance_list handle, const aclhip_clip* clips, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (clips == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null clip list");
+	aclhip_context::instance_list snapshot;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		aclhip_context::instance_list* list = find_list(context, handle);
+		if (list == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+		snapshot = *list;
+	}
+	device_guard guard(context->device);
+	ACLHIP_CHECK_HIP(context, hipMemcpyAsync(snapshot.clips(), clips, size_t(snapshot.num_instances) * sizeof(uint32_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+	const aclhip_status status = order_list(context, snapshot, stream);		// (takes the context's lock itself)
+	if (status != ACLHIP_OK)
+		return status;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list != nullptr && list->d_memory == snapshot.d_memory)
+	{
+		list->ordered = true;
+		list->changed_since_ordered = 0;
+		list->num_orderings++;
+	}
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_instance_list_update(aclhip_context* context, aclhip_instance_list handle, const uint32_t* instances, const aclhip_clip* clips, uint32_t count, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (count == 0)
+		return ACLHIP_OK;
+	if (instances == nullptr || clips == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null update lists");
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+	if (!list->ordered)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_set_clips comes first");
+	device_guard guard(context->device);
+	note_launch_stream(context, static_cast<hipStream_t>(stream));
+	hipLaunchKernelGGL(update_instance_list_kernel, dim3((count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+		instances, clips, count, list->num_instances, list->clips(), list->positions(), list->ordered_clips());
+	ACLHIP_CHECK_HIP(context, hipGetLastError());
+	list->changed_since_ordered = uint32_t(std::min<uint64_t>(uint64_t(list->changed_since_ordered) + count, 0xFFFFFFFFull));
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, aclhip_instance_list handle, const float* sample_times, const aclhip_decompress_params* params,
+	const aclhip_output_desc* output, int poses_in_instance_order, void* poses, uint64_t pose_stride_bytes, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_context::instance_list snapshot;
+	bool reorder = false;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		aclhip_context::instance_list* list = find_list(context, handle);
+		if (list == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+		if (!list->ordered)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_set_clips comes first");
+		// enough of the list plays other clips than when it was ordered: order it again, in front of this decode
+		static const uint32_t reorder_divisor = []() { const char* value = std::getenv("ACLHIP_LIST_REORDER_DIVISOR"); return value != nullptr ? uint32_t(std::max(1L, std::atol(value))) : 8u; }();		// (measurement knob)
+		reorder = uint64_t(list->changed_since_ordered) * reorder_divisor >= list->num_instances;
+		if (reorder)
+		{
+			list->changed_since_ordered = 0;
+			list->num_orderings++;
+		}
+		snapshot = *list;
+	}
+	aclhip_status status = check_batch_arguments(context, snapshot.clips(), sample_times, snapshot.num_instances, poses, pose_stride_bytes);
+	if (status != ACLHIP_OK)
+		return status;
+	if (output != nullptr && output->rows != nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an instance list decides the rows itself (poses_in_instance_order)");
+
+	decode_params device_params;
+	status = resolve_params(context, params, device_params);
+	if (status == ACLHIP_OK)
+		status = apply_output_desc(context, output, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+	device_params.time_indices = snapshot.order();
+	device_params.instance_rows = poses_in_instance_order != 0 ? snapshot.order() : nullptr;
+
+	device_guard guard(context->device);
+	if (reorder)
+	{
+		status = order_instances_on_device(context, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
+		if (status != ACLHIP_OK)
+			return status;
+	}
+	return launch_tracks(context, snapshot.ordered_clips(), sample_times, snapshot.num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" aclhip_status aclhip_instance_list_get_order(aclhip_context* context, aclhip_instance_list handle, const uint32_t** out_order, uint64_t* out_num_orderings)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+	if (out_order != nullptr)
+		*out_order = list->order();
+	if (out_num_orderings != nullptr)
+		*out_num_orderings = list->num_orderings;
+	return ACLHIP_OK;
+}

@@ -772,4 +772,3 @@
 				store_streaming(&pose[r * k_wave_size], value);
 		}
 	}
-

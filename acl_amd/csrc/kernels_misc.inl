@@ -101,7 +101,10 @@
 
 	// Device scope atomics on a handful of addresses (one per clip) run at the memory fabric's pace, serialized per address: a
 	// workgroup first gathers its 2048 instances per clip in an LDS hash table (LDS atomics), then touches each of its clips' bins once.
-	constexpr uint32_t k_order_block_size = 1024;
+#if !defined(ACLHIP_ORDER_BLOCK_SIZE)
+	#define ACLHIP_ORDER_BLOCK_SIZE 1024
+#endif
+	constexpr uint32_t k_order_block_size = ACLHIP_ORDER_BLOCK_SIZE;
 	#if !defined(ACLHIP_ORDER_INSTANCES_PER_THREAD)
 #define ACLHIP_ORDER_INSTANCES_PER_THREAD 2
 #endif
@@ -199,7 +202,8 @@
 
 	// every instance takes the next position of its clip and lands in the slot that position maps to
 	__global__ __launch_bounds__(k_order_block_size) void order_scatter_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
-		uint32_t num_bins, uint32_t* __restrict__ bins, order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times)
+		uint32_t num_bins, uint32_t* __restrict__ bins, order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times,
+		uint32_t* __restrict__ out_positions)
 	{
 		__shared__ order_table table;
 		__shared__ order_layout layout;
@@ -234,5 +238,242 @@
 				out_clip_ids[destination] = clip_id[k];
 			if (out_sample_times != nullptr)
 				out_sample_times[destination] = sample_times[instance];
+			if (out_positions != nullptr)
+				out_positions[instance] = destination;
 		}
 	}
+
+	// ---- the same order without device scope atomics: per workgroup histograms laid out as a matrix ----
+	// (device scope atomics on a few hundred hot addresses are what the three kernels above spend their time on: 23 us for 64k
+	// instances.) While the clip table has at most k_order_direct_bins entries a workgroup counts its instances per clip in a directly
+	// indexed LDS histogram and writes its row of a [workgroup][bin] matrix; one workgroup turns the matrix into first positions, bin
+	// major (all of bin 0's workgroups, then bin 1's ...); every workgroup then places its instances from its own row. No global atomic,
+	// nothing to zero between calls.
+	constexpr uint32_t k_order_direct_bins = 8192;			// 32 KB of LDS
+	constexpr uint32_t k_order_direct_block_size = 1024;
+
+	__global__ __launch_bounds__(k_order_direct_block_size) void order_histogram_kernel(const uint32_t* __restrict__ clip_ids, uint32_t num_instances, uint32_t instances_per_block,
+		uint32_t num_bins, uint32_t* __restrict__ histograms)
+	{
+		__shared__ uint32_t histogram[k_order_direct_bins];
+		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
+			histogram[bin] = 0;
+		__syncthreads();
+		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
+		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
+			atomicAdd(&histogram[min(clip_ids[instance], num_bins - 1)], 1u);
+		__syncthreads();
+		// bin major: entry bin * gridDim + block (the order the positions are handed out in)
+		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
+			histograms[size_t(bin) * gridDim.x + blockIdx.x] = histogram[bin];
+	}
+
+	// histograms[bin][block] -> first position of (bin, block), in place: an exclusive scan over the matrix as it lies in memory. One
+	// workgroup, k_order_scan_per_thread consecutive entries per thread and pass (requested together, then summed)
+	constexpr uint32_t k_order_scan_per_thread = 16;
+
+	__global__ __launch_bounds__(k_order_direct_block_size) void order_offsets_kernel(uint32_t* __restrict__ histograms, uint32_t num_entries)
+	{
+		__shared__ uint32_t wave_totals[k_order_direct_block_size / k_wave_size];
+		__shared__ uint32_t carry;
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave = threadIdx.x / k_wave_size;
+		if (threadIdx.x == 0)
+			carry = 0;
+		__syncthreads();
+		for (uint32_t base = 0; base < num_entries; base += k_order_direct_block_size * k_order_scan_per_thread)
+		{
+			const uint32_t first = base + threadIdx.x * k_order_scan_per_thread;
+			uint32_t counts[k_order_scan_per_thread];
+			#pragma unroll
+			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
+				counts[k] = first + k < num_entries ? histograms[first + k] : 0u;
+			uint32_t sum = 0;
+			#pragma unroll
+			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
+				sum += counts[k];
+			uint32_t inclusive = sum;
+			for (uint32_t step = 1; step < k_wave_size; step *= 2)
+			{
+				const uint32_t below = __shfl_up(inclusive, step);
+				if (lane >= step)
+					inclusive += below;
+			}
+			if (lane == k_wave_size - 1)
+				wave_totals[wave] = inclusive;
+			__syncthreads();
+			uint32_t position = carry + inclusive - sum;
+			for (uint32_t w = 0; w < wave; ++w)
+				position += wave_totals[w];
+			#pragma unroll
+			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
+			{
+				if (first + k < num_entries)
+					histograms[first + k] = position;
+				position += counts[k];
+			}
+			__syncthreads();
+			if (threadIdx.x == k_order_direct_block_size - 1)
+				carry = position;
+			__syncthreads();
+		}
+	}
+
+	__global__ __launch_bounds__(k_order_direct_block_size) void order_place_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		uint32_t instances_per_block, uint32_t num_bins, const uint32_t* __restrict__ offsets, order_layout layout_argument,
+		uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times, uint32_t* __restrict__ out_positions)
+	{
+		__shared__ uint32_t cursors[k_order_direct_bins];
+		__shared__ order_layout layout;
+		if (threadIdx.x < sizeof(order_layout) / 4)
+			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
+		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
+			cursors[bin] = offsets[size_t(bin) * gridDim.x + blockIdx.x];
+		__syncthreads();
+		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
+		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
+		{
+			const uint32_t clip_id = clip_ids[instance];
+			const uint32_t destination = order_slot_of(layout, atomicAdd(&cursors[min(clip_id, num_bins - 1)], 1u));
+			out_order[destination] = instance;
+			if (out_clip_ids != nullptr)
+				out_clip_ids[destination] = clip_id;
+			if (out_sample_times != nullptr)
+				out_sample_times[destination] = sample_times[instance];
+			if (out_positions != nullptr)
+				out_positions[instance] = destination;
+		}
+	}
+
+	// Instance lists kept in decode order (aclhip_instance_list_update): instance instances[k] now plays clips[k]. It keeps its slot --
+	// a full re-order follows once enough of the list has changed (host_lists.inl) --, the clip handle the decode reads for that slot changes.
+	__global__ __launch_bounds__(256) void update_instance_list_kernel(const uint32_t* __restrict__ instances, const uint32_t* __restrict__ new_clips, uint32_t count,
+		uint32_t num_instances, uint32_t* __restrict__ list_clips, const uint32_t* __restrict__ positions, uint32_t* __restrict__ ordered_clips)
+	{
+		const uint32_t index = blockIdx.x * blockDim.x + threadIdx.x;
+		if (index >= count)
+			return;
+		const uint32_t instance = instances[index];
+		if (instance >= num_instances)
+			return;
+		list_clips[instance] = new_clips[index];
+		ordered_clips[positions[instance]] = new_clips[index];
+	}
+
+#if defined(ACLHIP_EXPERIMENTS)
+	// ---- aclhip_order_instances_device in ONE launch (ACLHIP_ORDER_LAUNCHES=1) -- measured 25.4 us against 23.5 us for the three launches it replaces ----
+	// The same order in ONE launch (three launches cost ~15 us before they do any work): every workgroup gathers its 2048 instances per
+	// clip in its LDS table and adds them to the clips' counters; the LAST workgroup to arrive turns the counters into cursors (and
+	// leaves them zeroed for the next call) and says so; everybody waits for that, then takes positions and scatters.
+	// All workgroups wait for one another: the host launches this form only while the grid fits the device (one workgroup per CU).
+	struct order_control
+	{
+		uint32_t arrived;		// workgroups that have added their counts (back to 0 when the last one has arrived)
+		uint32_t scanned;		// calls whose cursors are complete: every workgroup reads it when it starts and waits for the next value
+								// (nothing a captured hipGraph would have to change between replays)
+	};
+
+	__global__ __launch_bounds__(k_order_block_size) void order_instances_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		uint32_t num_bins, uint32_t* __restrict__ counters, uint32_t* __restrict__ cursors, order_control* __restrict__ control,
+		order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times,
+		uint32_t* __restrict__ out_positions)
+	{
+		__shared__ order_table table;
+		__shared__ order_layout layout;
+		__shared__ uint32_t wave_totals[k_order_block_size / k_wave_size];
+		__shared__ uint32_t carry, is_last, generation;
+		if (threadIdx.x == 0)
+			generation = __hip_atomic_load(&control->scanned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);		// (before this workgroup arrives: the scan cannot have happened yet)
+		if (threadIdx.x < sizeof(order_layout) / 4)
+			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
+		order_table_clear(table);
+
+		uint32_t clip_id[k_order_instances_per_thread], slot[k_order_instances_per_thread], rank[k_order_instances_per_thread];
+		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		{
+			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
+			if (instance < num_instances)
+			{
+				clip_id[k] = clip_ids[instance];
+				slot[k] = order_table_insert(table, min(clip_id[k], num_bins - 1), rank[k]);
+			}
+		}
+		__syncthreads();
+		for (uint32_t entry = threadIdx.x; entry < k_order_table_size; entry += k_order_block_size)
+			if (table.keys[entry] != k_order_empty_key)
+				__hip_atomic_fetch_add(&counters[table.keys[entry]], table.counts[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+
+		// the last workgroup to arrive scans
+		if (threadIdx.x == 0)
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			is_last = __hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+			carry = 0;
+		}
+		__syncthreads();
+		if (is_last != 0)
+		{
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+			const uint32_t wave = threadIdx.x / k_wave_size;
+			for (uint32_t base = 0; base < num_bins; base += k_order_block_size)
+			{
+				const uint32_t bin = base + threadIdx.x;
+				const uint32_t count = bin < num_bins ? __hip_atomic_exchange(&counters[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				uint32_t inclusive = count;
+				for (uint32_t step = 1; step < k_wave_size; step *= 2)
+				{
+					const uint32_t below = __shfl_up(inclusive, step);
+					if (lane >= step)
+						inclusive += below;
+				}
+				if (lane == k_wave_size - 1)
+					wave_totals[wave] = inclusive;
+				__syncthreads();
+				uint32_t first = carry + inclusive - count;
+				for (uint32_t w = 0; w < wave; ++w)
+					first += wave_totals[w];
+				if (bin < num_bins)
+					__hip_atomic_store(&cursors[bin], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__syncthreads();
+				if (threadIdx.x == k_order_block_size - 1)
+					carry = first + count;
+				__syncthreads();
+			}
+			if (threadIdx.x == 0)
+			{
+				__hip_atomic_store(&control->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+				__hip_atomic_store(&control->scanned, generation + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+		if (threadIdx.x == 0)
+		{
+			while (__hip_atomic_load(&control->scanned, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == generation)
+				__builtin_amdgcn_s_sleep(2);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		}
+		__syncthreads();
+
+		// the workgroup's instances of a clip take consecutive positions: counts[] becomes the first of them
+		for (uint32_t entry = threadIdx.x; entry < k_order_table_size; entry += k_order_block_size)
+			if (table.keys[entry] != k_order_empty_key)
+				table.counts[entry] = __hip_atomic_fetch_add(&cursors[table.keys[entry]], table.counts[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();
+		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		{
+			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
+			if (instance >= num_instances)
+				continue;
+			const uint32_t destination = order_slot_of(layout, table.counts[slot[k]] + rank[k]);
+			out_order[destination] = instance;
+			if (out_clip_ids != nullptr)
+				out_clip_ids[destination] = clip_id[k];
+			if (out_sample_times != nullptr)
+				out_sample_times[destination] = sample_times[instance];
+			if (out_positions != nullptr)
+				out_positions[instance] = destination;
+		}
+	}
+#endif

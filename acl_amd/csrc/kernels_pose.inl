@@ -228,7 +228,7 @@
 
 		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
-		const float sample_time = as_constant(sample_times)[instance];
+		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
 		{
@@ -541,7 +541,7 @@
 			return;
 
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
-		const float sample_time = as_constant(sample_times)[instance];
+		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
 		{

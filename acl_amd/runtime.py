@@ -36,7 +36,8 @@ EXPORTED_SYMBOLS = [
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
-    "aclhip_forget_stream",
+    "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
+    "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
 ]
 
@@ -318,6 +319,34 @@ class Context:
 
     def unregister_clip(self, clip):
         self._check(self._lib.aclhip_unregister_clip(self._handle, clip))
+
+    # ---- persistent instance lists (aclhip_instance_list_*): device pointers, stream ordered ----
+    def instance_list_create(self, num_instances):
+        handle = ctypes.c_uint32(INVALID_HANDLE)
+        self._check(self._lib.aclhip_instance_list_create(self._handle, ctypes.c_uint32(num_instances), ctypes.byref(handle)))
+        return handle.value
+
+    def instance_list_destroy(self, instance_list):
+        self._check(self._lib.aclhip_instance_list_destroy(self._handle, ctypes.c_uint32(instance_list)))
+
+    def instance_list_set_clips(self, instance_list, clips_ptr, stream=None):
+        self._check(self._lib.aclhip_instance_list_set_clips(self._handle, ctypes.c_uint32(instance_list), ctypes.c_void_p(clips_ptr), ctypes.c_void_p(stream)))
+
+    def instance_list_update(self, instance_list, instances_ptr, clips_ptr, count, stream=None):
+        self._check(self._lib.aclhip_instance_list_update(self._handle, ctypes.c_uint32(instance_list), ctypes.c_void_p(instances_ptr), ctypes.c_void_p(clips_ptr),
+                                                          ctypes.c_uint32(count), ctypes.c_void_p(stream)))
+
+    def decompress_tracks_list(self, instance_list, times_ptr, poses_ptr, pose_stride_bytes, params=None, output=None, poses_in_instance_order=False, stream=None):
+        params = params if params is not None else default_params()
+        self._check(self._lib.aclhip_decompress_tracks_list(self._handle, ctypes.c_uint32(instance_list), ctypes.c_void_p(times_ptr), ctypes.byref(params),
+                                                            ctypes.byref(output) if output is not None else None, ctypes.c_int(1 if poses_in_instance_order else 0),
+                                                            ctypes.c_void_p(poses_ptr), ctypes.c_uint64(pose_stride_bytes), ctypes.c_void_p(stream)))
+
+    def instance_list_order(self, instance_list):
+        """(device address of the slot -> instance order, number of orderings so far)"""
+        order, count = ctypes.c_void_p(0), ctypes.c_uint64(0)
+        self._check(self._lib.aclhip_instance_list_get_order(self._handle, ctypes.c_uint32(instance_list), ctypes.byref(order), ctypes.byref(count)))
+        return order.value, count.value
 
     def forget_stream(self, stream):
         """aclhip_forget_stream: before destroying a stream the context has launched on"""

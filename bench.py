@@ -134,7 +134,10 @@ def load_database_fixture():
 class Job:
     """Registered clips, instance list and pose buffer of one workload in HBM, and the launch through the C ABI.
     order: "random" (as drawn), "by_clip" (host bucketed), "locality" (aclhip_order_instances_for_locality on the host, setup),
-    "device" (aclhip_order_instances_device in front of EVERY launch, on the launch stream: the ordering is part of the step).
+    "device" (aclhip_order_instances_device in front of EVERY launch, on the launch stream: the ordering is part of the step),
+    "list" (a persistent aclhip_instance_list: ordered once at setup; EVERY step 1 % of the instances change clip through
+    aclhip_instance_list_update and the list is decoded with aclhip_decompress_tracks_list -- the library re-orders it when an
+    eighth of it has changed: update, decode and the re-orders that fall into the timed steps are all part of the step).
     layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
     def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48"):
@@ -229,6 +232,20 @@ class Job:
 
         if order == "device":
             self._order_args = (handle, self.d_source_clips.data_ptr(), self.d_source_times.data_ptr(), n, self.d_order.data_ptr(), clips_ptr, times_ptr, stream_ptr)
+        self.instance_list = None
+        if order == "list":
+            # 16 pre-drawn update sets (1 % of the instances each, new clips drawn like the old ones), cycled through by the steps
+            update_rng = np.random.default_rng(3000 + rank)
+            count = max(1, n // 100)
+            self._updates = []
+            for _ in range(16):
+                instances = update_rng.choice(n, size=count, replace=False).astype(np.int32)
+                new_clips = self.handles[update_rng.integers(0, len(self.clips), size=count)].astype(np.int32)
+                self._updates.append((torch.from_numpy(instances).to(self.device), torch.from_numpy(new_clips).to(self.device), count))
+            self._update_index = 0
+            self.instance_list = context.instance_list_create(n)
+            context.instance_list_set_clips(self.instance_list, clips_ptr, stream=stream_ptr)
+            self.stream.synchronize()
 
     def order_step(self):
         status = self.lib.aclhip_order_instances_device(*self._order_args)
@@ -236,6 +253,12 @@ class Job:
             raise SystemExit(f"the device side ordering failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
 
     def step(self):
+        if self.instance_list is not None:
+            instances, new_clips, count = self._updates[self._update_index % len(self._updates)]
+            self._update_index += 1
+            self.context.instance_list_update(self.instance_list, instances.data_ptr(), new_clips.data_ptr(), count, stream=self.stream.cuda_stream)
+            self.context.decompress_tracks_list(self.instance_list, self.d_times.data_ptr(), self.d_poses.data_ptr(), self.pose_stride, params=self.params, stream=self.stream.cuda_stream)
+            return
         if self._order_args is not None:
             self.order_step()
         status = self._launch(*self._args)
@@ -296,6 +319,8 @@ class Job:
     def close(self):
         self.torch.cuda.synchronize(self.device)
         rejected = self.context.rejected_instance_count()
+        if self.instance_list is not None:
+            self.context.instance_list_destroy(self.instance_list)
         for handle in self.handles:
             self.context.unregister_clip(int(handle))
         if self.database is not None:
@@ -387,6 +412,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
             "kernel_ms_order_reused": decode_ms_order_reused,  # the decode alone in that order (an instance list ordered once, sample times refreshed per frame)
+            "list_orderings": None if job.instance_list is None else int(job.context.instance_list_order(job.instance_list)[1]),     # order "list": times the library (re-)ordered the list, setup included
             "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload for all of the workload's clips (setup)
             "launches_timed": repeats,
         }
@@ -529,7 +555,7 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=sorted(WORKLOAD_TEXT))
     parser.add_argument("--instances", type=int, default=INSTANCES_PER_GPU, help="instances per GPU")
-    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device"],
+    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "list"],
                         help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup); "
                              "aclhip_order_instances_device in front of every launch (part of the step)")
     parser.add_argument("--keep-rows", action="store_true", help="with --order locality: store every pose in its instance's ORIGINAL row")
@@ -620,7 +646,8 @@ def main():
         workload_text = WORKLOAD_TEXT[args.workload]
         if args.order != "random":
             workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order",
-                              "device": ", ordered by aclhip_order_instances_device in front of every launch (inside the step)"}[args.order]
+                              "device": ", ordered by aclhip_order_instances_device in front of every launch (inside the step)",
+                              "list": ", kept in a persistent aclhip_instance_list: 1 % of the instances change clip in every step (inside the step), the library re-orders when 1/8 has changed"}[args.order]
             workload_text += ", poses scattered back to their original rows" if args.keep_rows else ""
         result = {
             "metric": "poses/sec (whole node), 64k clip instances x 100 bones per GPU, seek + decompress_tracks",
@@ -694,6 +721,7 @@ def main():
             measure_job("256_clips", rank, device_index),
             measure_job("256_clips", rank, device_index, order="locality"),
             measure_job("256_clips", rank, device_index, order="device"),          # ordered on the GPU in front of every launch: the ordering is in kernel_ms
+            measure_job("256_clips", rank, device_index, order="list"),            # persistent instance list: 1 % of the instances change clip per step, inside the step
             measure_job("cinematic", rank, device_index, repeats=150),
             measure_job("database", rank, device_index),
             # scalar track lists and the pose consumers fused into the decode

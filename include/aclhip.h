@@ -312,6 +312,33 @@ aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_insta
 aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);
 
+/* ---- persistent instance lists: the library keeps the decode order -------------------------------------------------------------
+ * (No reference counterpart: the reference decodes one pose per call. SURVEY.md section 7: "sort/bucket instances by clip for L2
+ * locality".) A batch that draws on hundreds of clips decodes a fifth faster in locality order (aclhip_order_instances_for_locality),
+ * but ordering a list costs more than one decode of it gains. Which character plays which clip changes rarely, the sample times
+ * every frame: an instance list object keeps the clip assignment of `num_instances` instances IN DECODE ORDER across frames.
+ *   aclhip_instance_list_set_clips   every instance's clip (device array in the caller's instance order); orders the list on `stream`
+ *   aclhip_instance_list_update      instances[k] now plays clips[k] (device arrays, `count` entries, stream ordered). The instance keeps
+ *                                    its slot; once an eighth of the list has changed since it was last ordered, the next decode
+ *                                    re-orders it first (one launch, on the decode's stream)
+ *   aclhip_decompress_tracks_list    decodes the list: sample_times[i] is instance i's sample time (the caller's order, gathered through
+ *                                    the list's order by the decode itself). Poses land in SLOT order (pose row j = instance order[j],
+ *                                    aclhip_instance_list_get_order) -- 1 KiB stores to consecutive rows, what the write path likes -- or,
+ *                                    with poses_in_instance_order != 0, in row i for instance i (scattered rows: measured 20 % slower).
+ *                                    `output` as in aclhip_decompress_tracks_batch_out (its `rows` must be NULL), or NULL.
+ * All calls of one list must be made in stream order (one stream, or the caller's events between streams). */
+typedef uint32_t aclhip_instance_list;
+
+aclhip_status aclhip_instance_list_create(aclhip_context* context, uint32_t num_instances, aclhip_instance_list* out_list);
+aclhip_status aclhip_instance_list_destroy(aclhip_context* context, aclhip_instance_list list);
+aclhip_status aclhip_instance_list_set_clips(aclhip_context* context, aclhip_instance_list list, const aclhip_clip* clips, void* stream);
+aclhip_status aclhip_instance_list_update(aclhip_context* context, aclhip_instance_list list, const uint32_t* instances, const aclhip_clip* clips, uint32_t count, void* stream);
+aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, aclhip_instance_list list, const float* sample_times, const aclhip_decompress_params* params,
+	const aclhip_output_desc* output, int poses_in_instance_order, void* poses, uint64_t pose_stride_bytes, void* stream);
+/* the list's order, slot -> instance (device pointer, num_instances entries; contents change when the list is re-ordered, stream
+ * ordered with the decodes) and how often the list has been (re-)ordered so far */
+aclhip_status aclhip_instance_list_get_order(aclhip_context* context, aclhip_instance_list list, const uint32_t** out_order, uint64_t* out_num_orderings);
+
 /* Replaces seek() + decompress_track(track_indices[i], writer) (decompress.h:172; decompress_track_v0 :1753-2050):
  * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers. */
 aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,

@@ -1,0 +1,118 @@
+"""Persistent instance lists (aclhip_instance_list_*): the library keeps an instance list in decode (locality) order across frames --
+ordered once, patched in place when instances change clip, re-ordered before a decode once an eighth of it has changed -- and
+decodes it with the frame's sample times gathered through that order. Every pose of every frame against the oracle. Needs a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+import helpers
+from test_order_instances import check_order
+
+pytestmark = pytest.mark.gpu
+
+
+_hip = None
+
+
+def _read_order(address, n):
+    """the list's slot -> instance order (a device address the library owns) copied to the host"""
+    global _hip
+    if _hip is None:
+        _hip = ctypes.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    out = np.zeros(n, dtype=np.uint32)
+    assert _hip.hipMemcpy(out.ctypes.data, address, n * 4, 2) == 0      # hipMemcpyDeviceToHost
+    return out
+
+
+@pytest.mark.parametrize("num_instances,num_clips,big_rig_tracks", [(1, 1, 0), (5000, 7, 0), (65536, 256, 0), (6000, 9, 300)])
+def test_list_decodes_follow_the_oracle_through_updates_and_reorders(num_instances, num_clips, big_rig_tracks):
+    rng = np.random.default_rng(num_instances + num_clips)
+    clips = [synth.build_clip(seed=500 + i, num_tracks=int(rng.integers(40, 101)), num_samples=int(rng.integers(2, 90)), has_scale=int(i % 5 == 0)) for i in range(num_clips)]
+    if big_rig_tracks:
+        clips[0] = synth.build_clip(seed=499, num_tracks=big_rig_tracks, num_samples=40, has_scale=1)
+    blobs = [c.blob for c in clips]
+    durations = np.array([c.duration for c in clips], dtype=np.float32)
+    max_tracks = max(c.num_tracks for c in clips)
+    windows = -(-max_tracks * 3 // 312)
+    n = num_instances
+    device = torch.device("cuda", 0)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        stream = torch.cuda.Stream(device)
+        which = rng.integers(0, num_clips, size=n)
+        d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+        d_times = torch.zeros(n, dtype=torch.float32, device=device)
+        d_poses = torch.zeros((n, max_tracks, 12), dtype=torch.float32, device=device)
+        d_rows = torch.zeros((n, max_tracks, 12), dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+
+        instance_list = context.instance_list_create(n)
+        with pytest.raises(runtime.AclHipError):       # nothing to decode before the clips are set
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_poses.data_ptr(), max_tracks * 48, stream=stream.cuda_stream)
+        context.instance_list_set_clips(instance_list, d_clips.data_ptr(), stream=stream.cuda_stream)
+        order_address, orderings = context.instance_list_order(instance_list)
+        assert orderings == 1
+
+        changed_total = 0
+        for frame in range(12):
+            # a few instances change clip (1 % per frame; more in one frame so that a re-order happens inside the test's frames)
+            num_changes = max(1, n // 100) if frame != 6 else max(1, n // 20)
+            changed = rng.choice(n, size=min(num_changes, n), replace=False).astype(np.int32)
+            new_which = rng.integers(0, num_clips, size=changed.size)
+            which[changed] = new_which
+            d_changed = torch.from_numpy(changed).to(device)
+            d_new = torch.from_numpy(handles[new_which].astype(np.int32)).to(device)
+            torch.cuda.synchronize(device)
+            context.instance_list_update(instance_list, d_changed.data_ptr(), d_new.data_ptr(), changed.size, stream=stream.cuda_stream)
+            changed_total += changed.size
+
+            times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+            with torch.cuda.stream(stream):
+                d_times.copy_(torch.from_numpy(times), non_blocking=False)
+                d_poses.zero_()         # (rows past a clip's own tracks keep what the buffer held: the oracle's rows are zero there)
+                d_rows.zero_()
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_poses.data_ptr(), max_tracks * 48, stream=stream.cuda_stream)
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_rows.data_ptr(), max_tracks * 48, poses_in_instance_order=True, stream=stream.cuda_stream)
+            stream.synchronize()
+
+            order = _read_order(order_address, n)
+            assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32))
+            expected = ob.oracle_decompress_tracks_batch(blobs, which.astype(np.uint32), times, max_tracks)
+            assert helpers.bit_equal(d_rows.cpu().numpy(), expected), frame
+            assert helpers.bit_equal(d_poses.cpu().numpy(), expected[order]), frame
+        _, orderings = context.instance_list_order(instance_list)
+        assert orderings >= 2 or n < 16, orderings          # the list was re-ordered along the way ...
+        assert orderings <= 6 or n < 100, orderings         # ... but not every frame
+        # right after a re-order the list is in locality order for the clips the instances play NOW
+        context.instance_list_set_clips(instance_list, torch.from_numpy(handles[which].astype(np.int32)).to(device).data_ptr(), stream=stream.cuda_stream)
+        stream.synchronize()
+        check_order(handles[which], _read_order(order_address, n), windows, stable=False)
+        assert context.rejected_instance_count() == 0
+        context.instance_list_destroy(instance_list)
+        with pytest.raises(runtime.AclHipError):
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_poses.data_ptr(), max_tracks * 48, stream=stream.cuda_stream)
+
+
+def test_single_launch_order_equals_the_three_launch_order_in_structure():
+    """aclhip_order_instances_device orders in ONE launch while the grid fits the device (every workgroup waits for the last one's
+    scan); larger lists take three launches. Both give a valid locality order; the one-launch form survives being replayed (nothing in
+    it depends on a per-call value: hipGraphs)."""
+    rng = np.random.default_rng(3)
+    clips = [synth.build_clip(seed=600 + i, num_tracks=50, num_samples=20) for i in range(40)]
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        for n in (100, 70000, 600000):          # 1, 35 (one launch) and 293 workgroups (three launches on a 256 CU device)
+            which = rng.integers(0, len(clips), size=n)
+            d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+            d_order = torch.zeros(n, dtype=torch.int32, device=device)
+            for _ in range(3):                  # the same scratch, call after call
+                context.order_instances_device(d_clips.data_ptr(), 0, n, d_order.data_ptr(), 0, 0)
+                torch.cuda.synchronize(device)
+                check_order(handles[which], d_order.cpu().numpy().astype(np.uint32), 1, stable=False)
