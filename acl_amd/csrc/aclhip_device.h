@@ -193,6 +193,7 @@ namespace aclhip
 		const uint8_t* instance_rounding_policies;
 		const uint32_t* instance_rows;	// pose kernels: row of the pose buffer each instance writes, or null (row = instance index)
 		const uint32_t* time_indices;	// pose kernels: entry of sample_times each instance reads, or null (its own): instance lists kept in decode order
+		const uint8_t* skip_tracks;		// compact pose kernels: per track, bit k set = its sub-track of kind k is not stored (aclhip_output_desc::skip_tracks), or null
 		uint8_t rounding_policy;
 		uint8_t looping_policy;
 		uint8_t normalization;

@@ -404,6 +404,10 @@ namespace
 			if (ok && output->rows != nullptr)
 				ok = upload(output->rows, sizeof(uint32_t) * num_instances, &d_rows);
 			local_output.rows = static_cast<const uint32_t*>(d_rows);
+			void* d_skip_tracks = nullptr;
+			if (ok && output->skip_tracks != nullptr)
+				ok = upload(output->skip_tracks, std::max<uint32_t>(max_tracks, 1), &d_skip_tracks);
+			local_output.skip_tracks = static_cast<const uint8_t*>(d_skip_tracks);
 		}
 		if (ok && local.default_values != nullptr)
 			ok = upload(local.default_values, size_t(std::max<uint32_t>(default_values_count, 1)) * 48, &d_defaults);

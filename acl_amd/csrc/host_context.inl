@@ -720,6 +720,7 @@ namespace
 		out.instance_rounding_policies = params->instance_rounding_policies;
 		out.instance_rows = nullptr;
 		out.time_indices = nullptr;
+		out.skip_tracks = nullptr;
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;
 		out.items_per_wave = 1;

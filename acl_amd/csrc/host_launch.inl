@@ -27,9 +27,9 @@ namespace
 			lds_bytes += extra_lds;
 		}
 		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
-		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0;
+		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
 		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
-		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0;
+		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && params.skip_tracks == nullptr;
 #if defined(ACLHIP_EXPERIMENTS)
 		{
 			// round 3's slower kernel variants, selected by environment knobs (host_experiments.inl)
@@ -116,6 +116,7 @@ namespace
 		if (output->layout == ACLHIP_LAYOUT_QV32)
 			params.skip_mask |= 4u;
 		params.instance_rows = output->rows;
+		params.skip_tracks = output->skip_tracks;
 		return ACLHIP_OK;
 	}
 }

@@ -322,7 +322,7 @@
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		ACLHIP_WAVE0_STAMP(2);
 
-		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults)
+		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults && params.skip_tracks == nullptr)
 		{
 			// Compact layouts, nothing else skipped (the common use): the window is RE-TILED on its way out -- lanes <-> consecutive 16 byte
 			// pieces of the OUTPUT, gathered from the QVV48 image in LDS -- so that every store instruction still writes 1 KiB of
@@ -444,6 +444,9 @@
 				// span of the pose, minus the dropped pieces.
 				const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
 				store = store && ((params.skip_mask >> kind) & 1u) == 0;
+				// track_writer::skip_track_rotation / _translation / _scale(track_index) (core/track_writer.h:189-191), launch wide
+				if (params.skip_tracks != nullptr && store)
+					store = ((params.skip_tracks[track_index] >> kind) & 1u) == 0;
 				if (params.layout == ACLHIP_LAYOUT_QVV48)
 				{
 					if (store)

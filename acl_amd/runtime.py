@@ -63,7 +63,7 @@ class OutputDesc(ctypes.Structure):
     """aclhip_output_desc"""
     _fields_ = [
         ("layout", ctypes.c_uint32), ("skip_rotations", ctypes.c_uint8), ("skip_translations", ctypes.c_uint8), ("skip_scales", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
-        ("rows", ctypes.c_void_p),
+        ("rows", ctypes.c_void_p), ("skip_tracks", ctypes.c_void_p),
     ]
 
 

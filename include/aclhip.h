@@ -121,6 +121,10 @@ typedef struct aclhip_output_desc
 	uint8_t skip_scales;					/* track_writer::skip_all_scales() */
 	uint8_t reserved0;
 	const uint32_t* rows;					/* DEVICE pointer or NULL: pose of instance i goes to row rows[i] (distinct) instead of row i */
+	const uint8_t* skip_tracks;				/* DEVICE pointer or NULL: track_writer::skip_track_rotation / _translation / _scale(track_index)
+											 * (core/track_writer.h:189-191) for the whole launch: one byte per track (as many as the largest clip of
+											 * the batch has tracks), bit 0 / 1 / 2 set = the track's rotation / translation / scale is skipped -- not
+											 * written, its bytes in the pose buffer are left untouched (an LOD that drops finger bones) */
 } aclhip_output_desc;
 
 typedef struct aclhip_clip_info
@@ -352,7 +356,8 @@ aclhip_status aclhip_decompress_tracks_host(aclhip_context* context, const aclhi
 	const aclhip_decompress_params* params, uint32_t default_values_count, void* poses, uint64_t pose_stride_bytes);
 aclhip_status aclhip_decompress_track_host(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, uint32_t default_values_count, void* transforms);
-/* aclhip_decompress_tracks_host with an output descriptor (output->rows: HOST pointer or NULL). Skipped sub-track kinds keep what `poses` held. */
+/* aclhip_decompress_tracks_host with an output descriptor (output->rows, output->skip_tracks: HOST pointers or NULL; skip_tracks holds one
+ * byte per track of the largest clip in the list). Skipped sub-tracks keep what `poses` held. */
 aclhip_status aclhip_decompress_tracks_host_out(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, uint32_t default_values_count, const aclhip_output_desc* output, void* poses, uint64_t pose_stride_bytes);
 

@@ -19,7 +19,7 @@ SHAPES = ["cmu_100", "scale_37", "stripped_wrap_scale", "raw_and_constant_rates"
           "two_samples_three_tracks", "one_sample"]
 
 
-def launch(context, handles, times, layout, skip=(0, 0, 0), rows=None, num_rows=None, max_tracks=None, params=None):
+def launch(context, handles, times, layout, skip=(0, 0, 0), rows=None, num_rows=None, max_tracks=None, params=None, skip_tracks=None):
     layout_id, bytes_per_track = runtime.LAYOUTS[layout]
     stride = (max_tracks * bytes_per_track + 15) // 16 * 16
     num_rows = num_rows or handles.size
@@ -32,6 +32,9 @@ def launch(context, handles, times, layout, skip=(0, 0, 0), rows=None, num_rows=
     if rows is not None:
         d_rows = torch.from_numpy(rows.astype(np.int32)).cuda()
         output.rows = d_rows.data_ptr()
+    if skip_tracks is not None:
+        d_skip_tracks = torch.from_numpy(skip_tracks.astype(np.uint8)).cuda()
+        output.skip_tracks = d_skip_tracks.data_ptr()
     context.decompress_tracks_batch_out(d_handles.data_ptr(), d_times.data_ptr(), handles.size, poses.data_ptr(), stride, output, params=params)
     torch.cuda.synchronize()
     return poses.cpu().numpy()[:, : max_tracks * bytes_per_track // 4].reshape(num_rows, max_tracks, bytes_per_track // 4)
@@ -166,3 +169,48 @@ def test_host_entry_point_and_cpp_writer_switches():
             assert status == 0
             assert helpers.exact(out, expected_through_layout(oracle, layout, skip)), layout
         context.unregister_clip(handle)
+
+
+@pytest.mark.parametrize("name", ["cmu_100", "cinematic_300", "raw_and_constant_rates"])
+@pytest.mark.parametrize("layout", ["qvv48", "qvv40", "qv32"])
+def test_per_track_skips_leave_the_callers_bytes(context, name, layout):
+    """track_writer::skip_track_rotation / _translation / _scale(track_index) (core/track_writer.h:189-191) for a whole launch:
+    aclhip_output_desc::skip_tracks, one byte per track. Oracle values where nothing is masked, the caller's bytes where a sub-track
+    is -- on top of the kinds skipped altogether, in every layout, through the device and the host entry points."""
+    clip = synth.build_clip(**CLIP_SPECS[name])
+    handle = context.register_clip(clip.blob)
+    rng = np.random.default_rng(len(name) + len(layout))
+    n = 130
+    times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+    oracle = ob.oracle_decompress_tracks_batch([clip.blob], np.zeros(n, dtype=np.uint32), times, clip.num_tracks)
+    handles = np.full(n, handle, dtype=np.uint32)
+    skip_tracks = rng.integers(0, 8, size=clip.num_tracks).astype(np.uint8)
+    skip_tracks[rng.uniform(size=clip.num_tracks) < 0.5] = 0          # half of the tracks keep everything
+    layout_id, bytes_per_track = runtime.LAYOUTS[layout]
+    width = bytes_per_track // 4
+    for skip in ((0, 0, 0), (0, 1, 0)):
+        got = launch(context, handles, times, layout, skip, max_tracks=clip.num_tracks, skip_tracks=skip_tracks)
+        expected = expected_through_layout(oracle, layout, skip)
+        # lanes of the masked sub-tracks go back to the fill value
+        lanes = {"qvv48": ((0, 4), (4, 8), (8, 12)), "qvv40": ((0, 4), (4, 7), (7, 10)), "qv32": ((0, 4), (4, 8), None)}[layout]
+        for kind in range(3):
+            if lanes[kind] is None:
+                continue
+            masked = (skip_tracks >> kind) & 1 == 1
+            expected[:, masked, lanes[kind][0]: lanes[kind][1]] = FILL
+        assert helpers.exact(got, expected), (name, layout, skip)
+    # the host convenience entry point takes the mask as a host array
+    out = np.full((n, clip.num_tracks, width), FILL, dtype=np.float32)
+    output = runtime.OutputDesc()
+    output.layout = layout_id
+    mask_host = np.ascontiguousarray(skip_tracks)
+    output.skip_tracks = mask_host.ctypes.data
+    params = runtime.default_params()
+    context._check(context._lib.aclhip_decompress_tracks_host_out(context._handle, handles.ctypes.data, times.ctypes.data, n, __import__("ctypes").byref(params), 0,
+                                                                  __import__("ctypes").byref(output), out.ctypes.data, clip.num_tracks * bytes_per_track))
+    expected = expected_through_layout(oracle, layout, (0, 0, 0))
+    for kind in range(3):
+        if lanes[kind] is not None:
+            expected[:, (skip_tracks >> kind) & 1 == 1, lanes[kind][0]: lanes[kind][1]] = FILL
+    assert helpers.exact(out, expected)
+    context.unregister_clip(handle)
