@@ -547,6 +547,53 @@ def measure_gather(job, dist, rank, world_size, mode, repeats=5):
     return result
 
 
+def measure_sharded_job(name, rank, world_size, device_index, dist, gather_mode, repeats, num_instances=INSTANCES_PER_GPU):
+    """N > 1: one of the 8-GPU configs of BASELINE.json (configs[3]: the 300-bone rig; configs[4]: database-bound clips whose tiers are
+    streamed in) on every rank's shard, timed like the headline -- barrier, `repeats` launches, device synchronized, barrier, MAX over
+    the ranks -- then the gathers of the shards. The database's residency advances on all ranks together
+    (acl_amd.sharding.stream_database_everywhere: rank 0's request is broadcast) inside the timed loop."""
+    from acl_amd import sharding
+    job = Job(name, rank, device_index, num_instances=num_instances)
+    torch = job.torch
+    on_device = dist.get_backend() == "nccl"
+    try:
+        job.prewarm(0.05)
+        schedule = job.stream_schedule(repeats)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(job.device)
+        dist.barrier()
+        t0 = time.perf_counter()
+        start.record(job.stream)
+        for i in range(repeats):
+            if i in schedule:
+                sharding.stream_database_everywhere(job.context, job.database, schedule[i][0], schedule[i][1], stream=job.stream.cuda_stream)
+            job.step()
+        stop.record(job.stream)
+        torch.cuda.synchronize(job.device)
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        times = torch.tensor([elapsed, float(start.elapsed_time(stop)) * 1e-3], dtype=torch.float64, device=job.device if on_device else "cpu")
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        elapsed, kernel_seconds = (float(v) for v in times.tolist())
+        kernel_ms = kernel_seconds * 1e3 / repeats
+        algorithmic = job.algorithmic_bytes()
+        entry = {
+            "workload": name, "config": WORKLOAD_TEXT[name], "n_gpus": world_size, "instances_per_gpu": job.num_instances, "bones": job.max_tracks,
+            "distinct_clips": len(job.clips), "pose_bytes": job.pose_stride, "kernel": job.kernel_name(),
+            "launches_timed": repeats, "ms_per_step": elapsed / repeats * 1e3,
+            "poses_per_s": job.num_instances * world_size * repeats / elapsed,          # whole job: every rank's shard over the slowest rank's time
+            "kernel_ms": kernel_ms,                                                     # slowest rank, HIP events on its launch stream
+            "algorithmic_bytes_per_gpu": int(algorithmic), "achieved_per_gpu": algorithmic / (kernel_ms * 1e-3) / 1e9,
+            "frac": algorithmic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "database_chunks_streamed_in_together": len(schedule),
+        }
+        if gather_mode != "none":
+            entry["gather"] = measure_gather(job, dist, rank, world_size, gather_mode)
+        return entry
+    finally:
+        job.close()
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -709,10 +756,25 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         gather.update(measure_gather(job, dist, rank, world_size, args.gather))
         gather["status"] = "done"
-        finished.set()
 
     headline = (job.clips, job.clip_indices, job.times, job.pose_stride // 4 if job.is_scalar else job.max_tracks, job.is_scalar, job.database is not None, job.consumers is not None)
     job.close()
+
+    if distributed and not args.no_extras and not profiling and args.workload == "one_clip":
+        # BASELINE.json's 8-GPU configs on this many GPUs: the 300-bone rig (65 536 instances per GPU, 944 MB shards: the gathers that
+        # matter) and the database-bound clips (32 768 per GPU, tiers streamed in on all ranks together). Still under the watchdog.
+        sharded = []
+        if rank == 0:
+            result["workloads"] = sharded
+        # (ACLHIP_BENCH_SHARDED_INSTANCES: instances per GPU of the rig shard, the database shard takes half; dry runs on one GPU use it)
+        sharded_instances = int(os.environ.get("ACLHIP_BENCH_SHARDED_INSTANCES", str(INSTANCES_PER_GPU)))
+        for name, instances, repeats in (("cinematic", sharded_instances, 100), ("database", max(sharded_instances // 2, 1), 200)):
+            try:
+                sharded.append(measure_sharded_job(name, rank, world_size, device_index, dist, args.gather, repeats, num_instances=instances))
+            except Exception as error:      # noqa: BLE001 -- reported in the line; the headline stands on its own
+                sharded.append({"workload": name, "error": repr(error)[:300]})
+    if distributed and args.gather != "none":
+        finished.set()
 
     extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU
     if rank == 0 and extras:

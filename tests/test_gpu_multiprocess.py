@@ -83,7 +83,7 @@ def test_peer_gather_between_processes(tmp_path, world_size):
 def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, instances):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` exactly as the driver launches it, ranks sharing the one
     GPU (ACLHIP_BENCH_BACKEND=gloo): the line must carry the whole-job rate and both gathers, timed separately from the decode."""
-    env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_SHARDED_INSTANCES="1024")
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--workload", workload, "--instances", str(instances), "--gather", "both"]
     completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
@@ -97,3 +97,30 @@ def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, insta
     assert "p2p_error" not in gather and "rccl_all_gather_error" not in gather, gather
     assert gather["p2p_to_rank0_ms"] > 0 and gather["rccl_all_gather_ms"] > 0
     assert gather["shard_bytes"] == instances * result["config"]["pose_bytes"]
+
+
+def test_bench_at_8_ranks_covers_the_8_gpu_configs():
+    """The driver's own launch, `torchrun --nproc-per-node 8 bench.py --gpus 8`, as a dry run on the one test GPU (small shards): after
+    the headline the line carries BASELINE.json's 8-GPU configs -- the 300-bone rig shards and the database-bound clips whose tiers
+    stream in on all ranks together -- each with its whole-job rate and both gathers."""
+    world_size = 8
+    env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_SHARDED_INSTANCES="512")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--instances", "2048"]
+    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert completed.returncode == 0, completed.stderr[-3000:]
+    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, completed.stdout[-2000:]
+    result = json.loads(lines[0])
+    assert result["n_gpus"] == world_size and result["gather"]["status"] == "done"
+    workloads = {entry["workload"]: entry for entry in result["workloads"]}
+    assert set(workloads) == {"cinematic", "database"}, result["workloads"]
+    for name, instances in (("cinematic", 512), ("database", 256)):
+        entry = workloads[name]
+        assert "error" not in entry, entry
+        assert entry["n_gpus"] == world_size and entry["instances_per_gpu"] == instances and entry["poses_per_s"] > 0 and entry["kernel_ms"] > 0
+        gather = entry["gather"]
+        assert "p2p_error" not in gather and "rccl_all_gather_error" not in gather, gather
+        assert gather["p2p_to_rank0_ms"] > 0 and gather["rccl_all_gather_ms"] > 0 and gather["shard_bytes"] == instances * entry["pose_bytes"]
+    assert workloads["cinematic"]["bones"] == 300
+    assert workloads["database"]["database_chunks_streamed_in_together"] > 0
