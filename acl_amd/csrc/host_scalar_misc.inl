@@ -507,6 +507,92 @@ extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, 
 	return ACLHIP_OK;
 }
 
+extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* context, void* poses, uint64_t pose_stride_bytes, uint32_t num_instances, uint32_t num_tracks,
+	uint32_t repeats, void* stream, float* out_gb_per_second, uint32_t* out_waves_per_cu)
+{
+	if (context == nullptr || poses == nullptr || out_gb_per_second == nullptr || repeats == 0 || num_instances == 0 || num_tracks == 0
+		|| (reinterpret_cast<uintptr_t>(poses) & 15u) != 0 || (pose_stride_bytes & 15u) != 0 || pose_stride_bytes < uint64_t(num_tracks) * 48)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+
+	device_guard guard(context->device);
+	hipStream_t hip_stream = static_cast<hipStream_t>(stream);
+	const uint32_t pose_quads = num_tracks * 3;
+	const uint32_t windows = (pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
+	const uint64_t num_waves = uint64_t(num_instances) * windows;
+	if (num_waves > 0xFFFFFFF0ull)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	const uint32_t num_blocks = uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block);
+	ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(pose_store_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+	hipEvent_t start, stop;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	// workgroups of 4 waves per CU by the LDS a workgroup asks for: 20 KB -> 8 (32 waves), 40 KB -> 4, 52 KB -> 3, 80 KB -> 2 (8 waves);
+	// 0 / 3 / 6 dependent scalar loads in front of the stores (a 16 KB table of indices, resident in the L2s)
+	uint32_t* chain = nullptr;
+	{
+		std::vector<uint32_t> host_chain(4096);
+		for (uint32_t i = 0; i < 4096; ++i)
+			host_chain[i] = (i * 1237u + 511u) & 4095u;
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&chain), host_chain.size() * sizeof(uint32_t)));
+		if (hipMemcpy(chain, host_chain.data(), host_chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
+		{
+			(void)hipFree(chain);
+			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the probe's table failed");
+		}
+	}
+	const uint32_t lds_bytes[4] = { 20 * 1024, 40 * 1024, 52 * 1024, 80 * 1024 };
+	const uint32_t waves_per_cu[4] = { 32, 16, 12, 8 };
+	float best = 0.0f;
+	for (uint32_t shape = 0; shape < 4; ++shape)
+		for (uint32_t hops = 0; hops <= 6; hops += 3)
+		{
+			hipLaunchKernelGGL(pose_store_stream_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes[shape], hip_stream, static_cast<uint8_t*>(poses), pose_stride_bytes, num_instances, pose_quads, windows, chain, hops, 0.0f);
+			(void)hipEventRecord(start, hip_stream);
+			for (uint32_t i = 0; i < repeats; ++i)
+				hipLaunchKernelGGL(pose_store_stream_kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes[shape], hip_stream, static_cast<uint8_t*>(poses), pose_stride_bytes, num_instances, pose_quads, windows, chain, hops, float(i));
+			(void)hipEventRecord(stop, hip_stream);
+			float elapsed_ms = 0.0f;
+			if (hipEventSynchronize(stop) != hipSuccess || hipEventElapsedTime(&elapsed_ms, start, stop) != hipSuccess)
+			{
+				(void)hipFree(chain);
+				return fail(context, ACLHIP_ERROR_DEVICE, "the store stream probe failed");
+			}
+			const float rate = float(double(num_instances) * pose_quads * 16.0 * repeats / (double(elapsed_ms) * 1.0e-3) / 1.0e9);
+			if (rate > best)
+			{
+				best = rate;
+				if (out_waves_per_cu != nullptr)
+					*out_waves_per_cu = waves_per_cu[shape];
+			}
+		}
+	(void)hipFree(chain);
+	// ... and the runtime's own fill of the same bytes (hipMemsetAsync: few waves, each sweeping a large contiguous range): the decode
+	// of one-window poses, paced by its seek, comes out ahead of every pose shaped store-only launch above, not of this one
+	{
+		const size_t fill_bytes = size_t(num_instances - 1) * pose_stride_bytes + size_t(pose_quads) * 16;
+		(void)hipMemsetAsync(poses, 0, fill_bytes, hip_stream);
+		(void)hipEventRecord(start, hip_stream);
+		for (uint32_t i = 0; i < repeats; ++i)
+			(void)hipMemsetAsync(poses, int(i & 1), fill_bytes, hip_stream);
+		(void)hipEventRecord(stop, hip_stream);
+		float elapsed_ms = 0.0f;
+		if (hipEventSynchronize(stop) == hipSuccess && hipEventElapsedTime(&elapsed_ms, start, stop) == hipSuccess && elapsed_ms > 0.0f)
+		{
+			const float rate = float(double(fill_bytes) * repeats / (double(elapsed_ms) * 1.0e-3) / 1.0e9);
+			if (rate > best)
+			{
+				best = rate;
+				if (out_waves_per_cu != nullptr)
+					*out_waves_per_cu = 0;		// the runtime's fill kernel
+			}
+		}
+	}
+	(void)hipEventDestroy(start);
+	(void)hipEventDestroy(stop);
+	*out_gb_per_second = best;
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second)
 {
 	if (context == nullptr || buffer == nullptr || out_gb_per_second == nullptr || repeats == 0 || size_bytes < 16 || (reinterpret_cast<uintptr_t>(buffer) & 15u) != 0)

@@ -75,6 +75,37 @@
 			destination[quad] = value;
 	}
 
+	// Measurement aid: what the write path sustains for the pose kernels' OWN store pattern -- one wave per pose window, 1 KiB streaming
+	// stores to the window's rows, nothing else -- with the workgroups per CU limited by the LDS the launch asks for. The best of a few
+	// occupancies is the ceiling bench.py quotes next to the 8 TB/s of the HBM3E specification: no kernel that writes these poses in
+	// this pattern can be faster (6.0 - 6.7 TB/s: profiles/r03_experiments.md, tools/write_probe5.hip).
+	// `chain_hops` dependent scalar loads in front of the stores pace the stream the way a decode's seek does: a write stream that is
+	// paced reaches more than one issued as fast as waves can start, so the ceiling is the best over both knobs.
+	__global__ __launch_bounds__(k_block_size) void pose_store_stream_kernel(uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t num_instances,
+		uint32_t pose_quads, uint32_t windows_per_instance, const uint32_t* __restrict__ chain, uint32_t chain_hops, float seed)
+	{
+		extern __shared__ uint8_t occupancy_padding[];
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t work_item = blockIdx.x * k_waves_per_block + __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		uint32_t hop = work_item & 4095u;
+		for (uint32_t h = 0; h < chain_hops; ++h)
+			hop = as_constant(chain)[hop & 4095u] + h;
+		const uint32_t instance = work_item / windows_per_instance;
+		const uint32_t first_quad = (work_item - instance * windows_per_instance) * k_image_chunk_quads;
+		if (instance >= num_instances || first_quad >= pose_quads)
+			return;
+		const uint32_t window_quads = min(pose_quads - first_quad, k_image_chunk_quads);
+		f32x4* pose = reinterpret_cast<f32x4*>(poses + uint64_t(instance) * pose_stride_bytes) + first_quad + lane;
+		const f32x4 value = { seed, seed + 1.0f, float(hop), float(work_item) };
+		constexpr uint32_t k_rows = (k_image_chunk_quads + k_wave_size - 1) / k_wave_size;
+		#pragma unroll
+		for (uint32_t r = 0; r < k_rows; ++r)
+			if (r * k_wave_size + lane < window_quads)
+				store_streaming(&pose[r * k_wave_size], value);
+		if (seed == -1.0f && occupancy_padding[0] == 255)
+			store_streaming(pose, value);		// keeps the LDS allocation alive
+	}
+
 	// ---- decode order for batches that draw on many clips (aclhip_order_instances_device; host twin in host_launch.inl) ----
 	// Slot j of a launch (the j-th instance of the list) starts at wave j * windows_per_instance, workgroup b holds k_waves_per_block
 	// consecutive waves and runs on XCD b % 8: which slots an XCD serves repeats with a period of at most 32 slots. The instances are

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_register_clip", "aclhip_unregister_clip", "aclhip_get_clip_info", "aclhip_clip_matches",
     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
     "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
-    "aclhip_measure_write_bandwidth", "aclhip_describe_tracks_kernel",
+    "aclhip_measure_write_bandwidth", "aclhip_measure_pose_store_bandwidth", "aclhip_describe_tracks_kernel",
     "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
     "aclhip_database_stream_in", "aclhip_database_stream_out",
     "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
@@ -634,6 +634,13 @@ class Context:
         gbps = ctypes.c_float(0.0)
         self._check(self._lib.aclhip_measure_write_bandwidth(self._handle, buffer_ptr, size_bytes, repeats, stream, ctypes.byref(gbps)))
         return gbps.value
+
+    def measure_pose_store_bandwidth(self, poses_ptr, pose_stride_bytes, num_instances, num_tracks, repeats=20, stream=None):
+        """(GB/s, waves per CU) of the pose batch's own store stream alone, best of 32 / 16 / 12 / 8 resident waves per CU"""
+        gbps, waves = ctypes.c_float(0.0), ctypes.c_uint32(0)
+        self._check(self._lib.aclhip_measure_pose_store_bandwidth(self._handle, ctypes.c_void_p(poses_ptr), ctypes.c_uint64(pose_stride_bytes), ctypes.c_uint32(num_instances),
+                                                                  ctypes.c_uint32(num_tracks), ctypes.c_uint32(repeats), ctypes.c_void_p(stream), ctypes.byref(gbps), ctypes.byref(waves)))
+        return gbps.value, waves.value
 
     def tracks_kernel_name(self, params=None):
         params = params if params is not None else default_params()

@@ -393,6 +393,9 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
         algorithmic = job.algorithmic_bytes()
         achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
         kernel = job.kernel_name()
+        achievable = None
+        if not job.is_scalar and job.layout == "qvv48":
+            achievable = job.context.measure_pose_store_bandwidth(job.d_poses.data_ptr(), job.pose_stride, job.num_instances, job.max_tracks, repeats=10, stream=job.stream.cuda_stream)[0]
         return {
             "workload": traffic_key_of(name, job.order, job.layout, job.keep_rows) or f"{name}, {job.order} order, rows kept",
             "config": WORKLOAD_TEXT[name],
@@ -408,6 +411,8 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "algorithmic_bytes": int(algorithmic),
             "achieved": achieved,
             "frac": achieved / HBM_PEAK_GBPS,
+            "achievable_store_gbps": achievable,       # this batch's own write stream alone, best occupancy (aclhip_measure_pose_store_bandwidth)
+            "frac_of_achievable": None if not achievable else achieved / achievable,
             "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
@@ -685,6 +690,11 @@ def main():
     algorithmic_bytes = job.algorithmic_bytes()
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
     fill_gbps = job.context.measure_write_bandwidth(job.d_poses.data_ptr(), job.num_instances * job.pose_stride, repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
+    # the ceiling of THIS batch's write stream on THIS device: the pose kernels' own store pattern, nothing decoded, best occupancy
+    achievable_gbps = achievable_waves = None
+    if not job.is_scalar and job.layout == "qvv48":
+        achievable_gbps, achievable_waves = job.context.measure_pose_store_bandwidth(job.d_poses.data_ptr(), job.pose_stride, job.num_instances, job.max_tracks,
+                                                                                     repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
 
     kernel_name = job.kernel_name()
     result = None
@@ -733,6 +743,11 @@ def main():
                 "kernel_ms_back_to_back": kernel_ms_back_to_back,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
                 "plain_store_stream_gbps": fill_gbps,      # a plain 16 B per lane store sweep over the same pose buffer, for scale (not a ceiling: DESIGN.md 6)
+                # the batch's own write stream alone (one wave per pose window, the kernels' 1 KiB streaming stores, nothing decoded) at the
+                # occupancy that suits it best: what no kernel writing these poses in this pattern can exceed on this device
+                "achievable_store_gbps": achievable_gbps,
+                "achievable_store_waves_per_cu": achievable_waves,
+                "frac_of_achievable": None if not achievable_gbps else achieved_gbps / achievable_gbps,
             },
         }
     if distributed and args.gather != "none":

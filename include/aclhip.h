@@ -508,6 +508,15 @@ aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhi
  * GB/s reached: the practical ceiling of a pose shaped write stream on this device, to read roofline fractions against. */
 aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second);
 
+/* The write stream of a pose batch ALONE: one wave per pose window storing the window's rows with the pose kernels' own 1 KiB streaming
+ * stores into `poses` (DEVICE pointer; num_instances rows of pose_stride_bytes, num_tracks 48 byte records each), nothing decoded,
+ * at 32 / 16 / 12 / 8 resident waves per CU and with 0 / 3 / 6 dependent scalar loads pacing every wave, and the runtime's own fill of
+ * the same bytes (hipMemsetAsync). Returns the best rate (and the occupancy that reached it; 0 = the runtime's fill): the write
+ * bandwidth this device gives a store stream over this buffer, the denominator to read a decode's roofline fraction against besides
+ * the 8 TB/s of the specification. OVERWRITES `poses`. Measurement aid (bench.py: roofline.achievable_store_gbps). */
+aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* context, void* poses, uint64_t pose_stride_bytes, uint32_t num_instances, uint32_t num_tracks,
+	uint32_t repeats, void* stream, float* out_gb_per_second, uint32_t* out_waves_per_cu);
+
 /* Algorithmic bytes of one batch under the compulsory-HBM model of DESIGN.md: poses written plus each distinct
  * clip's touched bytes once. `clips` is a HOST pointer here. */
 aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,
