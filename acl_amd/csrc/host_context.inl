@@ -115,6 +115,7 @@ struct aclhip_context
 		uint32_t* bins = nullptr;
 		size_t capacity = 0;						// words allocated
 		size_t zeroed_bins = 0;						// the counters | cursors layout (padded bins per half) the words were zeroed for; 0: not zeroed
+		uint32_t* barrier = nullptr;				// the one launch form's barrier words (order_control), zeroed when allocated
 	};
 	std::vector<order_scratch> order_scratches;
 	// aclhip_instance_list_*: instance lists kept in decode order (host_lists.inl)
@@ -885,7 +886,10 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 		if (context->d_rejected != nullptr)
 			(void)hipFree(context->d_rejected);
 		for (const aclhip_context::order_scratch& scratch : context->order_scratches)
+		{
 			(void)hipFree(scratch.bins);
+			(void)hipFree(scratch.barrier);
+		}
 	}
 	delete context;
 }

@@ -133,3 +133,9 @@ namespace
 		return ACLHIP_OK;
 	}
 }
+
+// wall clock stamps of the last order_instances_grid_kernel launch: [workgroup][8] (tools/order_phases.py)
+extern "C" int aclhip_exp_read_order_stamps(unsigned long long* out)
+{
+	return int(hipMemcpyFromSymbol(out, HIP_SYMBOL(aclhip::g_order_stamps), sizeof(unsigned long long) * 64 * 8));
+}

@@ -255,8 +255,6 @@ namespace
 		uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, uint32_t* out_positions, void* stream_handle);
 }
 
-constexpr size_t order_control_words = 4;		// room behind the counters for the one launch experiment's control words
-
 extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream_handle)
 {
@@ -310,50 +308,48 @@ aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_cl
 		return ACLHIP_OK;
 	};
 
-	// ACLHIP_ORDER_LAUNCHES=3 forces the older form (LDS hash tables + device scope atomics), what large clip tables take anyway
+	// ACLHIP_ORDER_LAUNCHES=3 forces the older form (three launches: LDS hash tables + device scope atomics), what clip tables of more
+	// than k_order_direct_bins entries take anyway
 	static const int forced_form = []() { const char* value = std::getenv("ACLHIP_ORDER_LAUNCHES"); return value != nullptr ? int(value[0] - '0') : 0; }();
-	if (num_bins <= k_order_direct_bins && forced_form == 0)
+	if (num_bins <= k_order_direct_bins && forced_form != 3)
 	{
-		// per workgroup histograms as a [workgroup][bin] matrix: no device scope atomic, nothing to zero between calls
-		// (few, large workgroups: the matrix the middle kernel scans has workgroups x bins entries, and one workgroup scans it)
-		static const uint32_t instances_per_order_block = []() { const char* value = std::getenv("ACLHIP_ORDER_INSTANCES_PER_BLOCK"); return value != nullptr ? uint32_t(std::atol(value)) : 4096u; }();
-		const uint32_t num_blocks = std::min<uint32_t>((num_instances + instances_per_order_block - 1) / instances_per_order_block, std::max<uint32_t>(context->num_compute_units, 1));
+		// as many workgroups as keep the matrix small (every workgroup reads all of it), all of them resident at once
+		static const uint32_t max_log2_blocks = []() { const char* value = std::getenv("ACLHIP_ORDER_GRID_LOG2_BLOCKS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_grid_max_log2_blocks; }();
+		uint32_t log2_blocks = 0;
+		while (log2_blocks < max_log2_blocks && (2u << log2_blocks) * k_order_direct_block_size <= num_instances
+			&& (size_t(num_bins) << (log2_blocks + 1)) <= k_order_grid_entries && (2u << log2_blocks) <= context->num_compute_units)
+			++log2_blocks;
+		const uint32_t num_blocks = 1u << log2_blocks;
 		const uint32_t instances_per_block = (num_instances + num_blocks - 1) / num_blocks;
-		const aclhip_status status = reserve(size_t(num_blocks) * num_bins);
+		const aclhip_status status = reserve(size_t(num_blocks) * num_bins + num_bins);		// the matrix | the bins' totals
 		if (status != ACLHIP_OK)
 			return status;
-		hipLaunchKernelGGL(order_histogram_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, num_instances, instances_per_block, num_bins, scratch->bins);
-		hipLaunchKernelGGL(order_offsets_kernel, dim3(1), dim3(k_order_direct_block_size), 0, stream, scratch->bins, num_blocks * num_bins);
-		hipLaunchKernelGGL(order_place_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block, num_bins,
-			scratch->bins, layout, out_order, out_clips, out_sample_times, out_positions);
+		if (scratch->barrier == nullptr)
+		{
+			ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->barrier), sizeof(order_control)));
+			ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), context->copy_stream));		// not the caller's stream: it may be capturing
+			ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
+		}
+		hipLaunchKernelGGL(order_instances_grid_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block,
+			num_bins, log2_blocks, scratch->bins, reinterpret_cast<order_control*>(scratch->barrier), layout, out_order, out_clips, out_sample_times, out_positions);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}
-
 	const size_t padded_bins = (size_t(num_bins) + 4095) / 4096 * 4096;
 	{
-		const aclhip_status status = reserve(padded_bins * 2 + order_control_words);
+		const aclhip_status status = reserve(padded_bins * 2);
 		if (status != ACLHIP_OK)
 			return status;
 	}
 	if (scratch->zeroed_bins != padded_bins)
 	{
-		ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->bins, 0, (padded_bins * 2 + order_control_words) * sizeof(uint32_t), stream));		// once: every call leaves the counters at zero
+		ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->bins, 0, (padded_bins * 2) * sizeof(uint32_t), stream));		// once: every call leaves the counters at zero
 		scratch->zeroed_bins = padded_bins;
 	}
 	uint32_t* counters = scratch->bins;
 	uint32_t* cursors = scratch->bins + padded_bins;
 
 	const uint32_t num_blocks = (num_instances + k_order_instances_per_block - 1) / k_order_instances_per_block;
-#if defined(ACLHIP_EXPERIMENTS)
-	if (forced_form == 1 && num_blocks <= context->num_compute_units)
-	{
-		hipLaunchKernelGGL(order_instances_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins,
-			counters, cursors, reinterpret_cast<order_control*>(scratch->bins + padded_bins * 2), layout, out_order, out_clips, out_sample_times, out_positions);
-		ACLHIP_CHECK_HIP(context, hipGetLastError());
-		return ACLHIP_OK;
-	}
-#endif
 	hipLaunchKernelGGL(order_count_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, num_instances, num_bins, counters);
 	hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counters, cursors, num_bins);
 	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times, out_positions);

@@ -274,108 +274,6 @@
 		}
 	}
 
-	// ---- the same order without device scope atomics: per workgroup histograms laid out as a matrix ----
-	// (device scope atomics on a few hundred hot addresses are what the three kernels above spend their time on: 23 us for 64k
-	// instances.) While the clip table has at most k_order_direct_bins entries a workgroup counts its instances per clip in a directly
-	// indexed LDS histogram and writes its row of a [workgroup][bin] matrix; one workgroup turns the matrix into first positions, bin
-	// major (all of bin 0's workgroups, then bin 1's ...); every workgroup then places its instances from its own row. No global atomic,
-	// nothing to zero between calls.
-	constexpr uint32_t k_order_direct_bins = 8192;			// 32 KB of LDS
-	constexpr uint32_t k_order_direct_block_size = 1024;
-
-	__global__ __launch_bounds__(k_order_direct_block_size) void order_histogram_kernel(const uint32_t* __restrict__ clip_ids, uint32_t num_instances, uint32_t instances_per_block,
-		uint32_t num_bins, uint32_t* __restrict__ histograms)
-	{
-		__shared__ uint32_t histogram[k_order_direct_bins];
-		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
-			histogram[bin] = 0;
-		__syncthreads();
-		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
-		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
-			atomicAdd(&histogram[min(clip_ids[instance], num_bins - 1)], 1u);
-		__syncthreads();
-		// bin major: entry bin * gridDim + block (the order the positions are handed out in)
-		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
-			histograms[size_t(bin) * gridDim.x + blockIdx.x] = histogram[bin];
-	}
-
-	// histograms[bin][block] -> first position of (bin, block), in place: an exclusive scan over the matrix as it lies in memory. One
-	// workgroup, k_order_scan_per_thread consecutive entries per thread and pass (requested together, then summed)
-	constexpr uint32_t k_order_scan_per_thread = 16;
-
-	__global__ __launch_bounds__(k_order_direct_block_size) void order_offsets_kernel(uint32_t* __restrict__ histograms, uint32_t num_entries)
-	{
-		__shared__ uint32_t wave_totals[k_order_direct_block_size / k_wave_size];
-		__shared__ uint32_t carry;
-		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
-		const uint32_t wave = threadIdx.x / k_wave_size;
-		if (threadIdx.x == 0)
-			carry = 0;
-		__syncthreads();
-		for (uint32_t base = 0; base < num_entries; base += k_order_direct_block_size * k_order_scan_per_thread)
-		{
-			const uint32_t first = base + threadIdx.x * k_order_scan_per_thread;
-			uint32_t counts[k_order_scan_per_thread];
-			#pragma unroll
-			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
-				counts[k] = first + k < num_entries ? histograms[first + k] : 0u;
-			uint32_t sum = 0;
-			#pragma unroll
-			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
-				sum += counts[k];
-			uint32_t inclusive = sum;
-			for (uint32_t step = 1; step < k_wave_size; step *= 2)
-			{
-				const uint32_t below = __shfl_up(inclusive, step);
-				if (lane >= step)
-					inclusive += below;
-			}
-			if (lane == k_wave_size - 1)
-				wave_totals[wave] = inclusive;
-			__syncthreads();
-			uint32_t position = carry + inclusive - sum;
-			for (uint32_t w = 0; w < wave; ++w)
-				position += wave_totals[w];
-			#pragma unroll
-			for (uint32_t k = 0; k < k_order_scan_per_thread; ++k)
-			{
-				if (first + k < num_entries)
-					histograms[first + k] = position;
-				position += counts[k];
-			}
-			__syncthreads();
-			if (threadIdx.x == k_order_direct_block_size - 1)
-				carry = position;
-			__syncthreads();
-		}
-	}
-
-	__global__ __launch_bounds__(k_order_direct_block_size) void order_place_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
-		uint32_t instances_per_block, uint32_t num_bins, const uint32_t* __restrict__ offsets, order_layout layout_argument,
-		uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times, uint32_t* __restrict__ out_positions)
-	{
-		__shared__ uint32_t cursors[k_order_direct_bins];
-		__shared__ order_layout layout;
-		if (threadIdx.x < sizeof(order_layout) / 4)
-			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
-		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
-			cursors[bin] = offsets[size_t(bin) * gridDim.x + blockIdx.x];
-		__syncthreads();
-		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
-		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
-		{
-			const uint32_t clip_id = clip_ids[instance];
-			const uint32_t destination = order_slot_of(layout, atomicAdd(&cursors[min(clip_id, num_bins - 1)], 1u));
-			out_order[destination] = instance;
-			if (out_clip_ids != nullptr)
-				out_clip_ids[destination] = clip_id;
-			if (out_sample_times != nullptr)
-				out_sample_times[destination] = sample_times[instance];
-			if (out_positions != nullptr)
-				out_positions[instance] = destination;
-		}
-	}
-
 	// Instance lists kept in decode order (aclhip_instance_list_update): instance instances[k] now plays clips[k]. It keeps its slot --
 	// a full re-order follows once enough of the list has changed (host_lists.inl) --, the clip handle the decode reads for that slot changes.
 	__global__ __launch_bounds__(256) void update_instance_list_kernel(const uint32_t* __restrict__ instances, const uint32_t* __restrict__ new_clips, uint32_t count,
@@ -391,120 +289,200 @@
 		ordered_clips[positions[instance]] = new_clips[index];
 	}
 
-#if defined(ACLHIP_EXPERIMENTS)
-	// ---- aclhip_order_instances_device in ONE launch (ACLHIP_ORDER_LAUNCHES=1) -- measured 25.4 us against 23.5 us for the three launches it replaces ----
-	// The same order in ONE launch (three launches cost ~15 us before they do any work): every workgroup gathers its 2048 instances per
-	// clip in its LDS table and adds them to the clips' counters; the LAST workgroup to arrive turns the counters into cursors (and
-	// leaves them zeroed for the next call) and says so; everybody waits for that, then takes positions and scatters.
-	// All workgroups wait for one another: the host launches this form only while the grid fits the device (one workgroup per CU).
+	// ---- the same order without device scope atomics on the bins: per workgroup histograms laid out as a matrix, ONE launch ----
+	// (Device scope atomics on a few hundred hot addresses are what the three kernels above spend their time on: 23 us for 64k
+	// instances; three dependent launches cost ~5 us each before they do any work.) While the clip table has at most
+	// k_order_direct_bins entries, every workgroup counts its instances per clip in a directly indexed LDS histogram and writes its
+	// column of a [bin][workgroup] matrix; the workgroups meet at a barrier in global memory; every workgroup turns its share of the
+	// rows into prefix sums (in place) and row totals; a second barrier; every workgroup derives its own first positions from the
+	// totals and its column and places its instances. The only device scope atomics are the barriers': one add per workgroup and
+	// barrier, one polled word. Nothing to zero between calls.
+	// The workgroups wait for one another: the host launches this form with at most 64 workgroups and never more than the device
+	// has compute units (all of them become resident as soon as whatever else runs on the device drains).
+	// Measured (64k instances, 257 bins, back to back): 10.4 us; the same matrix in three launches (histogram | one workgroup scans
+	// the matrix | place) 16.8 us; one launch where every workgroup reads the whole matrix behind ONE barrier 15.4 us (14 us of
+	// agent scope loads with 64 workgroups); with agent scope fences instead of agent scope accesses 20.6 us.
+	constexpr uint32_t k_order_direct_bins = 8192;			// 32 KB of LDS
+	constexpr uint32_t k_order_direct_block_size = 1024;
+
 	struct order_control
 	{
-		uint32_t arrived;		// workgroups that have added their counts (back to 0 when the last one has arrived)
-		uint32_t scanned;		// calls whose cursors are complete: every workgroup reads it when it starts and waits for the next value
-								// (nothing a captured hipGraph would have to change between replays)
+		uint32_t arrived;		// workgroups whose column is written (back to 0 when the last one has arrived)
+		uint32_t padding[31];	// (the polls of the word below must not queue in front of the adds to the word above)
+		uint32_t generation;	// barriers passed: every workgroup reads it when it starts and waits for the next value (nothing
+								// a captured hipGraph would have to change between replays)
+		uint32_t more_padding[31];
 	};
+	constexpr uint32_t k_order_grid_entries = 1u << 19;			// bins x workgroups the one launch form takes
+	constexpr uint32_t k_order_grid_max_log2_blocks = 6;
+#if !defined(ACLHIP_ORDER_POLL_SLEEP)
+	#define ACLHIP_ORDER_POLL_SLEEP 4
+#endif
+	constexpr uint32_t k_order_barrier_poll_sleep = ACLHIP_ORDER_POLL_SLEEP;		// x 64 clocks between two polls
+	constexpr uint32_t k_order_barrier_max_polls = 1u << 22;	// seconds: only a device fault in an earlier call leaves the barrier unusable
 
-	__global__ __launch_bounds__(k_order_block_size) void order_instances_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
-		uint32_t num_bins, uint32_t* __restrict__ counters, uint32_t* __restrict__ cursors, order_control* __restrict__ control,
-		order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times,
-		uint32_t* __restrict__ out_positions)
+	// All workgroups of the grid have arrived (false: gave up waiting). `generation`: thread 0's, the value the barrier's word has to leave.
+	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t generation, uint32_t& passed)
 	{
-		__shared__ order_table table;
-		__shared__ order_layout layout;
-		__shared__ uint32_t wave_totals[k_order_block_size / k_wave_size];
-		__shared__ uint32_t carry, is_last, generation;
-		if (threadIdx.x == 0)
-			generation = __hip_atomic_load(&control->scanned, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);		// (before this workgroup arrives: the scan cannot have happened yet)
-		if (threadIdx.x < sizeof(order_layout) / 4)
-			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
-		order_table_clear(table);
-
-		uint32_t clip_id[k_order_instances_per_thread], slot[k_order_instances_per_thread], rank[k_order_instances_per_thread];
-		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
-		{
-			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
-			if (instance < num_instances)
-			{
-				clip_id[k] = clip_ids[instance];
-				slot[k] = order_table_insert(table, min(clip_id[k], num_bins - 1), rank[k]);
-			}
-		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__syncthreads();
-		for (uint32_t entry = threadIdx.x; entry < k_order_table_size; entry += k_order_block_size)
-			if (table.keys[entry] != k_order_empty_key)
-				__hip_atomic_fetch_add(&counters[table.keys[entry]], table.counts[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__syncthreads();
-
-		// the last workgroup to arrive scans
 		if (threadIdx.x == 0)
 		{
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			is_last = __hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
-			carry = 0;
-		}
-		__syncthreads();
-		if (is_last != 0)
-		{
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			const uint32_t lane = threadIdx.x & (k_wave_size - 1);
-			const uint32_t wave = threadIdx.x / k_wave_size;
-			for (uint32_t base = 0; base < num_bins; base += k_order_block_size)
-			{
-				const uint32_t bin = base + threadIdx.x;
-				const uint32_t count = bin < num_bins ? __hip_atomic_exchange(&counters[bin], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-				uint32_t inclusive = count;
-				for (uint32_t step = 1; step < k_wave_size; step *= 2)
-				{
-					const uint32_t below = __shfl_up(inclusive, step);
-					if (lane >= step)
-						inclusive += below;
-				}
-				if (lane == k_wave_size - 1)
-					wave_totals[wave] = inclusive;
-				__syncthreads();
-				uint32_t first = carry + inclusive - count;
-				for (uint32_t w = 0; w < wave; ++w)
-					first += wave_totals[w];
-				if (bin < num_bins)
-					__hip_atomic_store(&cursors[bin], first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__syncthreads();
-				if (threadIdx.x == k_order_block_size - 1)
-					carry = first + count;
-				__syncthreads();
-			}
-			if (threadIdx.x == 0)
+			uint32_t open = 1;
+			if (__hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
 			{
 				__hip_atomic_store(&control->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-				__hip_atomic_store(&control->scanned, generation + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");		// (arrived is back to 0 before anybody passes)
+				__hip_atomic_store(&control->generation, generation + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			else
+			{
+				uint32_t polls = 0;
+				while (__hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation && ++polls < k_order_barrier_max_polls)
+					__builtin_amdgcn_s_sleep(k_order_barrier_poll_sleep);
+				open = polls < k_order_barrier_max_polls ? 1u : 0u;
+			}
+			passed = open;
+		}
+		__syncthreads();
+		return passed != 0;
+	}
+
+#if defined(ACLHIP_EXPERIMENTS)
+	// wall clock stamps (10 ns units) of workgroup phases: tools/order_phases.py
+	__device__ unsigned long long g_order_stamps[64 * 8];
+	#define ACLHIP_ORDER_STAMP(index) do { if (threadIdx.x == 0 && blockIdx.x < 64) g_order_stamps[blockIdx.x * 8 + (index)] = wall_clock64(); } while (false)
+#else
+	#define ACLHIP_ORDER_STAMP(index) do { } while (false)
+#endif
+
+	__global__ __launch_bounds__(k_order_direct_block_size) void order_instances_grid_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
+		uint32_t instances_per_block, uint32_t num_bins, uint32_t log2_blocks, uint32_t* histograms, order_control* control, order_layout layout_argument,
+		uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times, uint32_t* __restrict__ out_positions)
+	{
+		__shared__ uint32_t cursors[k_order_direct_bins];		// instances per bin of this workgroup, then their first positions
+		__shared__ order_layout layout;
+		__shared__ uint32_t wave_totals[k_order_direct_block_size / k_wave_size];
+		__shared__ uint32_t passed;
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave = threadIdx.x / k_wave_size;
+		ACLHIP_ORDER_STAMP(0);
+		uint32_t generation = 0;
+		if (threadIdx.x == 0)
+			generation = __hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (before this workgroup arrives: the barrier cannot have opened yet)
+		if (threadIdx.x < sizeof(order_layout) / 4)
+			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
+		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
+			cursors[bin] = 0;
+		__syncthreads();
+		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
+		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
+			atomicAdd(&cursors[min(clip_ids[instance], num_bins - 1)], 1u);
+		__syncthreads();
+		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
+			__hip_atomic_store(&histograms[(size_t(bin) << log2_blocks) + blockIdx.x], cursors[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+		// the barrier. An agent scope release / acquire FENCE writes back / invalidates the whole L2 of the workgroup's XCD (the XCDs'
+		// L2s are not coherent with one another). Instead everything the workgroups tell one another -- the matrix, the barrier's
+		// words -- is written and read with agent scope accesses (they go to the point the XCDs share), and a workgroup arrives when
+		// its stores have been acknowledged (the workgroup scope fence waits for them).
+		ACLHIP_ORDER_STAMP(1);
+		if (!order_grid_barrier(control, generation, passed))
+			return;
+		ACLHIP_ORDER_STAMP(3);
+
+		// Every workgroup turns the rows of ITS share of the bins into "instances in the workgroups in front" (in place) and the
+		// bin's total (behind the matrix): a bin's 1 << log2_blocks entries lie in consecutive lanes of one wave. (Every workgroup
+		// reading the whole matrix instead: 14 us of agent scope loads for 64 workgroups x 257 bins.)
+		const uint32_t num_blocks = 1u << log2_blocks;
+		uint32_t* bin_totals = histograms + (size_t(num_bins) << log2_blocks);
+		{
+			const uint32_t bins_per_block = (num_bins + num_blocks - 1) >> log2_blocks;
+			const uint32_t first_bin = blockIdx.x * bins_per_block, end_bin = min(first_bin + bins_per_block, num_bins);
+			const uint32_t first_entry = first_bin << log2_blocks, end_entry = end_bin << log2_blocks;
+			const uint32_t lane_in_row = lane & (num_blocks - 1);
+			for (uint32_t base = first_entry; base < end_entry; base += k_order_direct_block_size)
+			{
+				const uint32_t entry = base + threadIdx.x;
+				const uint32_t count = entry < end_entry ? __hip_atomic_load(&histograms[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				uint32_t inclusive = count;
+				for (uint32_t step = 1; step < num_blocks; step *= 2)
+				{
+					const uint32_t lower = __shfl_up(inclusive, step);
+					if (lane_in_row >= step)
+						inclusive += lower;
+				}
+				if (entry < end_entry)
+				{
+					__hip_atomic_store(&histograms[entry], inclusive - count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (lane_in_row == num_blocks - 1)
+						__hip_atomic_store(&bin_totals[entry >> log2_blocks], inclusive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
 			}
 		}
-		if (threadIdx.x == 0)
+		ACLHIP_ORDER_STAMP(2);
+		if (!order_grid_barrier(control, generation + 1u, passed))
+			return;
+		ACLHIP_ORDER_STAMP(4);
+
+		// first position of a bin = instances of the bins in front of it; this workgroup starts behind the ones in front of it.
+		// Consecutive bins per thread, as few as cover the table (the loads are agent scope: a microsecond, whatever their number)
+		constexpr uint32_t max_bins_per_thread = k_order_direct_bins / k_order_direct_block_size;
 		{
-			while (__hip_atomic_load(&control->scanned, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == generation)
-				__builtin_amdgcn_s_sleep(2);
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const uint32_t bins_per_thread = (num_bins + k_order_direct_block_size - 1) / k_order_direct_block_size;
+			const uint32_t first_bin = threadIdx.x * bins_per_thread;
+			uint32_t counts[max_bins_per_thread], in_front[max_bins_per_thread];
+			#pragma unroll
+			for (uint32_t k = 0; k < max_bins_per_thread; ++k)
+			{
+				const bool valid = k < bins_per_thread && first_bin + k < num_bins;
+				counts[k] = valid ? __hip_atomic_load(&bin_totals[first_bin + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				in_front[k] = valid ? __hip_atomic_load(&histograms[(size_t(first_bin + k) << log2_blocks) + blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			}
+			uint32_t sum = 0;
+			#pragma unroll
+			for (uint32_t k = 0; k < max_bins_per_thread; ++k)
+				sum += counts[k];
+			uint32_t inclusive = sum;
+			for (uint32_t step = 1; step < k_wave_size; step *= 2)
+			{
+				const uint32_t lower = __shfl_up(inclusive, step);
+				if (lane >= step)
+					inclusive += lower;
+			}
+			if (lane == k_wave_size - 1)
+				wave_totals[wave] = inclusive;
+			__syncthreads();
+			uint32_t position = inclusive - sum;
+			for (uint32_t w = 0; w < wave; ++w)
+				position += wave_totals[w];
+			#pragma unroll
+			for (uint32_t k = 0; k < max_bins_per_thread; ++k)
+			{
+				if (k < bins_per_thread && first_bin + k < num_bins)
+					cursors[first_bin + k] = position + in_front[k];
+				position += counts[k];
+			}
 		}
 		__syncthreads();
+		ACLHIP_ORDER_STAMP(5);
 
-		// the workgroup's instances of a clip take consecutive positions: counts[] becomes the first of them
-		for (uint32_t entry = threadIdx.x; entry < k_order_table_size; entry += k_order_block_size)
-			if (table.keys[entry] != k_order_empty_key)
-				table.counts[entry] = __hip_atomic_fetch_add(&cursors[table.keys[entry]], table.counts[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__syncthreads();
-		for (uint32_t k = 0; k < k_order_instances_per_thread; ++k)
+		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
 		{
-			const uint32_t instance = blockIdx.x * k_order_instances_per_block + k * k_order_block_size + threadIdx.x;
-			if (instance >= num_instances)
-				continue;
-			const uint32_t destination = order_slot_of(layout, table.counts[slot[k]] + rank[k]);
+			const uint32_t clip_id = clip_ids[instance];
+			const uint32_t destination = order_slot_of(layout, atomicAdd(&cursors[min(clip_id, num_bins - 1)], 1u));
 			out_order[destination] = instance;
 			if (out_clip_ids != nullptr)
-				out_clip_ids[destination] = clip_id[k];
+				out_clip_ids[destination] = clip_id;
 			if (out_sample_times != nullptr)
 				out_sample_times[destination] = sample_times[instance];
 			if (out_positions != nullptr)
 				out_positions[instance] = destination;
 		}
-	}
+		ACLHIP_ORDER_STAMP(6);
+#if defined(ACLHIP_EXPERIMENTS)
+		__builtin_amdgcn_s_waitcnt(0);		// (vmcnt 0: the stores acknowledged)
+		__syncthreads();
+		ACLHIP_ORDER_STAMP(7);
 #endif
+	}

@@ -112,3 +112,91 @@ def test_a_registry_of_20000_clips_scans_in_several_rounds():
         assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), instance_clips[order])
         for handle in handles[::-1]:
             context.unregister_clip(int(handle))
+
+
+@pytest.mark.parametrize("num_clips", [1, 300, 1500, 8000])
+def test_the_one_launch_form_at_every_grid_size(num_clips):
+    """order_instances_grid_kernel: 1 .. 64 workgroups that meet at two barriers in global memory (the number of workgroups follows the
+    batch size and the clip table), batch sizes around the workgroup boundaries, the same scratch used again and again"""
+    clip = synth.build_clip(seed=5, num_tracks=3, num_samples=2)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(clip.blob, check_hash=False) for _ in range(num_clips)], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        rng = np.random.default_rng(num_clips)
+        stream = torch.cuda.Stream(device)
+        for n in (1, 63, 1024, 2047, 2048, 2049, 5000, 40000, 65535, 65536, 70001, 200000):
+            for repeat in range(3):
+                instance_clips = handles[rng.integers(0, handles.size, size=n)]
+                if repeat == 2:
+                    instance_clips = np.sort(instance_clips)[::-1].copy()       # whole workgroups that hold one clip only
+                times = rng.uniform(0.0, 1.0, size=n).astype(np.float32)
+                _, _, d_order, d_out_clips, d_out_times = _order_on_device(context, device, instance_clips, times, stream)
+                stream.synchronize()
+                order = d_order.cpu().numpy().astype(np.uint32)
+                check_order(instance_clips, order, 1, stable=False)
+                assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), instance_clips[order])
+                assert np.array_equal(d_out_times.cpu().numpy().view(np.uint32), times[order].view(np.uint32))
+        for handle in handles[::-1]:
+            context.unregister_clip(int(handle))
+
+
+def test_the_one_launch_form_on_two_streams_and_replayed_from_a_graph():
+    """two streams order at the same time (each has its own scratch and barrier words); a captured order replays with new clip
+    handles in the same buffers (the barrier's generation word is read by the kernel, not passed by the host)"""
+    clip = synth.build_clip(seed=5, num_tracks=3, num_samples=2)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(clip.blob, check_hash=False) for _ in range(200)], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        rng = np.random.default_rng(9)
+        n = 65536
+        streams = [torch.cuda.Stream(device) for _ in range(2)]
+        buffers = []
+        for stream in streams:
+            d_clips = torch.zeros((n,), dtype=torch.int32, device=device)
+            d_times = torch.zeros((n,), dtype=torch.float32, device=device)
+            d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+            d_out_clips = torch.full((n,), -1, dtype=torch.int32, device=device)
+            d_out_times = torch.zeros((n,), dtype=torch.float32, device=device)
+            buffers.append((d_clips, d_times, d_order, d_out_clips, d_out_times))
+        torch.cuda.synchronize(device)
+
+        def call(k):
+            d_clips, d_times, d_order, d_out_clips, d_out_times = buffers[k]
+            context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr(), d_out_times.data_ptr(),
+                                           stream=streams[k].cuda_stream)
+
+        for k in range(2):
+            call(k)             # first calls: scratch and barrier words are allocated outside any capture
+        torch.cuda.synchronize(device)
+
+        for round_index in range(4):
+            lists = [handles[rng.integers(0, handles.size, size=n)] for _ in range(2)]
+            for k in range(2):
+                buffers[k][0].copy_(torch.from_numpy(lists[k].astype(np.int32)))
+            torch.cuda.synchronize(device)
+            for _ in range(8):
+                for k in range(2):
+                    call(k)
+            torch.cuda.synchronize(device)
+            for k in range(2):
+                order = buffers[k][2].cpu().numpy().astype(np.uint32)
+                check_order(lists[k], order, 1, stable=False)
+                assert np.array_equal(buffers[k][3].cpu().numpy().astype(np.uint32), lists[k][order])
+
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=streams[0]):
+            call(0)
+        for replay in range(5):
+            instance_clips = handles[rng.integers(0, handles.size, size=n)]
+            buffers[0][0].copy_(torch.from_numpy(instance_clips.astype(np.int32)))
+            torch.cuda.synchronize(device)
+            graph.replay()
+            if replay == 2:
+                call(0)         # a plain call between two replays moves the generation on: the replays do not care
+            torch.cuda.synchronize(device)
+            order = buffers[0][2].cpu().numpy().astype(np.uint32)
+            check_order(instance_clips, order, 1, stable=False)
+            assert np.array_equal(buffers[0][3].cpu().numpy().astype(np.uint32), instance_clips[order])
+        del graph
+        for handle in handles[::-1]:
+            context.unregister_clip(int(handle))
