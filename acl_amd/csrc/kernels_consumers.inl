@@ -151,7 +151,8 @@
 	//   kUnitScale     object space without a base while no registered clip has a scale other than 1: the images hold rotation |
 	//                  translation only (32 of a transform's 48 bytes)
 	//   kMirrored      some registered clip may decode a NEGATIVE scale (or the base is a caller's pose buffer): rtm::qvv_mul's matrix
-	//                  route is compiled in (10 more registers: one wave per SIMD less). Transforms that would take it are counted either way.
+	//                  route is compiled in (10 more registers: one wave per SIMD less) and the transforms that take it are counted; without it
+	//                  none can occur (scales that are sums and products of non negative values).
 	constexpr uint32_t k_consumer_base_none = 0, k_consumer_base_buffer = 1, k_consumer_base_second_wave = 2, k_consumer_base_fused = 3;
 
 	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored>
@@ -269,9 +270,12 @@
 				const qvv base = load_qvv(base_source, transform_index);
 				store_qvv(image, transform_index, apply_additive_to_base<kMirrored>(consumers.additive_format, base, additive));
 				// additive_clip_format8::relative is a qvv_mul (core/additive_utils.h:128-160)
-				const uint64_t mirrored = __ballot(consumers.additive_format == 1 && qvv_mul_takes_matrix_path(additive, base));
-				if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
-					atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
+				if constexpr (kMirrored)
+				{
+					const uint64_t mirrored = __ballot(consumers.additive_format == 1 && qvv_mul_takes_matrix_path(additive, base));
+					if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
+						atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
+				}
 			}
 		}
 
@@ -330,12 +334,22 @@
 								else
 								{
 									const qvv child = load_qvv(slot_image, pair & 0xFFFFu), parent = load_qvv(slot_image, pair >> 16);
-									const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
-									if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
-										atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
-									qvv object = qvv_mul(child, parent);
-									if (kMirrored && mirrored != 0 && qvv_mul_takes_matrix_path(child, parent))
-										object = qvv_mul_through_matrices(child, parent);
+									qvv object;
+									if constexpr (kMirrored)
+									{
+										const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
+										if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
+											atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
+										object = qvv_mul(child, parent);
+										if (mirrored != 0 && qvv_mul_takes_matrix_path(child, parent))
+											object = qvv_mul_through_matrices(child, parent);
+									}
+									else
+									{
+										// no registered clip can decode a negative scale and the base is a clip: products and sums of non
+										// negative scales -- nothing to count, nothing to route
+										object = qvv_mul(child, parent);
+									}
 									object.rotation = quat_normalize(object.rotation);
 									store_qvv(slot_image, pair & 0xFFFFu, object);
 								}

@@ -482,11 +482,13 @@ aclhip_status aclhip_push_poses_to_peer(aclhip_context* context, void* peer_buff
  * the reference silently returns in those cases (impl/decompression.transform.h:1532-1537,1766-1768). */
 aclhip_status aclhip_get_rejected_instance_count(aclhip_context* context, uint64_t* out_count);
 
-/* Number of transforms the pose consumers combined with rtm::qvv_mul semantics (local -> object space, the `relative` additive format)
- * while a NEGATIVE scale component was involved, since the context was created. For those RTM composes 3x4 matrices instead of
- * quaternions (mirrored rigs); that path is not restated here (RTM is absent from the reference checkout): the kernels
- * use the quaternion formula for every scale and count, so a caller can tell that such results follow a different formula than the
- * reference's. 0 for every rig with non-negative scales. Waits for the device like aclhip_get_rejected_instance_count. */
+/* Number of transforms the pose consumers combined through rtm::qvv_mul's MATRIX route (local -> object space, the `relative`
+ * additive format) because a NEGATIVE scale component was involved, since the context was created: mirrored rigs, for which RTM
+ * composes 3x4 matrices instead of quaternions, and so do the kernels (qvv_mul_through_matrices, bit for bit the oracle's restatement;
+ * pinned by an fp64 matrix chain in tests/test_pose_consumers_oracle.py). The route is compiled into a launch only while some
+ * registered clip can decode a negative scale (found at registration from defaults, constants, clip ranges and raw segments) or the
+ * base is a caller's pose buffer. 0 for every rig with non-negative scales. Waits for the device like
+ * aclhip_get_rejected_instance_count. */
 aclhip_status aclhip_get_negative_scale_count(aclhip_context* context, uint64_t* out_count);
 
 /* ---- measurement helpers ---------------------------------------------------------------------- */
