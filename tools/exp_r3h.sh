@@ -1,4 +1,6 @@
-# scalar lists: what bounds the float1f kernel -- timing only variants (wrong results): no stores / no field arithmetic
+# scalar lists: what bounds the float1f kernel -- timing only variants (wrong results): no stores / no field arithmetic.
+# The two libraries were built from the hand-written float1f decode of round 3 with -DACLHIP_EXP_SCALAR_NO_STORES / _NO_DECODE; that
+# decode is not kept (same time as the shipped one), so this script documents the run rather than reproducing it.
 run() {
 timeout 300 python bench.py --workload scalar --steps 600 --warmup 100 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
 import sys,json
