@@ -108,7 +108,8 @@ namespace aclhip
 	class device
 	{
 	public:
-		explicit device(int device_index = 0) { if (aclhip_create(device_index, &m_context) != ACLHIP_OK) m_context = nullptr; }
+		// (a library built from another include/aclhip.h would read this header's structs wrongly: no context then)
+		explicit device(int device_index = 0) { if (aclhip_abi_version() != ACLHIP_ABI_VERSION || aclhip_create(device_index, &m_context) != ACLHIP_OK) m_context = nullptr; }
 		~device() { aclhip_destroy(m_context); }
 		device(const device&) = delete;
 		device& operator=(const device&) = delete;

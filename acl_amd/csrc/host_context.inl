@@ -779,6 +779,11 @@ extern "C" void aclhip_default_params(aclhip_decompress_params* out_params)
 	out_params->default_scale_mode = ACLHIP_DEFAULT_LEGACY;
 }
 
+extern "C" uint32_t aclhip_abi_version(void)
+{
+	return ACLHIP_ABI_VERSION;
+}
+
 extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_context)
 {
 	if (out_context == nullptr)

@@ -24,7 +24,7 @@ DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY = 0, 1, 2, 3
 INVALID_HANDLE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [
-    "aclhip_status_string", "aclhip_last_error_message", "aclhip_create", "aclhip_destroy", "aclhip_default_params",
+    "aclhip_status_string", "aclhip_last_error_message", "aclhip_abi_version", "aclhip_create", "aclhip_destroy", "aclhip_default_params",
     "aclhip_register_clip", "aclhip_unregister_clip", "aclhip_get_clip_info", "aclhip_clip_matches",
     "aclhip_decompress_tracks_batch", "aclhip_decompress_track_batch", "aclhip_decompress_tracks_host", "aclhip_decompress_track_host",
     "aclhip_get_rejected_instance_count", "aclhip_time_decompress_tracks_batch", "aclhip_batch_algorithmic_bytes",
@@ -67,6 +67,7 @@ class OutputDesc(ctypes.Structure):
     ]
 
 
+ABI_VERSION = 3             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
 PEER_HANDLE_BYTES = 72      # ACLHIP_PEER_HANDLE_BYTES
 LAYOUT_QVV48, LAYOUT_QVV40, LAYOUT_QV32 = 0, 1, 2  # aclhip_pose_layout
 LAYOUTS = {"qvv48": (LAYOUT_QVV48, 48), "qvv40": (LAYOUT_QVV40, 40), "qv32": (LAYOUT_QV32, 32)}     # name -> (aclhip_pose_layout, bytes per track)
@@ -149,6 +150,10 @@ def load_library():
     lib.aclhip_status_string.restype = ctypes.c_char_p
     lib.aclhip_last_error_message.argtypes = [vp]
     lib.aclhip_last_error_message.restype = ctypes.c_char_p
+    lib.aclhip_abi_version.argtypes = []
+    lib.aclhip_abi_version.restype = ctypes.c_uint32
+    if lib.aclhip_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{_LIB_PATH} was built with ABI version {lib.aclhip_abi_version()}, this binding mirrors version {ABI_VERSION}: rebuild the library")
     lib.aclhip_create.argtypes = [i32, ctypes.POINTER(vp)]
     lib.aclhip_destroy.argtypes = [vp]
     lib.aclhip_destroy.restype = None

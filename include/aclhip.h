@@ -152,6 +152,12 @@ const char* aclhip_status_string(aclhip_status status);
 /* Message of the last failing call made on the CALLING thread (empty string when none); `context` is not used to find it. */
 const char* aclhip_last_error_message(const aclhip_context* context);
 
+/* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks).
+ * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
+ * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
+#define ACLHIP_ABI_VERSION 3u
+uint32_t aclhip_abi_version(void);
+
 /* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are
  * 128 byte stack objects, decompression/impl/decompression_context.transform.h:53-116). */
 aclhip_status aclhip_create(int device_index, aclhip_context** out_context);

@@ -96,3 +96,15 @@ def test_cpp_mirror_and_its_drivers_compile_warning_free():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for source in ("context_mirror_test.cpp", "database_mirror_test.cpp", "scalar_mirror_test.cpp", "pose_consumers_mirror_test.cpp"):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", os.path.join(root, "tests", "cpp", source)], check=True)
+
+
+def test_header_library_and_binding_agree_on_the_abi_version():
+    """a caller built against another include/aclhip.h hands over structs of another shape (found in round 3: a stale adapter binary
+    passed an aclhip_output_desc without `skip_tracks`): the header carries a version, the library reports the one it was built with"""
+    header = open(os.path.join(ROOT, "include", "aclhip.h")).read()
+    declared = int(re.search(r"#define\s+ACLHIP_ABI_VERSION\s+(\d+)u", header).group(1))
+    lib = runtime.load_library()
+    assert lib.aclhip_abi_version() == declared == runtime.ABI_VERSION
+    # the binding's mirror of the struct that changed last: layout u32 | 3 skip bytes + 1 reserved | rows | skip_tracks
+    assert ctypes.sizeof(runtime.OutputDesc) == 24
+    assert runtime.OutputDesc.skip_tracks.offset == 16
