@@ -801,6 +801,8 @@ def main():
             measure_job("256_clips", rank, device_index, order="list"),            # persistent instance list: 1 % of the instances change clip per step, inside the step
             measure_job("cinematic", rank, device_index, repeats=150),
             measure_job("database", rank, device_index),
+            measure_job("database", rank, device_index, order="locality"),         # the same instances laid out in aclhip_order_instances_for_locality order
+            measure_job("database", rank, device_index, order="list"),             # ... kept in a persistent instance list, 1 % changing clip per step
             # scalar track lists and the pose consumers fused into the decode
             measure_job("scalar", rank, device_index),
             measure_job("object_space", rank, device_index, repeats=150),

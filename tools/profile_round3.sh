@@ -46,8 +46,11 @@ run_workload one_clip "one_clip" --workload one_clip
 run_workload 256_clips "256_clips" --workload 256_clips
 run_workload 256_clips_locality "256_clips, locality order" --workload 256_clips --order locality
 run_workload 256_clips_list "256_clips, list order" --workload 256_clips --order list
+run_workload 256_clips_device "256_clips, device order" --workload 256_clips --order device
 run_workload cinematic "cinematic" --workload cinematic
 run_workload database "database" --workload database
+run_workload database_locality "database, locality order" --workload database --order locality
+run_workload database_list "database, list order" --workload database --order list
 run_workload one_clip_qv32 "one_clip, qv32" --workload one_clip --layout qv32
 run_workload one_clip_qvv40 "one_clip, qvv40" --workload one_clip --layout qvv40
 run_workload scalar "scalar" --workload scalar
