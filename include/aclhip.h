@@ -336,7 +336,10 @@ aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhi
  *                                    aclhip_instance_list_get_order) -- 1 KiB stores to consecutive rows, what the write path likes -- or,
  *                                    with poses_in_instance_order != 0, in row i for instance i (scattered rows: measured 20 % slower).
  *                                    `output` as in aclhip_decompress_tracks_batch_out (its `rows` must be NULL), or NULL.
- * All calls of one list must be made in stream order (one stream, or the caller's events between streams). */
+ * All calls of one list must be made in stream order (one stream, or the caller's events between streams). WHEN a list is re-ordered
+ * is decided on the host at the time of the call: a decode captured into a hipGraph replays what was decided when it was captured
+ * (capture aclhip_order_instances_device + aclhip_decompress_tracks_batch instead when the order has to follow the replays' data).
+ * An update that names an instance twice leaves either of the two clips. */
 typedef uint32_t aclhip_instance_list;
 
 aclhip_status aclhip_instance_list_create(aclhip_context* context, uint32_t num_instances, aclhip_instance_list* out_list);
