@@ -319,9 +319,13 @@
 	#define ACLHIP_ORDER_POLL_SLEEP 4
 #endif
 	constexpr uint32_t k_order_barrier_poll_sleep = ACLHIP_ORDER_POLL_SLEEP;		// x 64 clocks between two polls
-	constexpr uint32_t k_order_barrier_max_polls = 1u << 22;	// seconds: only a device fault in an earlier call leaves the barrier unusable
+	constexpr uint32_t k_order_barrier_max_polls = 1u << 22;	// seconds
 
-	// All workgroups of the grid have arrived (false: gave up waiting). `generation`: thread 0's, the value the barrier's word has to leave.
+	// All workgroups of the grid have arrived. `generation`: thread 0's, the value the barrier's word has to leave.
+	// A barrier that does not open within seconds cannot open any more -- a fault in an earlier call left its words behind, or so many
+	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident (nine and more at 64
+	// workgroups each) -- and the kernel TRAPS: the launch fails loudly (the queue reports a hardware exception) instead of leaving a
+	// half written order behind for the decode that follows.
 	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t generation, uint32_t& passed)
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -341,6 +345,8 @@
 				while (__hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation && ++polls < k_order_barrier_max_polls)
 					__builtin_amdgcn_s_sleep(k_order_barrier_poll_sleep);
 				open = polls < k_order_barrier_max_polls ? 1u : 0u;
+				if (open == 0)
+					__builtin_trap();
 			}
 			passed = open;
 		}

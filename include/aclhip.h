@@ -311,12 +311,15 @@ aclhip_status aclhip_order_instances_for_locality(const aclhip_context* context,
  * ceil(3 * num_tracks of the largest clip / ACLHIP_WINDOW_QUADS) wavefronts per pose (1 up to 104 tracks). Host only. */
 aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_instance, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order);
 
-/* The same order computed on the GPU for instance lists that live there (all pointers DEVICE pointers, stream ordered: three small
- * kernels on `stream`, counters kept per stream by the context, no host synchronization). Writes the permutation to out_order and,
+/* The same order computed on the GPU for instance lists that live there (all pointers DEVICE pointers, stream ordered: ONE launch
+ * on `stream` -- at most 64 workgroups that meet at barriers in global memory; three launches for registries of more than 8 192
+ * clips --, scratch kept per stream by the context, no host synchronization). The one launch form needs all its workgroups resident
+ * together: it is sized for that on a device the process has to itself or shares with a few others; a barrier that does not open
+ * within seconds traps (the launch fails, the queue reports it) rather than leave a half written order behind. Writes the permutation to out_order and,
  * when the pointers are not NULL, the permuted lists out_clips[k] = clips[out_order[k]], out_sample_times[k] =
  * sample_times[out_order[k]] (the arguments of the decode that follows on the same stream; rows = out_order puts the poses back
  * in the caller's rows). Which instance of a clip takes which of the clip's slots is decided by atomics: every call returns a valid
- * order, not the same one. The first call on a stream allocates that stream's counters: make it before capturing the stream into a
+ * order, not the same one. The first call on a stream allocates that stream's scratch: make it before capturing the stream into a
  * hipGraph. An instance list usually outlives a frame (which character plays which clip changes rarely, the
  * sample times every frame): order once, keep the lists in that order. */
 aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
