@@ -832,13 +832,40 @@ namespace aclhip
 		float4 scale;			// w = 0
 	};
 
+	// rtm::quat_mul, x86 form: every lane sums its four products pairwise, signs folded into the products:
+	//   x = ((rw * lx) +  (rx * lw)) + ( (ry * lz) + -(rz * ly))
+	//   y = ((rw * ly) + -(rx * lz)) + ( (ry * lw) +  (rz * lx))
+	//   z = ((rw * lz) +  (rx * ly)) + (-(ry * lx) +  (rz * lw))
+	//   w = ((rw * lw) + -(rx * lx)) + (-(ry * ly) + -(rz * lz))
+	// Written as 8 v_pk_mul_f32 + 6 v_pk_add_f32 on the register pairs (x, y) and (z, w): the swizzles, broadcasts and signs are the
+	// instructions' own op_sel / neg modifiers (negating an operand negates the product exactly; the sums keep the order above). The
+	// compiler's version of the same C++ spends 10 more v_mov_b32 per product on building swizzled pairs -- and the object space walk
+	// is three products per transform on a kernel that is bound by VALU issue.
+	// A packed fp32 result may be read two instructions later at the earliest (the compiler pads its own; the order below keeps that
+	// distance and the trailing s_nop covers whatever follows the block).
+	typedef float f32x2_lanes __attribute__((ext_vector_type(2)));
 	__device__ __forceinline__ float4 quat_mul(float4 lhs, float4 rhs)
 	{
-		const float x = ((rhs.w * lhs.x) + (rhs.x * lhs.w)) + ((rhs.y * lhs.z) + -(rhs.z * lhs.y));
-		const float y = ((rhs.w * lhs.y) + -(rhs.x * lhs.z)) + ((rhs.y * lhs.w) + (rhs.z * lhs.x));
-		const float z = ((rhs.w * lhs.z) + (rhs.x * lhs.y)) + (-(rhs.y * lhs.x) + (rhs.z * lhs.w));
-		const float w = ((rhs.w * lhs.w) + -(rhs.x * lhs.x)) + (-(rhs.y * lhs.y) + -(rhs.z * lhs.z));
-		return make_float4(x, y, z, w);
+		const f32x2_lanes l01 = { lhs.x, lhs.y }, l23 = { lhs.z, lhs.w }, r01 = { rhs.x, rhs.y }, r23 = { rhs.z, rhs.w };
+		f32x2_lanes t1, t2, t3, t4, u1, u2, u3, u4, xy, zw;
+		asm("v_pk_mul_f32 %0, %13, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t1 = { rw * lx,  rw * ly }
+			"v_pk_mul_f32 %1, %12, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// t2 = { rx * lw, -rx * lz }
+			"v_pk_mul_f32 %2, %12, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t3 = { ry * lz,  ry * lw }
+			"v_pk_mul_f32 %3, %13, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// t4 = { -rz * ly, rz * lx }
+			"v_pk_mul_f32 %4, %13, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// u1 = { rw * lz,  rw * lw }
+			"v_pk_mul_f32 %5, %12, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u2 = { rx * ly, -rx * lx }
+			"v_pk_mul_f32 %6, %12, %10 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"		// u3 = { -ry * lx, -ry * ly }
+			"v_pk_mul_f32 %7, %13, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u4 = { rz * lw, -rz * lz }
+			"v_pk_add_f32 %0, %0, %1\n\t"
+			"v_pk_add_f32 %2, %2, %3\n\t"
+			"v_pk_add_f32 %4, %4, %5\n\t"
+			"v_pk_add_f32 %6, %6, %7\n\t"
+			"v_pk_add_f32 %8, %0, %2\n\t"
+			"v_pk_add_f32 %9, %4, %6\n\t"
+			"s_nop 0"
+			: "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(xy), "=&v"(zw)
+			: "v"(l01), "v"(l23), "v"(r01), "v"(r23));
+		return make_float4(xy.x, xy.y, zw.x, zw.y);
 	}
 
 	// quat_mul(quat_mul(conjugate(rotation), (vector.xyz, 0)), rotation); the W lane of the result is numeric residue and dropped
