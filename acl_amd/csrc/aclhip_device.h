@@ -841,39 +841,66 @@ namespace aclhip
 	// instructions' own op_sel / neg modifiers (negating an operand negates the product exactly; the sums keep the order above). The
 	// compiler's version of the same C++ spends 10 more v_mov_b32 per product on building swizzled pairs -- and the object space walk
 	// is three products per transform on a kernel that is bound by VALU issue.
-	// A packed fp32 result may be read two instructions later at the earliest (the compiler pads its own; the order below keeps that
-	// distance and the trailing s_nop covers whatever follows the block).
+	// A packed fp32 result may be read two instructions later at the earliest (gfx940+; the compiler pads its own instructions but
+	// does not look inside an asm block: the order below keeps that distance, the s_nop in front and behind cover the block's edges).
 	typedef float f32x2_lanes __attribute__((ext_vector_type(2)));
-	__device__ __forceinline__ float4 quat_mul(float4 lhs, float4 rhs)
+	// kConjugateLhs: the product of conjugate(lhs) and rhs -- the signs of lx, ly, lz fold into the same modifiers
+	template<bool kConjugateLhs>
+	__device__ __forceinline__ float4 quat_mul_packed(float4 lhs, float4 rhs)
 	{
 		const f32x2_lanes l01 = { lhs.x, lhs.y }, l23 = { lhs.z, lhs.w }, r01 = { rhs.x, rhs.y }, r23 = { rhs.z, rhs.w };
 		f32x2_lanes t1, t2, t3, t4, u1, u2, u3, u4, xy, zw;
-		asm("v_pk_mul_f32 %0, %13, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t1 = { rw * lx,  rw * ly }
-			"v_pk_mul_f32 %1, %12, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// t2 = { rx * lw, -rx * lz }
-			"v_pk_mul_f32 %2, %12, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t3 = { ry * lz,  ry * lw }
-			"v_pk_mul_f32 %3, %13, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// t4 = { -rz * ly, rz * lx }
-			"v_pk_mul_f32 %4, %13, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// u1 = { rw * lz,  rw * lw }
-			"v_pk_mul_f32 %5, %12, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u2 = { rx * ly, -rx * lx }
-			"v_pk_mul_f32 %6, %12, %10 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"		// u3 = { -ry * lx, -ry * ly }
-			"v_pk_mul_f32 %7, %13, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u4 = { rz * lw, -rz * lz }
-			"v_pk_add_f32 %0, %0, %1\n\t"
-			"v_pk_add_f32 %2, %2, %3\n\t"
-			"v_pk_add_f32 %4, %4, %5\n\t"
-			"v_pk_add_f32 %6, %6, %7\n\t"
-			"v_pk_add_f32 %8, %0, %2\n\t"
-			"v_pk_add_f32 %9, %4, %6\n\t"
-			"s_nop 0"
-			: "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(xy), "=&v"(zw)
-			: "v"(l01), "v"(l23), "v"(r01), "v"(r23));
+		if constexpr (!kConjugateLhs)
+			asm("s_nop 0\n\t"																				// (an operand may come straight out of a packed instruction of the compiler's)
+				"v_pk_mul_f32 %0, %13, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t1 = { rw * lx,  rw * ly }
+				"v_pk_mul_f32 %1, %12, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// t2 = { rx * lw, -rx * lz }
+				"v_pk_mul_f32 %2, %12, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// t3 = { ry * lz,  ry * lw }
+				"v_pk_mul_f32 %3, %13, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// t4 = { -rz * ly, rz * lx }
+				"v_pk_mul_f32 %4, %13, %11 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// u1 = { rw * lz,  rw * lw }
+				"v_pk_mul_f32 %5, %12, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u2 = { rx * ly, -rx * lx }
+				"v_pk_mul_f32 %6, %12, %10 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"		// u3 = { -ry * lx, -ry * ly }
+				"v_pk_mul_f32 %7, %13, %11 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// u4 = { rz * lw, -rz * lz }
+				"v_pk_add_f32 %0, %0, %1\n\t"
+				"v_pk_add_f32 %2, %2, %3\n\t"
+				"v_pk_add_f32 %4, %4, %5\n\t"
+				"v_pk_add_f32 %6, %6, %7\n\t"
+				"v_pk_add_f32 %8, %0, %2\n\t"
+				"v_pk_add_f32 %9, %4, %6\n\t"
+				"s_nop 0"
+				: "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(xy), "=&v"(zw)
+				: "v"(l01), "v"(l23), "v"(r01), "v"(r23));
+		else
+			asm("s_nop 0\n\t"
+				"v_pk_mul_f32 %0, %13, %10 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[1,0]\n\t"		// t1 = { rw * -lx,  rw * -ly }
+				"v_pk_mul_f32 %1, %12, %11 op_sel:[0,1] op_sel_hi:[0,0]\n\t"								// t2 = { rx * lw, -rx * -lz }
+				"v_pk_mul_f32 %2, %12, %11 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// t3 = { ry * -lz,  ry * lw }
+				"v_pk_mul_f32 %3, %13, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]\n\t"		// t4 = { -rz * -ly, rz * -lx }
+				"v_pk_mul_f32 %4, %13, %11 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// u1 = { rw * -lz,  rw * lw }
+				"v_pk_mul_f32 %5, %12, %10 op_sel:[0,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,0]\n\t"		// u2 = { rx * -ly, -rx * -lx }
+				"v_pk_mul_f32 %6, %12, %10 op_sel:[1,0] op_sel_hi:[1,1]\n\t"								// u3 = { -ry * -lx, -ry * -ly }
+				"v_pk_mul_f32 %7, %13, %11 op_sel:[0,1] op_sel_hi:[0,0]\n\t"								// u4 = { rz * lw, -rz * -lz }
+				"v_pk_add_f32 %0, %0, %1\n\t"
+				"v_pk_add_f32 %2, %2, %3\n\t"
+				"v_pk_add_f32 %4, %4, %5\n\t"
+				"v_pk_add_f32 %6, %6, %7\n\t"
+				"v_pk_add_f32 %8, %0, %2\n\t"
+				"v_pk_add_f32 %9, %4, %6\n\t"
+				"s_nop 0"
+				: "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(xy), "=&v"(zw)
+				: "v"(l01), "v"(l23), "v"(r01), "v"(r23));
 		return make_float4(xy.x, xy.y, zw.x, zw.y);
+	}
+
+	__device__ __forceinline__ float4 quat_mul(float4 lhs, float4 rhs)
+	{
+		return quat_mul_packed<false>(lhs, rhs);
 	}
 
 	// quat_mul(quat_mul(conjugate(rotation), (vector.xyz, 0)), rotation); the W lane of the result is numeric residue and dropped
 	__device__ __forceinline__ float4 quat_mul_vector3(float4 vector, float4 rotation)
 	{
 		const float4 vector_quat = make_float4(vector.x, vector.y, vector.z, 0.0f);
-		const float4 inv_rotation = make_float4(-rotation.x, -rotation.y, -rotation.z, rotation.w);
-		const float4 result = quat_mul(quat_mul(inv_rotation, vector_quat), rotation);
+		const float4 result = quat_mul(quat_mul_packed<true>(rotation, vector_quat), rotation);
 		return make_float4(result.x, result.y, result.z, 0.0f);
 	}
 
