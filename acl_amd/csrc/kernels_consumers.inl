@@ -82,7 +82,7 @@
 		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
 		{
 			const uint32_t quad = entry.quad_index;
-			image[quad] = apply_additive_sub_track(additive_format, quad - (quad / 3u) * 3u, value, image[quad]);
+			image[quad] = apply_additive_sub_track(additive_format, quad - entry.track_index * 3u, value, image[quad]);
 		}
 	};
 

@@ -299,9 +299,8 @@
 	// barrier, one polled word. Nothing to zero between calls.
 	// The workgroups wait for one another: the host launches this form with at most 64 workgroups and never more than the device
 	// has compute units (all of them become resident as soon as whatever else runs on the device drains).
-	// Measured (64k instances, 257 bins, back to back): 10.4 us; the same matrix in three launches (histogram | one workgroup scans
-	// the matrix | place) 16.8 us; one launch where every workgroup reads the whole matrix behind ONE barrier 15.4 us (14 us of
-	// agent scope loads with 64 workgroups); with agent scope fences instead of agent scope accesses 20.6 us.
+	// Measured (64k instances, 257 bins, back to back): see DESIGN 4.10; the same matrix in three launches (histogram | one workgroup
+	// scans the matrix | place) 16.8 us; one launch where every workgroup reads the whole matrix behind ONE barrier 15.4 - 20.6 us.
 	constexpr uint32_t k_order_direct_bins = 8192;			// 32 KB of LDS
 	constexpr uint32_t k_order_direct_block_size = 1024;
 
@@ -321,22 +320,28 @@
 	constexpr uint32_t k_order_barrier_poll_sleep = ACLHIP_ORDER_POLL_SLEEP;		// x 64 clocks between two polls
 	constexpr uint32_t k_order_barrier_max_polls = 1u << 22;	// seconds
 
-	// All workgroups of the grid have arrived. `generation`: thread 0's, the value the barrier's word has to leave.
+	// All workgroups of the grid have arrived, and what they wrote before is visible. `generation`: thread 0's, the value the barrier's
+	// word has to leave. The XCDs' L2s are not coherent with one another: an arriving workgroup RELEASES at agent scope (its L2 writes
+	// back), a passing one ACQUIRES (its L2 forgets what other XCDs own) -- one thread per workgroup does both, once, behind a
+	// workgroup barrier in front of which every wave has waited for its own stores; the polls in between are relaxed loads.
+	// (Round 3 first shipped this with agent scope ACCESSES and no fences -- 1.5 us faster, and right on an idle device; with sixteen
+	// orderings in flight at once, tools/order_stress.py caught one wrong order in 640 000: an acknowledged write-through is not yet
+	// a visible one.)
 	// A barrier that does not open within seconds cannot open any more -- a fault in an earlier call left its words behind, or so many
-	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident (nine and more at 64
-	// workgroups each) -- and the kernel TRAPS: the launch fails loudly (the queue reports a hardware exception) instead of leaving a
-	// half written order behind for the decode that follows.
+	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident -- and the kernel
+	// TRAPS: the launch fails loudly (the queue reports a hardware exception) instead of leaving a half written order behind for
+	// the decode that follows.
 	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t generation, uint32_t& passed)
 	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);		// (vmcnt 0: this wave's stores have reached the L2)
 		__syncthreads();
 		if (threadIdx.x == 0)
 		{
 			uint32_t open = 1;
-			if (__hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
+			if (__hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
 			{
 				__hip_atomic_store(&control->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");		// (arrived is back to 0 before anybody passes)
+				__builtin_amdgcn_s_waitcnt(0);		// (arrived is back to 0 before anybody passes)
 				__hip_atomic_store(&control->generation, generation + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			else
@@ -348,6 +353,7 @@
 				if (open == 0)
 					__builtin_trap();
 			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			passed = open;
 		}
 		__syncthreads();
@@ -386,12 +392,9 @@
 			atomicAdd(&cursors[min(clip_ids[instance], num_bins - 1)], 1u);
 		__syncthreads();
 		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
-			__hip_atomic_store(&histograms[(size_t(bin) << log2_blocks) + blockIdx.x], cursors[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			histograms[(size_t(bin) << log2_blocks) + blockIdx.x] = cursors[bin];
 
-		// the barrier. An agent scope release / acquire FENCE writes back / invalidates the whole L2 of the workgroup's XCD (the XCDs'
-		// L2s are not coherent with one another). Instead everything the workgroups tell one another -- the matrix, the barrier's
-		// words -- is written and read with agent scope accesses (they go to the point the XCDs share), and a workgroup arrives when
-		// its stores have been acknowledged (the workgroup scope fence waits for them).
+		// every column is written and visible
 		ACLHIP_ORDER_STAMP(1);
 		if (!order_grid_barrier(control, generation, passed))
 			return;
@@ -410,7 +413,7 @@
 			for (uint32_t base = first_entry; base < end_entry; base += k_order_direct_block_size)
 			{
 				const uint32_t entry = base + threadIdx.x;
-				const uint32_t count = entry < end_entry ? __hip_atomic_load(&histograms[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				const uint32_t count = entry < end_entry ? histograms[entry] : 0u;
 				uint32_t inclusive = count;
 				for (uint32_t step = 1; step < num_blocks; step *= 2)
 				{
@@ -420,9 +423,9 @@
 				}
 				if (entry < end_entry)
 				{
-					__hip_atomic_store(&histograms[entry], inclusive - count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					histograms[entry] = inclusive - count;
 					if (lane_in_row == num_blocks - 1)
-						__hip_atomic_store(&bin_totals[entry >> log2_blocks], inclusive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						bin_totals[entry >> log2_blocks] = inclusive;
 				}
 			}
 		}
@@ -442,8 +445,8 @@
 			for (uint32_t k = 0; k < max_bins_per_thread; ++k)
 			{
 				const bool valid = k < bins_per_thread && first_bin + k < num_bins;
-				counts[k] = valid ? __hip_atomic_load(&bin_totals[first_bin + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-				in_front[k] = valid ? __hip_atomic_load(&histograms[(size_t(first_bin + k) << log2_blocks) + blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				counts[k] = valid ? bin_totals[first_bin + k] : 0u;
+				in_front[k] = valid ? histograms[(size_t(first_bin + k) << log2_blocks) + blockIdx.x] : 0u;
 			}
 			uint32_t sum = 0;
 			#pragma unroll
