@@ -18,6 +18,8 @@ int main(int argc, char** argv)
 	if (argc != 3)
 		return 2;
 
+	if (aclhip_abi_version() != ACLHIP_ABI_VERSION)
+		return 7;		/* the library was built from another header than this translation unit */
 	aclhip_default_params(&params);
 	if (params.rounding_policy != ACLHIP_ROUND_NONE || params.looping_policy != ACLHIP_LOOP_AS_COMPRESSED || params.normalization != ACLHIP_NORMALIZE_LERP_ONLY)
 		return 3;		/* default_transform_decompression_settings + as_compressed looping */

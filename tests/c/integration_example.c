@@ -1,4 +1,4 @@
-/* The call sequences INTEGRATION.md shows (sections 1, 3, 4b, 5), as one C99 translation unit that must compile and link against
+/* The call sequences INTEGRATION.md shows (sections 1 incl. instance lists and per track skips, 3, 4b, 5), as one C99 translation unit that must compile and link against
  * libaclhip.so with the signatures the document uses. Never run: tests/test_capi_symbols.py only builds it. */
 #include "aclhip.h"
 
@@ -37,6 +37,24 @@ int integration_example(const void* tracks, uint64_t tracks_size, const void* co
 		aclhip_output_desc output = { 0 };
 		output.layout = ACLHIP_LAYOUT_QV32;
 		s = aclhip_decompress_tracks_batch_out(gpu, d_clips, d_times, num_instances, &params, &output, d_poses, (uint64_t)max_tracks * 32, hip_stream);
+	}
+	{
+		/* an instance list that keeps its decode order across frames; per track skips; a stream the engine destroys */
+		aclhip_instance_list characters;
+		const uint32_t* d_order = NULL;
+		uint64_t orderings = 0;
+		aclhip_output_desc output = { 0 };
+		output.skip_tracks = (const uint8_t*)d_bones;		/* (one byte per track in device memory) */
+		s = aclhip_instance_list_create(gpu, num_instances, &characters);
+		s = aclhip_instance_list_set_clips(gpu, characters, d_clips, hip_stream);
+		s = aclhip_instance_list_update(gpu, characters, d_rows, d_ordered_clips, 3, hip_stream);
+		s = aclhip_decompress_tracks_list(gpu, characters, d_times, NULL, NULL, 0, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+		s = aclhip_decompress_tracks_list(gpu, characters, d_times, &params, &output, 1, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+		s = aclhip_instance_list_get_order(gpu, characters, &d_order, &orderings);
+		s = aclhip_instance_list_destroy(gpu, characters);
+		s = aclhip_forget_stream(gpu, hip_stream);
+		if (aclhip_abi_version() != ACLHIP_ABI_VERSION)
+			return 1;
 	}
 
 	/* section 3 */
