@@ -347,6 +347,41 @@ def measured_traffic(key, kernel_name):
     return None
 
 
+def live_traffic(workload, order, layout, kernel_name, timeout_s=150):
+    """HBM bytes per launch of the decode kernel measured NOW: this same command (a few steps of it) in two rocprofv3 --pmc passes of
+    their own, FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), mean over the
+    dispatches of `kernel_name`. None when rocprofv3 is not there or a pass fails (the committed profiles/traffic.json stays)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    means = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        directory = tempfile.mkdtemp(prefix="aclhip_pmc_", dir="/tmp")
+        try:
+            command = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", directory, "-o", "pass", "--", sys.executable, os.path.abspath(__file__),
+                       "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--workload", workload, "--order", order, "--layout", layout]
+            environment = dict(os.environ, ACLHIP_BENCH_PROFILING="1", TMPDIR="/tmp")
+            subprocess.run(command, cwd="/tmp", env=environment, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            values = []
+            for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if row["Counter_Name"] == counter and kernel_name in row["Kernel_Name"]:
+                        values.append(float(row["Counter_Value"]))
+            if not values:
+                return None
+            means[counter] = sum(values) / len(values)
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(directory, ignore_errors=True)
+    return int((2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0)
+
+
 def traffic_key_of(workload, order, layout, keep_rows=False):
     if keep_rows:
         return None
@@ -610,6 +645,7 @@ def main():
     parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "list"],
                         help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup); "
                              "aclhip_order_instances_device in front of every launch (part of the step)")
+    parser.add_argument("--no-live-traffic", action="store_true", help="default run: keep roofline.traffic from profiles/traffic.json instead of measuring it with two rocprofv3 --pmc passes")
     parser.add_argument("--keep-rows", action="store_true", help="with --order locality: store every pose in its instance's ORIGINAL row")
     parser.add_argument("--layout", default="qvv48", choices=["qvv48", "qvv40", "qv32"], help="output layout (aclhip_output_desc)")
     parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
@@ -792,6 +828,15 @@ def main():
         finished.set()
 
     extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU
+    if rank == 0 and extras and not args.no_live_traffic:
+        # roofline.traffic measured by THIS run (two counter passes of a few steps of this command, after the timed region) instead of
+        # read back from profiles/traffic.json
+        measured = live_traffic(args.workload, args.order, args.layout, kernel_name)
+        result["roofline"]["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes)"
+        if measured is not None:
+            result["roofline"]["traffic_committed"] = result["roofline"]["traffic"]
+            result["roofline"]["traffic"] = measured
+            result["roofline"]["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of 12 launches each, FETCH_SIZE x 2 (gfx950)"
     if rank == 0 and extras:
         # the other north-star configs, measured in this process outside the timed region (about 0.2 s of launches each)
         result["workloads"] = [
