@@ -347,7 +347,7 @@ def measured_traffic(key, kernel_name):
     return None
 
 
-def live_traffic(workload, order, layout, kernel_name, timeout_s=150):
+def live_traffic(workload, order, layout, kernel_name, timeout_s=60):
     """HBM bytes per launch of the decode kernel measured NOW: this same command (a few steps of it) in two rocprofv3 --pmc passes of
     their own, FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), mean over the
     dispatches of `kernel_name`. None when rocprofv3 is not there or a pass fails (the committed profiles/traffic.json stays)."""
