@@ -100,15 +100,14 @@ def test_list_decodes_follow_the_oracle_through_updates_and_reorders(num_instanc
 
 
 def test_single_launch_order_equals_the_three_launch_order_in_structure():
-    """aclhip_order_instances_device orders in ONE launch while the grid fits the device (every workgroup waits for the last one's
-    scan); larger lists take three launches. Both give a valid locality order; the one-launch form survives being replayed (nothing in
-    it depends on a per-call value: hipGraphs)."""
+    """aclhip_order_instances_device at three batch sizes -- 1, 64 and 64 (larger) workgroups of the one launch form --, the same scratch
+    call after call: every result is a valid locality order."""
     rng = np.random.default_rng(3)
     clips = [synth.build_clip(seed=600 + i, num_tracks=50, num_samples=20) for i in range(40)]
     with runtime.Context(0) as context:
         handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
         device = torch.device("cuda", 0)
-        for n in (100, 70000, 600000):          # 1, 35 (one launch) and 293 workgroups (three launches on a 256 CU device)
+        for n in (100, 70000, 600000):
             which = rng.integers(0, len(clips), size=n)
             d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
             d_order = torch.zeros(n, dtype=torch.int32, device=device)
@@ -116,3 +115,47 @@ def test_single_launch_order_equals_the_three_launch_order_in_structure():
                 context.order_instances_device(d_clips.data_ptr(), 0, n, d_order.data_ptr(), 0, 0)
                 torch.cuda.synchronize(device)
                 check_order(handles[which], d_order.cpu().numpy().astype(np.uint32), 1, stable=False)
+
+
+@pytest.mark.parametrize("layout", ["qvv48", "qvv40", "qv32"])
+def test_list_decodes_take_output_descriptors(layout):
+    """aclhip_decompress_tracks_list with an aclhip_output_desc -- pose layout, a skipped sub-track kind, per track skips --, in slot
+    order and in instance order: the same bytes as aclhip_decompress_tracks_batch_out writes for the same instances"""
+    rng = np.random.default_rng(7)
+    clips = [synth.build_clip(seed=700 + i, num_tracks=60, num_samples=30, has_scale=1) for i in range(9)]
+    layout_id, bytes_per_track = runtime.LAYOUTS[layout]
+    n, tracks = 3000, 60
+    floats_per_track = bytes_per_track // 4
+    device = torch.device("cuda", 0)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        which = rng.integers(0, len(clips), size=n)
+        times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+        d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+        d_times = torch.from_numpy(times).to(device)
+        skips = rng.integers(0, 8, size=tracks).astype(np.uint8)          # bit 0 / 1 / 2: rotation / translation / scale of that track
+        d_skips = torch.from_numpy(skips).to(device)
+        output = runtime.OutputDesc()
+        output.layout = layout_id
+        output.skip_translations = 1
+        output.skip_tracks = d_skips.data_ptr()
+        fill = 123.25
+        d_direct = torch.full((n, tracks, floats_per_track), fill, dtype=torch.float32, device=device)
+        d_slots = torch.full((n, tracks, floats_per_track), fill, dtype=torch.float32, device=device)
+        d_rows = torch.full((n, tracks, floats_per_track), fill, dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        context.decompress_tracks_batch_out(d_clips.data_ptr(), d_times.data_ptr(), n, d_direct.data_ptr(), tracks * bytes_per_track, output)
+        instance_list = context.instance_list_create(n)
+        context.instance_list_set_clips(instance_list, d_clips.data_ptr())
+        context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_slots.data_ptr(), tracks * bytes_per_track, output=output)
+        context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_rows.data_ptr(), tracks * bytes_per_track, output=output, poses_in_instance_order=True)
+        torch.cuda.synchronize(device)
+        order = _read_order(context.instance_list_order(instance_list)[0], n)
+        direct = d_direct.cpu().numpy()
+        assert np.any(direct != fill) and np.any(direct == fill)         # something was written, something was skipped
+        assert np.array_equal(d_rows.cpu().numpy().view(np.uint32), direct.view(np.uint32))
+        assert np.array_equal(d_slots.cpu().numpy().view(np.uint32), direct[order].view(np.uint32))
+        with pytest.raises(runtime.AclHipError):                        # the list decides the rows itself
+            output.rows = d_clips.data_ptr()
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_slots.data_ptr(), tracks * bytes_per_track, output=output)
+        context.instance_list_destroy(instance_list)
