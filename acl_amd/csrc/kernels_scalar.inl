@@ -444,14 +444,19 @@
 			frames[k].blob = clip.blob;
 			frames[k].frame_bit_offset[0] = key_frame0 * num_bits_per_frame;
 			frames[k].frame_bit_offset[1] = key_frame1 * num_bits_per_frame;
+			// Two key frames that follow each other in the blob (the usual case: key_frame1 = key_frame0 + 1, or the same frame at the
+			// ends of the clip) travel as ONE copy into the instance's two slots (half the copy instructions: 64 x 16 bytes each);
+			// a pair that wraps around the end of a looping clip travels as two.
+			const bool adjacent = key_frame1 - key_frame0 <= 1u;
 			#pragma unroll
 			for (uint32_t key = 0; key < 2; ++key)
 			{
-				const uint32_t first_bit = animated_bit_base + frames[k].frame_bit_offset[key];
+				const uint32_t first_bit = animated_bit_base + frames[k].frame_bit_offset[adjacent ? 0 : key];
+				const uint32_t last_bit = animated_bit_base + frames[k].frame_bit_offset[adjacent ? 1 : key] + num_bits_per_frame;
 				const uint32_t first_byte = (first_bit >> 3) & ~15u;
-				const uint32_t num_bytes = (((first_bit + num_bits_per_frame + 7u) >> 3) + 8u) - first_byte;
-				uint8_t* destination = wave_lds + (k * 2u + key) * frame_lds_bytes;
-				if (k < count)
+				const uint32_t num_bytes = (((last_bit + 7u) >> 3) + 8u) - first_byte;
+				uint8_t* destination = wave_lds + (k * 2u + (adjacent ? 0u : key)) * frame_lds_bytes;
+				if (k < count && (key == 0 || !adjacent))
 					for (uint32_t base = 0; base < num_bytes; base += k_wave_size * 16u)
 					{
 						if (base + lane * 16u < num_bytes)
