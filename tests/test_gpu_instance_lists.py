@@ -159,3 +159,40 @@ def test_list_decodes_take_output_descriptors(layout):
             output.rows = d_clips.data_ptr()
             context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_slots.data_ptr(), tracks * bytes_per_track, output=output)
         context.instance_list_destroy(instance_list)
+
+
+def test_a_captured_list_decode_replays_with_new_sample_times():
+    """aclhip_decompress_tracks_list captured into a hipGraph: the replays decode the list in the order it had when it was captured,
+    with whatever sample times the buffer holds by then (the header says so: when to re-order is decided on the host, at call time)"""
+    rng = np.random.default_rng(11)
+    clips = [synth.build_clip(seed=800 + i, num_tracks=80, num_samples=40) for i in range(12)]
+    blobs = [c.blob for c in clips]
+    durations = np.array([c.duration for c in clips], dtype=np.float32)
+    n, tracks = 8192, 80
+    device = torch.device("cuda", 0)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        which = rng.integers(0, len(clips), size=n)
+        stream = torch.cuda.Stream(device)
+        d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+        d_times = torch.zeros(n, dtype=torch.float32, device=device)
+        d_rows = torch.zeros((n, tracks, 12), dtype=torch.float32, device=device)
+        torch.cuda.synchronize(device)
+        instance_list = context.instance_list_create(n)
+        context.instance_list_set_clips(instance_list, d_clips.data_ptr(), stream=stream.cuda_stream)
+        context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_rows.data_ptr(), tracks * 48, poses_in_instance_order=True, stream=stream.cuda_stream)
+        stream.synchronize()
+
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_rows.data_ptr(), tracks * 48, poses_in_instance_order=True, stream=stream.cuda_stream)
+        for replay in range(4):
+            times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+            d_times.copy_(torch.from_numpy(times))
+            torch.cuda.synchronize(device)
+            graph.replay()
+            torch.cuda.synchronize(device)
+            expected = ob.oracle_decompress_tracks_batch(blobs, which.astype(np.uint32), times, tracks)
+            assert helpers.bit_equal(d_rows.cpu().numpy(), expected), replay
+        del graph
+        context.instance_list_destroy(instance_list)
