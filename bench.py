@@ -359,6 +359,9 @@ def live_traffic(workload, order, layout, kernel_name, timeout_s=60):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None
+    # never under a profiler that is already attached to this process (a counter pass next to somebody's trace of the same device)
+    if any(name.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for name in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     means = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         directory = tempfile.mkdtemp(prefix="aclhip_pmc_", dir="/tmp")
