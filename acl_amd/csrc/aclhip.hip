@@ -46,7 +46,7 @@ namespace aclhip
 {
 #include "kernels_pose.inl"
 #if defined(ACLHIP_EXPERIMENTS)
-#include "kernels_experiments.inl"		// round 3's slower variants (profiles/r03_experiments.md); not part of a default build
+#include "../../tools/experiments/kernels_experiments.inl"		// round 3's slower variants (profiles/r03_experiments.md); not part of a default build
 #endif
 #include "kernels_consumers.inl"
 #include "kernels_misc.inl"
@@ -63,7 +63,7 @@ using namespace aclhip;
 #include "host_clips.inl"
 #include "host_databases.inl"
 #if defined(ACLHIP_EXPERIMENTS)
-#include "host_experiments.inl"
+#include "../../tools/experiments/host_experiments.inl"
 #endif
 #include "host_launch.inl"
 #include "host_lists.inl"

@@ -166,6 +166,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_scaled = 1u << 6;					// scale sub-tracks, or a default scale other than 1: some scale of a pose may differ from 1
 	constexpr uint32_t k_clip_database_samples = 1u << 7;		// bound to a database: `samples` holds database_sample_record (tier metadata copied per sample)
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
+	constexpr uint32_t k_clip_negative_scale = 1u << 11;			// some scale sub-track may decode a negative component: rtm::qvv_mul then composes matrices (pose consumers)
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)
@@ -215,6 +216,12 @@ namespace aclhip
 		uint64_t base_pose_stride_bytes;
 		uint32_t additive_format;			// acl::additive_clip_format8; 0 = no base
 		uint32_t object_space;				// 1: local -> object space with the clip's hierarchy
+		// blend of K clip instances (aclhip_pose_consumers::num_blend_clips): the K - 1 further clips and sample times of instance i at
+		// [i * (K - 1) + j], its K weights at [i * K + k]
+		const uint32_t* blend_clip_ids;
+		const float* blend_sample_times;
+		const float* blend_weights;
+		uint32_t num_blend_clips;			// K; 0 / 1: no blend
 	};
 
 	// What seek leaves behind for the decode (persistent_transform_decompression_context_v0, decompression_context.transform.h:53-116)

@@ -683,6 +683,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.flags |= header.has_database() ? k_clip_has_database : 0u;
 		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
 		record.flags |= has_raw ? k_clip_has_raw : 0u;
+		record.flags |= negative_scale_possible ? k_clip_negative_scale : 0u;
 		record.num_segments = num_segments;
 		record.num_animated = num_animated;
 		if (header.has_database())

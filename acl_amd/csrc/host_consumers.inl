@@ -243,6 +243,11 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "base clips without base sample times");
 		if (has_base && !base_is_clip && (consumers.base_poses == nullptr || (consumers.base_pose_stride_bytes & 15u) != 0 || (reinterpret_cast<uintptr_t>(consumers.base_poses) & 15u) != 0))
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an additive format needs base clips or a 16 byte aligned base pose buffer");
+		const bool blend = consumers.num_blend_clips > 1;
+		if (consumers.num_blend_clips > ACLHIP_MAX_BLEND_CLIPS)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a blend of %u clips: at most %u", consumers.num_blend_clips, ACLHIP_MAX_BLEND_CLIPS);
+		if (blend && (consumers.blend_clips == nullptr || consumers.blend_sample_times == nullptr || consumers.blend_weights == nullptr))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a blend needs blend_clips, blend_sample_times and blend_weights");
 		// a consumer needs every sub-track of the pose: the track_writer's own defaults (what the resolved pose image holds)
 		if (params.standard_defaults == 0 || params.per_track_rounding != 0)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding, normalization != always");
@@ -255,18 +260,24 @@ namespace
 		// No clip with a scale other than 1 registered, no base to combine with: every scale of every pose is 1, in local and in object
 		// space -- the LDS images hold rotation | translation (32 of a transform's 48 bytes: half as many poses again per CU) and the
 		// scales are written on the way out
-		const bool unit_scale = !has_base && consumers.object_space != 0 && context->num_scaled_clips == 0 && std::getenv("ACLHIP_CONSUMER_KEEP_SCALE") == nullptr;
-		const uint32_t image_quads = unit_scale ? context->max_pose_quads / 3 * 2 : context->max_pose_quads;
+		const bool unit_scale = !has_base && !blend && consumers.object_space != 0 && context->num_scaled_clips == 0 && std::getenv("ACLHIP_CONSUMER_KEEP_SCALE") == nullptr;
+		// (sized for the BATCH like every pose launch: no pose of it is larger than its row, pose_launch_shape_of in host_launch.inl --
+		// one 3 500-bone asset in the registry does not take object space away from the 100-bone characters)
+		const uint32_t batch_quads = batch_pose_quads(context, ACLHIP_LAYOUT_QVV48, pose_stride_bytes);
+		const uint32_t image_quads = unit_scale ? batch_quads / 3 * 2 : batch_quads;
 		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(image_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
 		// additive0 / additive1 combine sub-track with sub-track: the base clip is decoded into the instance's image and the additive clip
 		// onto it by one wave; the relative format (a qvv_mul) needs both poses whole: a second wave, a second image
-		const bool fused_base = base_is_clip && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
+		// (a blend accumulates its clips in the instance's image before anything else happens to it: its base clip gets a wave and an image of its own)
+		const bool fused_base = base_is_clip && !blend && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
 		const bool two_waves = base_is_clip && !fused_base;
 		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1);
-		const size_t lds_schedule_bytes = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(context->max_hierarchy_words, 4), 4) * sizeof(uint32_t) : 0;
+		// a walk schedule of T transforms: 2 words + a step end per step + a pair per transform with a parent, at most 2 + 2 T words
+		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3)), 4), 4) : 0;
+		const size_t lds_schedule_bytes = size_t(lds_schedule_words) * sizeof(uint32_t);
 		constexpr size_t k_lds_bytes = 160 * 1024 - 128;		// the kernel's few static words
 		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
-			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a registered clip has %u transforms: too large for the pose consumers (%zu bytes of LDS per instance)", context->max_pose_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "poses of %u transforms (the pose stride, the largest registered clip): too large for the pose consumers (%zu bytes of LDS per instance)", batch_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
 		uint32_t log2_instances_per_block = 2;
 		if (const char* forced = std::getenv("ACLHIP_CONSUMER_LOG2_INSTANCES"))
 			log2_instances_per_block = std::min<uint32_t>(uint32_t(forced[0] - '0'), 3);
@@ -284,6 +295,10 @@ namespace
 		device_consumers.base_pose_stride_bytes = consumers.base_pose_stride_bytes;
 		device_consumers.additive_format = consumers.additive_format;
 		device_consumers.object_space = consumers.object_space != 0 ? 1 : 0;
+		device_consumers.blend_clip_ids = blend ? consumers.blend_clips : nullptr;
+		device_consumers.blend_sample_times = blend ? consumers.blend_sample_times : nullptr;
+		device_consumers.blend_weights = blend ? consumers.blend_weights : nullptr;
+		device_consumers.num_blend_clips = blend ? consumers.num_blend_clips : 0;
 
 		// one instantiation per (object space, kind of base, rotation | translation images)
 		const uint32_t base_kind = !has_base ? k_consumer_base_none : (!base_is_clip ? k_consumer_base_buffer : (fused_base ? k_consumer_base_fused : k_consumer_base_second_wave));
@@ -307,12 +322,29 @@ namespace
 				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false, true> },
 			},
 		};
-		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false> : kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind];
+		// the same with a blend in front (never fused, never rotation | translation images)
+		static const consumer_kernel blend_kernels[2][2][3] =
+		{
+			{
+				{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false, false, true>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false, true, true>,
+				  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false, false, true> },
+				{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, true, true>,
+				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, false, true> },
+			},
+			{
+				{ decompress_poses_consumer_kernel<false, k_consumer_base_none, false, false, true>, decompress_poses_consumer_kernel<false, k_consumer_base_buffer, false, true, true>,
+				  decompress_poses_consumer_kernel<false, k_consumer_base_second_wave, false, true, true> },
+				{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, true, true>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, true, true>,
+				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, true, true> },
+			},
+		};
+		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false>
+			: (blend ? blend_kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind] : kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind]);
 		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
 			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(waves_per_block * k_wave_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, params, device_consumers,
-			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, uint32_t(lds_bytes_per_instance), log2_instances_per_block, context->d_rejected);
+			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_image, uint32_t(lds_bytes_per_instance), log2_instances_per_block | (lds_schedule_words << 8), context->d_rejected);
 		ACLHIP_CHECK_HIP(context, hipGetLastError());
 		return ACLHIP_OK;
 	}
@@ -437,6 +469,17 @@ namespace
 			local_consumers.base_clips = static_cast<const aclhip_clip*>(d_base_clips);
 			local_consumers.base_sample_times = static_cast<const float*>(d_base_times);
 			local_consumers.base_poses = d_base_poses;
+			if (consumers->num_blend_clips > 1 && consumers->num_blend_clips <= ACLHIP_MAX_BLEND_CLIPS
+				&& consumers->blend_clips != nullptr && consumers->blend_sample_times != nullptr && consumers->blend_weights != nullptr)
+			{
+				const size_t others = size_t(num_instances) * (consumers->num_blend_clips - 1);
+				void* d_blend_clips = nullptr; void* d_blend_times = nullptr; void* d_blend_weights = nullptr;
+				ok = ok && upload(consumers->blend_clips, sizeof(uint32_t) * others, &d_blend_clips) && upload(consumers->blend_sample_times, sizeof(float) * others, &d_blend_times)
+					&& upload(consumers->blend_weights, sizeof(float) * size_t(num_instances) * consumers->num_blend_clips, &d_blend_weights);
+				local_consumers.blend_clips = static_cast<const aclhip_clip*>(d_blend_clips);
+				local_consumers.blend_sample_times = static_cast<const float*>(d_blend_times);
+				local_consumers.blend_weights = static_cast<const float*>(d_blend_weights);
+			}
 		}
 		if (!ok)
 		{

@@ -3,6 +3,65 @@
 
 namespace
 {
+	// The shape of a pose launch follows the BATCH, not the registry: a pose row of pose_stride_bytes holds at most pose_stride_bytes /
+	// bytes_per_track tracks, so no clip the batch may legally name is larger than that -- and none is larger than the largest registered
+	// clip. (The reference sizes its work per clip, decompression.transform.h:1526-1540; until round 4 every launch here was sized for
+	// the largest clip of the REGISTRY: one 551-bone crowd leader in the context and every batch of 100-bone characters launched six
+	// waves per instance, five of which left after the scalar prologue.) What the shape promises is checked again by the kernels
+	// against every clip they meet (launch_refuses_clip, kernels_pose.inl): a clip registered behind a captured launch's back is
+	// refused and counted, never decoded into a window or an LDS slot that is too small for it.
+	struct pose_launch_shape
+	{
+		uint32_t windows_per_instance;		// waves per instance: pose windows of the largest pose the batch can hold
+		uint32_t lds_quads_per_wave;		// quads of LDS every wave gets for its window's image
+		bool wide_key_loads;				// poses of several windows read the bitstream with one aligned request per key (kernels_pose.inl)
+	};
+
+	uint32_t batch_pose_quads(const aclhip_context* context, uint32_t layout, uint64_t pose_stride_bytes)
+	{
+		const uint32_t bytes_per_track = std::max<uint32_t>(aclhip_layout_bytes_per_track(layout), 1);
+		const uint64_t stride_quads = pose_stride_bytes / bytes_per_track * 3;
+		return uint32_t(std::min<uint64_t>(context->max_pose_quads, stride_quads));
+	}
+
+	// (the caller holds the registry lock)
+	pose_launch_shape pose_launch_shape_of(const aclhip_context* context, uint32_t layout, uint64_t pose_stride_bytes)
+	{
+		const uint32_t quads = batch_pose_quads(context, layout, pose_stride_bytes);
+		pose_launch_shape shape;
+		shape.windows_per_instance = std::max<uint32_t>((quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+		shape.lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(quads, 64), 64), k_image_chunk_quads);
+		// ACLHIP_WIDE_KEY_LOADS=0 / 1 overrides the choice (measurements, parity runs of the other unpack)
+		static const int wide_override = []() { const char* value = std::getenv("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
+		shape.wide_key_loads = wide_override >= 0 ? wide_override != 0 : shape.windows_per_instance > 1;
+		return shape;
+	}
+
+	typedef void (*pose_kernel)(const device_clip*, uint32_t, const uint32_t*, const float*, uint32_t, uint32_t, decode_params, uint8_t*, uint64_t, uint32_t, unsigned long long*);
+
+	// which kernel a pose launch of this shape and these settings takes, and its name (aclhip_describe_tracks_launch: rocprofv3 traces)
+	pose_kernel pose_kernel_of(const aclhip_context* context, const decode_params& params, const pose_launch_shape& shape, const char** out_name = nullptr)
+	{
+		// the common case (track_writer defaults, no per track rounding, normalization != always) copies a resolved pose image
+		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
+		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
+		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
+		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
+		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && params.skip_tracks == nullptr;
+		const char* name;
+		pose_kernel kernel;
+		if (native_layout && params.layout == ACLHIP_LAYOUT_QV32) { kernel = decompress_tracks_qv32_kernel; name = "decompress_tracks_qv32_kernel"; }
+		else if (native_layout) { kernel = decompress_tracks_qvv40_kernel; name = "decompress_tracks_qvv40_kernel"; }
+		else if (any_settings && compact) { kernel = decompress_tracks_any_settings_compact_kernel; name = "decompress_tracks_any_settings_compact_kernel"; }
+		else if (any_settings) { kernel = decompress_tracks_any_settings_kernel; name = "decompress_tracks_any_settings_kernel"; }
+		else if (compact) { kernel = decompress_tracks_compact_kernel; name = "decompress_tracks_compact_kernel"; }
+		else if (shape.wide_key_loads) { kernel = decompress_tracks_wide_loads_kernel; name = "decompress_tracks_wide_loads_kernel"; }
+		else { kernel = decompress_tracks_kernel; name = "decompress_tracks_kernel"; }
+		if (out_name != nullptr)
+			*out_name = name;
+		return kernel;
+	}
+
 	aclhip_status launch_tracks(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
@@ -10,29 +69,26 @@ namespace
 		std::lock_guard<std::mutex> lock(context->mutex);
 		note_launch_stream(context, stream);
 
-		// one wave per (instance, pose window); instances of clips with fewer windows than the largest registered clip leave waves idle
-		const uint32_t windows_per_instance = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+		// one wave per (instance, pose window)
+		const pose_launch_shape shape = pose_launch_shape_of(context, params.layout, pose_stride_bytes);
+		const uint32_t windows_per_instance = shape.windows_per_instance;
 		const uint64_t num_waves = uint64_t(num_instances) * windows_per_instance;
 		if (num_waves > 0xFFFFFFFFull - k_waves_per_block)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u pose windows", num_instances, windows_per_instance);
 		const uint32_t num_blocks = uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block);
 
-		// the common case (track_writer defaults, no per track rounding, normalization != always) copies a resolved pose image
-		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
-		const uint32_t lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(context->max_pose_quads, 64), 64), k_image_chunk_quads);
+		const uint32_t lds_quads_per_wave = shape.lds_quads_per_wave;
 		size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
 		{
 			// measurement aid: ACLHIP_EXTRA_LDS_BYTES inflates a workgroup's LDS so that fewer workgroups fit a CU (occupancy experiments)
 			static const size_t extra_lds = []() { const char* value = std::getenv("ACLHIP_EXTRA_LDS_BYTES"); return value != nullptr ? size_t(std::atol(value)) : size_t(0); }();
 			lds_bytes += extra_lds;
 		}
-		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
-		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
-		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
-		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && params.skip_tracks == nullptr;
 #if defined(ACLHIP_EXPERIMENTS)
 		{
-			// round 3's slower kernel variants, selected by environment knobs (host_experiments.inl)
+			// round 3's slower kernel variants, selected by environment knobs (tools/experiments/host_experiments.inl)
+			const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
+			const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
 			bool launched = false;
 			const aclhip_status experiment_status = launch_experimental_tracks(context, clips, sample_times, num_instances, params, poses, pose_stride_bytes, stream,
 				windows_per_instance, num_waves, num_blocks, any_settings, compact, lds_quads_per_wave, lds_bytes, launched);
@@ -40,12 +96,7 @@ namespace
 				return experiment_status;
 		}
 #endif
-		// poses of several windows read the bitstream with one aligned request per key (kernels_pose.inl); ACLHIP_WIDE_KEY_LOADS=0 / 1 overrides
-		static const int wide_override = []() { const char* value = std::getenv("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
-		const bool wide_key_loads = wide_override >= 0 ? wide_override != 0 : windows_per_instance > 1;
-		const auto kernel = native_layout ? (params.layout == ACLHIP_LAYOUT_QV32 ? decompress_tracks_qv32_kernel : decompress_tracks_qvv40_kernel)
-			: any_settings ? (compact ? decompress_tracks_any_settings_compact_kernel : decompress_tracks_any_settings_kernel)
-			: (compact ? decompress_tracks_compact_kernel : (wide_key_loads ? decompress_tracks_wide_loads_kernel : decompress_tracks_kernel));
+		const pose_kernel kernel = pose_kernel_of(context, params, shape);
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
@@ -251,19 +302,41 @@ extern "C" aclhip_status aclhip_order_instances_for_pose_windows(uint32_t window
 // not a reproducible one.
 namespace
 {
-	aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+	// windows_per_instance: waves per pose of the launch the order is for (0: the largest registered clip's)
+	aclhip_status order_instances_on_device(aclhip_context* context, uint32_t windows_per_instance, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 		uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, uint32_t* out_positions, void* stream_handle);
 }
 
 extern "C" aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream_handle)
 {
-	return order_instances_on_device(context, clips, sample_times, num_instances, out_order, out_clips, out_sample_times, nullptr, stream_handle);
+	return order_instances_on_device(context, 0, clips, sample_times, num_instances, out_order, out_clips, out_sample_times, nullptr, stream_handle);
+}
+
+extern "C" aclhip_status aclhip_order_instances_device_for_windows(aclhip_context* context, uint32_t windows_per_instance, const aclhip_clip* clips, const float* sample_times,
+	uint32_t num_instances, uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream_handle)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (windows_per_instance == 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a pose takes at least one window");
+	return order_instances_on_device(context, windows_per_instance, clips, sample_times, num_instances, out_order, out_clips, out_sample_times, nullptr, stream_handle);
+}
+
+extern "C" aclhip_status aclhip_pose_windows_of_launch(aclhip_context* context, uint32_t layout, uint64_t pose_stride_bytes, uint32_t* out_windows_per_instance)
+{
+	if (context == nullptr || out_windows_per_instance == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (aclhip_layout_bytes_per_track(layout) == 0)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown pose layout %u", layout);
+	std::lock_guard<std::mutex> lock(context->mutex);
+	*out_windows_per_instance = pose_launch_shape_of(context, layout, pose_stride_bytes).windows_per_instance;
+	return ACLHIP_OK;
 }
 
 namespace
 {
-aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
+aclhip_status order_instances_on_device(aclhip_context* context, uint32_t windows_per_instance, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, uint32_t* out_positions, void* stream_handle)
 {
 	if (context == nullptr)
@@ -274,7 +347,7 @@ aclhip_status order_instances_on_device(aclhip_context* context, const aclhip_cl
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null instance list or order buffer");
 
 	hipStream_t stream = static_cast<hipStream_t>(stream_handle);
-	const order_layout layout = make_order_layout(num_instances, windows_per_instance_of(context));
+	const order_layout layout = make_order_layout(num_instances, windows_per_instance != 0 ? windows_per_instance : windows_per_instance_of(context));
 
 	device_guard guard(context->device);
 	std::lock_guard<std::mutex> lock(context->mutex);		// the scratch of a stream is handed to one call at a time, in stream order

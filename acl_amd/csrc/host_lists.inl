@@ -10,6 +10,7 @@ struct aclhip_context::instance_list
 	uint32_t* d_memory = nullptr;			// clips (instance order) | order (slot -> instance) | positions (instance -> slot) | ordered clips (slot order)
 	uint32_t changed_since_ordered = 0;		// instances whose clip changed since the list was last ordered
 	bool ordered = false;
+	uint32_t ordered_for_windows = 0;		// waves per pose of the launch shape the order was made for (the slot -> XCD map depends on it); 0: the registry's at that time
 	uint64_t num_orderings = 0;
 
 	uint32_t* clips() const { return d_memory; }
@@ -33,12 +34,13 @@ namespace
 		return list < context->instance_lists.size() && context->instance_lists[list].in_use ? &context->instance_lists[list] : nullptr;
 	}
 
-	aclhip_status order_list(aclhip_context* context, aclhip_context::instance_list& list, void* stream)
+	aclhip_status order_list(aclhip_context* context, aclhip_context::instance_list& list, uint32_t windows_per_instance, void* stream)
 	{
-		const aclhip_status status = order_instances_on_device(context, list.clips(), nullptr, list.num_instances, list.order(), list.ordered_clips(), nullptr, list.positions(), stream);
+		const aclhip_status status = order_instances_on_device(context, windows_per_instance, list.clips(), nullptr, list.num_instances, list.order(), list.ordered_clips(), nullptr, list.positions(), stream);
 		if (status == ACLHIP_OK)
 		{
 			list.ordered = true;
+			list.ordered_for_windows = windows_per_instance;
 			list.changed_since_ordered = 0;
 			list.num_orderings++;
 		}
@@ -101,11 +103,16 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 		aclhip_context::instance_list* list = find_list(context, handle);
 		if (list == nullptr)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+		// the clips are about to be overwritten: whatever order the list had describes them no longer. It counts as ordered again
+		// only once the new order has been enqueued (a failure below leaves a list that refuses decodes, not one that decodes a stale assignment)
+		list->ordered = false;
 		snapshot = *list;
 	}
 	device_guard guard(context->device);
 	ACLHIP_CHECK_HIP(context, hipMemcpyAsync(snapshot.clips(), clips, size_t(snapshot.num_instances) * sizeof(uint32_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
-	const aclhip_status status = order_list(context, snapshot, stream);		// (takes the context's lock itself)
+	// (the shape of the decodes to come is not known yet: ordered for the largest registered clip, again by the first decode whose pose
+	// stride says otherwise)
+	const aclhip_status status = order_list(context, snapshot, 0, stream);		// (takes the context's lock itself)
 	if (status != ACLHIP_OK)
 		return status;
 	std::lock_guard<std::mutex> lock(context->mutex);
@@ -113,6 +120,7 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 	if (list != nullptr && list->d_memory == snapshot.d_memory)
 	{
 		list->ordered = true;
+		list->ordered_for_windows = 0;
 		list->changed_since_ordered = 0;
 		list->num_orderings++;
 	}
@@ -147,8 +155,19 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	// everything that can refuse the call comes first: the list's bookkeeping changes only when its (re-)ordering has been enqueued
+	if (output != nullptr && output->rows != nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an instance list decides the rows itself (poses_in_instance_order)");
+	decode_params device_params;
+	aclhip_status status = resolve_params(context, params, device_params);
+	if (status == ACLHIP_OK)
+		status = apply_output_desc(context, output, device_params);
+	if (status != ACLHIP_OK)
+		return status;
+
 	aclhip_context::instance_list snapshot;
 	bool reorder = false;
+	uint32_t windows_per_instance = 1, registry_windows = 1;
 	{
 		std::lock_guard<std::mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
@@ -156,37 +175,38 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
 		if (!list->ordered)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_set_clips comes first");
-		// enough of the list plays other clips than when it was ordered: order it again, in front of this decode
-		static const uint32_t reorder_divisor = []() { const char* value = std::getenv("ACLHIP_LIST_REORDER_DIVISOR"); return value != nullptr ? uint32_t(std::max(1L, std::atol(value))) : 8u; }();		// (measurement knob)
-		reorder = uint64_t(list->changed_since_ordered) * reorder_divisor >= list->num_instances;
-		if (reorder)
-		{
-			list->changed_since_ordered = 0;
-			list->num_orderings++;
-		}
 		snapshot = *list;
+		windows_per_instance = pose_launch_shape_of(context, device_params.layout, pose_stride_bytes).windows_per_instance;
+		registry_windows = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
 	}
-	aclhip_status status = check_batch_arguments(context, snapshot.clips(), sample_times, snapshot.num_instances, poses, pose_stride_bytes);
+	status = check_batch_arguments(context, snapshot.clips(), sample_times, snapshot.num_instances, poses, pose_stride_bytes);
 	if (status != ACLHIP_OK)
 		return status;
-	if (output != nullptr && output->rows != nullptr)
-		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an instance list decides the rows itself (poses_in_instance_order)");
 
-	decode_params device_params;
-	status = resolve_params(context, params, device_params);
-	if (status == ACLHIP_OK)
-		status = apply_output_desc(context, output, device_params);
-	if (status != ACLHIP_OK)
-		return status;
+	// enough of the list plays other clips than when it was ordered, or it was ordered for launches of another shape (which slot of a
+	// launch runs on which XCD follows from the waves a pose takes): order it again, in front of this decode
+	static const uint32_t reorder_divisor = []() { const char* value = std::getenv("ACLHIP_LIST_REORDER_DIVISOR"); return value != nullptr ? uint32_t(std::max(1L, std::atol(value))) : 8u; }();		// (measurement knob)
+	const uint32_t ordered_for = snapshot.ordered_for_windows != 0 ? snapshot.ordered_for_windows : registry_windows;
+	reorder = uint64_t(snapshot.changed_since_ordered) * reorder_divisor >= snapshot.num_instances || ordered_for != windows_per_instance;
+
 	device_params.time_indices = snapshot.order();
 	device_params.instance_rows = poses_in_instance_order != 0 ? snapshot.order() : nullptr;
 
 	device_guard guard(context->device);
 	if (reorder)
 	{
-		status = order_instances_on_device(context, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
+		status = order_instances_on_device(context, windows_per_instance, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
 		if (status != ACLHIP_OK)
 			return status;
+		std::lock_guard<std::mutex> lock(context->mutex);
+		aclhip_context::instance_list* list = find_list(context, handle);
+		if (list != nullptr && list->d_memory == snapshot.d_memory)
+		{
+			// (updates that arrived between the snapshot and here are part of what was just ordered or will count towards the next time)
+			list->changed_since_ordered -= std::min(list->changed_since_ordered, snapshot.changed_since_ordered);
+			list->ordered_for_windows = windows_per_instance;
+			list->num_orderings++;
+		}
 	}
 	return launch_tracks(context, snapshot.ordered_clips(), sample_times, snapshot.num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
 }

@@ -34,10 +34,14 @@ namespace
 		}
 		else
 		{
-			// one wave per (instance, 64 or 256 tracks); instances of shorter lists than the longest registered one leave waves idle
-			const uint32_t rows = context->max_scalar_tracks <= k_wave_size ? 1u : k_scalar_tracks_per_wave / k_wave_size;
+			// one wave per (instance, 64 or 256 tracks). Sized for the BATCH like the pose launches (pose_launch_shape_of): a row of
+			// out_stride_bytes holds at most out_stride_bytes / 4 tracks, a frame at most 32 bits per float of a row -- and neither is larger
+			// than the largest registered list's; the kernels check every list they meet against it (scalar_launch_refuses_clip)
+			const uint32_t batch_tracks = uint32_t(std::min<uint64_t>(context->max_scalar_tracks, out_stride_bytes / 4));
+			const uint32_t batch_frame_bytes = uint32_t(std::min<uint64_t>(context->max_scalar_frame_bytes, out_stride_bytes));
+			const uint32_t rows = batch_tracks <= k_wave_size ? 1u : k_scalar_tracks_per_wave / k_wave_size;
 			const uint32_t tracks_per_wave = rows * k_wave_size;
-			const uint32_t chunks_per_instance = std::max<uint32_t>((context->max_scalar_tracks + tracks_per_wave - 1) / tracks_per_wave, 1);
+			const uint32_t chunks_per_instance = std::max<uint32_t>((batch_tracks + tracks_per_wave - 1) / tracks_per_wave, 1);
 			const uint64_t num_waves = uint64_t(num_instances) * chunks_per_instance;
 			if (num_waves > 0xFFFFFFFFull - k_waves_per_block)
 				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "batch too large: %u instances x %u track chunks", num_instances, chunks_per_instance);
@@ -45,8 +49,8 @@ namespace
 			// LDS copy of both key frames per wave: the frame, the 16 byte alignment slack in front, 8 bytes behind. Skipped (global
 			// reads) when that would leave fewer than 4 workgroups per CU, and for short frames, where a handful of scattered reads
 			// is cheaper than the copy and its barrier (measured: 64 float1f tracks 16 vs 23 us, 256 tracks 38 vs 32 us)
-			uint32_t frame_lds_bytes = align_to_u32(context->max_scalar_frame_bytes + 16 + 8, 16);
-			if (size_t(frame_lds_bytes) * 2 * k_waves_per_block > 40 * 1024 || context->max_scalar_frame_bytes < 192)
+			uint32_t frame_lds_bytes = align_to_u32(batch_frame_bytes + 16 + 8, 16);
+			if (size_t(frame_lds_bytes) * 2 * k_waves_per_block > 40 * 1024 || batch_frame_bytes < 192)
 				frame_lds_bytes = 0;
 
 			// groups of k_scalar_group consecutive instances per wave (kernels_scalar.inl) when the frames of a group fit LDS with at least
@@ -494,19 +498,33 @@ extern "C" aclhip_status aclhip_time_decompress_poses_batch(aclhip_context* cont
 	return status;
 }
 
-extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity)
+extern "C" aclhip_status aclhip_describe_tracks_launch(aclhip_context* context, const aclhip_decompress_params* params, const aclhip_output_desc* output, uint64_t pose_stride_bytes,
+	char* out_name, uint32_t capacity, uint32_t* out_windows_per_instance)
 {
 	if (context == nullptr || out_name == nullptr || capacity == 0)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 	decode_params device_params;
-	const aclhip_status status = resolve_params(context, params, device_params);
+	aclhip_status status = resolve_params(context, params, device_params);
+	if (status == ACLHIP_OK)
+		status = apply_output_desc(context, output, device_params);
 	if (status != ACLHIP_OK)
 		return status;
-	const bool any_settings = device_params.standard_defaults == 0 || device_params.per_track_rounding != 0 || context->force_generic_kernel;
-	// (poses of several windows take the common case kernel that reads the bitstream one aligned request per key: launch_tracks)
-	const bool several_windows = context->max_pose_quads > k_image_chunk_quads;
-	std::snprintf(out_name, capacity, "%s", any_settings ? "decompress_tracks_any_settings_kernel" : (several_windows ? "decompress_tracks_wide_loads_kernel" : "decompress_tracks_kernel"));
+	// the very functions launch_tracks asks (shape from the batch's stride, kernel from shape and settings: ACLHIP_WIDE_KEY_LOADS and
+	// ACLHIP_FORCE_GENERIC_KERNEL included)
+	std::lock_guard<std::mutex> lock(context->mutex);
+	const pose_launch_shape shape = pose_launch_shape_of(context, device_params.layout, pose_stride_bytes);
+	const char* name = "";
+	(void)pose_kernel_of(context, device_params, shape, &name);
+	std::snprintf(out_name, capacity, "%s", name);
+	if (out_windows_per_instance != nullptr)
+		*out_windows_per_instance = shape.windows_per_instance;
 	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity)
+{
+	// rows as wide as the largest registered clip: what a caller that sizes its pose buffer from the registry launches
+	return aclhip_describe_tracks_launch(context, params, nullptr, ~uint64_t(0), out_name, capacity, nullptr);
 }
 
 extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* context, void* poses, uint64_t pose_stride_bytes, uint32_t num_instances, uint32_t num_tracks,
@@ -525,23 +543,37 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 	const uint32_t num_blocks = uint32_t((num_waves + k_waves_per_block - 1) / k_waves_per_block);
 	ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(pose_store_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-	hipEvent_t start, stop;
-	ACLHIP_CHECK_HIP(context, hipEventCreate(&start));
-	ACLHIP_CHECK_HIP(context, hipEventCreate(&stop));
+	// (released on every way out)
+	struct probe_resources
+	{
+		hipEvent_t start = nullptr, stop = nullptr;
+		uint32_t* chain = nullptr;
+		~probe_resources()
+		{
+			if (start != nullptr) (void)hipEventDestroy(start);
+			if (stop != nullptr) (void)hipEventDestroy(stop);
+			if (chain != nullptr) (void)hipFree(chain);
+		}
+	} resources;
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&resources.start));
+	ACLHIP_CHECK_HIP(context, hipEventCreate(&resources.stop));
+	const hipEvent_t start = resources.start, stop = resources.stop;
+	{
+		// the probe launches on the caller's stream like any decode: the context has to know the stream (retired clips wait for it)
+		std::lock_guard<std::mutex> lock(context->mutex);
+		note_launch_stream(context, hip_stream);
+	}
 	// workgroups of 4 waves per CU by the LDS a workgroup asks for: 20 KB -> 8 (32 waves), 40 KB -> 4, 52 KB -> 3, 80 KB -> 2 (8 waves);
 	// 0 / 3 / 6 dependent scalar loads in front of the stores (a 16 KB table of indices, resident in the L2s)
-	uint32_t* chain = nullptr;
 	{
 		std::vector<uint32_t> host_chain(4096);
 		for (uint32_t i = 0; i < 4096; ++i)
 			host_chain[i] = (i * 1237u + 511u) & 4095u;
-		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&chain), host_chain.size() * sizeof(uint32_t)));
-		if (hipMemcpy(chain, host_chain.data(), host_chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
-		{
-			(void)hipFree(chain);
+		ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&resources.chain), host_chain.size() * sizeof(uint32_t)));
+		if (hipMemcpy(resources.chain, host_chain.data(), host_chain.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess)
 			return fail(context, ACLHIP_ERROR_DEVICE, "uploading the probe's table failed");
-		}
 	}
+	uint32_t* const chain = resources.chain;
 	const uint32_t lds_bytes[4] = { 20 * 1024, 40 * 1024, 52 * 1024, 80 * 1024 };
 	const uint32_t waves_per_cu[4] = { 32, 16, 12, 8 };
 	float best = 0.0f;
@@ -555,10 +587,7 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 			(void)hipEventRecord(stop, hip_stream);
 			float elapsed_ms = 0.0f;
 			if (hipEventSynchronize(stop) != hipSuccess || hipEventElapsedTime(&elapsed_ms, start, stop) != hipSuccess)
-			{
-				(void)hipFree(chain);
 				return fail(context, ACLHIP_ERROR_DEVICE, "the store stream probe failed");
-			}
 			const float rate = float(double(num_instances) * pose_quads * 16.0 * repeats / (double(elapsed_ms) * 1.0e-3) / 1.0e9);
 			if (rate > best)
 			{
@@ -567,7 +596,6 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 					*out_waves_per_cu = waves_per_cu[shape];
 			}
 		}
-	(void)hipFree(chain);
 	// ... and the runtime's own fill of the same bytes (hipMemsetAsync: few waves, each sweeping a large contiguous range): the decode
 	// of one-window poses, paced by its seek, comes out ahead of every pose shaped store-only launch above, not of this one
 	{
@@ -589,8 +617,6 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 			}
 		}
 	}
-	(void)hipEventDestroy(start);
-	(void)hipEventDestroy(stop);
 	*out_gb_per_second = best;
 	return ACLHIP_OK;
 }

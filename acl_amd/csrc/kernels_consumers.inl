@@ -107,6 +107,76 @@
 		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, additive_image_writer{ image, additive_format });
 	}
 
+	// ---- blend of K clip instances (aclhip_pose_consumers::num_blend_clips; include/aclhip.h states the operation order) ----------------
+	// One image, one wave, like the fused additive path: the first clip is decoded into the image and scaled by its weight, every further
+	// clip is accumulated ONTO it sub-track by sub-track -- constant and default sub-tracks from the clip's base pose table, animated ones
+	// as they are decoded --, then the rotations are normalized. Rotations are sign aligned with what has been accumulated so far (the
+	// sign bias of quat_lerp_no_normalization, math/quatf.h:177-190, against the running sum instead of the first key).
+	__device__ __forceinline__ f32x4 blend_accumulate(uint32_t kind, f32x4 accumulated, float4 value, float weight)
+	{
+		if (kind == 0)
+		{
+			float dot = accumulated.x * value.x;
+			dot = dot + (accumulated.y * value.y);
+			dot = dot + (accumulated.z * value.z);
+			dot = dot + (accumulated.w * value.w);
+			const float signed_weight = dot < 0.0f ? -weight : weight;
+			return f32x4{ (value.x * signed_weight) + accumulated.x, (value.y * signed_weight) + accumulated.y, (value.z * signed_weight) + accumulated.z, (value.w * signed_weight) + accumulated.w };
+		}
+		return f32x4{ (value.x * weight) + accumulated.x, (value.y * weight) + accumulated.y, (value.z * weight) + accumulated.z, 0.0f };
+	}
+
+	struct blend_image_writer
+	{
+		f32x4* image;
+		float weight;
+		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
+		{
+			const uint32_t quad = entry.quad_index;
+			image[quad] = blend_accumulate(quad - entry.track_index * 3u, image[quad], value, weight);
+		}
+	};
+
+	// the first clip's pose, complete in `image`, times its weight
+	__device__ __forceinline__ void blend_scale_image(f32x4* image, uint32_t num_quads, float weight, uint32_t lane)
+	{
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+		{
+			const f32x4 value = image[quad];
+			const bool is_rotation = quad % 3u == 0;
+			image[quad] = f32x4{ value.x * weight, value.y * weight, value.z * weight, is_rotation ? value.w * weight : 0.0f };
+		}
+	}
+
+	__device__ __forceinline__ void blend_clip_onto_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
+		float weight, uint32_t lane, f32x4* image)
+	{
+		const uint32_t num_quads = clip.num_tracks * 3u;
+		for (uint32_t quad = lane; quad < num_quads; quad += k_wave_size)
+		{
+			float4 value = load_quad(clip.base_pose, quad);
+			const uint32_t marker = __float_as_uint(value.w);
+			if (int32_t(marker) < 0)
+			{
+				if ((marker & k_quad_animated) != 0)
+					continue;
+				value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
+			}
+			image[quad] = blend_accumulate(quad - (quad / 3u) * 3u, image[quad], value, weight);
+		}
+		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, blend_image_writer{ image, weight });
+	}
+
+	__device__ __forceinline__ void blend_normalize_rotations(f32x4* image, uint32_t num_tracks, uint32_t lane)
+	{
+		for (uint32_t track = lane; track < num_tracks; track += k_wave_size)
+		{
+			const f32x4 value = image[track * 3u];
+			const float4 rotation = quat_normalize(make_float4(value.x, value.y, value.z, value.w));
+			image[track * 3u] = f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
+		}
+	}
+
 	__device__ __forceinline__ void wave_lds_barrier()
 	{
 		__builtin_amdgcn_s_waitcnt(0);
@@ -155,18 +225,21 @@
 	//                  none can occur (scales that are sums and products of non negative values).
 	constexpr uint32_t k_consumer_base_none = 0, k_consumer_base_buffer = 1, k_consumer_base_second_wave = 2, k_consumer_base_fused = 3;
 
-	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored>
+	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored, bool kBlend = false>
 	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
-		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t log2_instances_per_block,
+		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t packed_block_shape,
 		unsigned long long* __restrict__ rejected_count)
 	{
+		// packed_block_shape: log2 of the instances per workgroup (bits 0..7) | words of LDS reserved for the shared walk schedule (bits 8..31)
+		const uint32_t log2_instances_per_block = packed_block_shape & 0xFFu;
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do
+		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do; bit 31: its schedule is NOT in the shared LDS copy
 		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
 		__shared__ uint32_t walk_tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
 
 		static_assert(!kUnitScale || (kObjectSpace && kBase == k_consumer_base_none), "rotation | translation images: object space without a base");
+		static_assert(!kBlend || (!kUnitScale && kBase != k_consumer_base_fused), "a blend accumulates whole qvv images; a base clip is decoded by a second wave");
 		constexpr bool has_base = kBase != k_consumer_base_none;
 		constexpr bool base_is_clip = kBase == k_consumer_base_second_wave || kBase == k_consumer_base_fused;
 		// a base clip under additive0 / additive1: ONE wave decodes the base into the instance's image and the additive clip onto it
@@ -203,8 +276,16 @@
 			// refused: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images, bases that
 			// are unknown or describe another number of transforms (the reference asserts matching track counts where it combines them).
 			// Both waves of an instance come to the same verdict; the first one reports it.
+			// A launch is shaped for its batch when it is enqueued (launch_consumers: LDS image sizes from the pose stride, kernel
+			// instantiation from what the registry holds) and meets its clips when it runs: a pose that does not fit the stride or the
+			// image, a scaled clip under the rotation | translation images, a clip that may decode a negative scale in a launch
+			// compiled without rtm::qvv_mul's matrix route -- registered behind a captured launch's back -- are refused here, not decoded wrongly.
+			constexpr bool multiplies_transforms = object_space || kBase == k_consumer_base_buffer || kBase == k_consumer_base_second_wave;
 			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr)
-				|| clip.num_tracks * (unit_scale ? 2u : 3u) > lds_quads_per_image || (unit_scale && (clip.flags & k_clip_scaled) != 0);
+				|| clip.num_tracks * (unit_scale ? 2u : 3u) > lds_quads_per_image || (unit_scale && (clip.flags & k_clip_scaled) != 0)
+				|| uint64_t(clip.num_tracks) * 48u > pose_stride_bytes
+				|| (kBase == k_consumer_base_buffer && uint64_t(clip.num_tracks) * 48u > consumers.base_pose_stride_bytes)
+				|| (!kMirrored && multiplies_transforms && (clip.flags & k_clip_negative_scale) != 0);
 
 			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
@@ -215,9 +296,22 @@
 			{
 				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
 				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
-				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks;
+				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
+					|| (!kMirrored && multiplies_transforms && (base_clip.flags & k_clip_negative_scale) != 0);
 				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
 					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
+			}
+
+			if (kBlend && !refused)
+			{
+				// every clip of the blend: known, a transform clip, as many tracks as the first
+				for (uint32_t k = 1; k < consumers.num_blend_clips; ++k)
+				{
+					const uint32_t blend_clip_id = as_constant(consumers.blend_clip_ids)[size_t(instance) * (consumers.num_blend_clips - 1u) + (k - 1u)];
+					const ACLHIP_CONSTANT device_clip* record = as_constant(clips) + (blend_clip_id < num_clips ? blend_clip_id : 0);
+					refused = refused || blend_clip_id >= num_clips || !is_transform_clip(record->flags) || record->num_tracks != clip.num_tracks
+						|| (!kMirrored && multiplies_transforms && (record->flags & k_clip_negative_scale) != 0);
+				}
 			}
 
 			if (refused)
@@ -240,16 +334,39 @@
 						decode_unit_scale_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					else
 						decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+					if constexpr (kBlend)
+					{
+						const uint32_t num_blend_clips = consumers.num_blend_clips;
+						const ACLHIP_CONSTANT float* weights = as_constant(consumers.blend_weights) + size_t(instance) * num_blend_clips;
+						wave_lds_barrier();		// the first pose is complete (its DMA has landed)
+						blend_scale_image(image, clip.num_tracks * 3u, weights[0], lane);
+						for (uint32_t k = 1; k < num_blend_clips; ++k)
+						{
+							const size_t entry = size_t(instance) * (num_blend_clips - 1u) + (k - 1u);
+							const device_clip blend_clip = load_clip(clips, as_constant(consumers.blend_clip_ids)[entry]);
+							wave_lds_barrier();		// every quad has its sum so far
+							blend_clip_onto_image(blend_clip, as_constant(consumers.blend_sample_times)[entry], rounding_policy, params, weights[k], lane, image);
+						}
+						wave_lds_barrier();
+						blend_normalize_rotations(image, clip.num_tracks, lane);
+					}
 					if (object_space)
 					{
 						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
 						// num_steps | words | step_end[num_steps] | transform | parent << 16 in step order
 						schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
 						num_levels = as_constant(schedule)[0];
-						// every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then)
+						// every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then).
+						// A schedule longer than the launch reserved LDS for (a hierarchy set behind a captured launch's back) stays in
+						// global memory and the walk reads it there.
 						const uint32_t num_words = as_constant(schedule)[1];
-						for (uint32_t word = lane; word < num_words; word += k_wave_size)
-							shared_schedule[word] = schedule[word];
+						if (num_words <= (packed_block_shape >> 8))
+						{
+							for (uint32_t word = lane; word < num_words; word += k_wave_size)
+								shared_schedule[word] = schedule[word];
+						}
+						else
+							num_levels |= 0x80000000u;
 					}
 				}
 			}
@@ -302,7 +419,8 @@
 				const uint32_t walk_slot = lane & ((1u << log2_instances_per_block) - 1u);
 				const uint32_t first = lane >> log2_instances_per_block;
 				f32x4* slot_image = reinterpret_cast<f32x4*>(dynamic_lds + size_t(walk_slot) * lds_bytes_per_instance);
-				const uint32_t slot_steps = walk_levels[walk_slot];
+				const uint32_t slot_steps = walk_levels[walk_slot] & 0x7FFFFFFFu;
+				const bool slot_schedule_is_shared = (walk_levels[walk_slot] & 0x80000000u) == 0;
 				const uint32_t* slot_schedule = walk_schedules[walk_slot];
 
 				const auto walk = [&](const auto* schedule_words, auto scale_is_one)
@@ -370,7 +488,7 @@
 					const uint32_t leader = uint32_t(__builtin_ctzll(walkers));
 					const uint64_t mine = reinterpret_cast<uint64_t>(slot_schedule);
 					const uint64_t first_schedule = (uint64_t(__shfl(uint32_t(mine >> 32), int(leader))) << 32) | __shfl(uint32_t(mine), int(leader));
-					const bool shared_copy = __all(int(slot_steps == 0 || mine == first_schedule)) != 0;
+					const bool shared_copy = __all(int(slot_steps == 0 || (mine == first_schedule && slot_schedule_is_shared))) != 0;
 					if (unit_scale)
 					{
 						if (shared_copy)

@@ -73,6 +73,24 @@
 		return make_float4(raw.x, raw.y, raw.z, raw.w);
 	}
 
+	// A launch's shape -- waves per instance, LDS quads per wave -- and the caller's pose stride are decided when the launch is ENQUEUED
+	// (pose_launch_shape_of, host_launch.inl), the clip an instance names is read when the wave RUNS: a captured hipGraph replayed after
+	// a larger clip was registered, or a caller whose stride is too small for a clip of its batch, would otherwise decode a pose into
+	// too few windows (tracks left stale without a word), into an LDS slot that overlaps the next wave's, or past the end of its row.
+	// Wave uniform, a handful of scalar instructions: such an instance is refused and counted like an unknown handle -- the reference's
+	// silent return (decompression.transform.h:1532-1537) -- and its pose row keeps what the caller had there.
+	__device__ __forceinline__ uint32_t layout_bytes_per_track(uint32_t layout)
+	{
+		return layout == ACLHIP_LAYOUT_QVV48 ? 48u : (layout == ACLHIP_LAYOUT_QVV40 ? 40u : 32u);
+	}
+
+	__device__ __forceinline__ bool launch_refuses_clip(const device_clip& clip, uint32_t windows_per_instance, uint32_t lds_quads_per_wave, uint32_t bytes_per_track, uint64_t pose_stride_bytes)
+	{
+		return num_pose_windows(clip.num_tracks) > windows_per_instance
+			|| min(clip.num_tracks * 3u, k_image_chunk_quads) > lds_quads_per_wave
+			|| uint64_t(clip.num_tracks) * bytes_per_track > pose_stride_bytes;
+	}
+
 	// What the any-settings pose kernel stores for a quad of the LDS image: default sub-tracks -- still tagged in their W lane, every
 	// other quad holds a real W >= +0 by now -- follow the default sub-track modes, the rest passes through.
 	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, bool& out_store)
@@ -230,7 +248,8 @@
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags)
+			|| launch_refuses_clip(clip, windows_per_instance, lds_quads_per_wave, kCompactOutput ? layout_bytes_per_track(params.layout) : 48u, pose_stride_bytes))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -546,7 +565,7 @@
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_transform_clip(clip.flags))
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags) || launch_refuses_clip(clip, windows_per_instance, lds_quads_per_wave, k_track_bytes, pose_stride_bytes))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);

@@ -223,6 +223,19 @@
 	// components of one width at a known bit offset of each frame.
 	constexpr uint32_t k_scalar_tracks_per_wave = 256;
 
+	// The shape of a scalar launch (waves per instance, LDS per key frame) is decided when it is enqueued, from the batch's row stride
+	// and the registry (launch_scalar); the list an instance names is read when the wave runs. A list with more tracks than the
+	// launch has waves for, a frame larger than its LDS slot, a row wider than the caller's stride -- a list registered behind a
+	// captured launch's back, a stride too small for a list of the batch -- is refused and counted (see launch_refuses_clip).
+	template<bool kFromLds>
+	__device__ __forceinline__ bool scalar_launch_refuses_clip(const device_clip& clip, uint32_t tracks_per_wave, uint32_t chunks_per_instance, uint32_t frame_lds_bytes, uint64_t out_stride_bytes)
+	{
+		const uint32_t num_components = (clip.flags >> k_clip_components_shift) & 7u;
+		return uint64_t(chunks_per_instance) * tracks_per_wave < clip.num_tracks
+			|| uint64_t(clip.num_tracks) * num_components * 4u > out_stride_bytes
+			|| (kFromLds && ((clip.num_animated + 7u) >> 3) + 24u > frame_lds_bytes);
+	}
+
 	// frame_lds_bytes != 0: both key frames' bits are DMA'd into LDS (one coalesced global_load_lds per KiB) while the track tables
 	// are fetched, and every bit field is two aligned LDS dwords away -- instead of 2 * C scattered, unaligned global reads per track
 	// through the texture unit, dependent on the table read. frame_lds_bytes == 0 (a registered list's frame does not fit): global reads.
@@ -233,14 +246,14 @@
 	__device__ __forceinline__ void decompress_scalar_tracks_instance(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t instance, uint32_t chunk,
 		const decode_params& params, uint8_t* __restrict__ out, uint64_t out_stride_bytes, uint32_t frame_lds_bytes, uint8_t* wave_lds, uint32_t lane,
-		unsigned long long* __restrict__ rejected_count)
+		unsigned long long* __restrict__ rejected_count, uint32_t chunks_per_instance)
 	{
 		constexpr uint32_t k_tracks_per_wave = kRows * k_wave_size;
 
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		const float sample_time = as_constant(sample_times)[instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_scalar_clip(clip.flags))
+		if (clip_id >= num_clips || !is_scalar_clip(clip.flags) || scalar_launch_refuses_clip<kFromLds>(clip, k_tracks_per_wave, chunks_per_instance, frame_lds_bytes, out_stride_bytes))
 		{
 			if (lane == 0 && chunk == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -360,7 +373,7 @@
 		if (instance >= num_instances)
 			return;
 		decompress_scalar_tracks_instance<kFromLds, kRows, kPolicies>(clips, num_clips, clip_ids, sample_times, instance, chunk, params, out, out_stride_bytes, frame_lds_bytes,
-			dynamic_lds + size_t(wave_in_block) * 2u * frame_lds_bytes, lane, rejected_count);
+			dynamic_lds + size_t(wave_in_block) * 2u * frame_lds_bytes, lane, rejected_count, chunks_per_instance);
 	}
 
 	// A track list's output row is small (256 float1f curves: 1 KiB) next to what a wave reads to produce it -- 4 KiB of track tables
@@ -411,14 +424,15 @@
 			uniform = uniform && ids[k] == ids[0];
 		const device_clip clip = load_clip(clips, uniform ? ids[0] : 0);
 		const uint32_t first_track = chunk * k_tracks_per_wave;
-		uniform = uniform && is_scalar_clip(clip.flags) && first_track < clip.num_tracks && clip.num_samples != 0;
+		uniform = uniform && is_scalar_clip(clip.flags) && first_track < clip.num_tracks && clip.num_samples != 0
+			&& !scalar_launch_refuses_clip<true>(clip, k_tracks_per_wave, chunks_per_instance, frame_lds_bytes, out_stride_bytes);
 		if (!uniform)
 		{
 			// mixed, refused or empty: one instance after the other through the first frame slots (each call waits for its own LDS reads)
 			for (uint32_t k = 0; k < count; ++k)
 			{
 				decompress_scalar_tracks_instance<true, kRows, kPolicies, kComponents>(clips, num_clips, clip_ids, sample_times, first_instance + k, chunk, params, out, out_stride_bytes,
-					frame_lds_bytes, wave_lds, lane, rejected_count);
+					frame_lds_bytes, wave_lds, lane, rejected_count, chunks_per_instance);
 				wave_lds_barrier();
 			}
 			return;

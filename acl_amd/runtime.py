@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
     "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
+    "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch",
 ]
 
 
@@ -56,6 +57,8 @@ class PoseConsumers(ctypes.Structure):
     _fields_ = [
         ("additive_format", ctypes.c_uint32), ("object_space", ctypes.c_uint32),
         ("base_clips", ctypes.c_void_p), ("base_sample_times", ctypes.c_void_p), ("base_poses", ctypes.c_void_p), ("base_pose_stride_bytes", ctypes.c_uint64),
+        ("num_blend_clips", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("blend_clips", ctypes.c_void_p), ("blend_sample_times", ctypes.c_void_p), ("blend_weights", ctypes.c_void_p),
     ]
 
 
@@ -67,7 +70,7 @@ class OutputDesc(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 3             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
+ABI_VERSION = 4             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
 PEER_HANDLE_BYTES = 72      # ACLHIP_PEER_HANDLE_BYTES
 LAYOUT_QVV48, LAYOUT_QVV40, LAYOUT_QV32 = 0, 1, 2  # aclhip_pose_layout
 LAYOUTS = {"qvv48": (LAYOUT_QVV48, 48), "qvv40": (LAYOUT_QVV40, 40), "qv32": (LAYOUT_QV32, 32)}     # name -> (aclhip_pose_layout, bytes per track)
@@ -210,6 +213,9 @@ def load_library():
     lib.aclhip_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp]
     lib.aclhip_decompress_poses_host.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64]
     lib.aclhip_time_decompress_poses_batch.argtypes = [vp, vp, vp, u32, pparams, pconsumers, vp, u64, vp, u32, ctypes.POINTER(ctypes.c_float)]
+    lib.aclhip_pose_windows_of_launch.argtypes = [vp, u32, u64, ctypes.POINTER(u32)]
+    lib.aclhip_order_instances_device_for_windows.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
+    lib.aclhip_describe_tracks_launch.argtypes = [vp, pparams, poutput, u64, ctypes.c_char_p, u32, ctypes.POINTER(u32)]
     _lib = lib
     return lib
 
@@ -440,6 +446,16 @@ class Context:
         """aclhip_order_instances_device: the locality order of a DEVICE instance list, stream ordered (device pointers)."""
         self._check(self._lib.aclhip_order_instances_device(self._handle, clips_ptr, times_ptr, num_instances, order_ptr, out_clips_ptr, out_times_ptr, stream))
 
+    def order_instances_device_for_windows(self, windows_per_instance, clips_ptr, times_ptr, num_instances, order_ptr, out_clips_ptr=None, out_times_ptr=None, stream=None):
+        """aclhip_order_instances_device_for_windows: the same for launches of `windows_per_instance` wavefronts per pose (pose_windows_of_launch)."""
+        self._check(self._lib.aclhip_order_instances_device_for_windows(self._handle, windows_per_instance, clips_ptr, times_ptr, num_instances, order_ptr, out_clips_ptr, out_times_ptr, stream))
+
+    def pose_windows_of_launch(self, pose_stride_bytes, layout=LAYOUT_QVV48):
+        """Wavefronts per instance of a pose launch with rows of `pose_stride_bytes` and the clips registered now."""
+        windows = ctypes.c_uint32(0)
+        self._check(self._lib.aclhip_pose_windows_of_launch(self._handle, int(layout), int(pose_stride_bytes), ctypes.byref(windows)))
+        return windows.value
+
     def decompress_track_batch(self, clips_ptr, times_ptr, tracks_ptr, num_instances, out_ptr, params=None, stream=None):
         params = params if params is not None else default_params()
         self._check(self._lib.aclhip_decompress_track_batch(self._handle, clips_ptr, times_ptr, tracks_ptr, num_instances, ctypes.byref(params), out_ptr, stream))
@@ -468,9 +484,10 @@ class Context:
         return ms.value
 
     def decompress_poses(self, clips, sample_times, additive_format=ADDITIVE_NONE, object_space=False, base_clips=None, base_sample_times=None, base_poses=None,
-                         params=None, num_tracks=None, out=None, instance_rounding=None):
+                         params=None, num_tracks=None, out=None, instance_rounding=None, blend_clips=None, blend_sample_times=None, blend_weights=None):
         """Host arrays in, host poses out: float32 [n, num_tracks, 12] after the consumers. The base of an additive instance is either
-        (base_clips[i], base_sample_times[i]) or base_poses[i] ([n, num_tracks, 12])."""
+        (base_clips[i], base_sample_times[i]) or base_poses[i] ([n, num_tracks, 12]). A blend of K clips per instance: blend_clips /
+        blend_sample_times [n, K - 1] (the further clips), blend_weights [n, K]."""
         clips = np.ascontiguousarray(clips, dtype=np.uint32)
         sample_times = np.ascontiguousarray(sample_times, dtype=np.float32)
         n = clips.size
@@ -494,6 +511,14 @@ class Context:
             base_poses = np.ascontiguousarray(base_poses, dtype=np.float32)
             consumers.base_poses = base_poses.ctypes.data
             consumers.base_pose_stride_bytes = base_poses.strides[0] if base_poses.ndim == 3 else num_tracks * 48
+        if blend_weights is not None:
+            blend_weights = np.ascontiguousarray(blend_weights, dtype=np.float32).reshape(n, -1)
+            blend_clips = np.ascontiguousarray(blend_clips, dtype=np.uint32).reshape(n, -1)
+            blend_sample_times = np.ascontiguousarray(blend_sample_times, dtype=np.float32).reshape(n, -1)
+            consumers.num_blend_clips = blend_weights.shape[1]
+            consumers.blend_clips = blend_clips.ctypes.data
+            consumers.blend_sample_times = blend_sample_times.ctypes.data
+            consumers.blend_weights = blend_weights.ctypes.data
         self._check(self._lib.aclhip_decompress_poses_host(self._handle, clips.ctypes.data, sample_times.ctypes.data, n, ctypes.byref(params), ctypes.byref(consumers), out.ctypes.data, num_tracks * 48))
         return out
 
@@ -647,10 +672,16 @@ class Context:
                                                                   ctypes.c_uint32(num_tracks), ctypes.c_uint32(repeats), ctypes.c_void_p(stream), ctypes.byref(gbps), ctypes.byref(waves)))
         return gbps.value, waves.value
 
-    def tracks_kernel_name(self, params=None):
+    def tracks_kernel_name(self, params=None, pose_stride_bytes=None, output=None):
+        """Name of the kernel a pose launch takes: for rows as wide as the largest registered clip, or (pose_stride_bytes given) for the
+        launch aclhip_decompress_tracks_batch_out makes with `output` and that stride."""
         params = params if params is not None else default_params()
         name = ctypes.create_string_buffer(128)
-        self._check(self._lib.aclhip_describe_tracks_kernel(self._handle, ctypes.byref(params), name, 128))
+        if pose_stride_bytes is None and output is None:
+            self._check(self._lib.aclhip_describe_tracks_kernel(self._handle, ctypes.byref(params), name, 128))
+        else:
+            stride = int(pose_stride_bytes) if pose_stride_bytes is not None else 0xFFFFFFFFFFFFFFFF
+            self._check(self._lib.aclhip_describe_tracks_launch(self._handle, ctypes.byref(params), ctypes.byref(output) if output is not None else None, stride, name, 128, None))
         return name.value.decode()
 
     def batch_algorithmic_bytes(self, clips):

@@ -45,16 +45,38 @@ WORKLOAD_TEXT = {
     "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
     "object_space": "the one_clip batch with local -> object space fused into the decode (pose consumers, SURVEY 8 f3)",
     "additive_object_space": "64k instances per GPU: an additive clip applied (additive1) onto a base clip instance decoded by the same wave, then local -> object space (SURVEY 8 f3)",
+    "blend_object_space": "64k instances per GPU, each the weighted blend of three clip instances (three 100-bone clips of one skeleton), then local -> object space (SURVEY 8 f3)",
+    "one_clip_mixed_registry": "the one_clip batch (4 800 byte rows) while the context ALSO holds a 300-bone rig and a 551-bone clip: the launch is shaped by the batch, not by the registry",
+    "track_requests": "4 M random (instance, bone) requests on the 100-bone clip: seek + decompress_track, one 48 byte qvv per request (SURVEY 8 a15)",
 }
+TRACK_REQUESTS = 1 << 22
+
+
+_workload_cache = {}
 
 
 def build_workload(name, rank, num_instances):
-    """Returns (list of SyntheticClip, instance->clip index array, sample times) for this rank's shard."""
+    """Returns (list of SyntheticClip, instance->clip index array, sample times) for this rank's shard (the same objects when asked again)."""
+    key = (name, rank, num_instances, os.environ.get("ACLHIP_BENCH_CLIP_SUBSET"))
+    if key not in _workload_cache:
+        clips, clip_indices, times = _build_workload(name, rank, num_instances)
+        _workload_cache[key] = (clips, clip_indices, times)
+    clips, clip_indices, times = _workload_cache[key]
+    return clips, clip_indices.copy(), times.copy()
+
+
+def _build_workload(name, rank, num_instances):
     from acl_amd import synth
 
     rng = np.random.default_rng(1000 + rank)
-    if name in ("one_clip", "object_space"):
+    if name in ("one_clip", "object_space", "one_clip_mixed_registry", "track_requests"):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
+        clip_indices = np.zeros(num_instances, dtype=np.uint32)
+    elif name == "blend_object_space":
+        # three clips of one skeleton (a locomotion blend): instance i blends clip_indices[i] with two more drawn in Job
+        clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0),
+                 synth.build_clip(seed=22, num_tracks=100, num_samples=241, sample_rate=30.0),
+                 synth.build_clip(seed=23, num_tracks=100, num_samples=181, sample_rate=30.0)]
         clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "additive_object_space":
         # instance = additive clip 1 applied onto base clip 0 (instance i's base time is drawn in Job), then local -> object space
@@ -163,14 +185,21 @@ class Job:
         else:
             self.handles = np.array([context.register_clip(c.blob) for c in self.clips], dtype=np.uint32)
         self.registration_ms = (time.perf_counter() - t0) * 1e3
+        self.bystanders = []
+        if name == "one_clip_mixed_registry":
+            # clips the batch never names: the configs[3] rig and a 551-bone crowd leader (docs/fight_scene_performance.md:19-22 of the reference)
+            for bystander in (synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1, scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8),
+                              synth.build_clip(seed=5, num_tracks=551, num_samples=61, sample_rate=30.0)):
+                self.bystanders.append(context.register_clip(bystander.blob))
 
         self.max_tracks = max(c.num_tracks for c in self.clips)
         self.num_instances = int(clip_indices.size)
+        self.track_requests = name == "track_requests"
         # bytes of one instance's output row: 48 / 40 / 32 per transform track by layout, 4 per component of a scalar track
         bytes_per_track = 4 * self.clips[0].num_components if self.is_scalar else runtime.LAYOUTS[layout][1]
         # rows start on 64 byte HBM access granules: a stride that is only a multiple of 16 (QVV40: 4000 bytes for 100 bones) leaves every
         # other pose's 1 KiB stores straddling granules (measured: 82 us instead of 44 us); 4800 / 14400 / 3200 already are multiples of 64
-        self.pose_stride = (self.max_tracks * bytes_per_track + 63) // 64 * 64
+        self.pose_stride = 48 if self.track_requests else (self.max_tracks * bytes_per_track + 63) // 64 * 64
 
         self.ordering_ms = None
         self.d_rows = None
@@ -205,7 +234,13 @@ class Job:
         clips_ptr, times_ptr, poses_ptr, stream_ptr = self.d_clips.data_ptr(), self.d_times.data_ptr(), self.d_poses.data_ptr(), self.stream.cuda_stream
         if self.is_scalar:
             self._launch, self._args = self.lib.aclhip_decompress_scalar_tracks_batch, (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), poses_ptr, self.pose_stride, stream_ptr)
-        elif name in ("object_space", "additive_object_space"):
+        elif self.track_requests:
+            # one request = (instance, bone): random bones of random instances, the reference's decompress_bone use (docs/decompression_performance.md)
+            track_rng = np.random.default_rng(4000 + rank)
+            self.d_tracks = torch.from_numpy(track_rng.integers(0, self.max_tracks, size=n).astype(np.int32)).to(self.device)
+            self._launch = self.lib.aclhip_decompress_track_batch
+            self._args = (handle, clips_ptr, times_ptr, self.d_tracks.data_ptr(), n, ctypes.byref(self.params), poses_ptr, stream_ptr)
+        elif name in ("object_space", "additive_object_space", "blend_object_space"):
             parents = synth.humanoid_hierarchy(self.max_tracks)     # 13 depths, 4-18 transforms wide
             for clip_handle in self.handles:
                 context.set_clip_hierarchy(int(clip_handle), parents)
@@ -218,6 +253,17 @@ class Job:
                 self.consumers.additive_format = runtime.ADDITIVE_ADDITIVE1
                 self.consumers.base_clips = self.d_base_clips.data_ptr()
                 self.consumers.base_sample_times = self.d_base_times.data_ptr()
+            if name == "blend_object_space":
+                blend_rng = np.random.default_rng(5000 + rank)
+                others = np.stack([np.full(n, 1), np.full(n, 2)], axis=1)
+                self.blend_others = others
+                other_times = np.stack([blend_rng.uniform(0.0, self.clips[k].duration, size=n) for k in (1, 2)], axis=1).astype(np.float32)
+                weights = blend_rng.dirichlet(np.ones(3), size=n).astype(np.float32)
+                self.d_blend_clips = torch.from_numpy(self.handles[others].astype(np.int32)).to(self.device)
+                self.d_blend_times = torch.from_numpy(other_times).to(self.device)
+                self.d_blend_weights = torch.from_numpy(weights).to(self.device)
+                self.consumers.num_blend_clips = 3
+                self.consumers.blend_clips, self.consumers.blend_sample_times, self.consumers.blend_weights = self.d_blend_clips.data_ptr(), self.d_blend_times.data_ptr(), self.d_blend_weights.data_ptr()
             self._launch = self.lib.aclhip_decompress_poses_batch
             self._args = (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), ctypes.byref(self.consumers), poses_ptr, self.pose_stride, stream_ptr)
         elif layout != "qvv48" or self.d_rows is not None:
@@ -293,18 +339,22 @@ class Job:
             return "decompress_scalar_tracks_grouped_kernel" if self.num_instances >= 16384 else "decompress_scalar_tracks_kernel"
         if self.consumers is not None:
             return "decompress_poses_consumer_kernel"
-        name = self.context.tracks_kernel_name(self.params)
-        if name == "decompress_tracks_kernel" and self.layout != "qvv48":
-            name = {"qv32": "decompress_tracks_qv32_kernel", "qvv40": "decompress_tracks_qvv40_kernel"}[self.layout]    # the compact layouts have kernels of their own
-        return name
+        if self.track_requests:
+            return "decompress_track_kernel"
+        # the library's own answer for this launch (rows of pose_stride bytes, this output descriptor): aclhip_describe_tracks_launch
+        return self.context.tracks_kernel_name(self.params, pose_stride_bytes=self.pose_stride, output=self.output)
 
     def algorithmic_bytes(self):
         """Compulsory-HBM model: bytes written for every instance (in the output layout) + every distinct clip's touched bytes once."""
         written, read = self.context.batch_algorithmic_bytes(self.handles[self.clip_indices])
+        if self.track_requests:
+            return self.num_instances * (48 + 12) + read              # a 48 byte transform out, clip handle + sample time + track index in, the clip once
         if not self.is_scalar:
             written = written // 48 * self.runtime.LAYOUTS[self.layout][1]
         if self.name == "additive_object_space":
             read += self.context.batch_algorithmic_bytes(self.handles[:1])[1]        # the base clip is read too; one pose per instance is written
+        if self.name == "blend_object_space":
+            read += self.context.batch_algorithmic_bytes(self.handles[1:])[1]        # the two other clips of every blend; one pose per instance is written
         return written + read
 
     def stream_schedule(self, steps):
@@ -321,7 +371,7 @@ class Job:
         rejected = self.context.rejected_instance_count()
         if self.instance_list is not None:
             self.context.instance_list_destroy(self.instance_list)
-        for handle in self.handles:
+        for handle in list(self.handles) + list(self.bystanders):
             self.context.unregister_clip(int(handle))
         if self.database is not None:
             self.context.unregister_database(self.database)
@@ -347,10 +397,65 @@ def measured_traffic(key, kernel_name):
     return None
 
 
-def live_traffic(workload, order, layout, kernel_name, timeout_s=60):
-    """HBM bytes per launch of the decode kernel measured NOW: this same command (a few steps of it) in two rocprofv3 --pmc passes of
-    their own, FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), mean over the
-    dispatches of `kernel_name`. None when rocprofv3 is not there or a pass fails (the committed profiles/traffic.json stays)."""
+# Every Job the default N = 1 run measures outside its timed region, in the order of the line's "workloads" / "layouts" entries:
+# (workload, Job options, launches timed). The same list drives the counter passes that measure every entry's HBM traffic (live_traffic).
+def default_run_specs():
+    return [
+        ("one_clip", {}, 300),                                      # the headline batch again (its traffic goes to roofline.traffic)
+        ("one_clip_mixed_registry", {}, 300),                       # ... while the context also holds a 300-bone rig and a 551-bone clip
+        ("256_clips", {}, 300),
+        ("256_clips", {"order": "locality"}, 300),
+        ("256_clips", {"order": "device"}, 300),                    # ordered on the GPU in front of every launch: the ordering is in kernel_ms
+        ("256_clips", {"order": "list"}, 300),                      # persistent instance list: 1 % of the instances change clip per step, inside the step
+        ("cinematic", {}, 150),
+        ("database", {}, 300),
+        ("database", {"order": "locality"}, 300),                   # the same instances laid out in aclhip_order_instances_for_locality order
+        ("database", {"order": "list"}, 300),                       # ... kept in a persistent instance list, 1 % changing clip per step
+        # single bone requests, scalar track lists, the pose consumers fused into the decode
+        ("track_requests", {"num_instances": TRACK_REQUESTS}, 100),
+        ("scalar", {}, 300),
+        ("object_space", {}, 150),
+        ("additive_object_space", {}, 100),
+        ("blend_object_space", {}, 100),
+        ("one_clip", {"layout": "qvv40"}, 300),
+        ("one_clip", {"layout": "qv32"}, 300),
+    ]
+
+
+def spec_key(name, options):
+    return traffic_key_of(name, options.get("order", "random"), options.get("layout", "qvv48"))
+
+
+def run_steps(job, steps):
+    """`steps` launches of the job; a database workload's tiers arrive chunk by chunk between them, like in the timed regions"""
+    schedule = job.stream_schedule(steps)
+    for i in range(steps):
+        if i in schedule:
+            job.context.database_stream_in(job.database, schedule[i][0], schedule[i][1], stream=job.stream.cuda_stream)
+        job.step()
+
+
+def traffic_pass(device_index, manifest_path, steps=12):
+    """Child of live_traffic, running under `rocprofv3 --pmc <one counter>`: a few launches of every spec of the default run, a marker
+    kernel (the library's plain store sweep over 4 KiB) behind each, and a manifest of what ran (workload key, decode kernel name)."""
+    manifest = []
+    for name, options, _ in default_run_specs():
+        job = Job(name, 0, device_index, **options)
+        try:
+            run_steps(job, steps)
+            job.torch.cuda.synchronize(job.device)
+            job.context.measure_write_bandwidth(job.d_poses.data_ptr(), 4096, repeats=1, stream=job.stream.cuda_stream)
+            manifest.append({"workload": spec_key(name, options), "kernel": job.kernel_name(), "steps": steps})
+        finally:
+            job.close()
+    json.dump(manifest, open(manifest_path, "w"))
+
+
+def live_traffic(timeout_s=240):
+    """HBM bytes per launch of the decode kernel of EVERY spec of the default run, measured NOW: this same script in two rocprofv3
+    --pmc passes of their own (traffic_pass above), FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of
+    MI355X_MICROARCH.md), mean over the dispatches of the spec's decode kernel between two markers. Returns {workload key: bytes} --
+    empty when rocprofv3 is not there, a profiler is already attached or a pass fails (the committed profiles/traffic.json stays)."""
     import csv
     import glob
     import shutil
@@ -358,31 +463,44 @@ def live_traffic(workload, order, layout, kernel_name, timeout_s=60):
     import tempfile
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return None
+        return {}
     # never under a profiler that is already attached to this process (a counter pass next to somebody's trace of the same device)
     if any(name.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for name in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None
+        return {}
     means = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         directory = tempfile.mkdtemp(prefix="aclhip_pmc_", dir="/tmp")
         try:
-            command = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", directory, "-o", "pass", "--", sys.executable, os.path.abspath(__file__),
-                       "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--workload", workload, "--order", order, "--layout", layout]
+            manifest_path = os.path.join(directory, "manifest.json")
+            command = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", directory, "-o", "pass", "--", sys.executable, os.path.abspath(__file__), "--traffic-pass", manifest_path]
             environment = dict(os.environ, ACLHIP_BENCH_PROFILING="1", TMPDIR="/tmp")
             subprocess.run(command, cwd="/tmp", env=environment, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            values = []
+            manifest = json.load(open(manifest_path))
+            rows = []
             for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    if row["Counter_Name"] == counter and kernel_name in row["Kernel_Name"]:
-                        values.append(float(row["Counter_Value"]))
-            if not values:
-                return None
-            means[counter] = sum(values) / len(values)
+                rows += [(int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"])) for row in csv.DictReader(open(path)) if row["Counter_Name"] == counter]
+            rows.sort()
+            groups, current, in_marker = [], [], False
+            for _, kernel, value in rows:
+                if "stream_write_kernel" in kernel:
+                    if not in_marker:
+                        groups.append(current)
+                        current = []
+                    in_marker = True
+                else:
+                    in_marker = False
+                    current.append((kernel, value))
+            if len(groups) != len(manifest):
+                return {}
+            for entry, group in zip(manifest, groups):
+                values = [value for kernel, value in group if entry["kernel"] in kernel]
+                if values:
+                    means.setdefault(entry["workload"], {})[counter] = sum(values) / len(values)
         except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-            return None
+            return {}
         finally:
             shutil.rmtree(directory, ignore_errors=True)
-    return int((2.0 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024.0)
+    return {key: int((2.0 * value["FETCH_SIZE"] + value["WRITE_SIZE"]) * 1024.0) for key, value in means.items() if len(value) == 2}
 
 
 def traffic_key_of(workload, order, layout, keep_rows=False):
@@ -404,13 +522,9 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
         job.prewarm(0.05)
         if job.database is not None:
             # the low importance tier arrives chunk by chunk between the launches, like in the headline database run
-            schedule = job.stream_schedule(repeats)
             start, stop = job.torch.cuda.Event(enable_timing=True), job.torch.cuda.Event(enable_timing=True)
             start.record(job.stream)
-            for i in range(repeats):
-                if i in schedule:
-                    job.context.database_stream_in(job.database, schedule[i][0], schedule[i][1], stream=job.stream.cuda_stream)
-                job.step()
+            run_steps(job, repeats)
             stop.record(job.stream)
             stop.synchronize()
             kernel_ms = float(start.elapsed_time(stop)) / repeats
@@ -432,7 +546,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
         achieved = algorithmic / (kernel_ms * 1e-3) / 1e9
         kernel = job.kernel_name()
         achievable = None
-        if not job.is_scalar and job.layout == "qvv48":
+        if not job.is_scalar and not job.track_requests and job.layout == "qvv48":
             achievable = job.context.measure_pose_store_bandwidth(job.d_poses.data_ptr(), job.pose_stride, job.num_instances, job.max_tracks, repeats=10, stream=job.stream.cuda_stream)[0]
         return {
             "workload": traffic_key_of(name, job.order, job.layout, job.keep_rows) or f"{name}, {job.order} order, rows kept",
@@ -449,9 +563,10 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "algorithmic_bytes": int(algorithmic),
             "achieved": achieved,
             "frac": achieved / HBM_PEAK_GBPS,
-            "achievable_store_gbps": achievable,       # this batch's own write stream alone, best occupancy (aclhip_measure_pose_store_bandwidth)
-            "frac_of_achievable": None if not achievable else achieved / achievable,
+            "best_store_only_gbps": achievable,        # this batch's own write stream alone, best of thirteen shapes (aclhip_measure_pose_store_bandwidth): a second denominator, not a bound
+            "frac_of_best_store_only": None if not achievable else achieved / achievable,
             "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
+            "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes)",
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
             "kernel_ms_order_reused": decode_ms_order_reused,  # the decode alone in that order (an instance list ordered once, sample times refreshed per frame)
@@ -637,6 +752,60 @@ def measure_sharded_job(name, rank, world_size, device_index, dist, gather_mode,
         job.close()
 
 
+def device_pci_bus_id(torch, device_index):
+    """hipDeviceGetPCIBusId of the device, or None when neither the runtime nor torch tells"""
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        buffer = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buffer, 64, int(device_index)) == 0:
+            return buffer.value.decode()
+    except (OSError, AttributeError):
+        pass
+    properties = torch.cuda.get_device_properties(device_index)
+    if hasattr(properties, "pci_bus_id"):
+        return f"{getattr(properties, 'pci_domain_id', 0):04x}:{properties.pci_bus_id:02x}:{getattr(properties, 'pci_device_id', 0):02x}"
+    return None
+
+
+def distributed_checks(torch, dist, rank, world_size, device_index, backend, kernel_ms):
+    """N > 1, every rank: what the first run on a real 8-GPU node should prove about itself before its numbers are read -- the
+    communicator has N ranks that can reduce (one all-reduce of ones on the device), the ranks sit on N DISTINCT GPUs (PCI bus ids),
+    every pair of GPUs this process sees can map each other's memory (what the peer gather needs), and no rank is a straggler
+    (kernel time of the timed region per rank). Returns the "checks" object of the line; nothing here raises."""
+    import socket
+    on_device = backend == "nccl"
+    checks = {"backend": backend, "n_gpus_claimed": world_size, "ok": True, "problems": []}
+    try:
+        ones = torch.ones(1, dtype=torch.float32, device=torch.device("cuda", device_index) if on_device else "cpu")
+        dist.all_reduce(ones)
+        checks["communicator_ranks"] = int(round(float(ones.item())))         # RCCL's own count of the ranks that took part
+        identities = [None] * world_size
+        dist.all_gather_object(identities, (socket.gethostname(), device_pci_bus_id(torch, device_index), int(device_index)))
+        checks["devices"] = [f"{host}/{bus}" for host, bus, _ in identities]
+        checks["distinct_devices"] = len({(host, bus) for host, bus, _ in identities})
+        visible = torch.cuda.device_count()
+        peers = [bool(torch.cuda.can_device_access_peer(device_index, other)) for other in range(visible) if other != device_index]
+        all_peers = [None] * world_size
+        dist.all_gather_object(all_peers, (int(sum(peers)), len(peers)))
+        checks["peer_access"] = [f"{have}/{of}" for have, of in all_peers]
+        per_rank = [None] * world_size
+        dist.all_gather_object(per_rank, float(kernel_ms))
+        checks["kernel_ms_per_rank"] = per_rank
+        checks["kernel_ms_min"], checks["kernel_ms_max"] = min(per_rank), max(per_rank)
+        if checks["communicator_ranks"] != world_size:
+            checks["problems"].append(f"the all-reduce counted {checks['communicator_ranks']} ranks, not {world_size}")
+        if on_device and checks["distinct_devices"] != world_size:
+            checks["problems"].append(f"{world_size} ranks on {checks['distinct_devices']} distinct GPUs")
+        if on_device and any(have != of for have, of in all_peers):
+            checks["problems"].append("some pair of GPUs cannot map each other's memory: the peer gather is skipped")
+        if checks["kernel_ms_max"] > 1.15 * checks["kernel_ms_min"]:
+            checks["problems"].append(f"straggler: rank {per_rank.index(max(per_rank))} takes {checks['kernel_ms_max'] / checks['kernel_ms_min']:.2f} x the fastest rank's kernel time")
+    except Exception as error:      # noqa: BLE001 -- reported in the line; the decode numbers stand on their own
+        checks["problems"].append(repr(error)[:300])
+    checks["ok"] = not checks["problems"]
+    return checks
+
+
 def main():
     parser = argparse.ArgumentParser()
     parser.add_argument("--gpus", type=int, default=1)
@@ -654,6 +823,7 @@ def main():
     parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
     parser.add_argument("--no-extras", action="store_true", help="only the headline workload: no other workloads, footprint sweep, layouts")
     parser.add_argument("--gather", default="both", choices=["none", "rccl", "p2p", "both"], help="N > 1: time the pose gather after the decode (reported separately)")
+    parser.add_argument("--traffic-pass", default=None, metavar="MANIFEST", help="internal (live_traffic): a few launches of every workload of the default run under rocprofv3 --pmc")
     # kept for the scripts of round 1
     parser.add_argument("--sort-by-clip", action="store_true", help="same as --order by_clip")
     parser.add_argument("--order-for-locality", action="store_true", help="same as --order locality")
@@ -691,7 +861,11 @@ def main():
             dist.init_process_group(backend=backend)
 
     profiling = os.environ.get("ACLHIP_BENCH_PROFILING", "0") == "1"
-    job = Job(args.workload, rank, device_index, num_instances=args.instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout)
+    if args.traffic_pass is not None:
+        traffic_pass(device_index, args.traffic_pass)
+        return
+    instances = TRACK_REQUESTS if args.workload == "track_requests" and args.instances == INSTANCES_PER_GPU else args.instances
+    job = Job(args.workload, rank, device_index, num_instances=instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout)
 
     # device pre-warm (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
     prewarm_launches = 0 if profiling else job.prewarm(0.15)
@@ -725,13 +899,14 @@ def main():
 
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
     kernel_ms = float(start_mark.elapsed_time(stop_mark)) / args.steps
+    checks = distributed_checks(torch, dist, rank, world_size, device_index, backend, kernel_ms) if distributed else None
     kernel_ms_back_to_back = None if profiling else job.kernel_ms(max(10, min(args.steps, 100)))
     algorithmic_bytes = job.algorithmic_bytes()
     achieved_gbps = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
     fill_gbps = job.context.measure_write_bandwidth(job.d_poses.data_ptr(), job.num_instances * job.pose_stride, repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
     # the ceiling of THIS batch's write stream on THIS device: the pose kernels' own store pattern, nothing decoded, best occupancy
     achievable_gbps = achievable_waves = None
-    if not job.is_scalar and job.layout == "qvv48":
+    if not job.is_scalar and not job.track_requests and job.layout == "qvv48":
         achievable_gbps, achievable_waves = job.context.measure_pose_store_bandwidth(job.d_poses.data_ptr(), job.pose_stride, job.num_instances, job.max_tracks,
                                                                                      repeats=1 if profiling else 20, stream=job.stream.cuda_stream)
 
@@ -782,13 +957,19 @@ def main():
                 "kernel_ms_back_to_back": kernel_ms_back_to_back,
                 "algorithmic_bytes_per_launch": int(algorithmic_bytes),
                 "plain_store_stream_gbps": fill_gbps,      # a plain 16 B per lane store sweep over the same pose buffer, for scale (not a ceiling: DESIGN.md 6)
-                # the batch's own write stream alone (one wave per pose window, the kernels' 1 KiB streaming stores, nothing decoded) at the
-                # occupancy that suits it best: what no kernel writing these poses in this pattern can exceed on this device
-                "achievable_store_gbps": achievable_gbps,
-                "achievable_store_waves_per_cu": achievable_waves,
-                "frac_of_achievable": None if not achievable_gbps else achieved_gbps / achievable_gbps,
+                # the batch's own write stream alone (one wave per pose window, the kernels' 1 KiB streaming stores, nothing decoded): the best
+                # of thirteen store-only shapes (four occupancies x three pacings, the runtime's fill). A second denominator next to the
+                # specification's 8 TB/s, NOT a bound: a decode whose stores are paced by its own loads can come out above it
+                "best_store_only_gbps": achievable_gbps,
+                "best_store_only_waves_per_cu": achievable_waves,
+                "frac_of_best_store_only": None if not achievable_gbps else achieved_gbps / achievable_gbps,
             },
         }
+    if rank == 0 and checks is not None:
+        result["checks"] = checks
+        result["roofline"]["kernel_ms_per_rank"] = checks.get("kernel_ms_per_rank")
+    if distributed and args.gather != "none" and checks is not None and any("peer gather is skipped" in problem for problem in checks["problems"]):
+        args.gather = "rccl" if args.gather in ("both", "rccl") else "none"
     if distributed and args.gather != "none":
         # The gathers are timed AFTER the decode numbers are final, under a watchdog: the decode line must reach the driver whatever a
         # collective or a peer mapping does on a node this code has never run on. A gather that does not come back within the limit is
@@ -831,37 +1012,27 @@ def main():
         finished.set()
 
     extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU
-    if rank == 0 and extras and not args.no_live_traffic:
-        # roofline.traffic measured by THIS run (two counter passes of a few steps of this command, after the timed region) instead of
-        # read back from profiles/traffic.json
-        measured = live_traffic(args.workload, args.order, args.layout, kernel_name)
-        result["roofline"]["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes)"
-        if measured is not None:
-            result["roofline"]["traffic_committed"] = result["roofline"]["traffic"]
-            result["roofline"]["traffic"] = measured
-            result["roofline"]["traffic_source"] = "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of 12 launches each, FETCH_SIZE x 2 (gfx950)"
     if rank == 0 and extras:
         # the other north-star configs, measured in this process outside the timed region (about 0.2 s of launches each)
-        result["workloads"] = [
-            measure_job("256_clips", rank, device_index),
-            measure_job("256_clips", rank, device_index, order="locality"),
-            measure_job("256_clips", rank, device_index, order="device"),          # ordered on the GPU in front of every launch: the ordering is in kernel_ms
-            measure_job("256_clips", rank, device_index, order="list"),            # persistent instance list: 1 % of the instances change clip per step, inside the step
-            measure_job("cinematic", rank, device_index, repeats=150),
-            measure_job("database", rank, device_index),
-            measure_job("database", rank, device_index, order="locality"),         # the same instances laid out in aclhip_order_instances_for_locality order
-            measure_job("database", rank, device_index, order="list"),             # ... kept in a persistent instance list, 1 % changing clip per step
-            # scalar track lists and the pose consumers fused into the decode
-            measure_job("scalar", rank, device_index),
-            measure_job("object_space", rank, device_index, repeats=150),
-            measure_job("additive_object_space", rank, device_index, repeats=100),
-        ]
+        specs = default_run_specs()
+        entries = [measure_job(name, rank, device_index, repeats=repeats, **options) for name, options, repeats in specs]
+        result["roofline"]["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes)"
+        if not args.no_live_traffic:
+            # EVERY entry's HBM traffic measured by THIS run (two counter passes of a few launches of every spec, after the timed regions)
+            # instead of read back from profiles/traffic.json
+            measured = live_traffic()
+            source = "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of 12 launches of every workload, FETCH_SIZE x 2 (gfx950)"
+            for entry in entries:
+                if entry["workload"] in measured:
+                    entry["traffic_committed"], entry["traffic"], entry["traffic_source"] = entry["traffic"], measured[entry["workload"]], source
+            if "one_clip" in measured:
+                result["roofline"]["traffic_committed"], result["roofline"]["traffic"], result["roofline"]["traffic_source"] = result["roofline"]["traffic"], measured["one_clip"], source
+        layout_entries = [entries[0]] + [e for e in entries if e["workload"] in ("one_clip, qvv40", "one_clip, qv32")]
+        result["workloads"] = [e for e in entries[1:] if e not in layout_entries]
+        result["layouts"] = [{key: entry[key] for key in ("layout", "pose_bytes", "kernel", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes", "traffic", "traffic_source")} for entry in layout_entries]
         result["footprint_sweep"] = [
             {key: entry[key] for key in ("instances", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}
             for entry in (measure_job("one_clip", rank, device_index, num_instances=n, repeats=200) for n in (32768, 65536, 131072))]
-        result["layouts"] = [
-            {key: entry[key] for key in ("layout", "pose_bytes", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}
-            for entry in (measure_job("one_clip", rank, device_index, layout=layout) for layout in ("qvv48", "qvv40", "qv32"))]
 
     if rank == 0:
         if world_size == 1 and not args.no_cpu_baseline:

@@ -152,10 +152,11 @@ const char* aclhip_status_string(aclhip_status status);
 /* Message of the last failing call made on the CALLING thread (empty string when none); `context` is not used to find it. */
 const char* aclhip_last_error_message(const aclhip_context* context);
 
-/* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks).
+/* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks;
+ * 4: aclhip_pose_consumers::num_blend_clips, blend_clips, blend_sample_times, blend_weights).
  * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
  * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
-#define ACLHIP_ABI_VERSION 3u
+#define ACLHIP_ABI_VERSION 4u
 uint32_t aclhip_abi_version(void);
 
 /* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are
@@ -276,7 +277,17 @@ aclhip_status aclhip_strip_database_tier(const void* compressed_database, uint64
  * with writer.write_rotation/translation/scale storing into
  *     (char*)poses + i * pose_stride_bytes + track_index * 48.
  * clips / sample_times / poses are DEVICE pointers; pose_stride_bytes must be a multiple of 16 and at least
- * 48 * num_tracks of the largest clip referenced. One wavefront decodes one window of 318 pose quads (106 tracks) of one instance. */
+ * 48 * num_tracks of the largest clip referenced. One wavefront decodes one window of 312 pose quads (104 tracks) of one instance.
+ *
+ * A launch is shaped by its BATCH: a row of pose_stride_bytes holds at most pose_stride_bytes / 48 tracks, so that -- or the largest
+ * registered clip, whichever is smaller -- decides how many wavefronts an instance gets and how much LDS each of them; what else the
+ * context holds (a 551-bone crowd leader next to the 100-bone characters of this batch) does not matter. The reference sizes its work
+ * per clip (impl/decompression.transform.h:1526-1540). The kernels check every clip they meet against the launch and REFUSE -- count,
+ * leave the pose row untouched: the reference's silent return, :1532-1537 -- an instance whose clip has more tracks than the stride
+ * holds, more pose windows than the launch has wavefronts for or a window larger than the launch's LDS slots: a caller's stride that
+ * is too small never writes outside its row, and a captured hipGraph replayed after a LARGER clip was registered refuses that
+ * clip's instances (aclhip_get_rejected_instance_count) instead of decoding them into a launch shaped before the clip existed. Keep
+ * rows as narrow as the batch needs: a stride of 14 400 bytes makes every instance a three-wavefront job. */
 aclhip_status aclhip_decompress_tracks_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, void* poses, uint64_t pose_stride_bytes, void* stream);
 
@@ -311,6 +322,13 @@ aclhip_status aclhip_order_instances_for_locality(const aclhip_context* context,
  * ceil(3 * num_tracks of the largest clip / ACLHIP_WINDOW_QUADS) wavefronts per pose (1 up to 104 tracks). Host only. */
 aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_instance, const aclhip_clip* clips, uint32_t num_instances, uint32_t* out_order);
 
+/* Wavefronts per instance of the launch aclhip_decompress_tracks_batch[_out] makes for poses of `layout` in rows of `pose_stride_bytes`
+ * with the clips registered now: min(largest registered clip, tracks the row holds) in pose windows of 104 tracks. Which slot of a
+ * launch runs on which XCD follows from it: the value to order an instance list for (aclhip_order_instances_for_pose_windows,
+ * aclhip_order_instances_device_for_windows). aclhip_order_instances_for_locality / _device assume rows as wide as the largest
+ * registered clip. */
+aclhip_status aclhip_pose_windows_of_launch(aclhip_context* context, uint32_t layout, uint64_t pose_stride_bytes, uint32_t* out_windows_per_instance);
+
 /* The same order computed on the GPU for instance lists that live there (all pointers DEVICE pointers, stream ordered: ONE launch
  * on `stream` -- at most 64 workgroups that meet at barriers in global memory; three launches for registries of more than 8 192
  * clips --, scratch kept per stream by the context, no host synchronization). The one launch form needs all its workgroups resident
@@ -324,6 +342,9 @@ aclhip_status aclhip_order_instances_for_pose_windows(uint32_t windows_per_insta
  * sample times every frame): order once, keep the lists in that order. */
 aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);
+/* The same for launches of `windows_per_instance` wavefronts per pose (aclhip_pose_windows_of_launch) instead of the largest registered clip's. */
+aclhip_status aclhip_order_instances_device_for_windows(aclhip_context* context, uint32_t windows_per_instance, const aclhip_clip* clips, const float* sample_times,
+	uint32_t num_instances, uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);
 
 /* ---- persistent instance lists: the library keeps the decode order -------------------------------------------------------------
  * (No reference counterpart: the reference decodes one pose per call. SURVEY.md section 7: "sort/bucket instances by clip for L2
@@ -339,6 +360,8 @@ aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhi
  *                                    aclhip_instance_list_get_order) -- 1 KiB stores to consecutive rows, what the write path likes -- or,
  *                                    with poses_in_instance_order != 0, in row i for instance i (scattered rows: measured 20 % slower).
  *                                    `output` as in aclhip_decompress_tracks_batch_out (its `rows` must be NULL), or NULL.
+ * A list is ordered for the shape of the launches that decode it (wavefronts per pose: aclhip_pose_windows_of_launch); a decode whose pose
+ * stride gives another shape than the list was last ordered for re-orders it first.
  * All calls of one list must be made in stream order (one stream, or the caller's events between streams). WHEN a list is re-ordered
  * is decided on the host at the time of the call: a decode captured into a hipGraph replays what was decided when it was captured
  * (capture aclhip_order_instances_device + aclhip_decompress_tracks_batch instead when the order has to follow the replays' data).
@@ -448,15 +471,34 @@ typedef struct aclhip_pose_consumers
 	const float* base_sample_times;		/* DEVICE [num_instances] ... base_sample_times[i], decoded by the same wave (same params) */
 	const void* base_poses;				/* DEVICE or NULL; used when base_clips is NULL: base pose i at base_poses + i * base_pose_stride_bytes, */
 	uint64_t base_pose_stride_bytes;	/* 48 bytes per transform like the output; must not alias `poses` */
+	/* Blend of K clip instances (no reference function -- the reference ships the arithmetic it is made of, quat_lerp's
+	 * sign bias and normalize, math/quatf.h:170-211): instance i is the weighted combination of K = num_blend_clips clip instances,
+	 * clips[i] at sample_times[i] first, then blend_clips[i * (K - 1) + j] at blend_sample_times[i * (K - 1) + j], j = 0 .. K - 2,
+	 * with weights blend_weights[i * K + k]. All K clips of an instance must have the same number of tracks (else refused and
+	 * counted). Per transform, in this operation order, fp32, never fused (ACLHIP_BLEND_* in DESIGN.md 4.7; oracle: aclo_blend_poses):
+	 *     rotation     acc = q_0 * w_0;  for k = 1 .. K-1:  dot = ((acc.x q_k.x + acc.y q_k.y) + acc.z q_k.z) + acc.w q_k.w,
+	 *                  acc = (q_k * (dot < 0 ? -w_k : w_k)) + acc;  rotation = quat_normalize(acc)   (the decoder's 1 / sqrt, math/quatf.h:200-211)
+	 *     translation  acc = t_0 * w_0;  acc = (t_k * w_k) + acc         scale: like the translation
+	 * The weights are the caller's (normally non negative with sum 1; they are not normalized here). The blended local pose then
+	 * takes the place of the decoded one: additive apply and object space follow as configured above. */
+	uint32_t num_blend_clips;			/* 0 or 1: no blend; 2 .. ACLHIP_MAX_BLEND_CLIPS */
+	uint32_t reserved0;
+	const aclhip_clip* blend_clips;		/* DEVICE [num_instances * (K - 1)] */
+	const float* blend_sample_times;	/* DEVICE [num_instances * (K - 1)] */
+	const float* blend_weights;			/* DEVICE [num_instances * K] */
 } aclhip_pose_consumers;
+
+#define ACLHIP_MAX_BLEND_CLIPS 4u
 
 /* aclhip_decompress_tracks_batch followed by the consumers, in one kernel. `params` as for aclhip_decompress_tracks_batch but
  * restricted to what a consumer can work with -- the track_writer's own default sub-track modes, no per track rounding,
  * normalization != always -- else ACLHIP_ERROR_INVALID_ARGUMENT. Instances the kernel refuses (and counts, see
  * aclhip_get_rejected_instance_count) leave their pose untouched: unknown or scalar clips, object_space for a clip without
- * hierarchy, a base clip with another number of tracks. Poses are limited by the 160 KiB of LDS a workgroup can use: about
- * 3400 transforms (3100 with object space, 1700 when the base is a clip); ACLHIP_ERROR_INVALID_ARGUMENT when the largest
- * registered clip does not fit.
+ * hierarchy, a base or blend clip with another number of tracks, a pose that does not fit its row. Poses are limited by the 160 KiB of
+ * LDS a workgroup can use: about 3400 transforms (3100 with object space, 1700 when the base is a clip). Like every pose launch this one
+ * is shaped by its batch -- pose_stride_bytes / 48 transforms, or the largest registered clip when that is smaller --
+ * (ACLHIP_ERROR_INVALID_ARGUMENT when THAT does not fit): a 3 500-bone asset in the registry does not take the consumers away from the
+ * 100-bone characters.
  * Asynchronous on `stream`. */
 aclhip_status aclhip_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream);
@@ -514,9 +556,14 @@ aclhip_status aclhip_time_decompress_tracks_batch(aclhip_context* context, const
 aclhip_status aclhip_time_decompress_poses_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	const aclhip_decompress_params* params, const aclhip_pose_consumers* consumers, void* poses, uint64_t pose_stride_bytes, void* stream, uint32_t repeats, float* out_ms_per_launch);
 
-/* Name of the kernel aclhip_decompress_tracks_batch would launch for `params` with the clips registered so far
- * (to match rocprofv3 kernel traces with bench results). */
+/* Name of the kernel aclhip_decompress_tracks_batch would launch for `params` with the clips registered so far, for pose rows as wide
+ * as the largest registered clip (to match rocprofv3 kernel traces with bench results). */
 aclhip_status aclhip_describe_tracks_kernel(aclhip_context* context, const aclhip_decompress_params* params, char* out_name, uint32_t capacity);
+
+/* The same for the launch aclhip_decompress_tracks_batch_out makes with `output` (may be NULL) and rows of `pose_stride_bytes`: the kernel's
+ * name and (optional) the wavefronts per instance -- answered by the functions the launch itself asks. */
+aclhip_status aclhip_describe_tracks_launch(aclhip_context* context, const aclhip_decompress_params* params, const aclhip_output_desc* output, uint64_t pose_stride_bytes,
+	char* out_name, uint32_t capacity, uint32_t* out_windows_per_instance);
 
 /* Streams `size_bytes` of 16 byte per lane stores into `buffer` (DEVICE pointer, 16 byte aligned) `repeats` times and returns the
  * GB/s reached: the practical ceiling of a pose shaped write stream on this device, to read roofline fractions against. */
@@ -525,9 +572,10 @@ aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buff
 /* The write stream of a pose batch ALONE: one wave per pose window storing the window's rows with the pose kernels' own 1 KiB streaming
  * stores into `poses` (DEVICE pointer; num_instances rows of pose_stride_bytes, num_tracks 48 byte records each), nothing decoded,
  * at 32 / 16 / 12 / 8 resident waves per CU and with 0 / 3 / 6 dependent scalar loads pacing every wave, and the runtime's own fill of
- * the same bytes (hipMemsetAsync). Returns the best rate (and the occupancy that reached it; 0 = the runtime's fill): the write
- * bandwidth this device gives a store stream over this buffer, the denominator to read a decode's roofline fraction against besides
- * the 8 TB/s of the specification. OVERWRITES `poses`. Measurement aid (bench.py: roofline.achievable_store_gbps). */
+ * the same bytes (hipMemsetAsync). Returns the best rate (and the occupancy that reached it; 0 = the runtime's fill): the BEST MEASURED
+ * STORE-ONLY RATE over this buffer among those thirteen shapes -- a second denominator to read a decode's roofline fraction against
+ * besides the 8 TB/s of the specification, not a bound: a decode whose stores are paced differently can come out above it.
+ * OVERWRITES `poses`. Measurement aid (bench.py: roofline.best_store_only_gbps). */
 aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* context, void* poses, uint64_t pose_stride_bytes, uint32_t num_instances, uint32_t num_tracks,
 	uint32_t repeats, void* stream, float* out_gb_per_second, uint32_t* out_waves_per_cu);
 

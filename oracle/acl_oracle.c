@@ -1438,6 +1438,104 @@ int aclo_decompress_poses_batch(const void* const* blobs, const uint32_t* clip_i
 	return result;
 }
 
+/* Blend of K local poses ("blend of N clips"). The reference ships no such function -- only the arithmetic it is made
+ * of: the sign bias and the normalize of its own quaternion interpolation (math/quatf.h:170-211). DEFINED here and in include/aclhip.h
+ * (aclhip_pose_consumers::num_blend_clips), pinned by an fp64 restatement in tests/test_pose_consumers_oracle.py. Per transform, fp32,
+ * one IEEE operation at a time, in this order:
+ *   rotation     acc = q_0 * w_0
+ *                for k = 1 .. K-1:  dot = ((acc.x q_k.x + acc.y q_k.y) + acc.z q_k.z) + acc.w q_k.w
+ *                                   acc = (q_k * (dot < 0 ? -w_k : w_k)) + acc          (multiply, then add)
+ *                rotation = acc * (1 / sqrt(((x x + y y) + z z) + w w))                  (quat_normalize above, math/quatf.h:200-211)
+ *   translation  acc = t_0 * w_0;  acc = (t_k * w_k) + acc                               scale: like the translation
+ * The weights are used as given (not normalized). poses[k]: 12 floats per transform. `out` may alias poses[0]. */
+void aclo_blend_poses(const float* const* poses, const float* weights, uint32_t num_poses, uint32_t num_transforms, float* out)
+{
+	uint32_t i, k, c;
+	for (i = 0; i < num_transforms; ++i)
+	{
+		const float* first = poses[0] + (uint64_t)i * 12;
+		float result[12];
+		for (c = 0; c < 4; ++c)
+			result[c] = first[c] * weights[0];
+		for (c = 0; c < 3; ++c)
+		{
+			result[4 + c] = first[4 + c] * weights[0];
+			result[8 + c] = first[8 + c] * weights[0];
+		}
+		for (k = 1; k < num_poses; ++k)
+		{
+			const float* pose = poses[k] + (uint64_t)i * 12;
+			float dot = result[0] * pose[0];
+			float signed_weight;
+			dot = dot + (result[1] * pose[1]);
+			dot = dot + (result[2] * pose[2]);
+			dot = dot + (result[3] * pose[3]);
+			signed_weight = dot < 0.0f ? -weights[k] : weights[k];
+			for (c = 0; c < 4; ++c)
+				result[c] = (pose[c] * signed_weight) + result[c];
+			for (c = 0; c < 3; ++c)
+			{
+				result[4 + c] = (pose[4 + c] * weights[k]) + result[4 + c];
+				result[8 + c] = (pose[8 + c] * weights[k]) + result[8 + c];
+			}
+		}
+		quat_normalize(result);
+		result[7] = 0.0f;
+		result[11] = 0.0f;
+		memcpy(out + (uint64_t)i * 12, result, sizeof(result));
+	}
+}
+
+/* aclo_decompress_poses_batch with a blend in front: instance i is the blend of num_blend_clips clip instances -- clip_indices[i] at
+ * sample_times[i] first, then blend_clip_indices[i * (K - 1) + j] at blend_sample_times[i * (K - 1) + j] -- with weights
+ * blend_weights[i * K + k]; the blended local pose then takes the additive apply and the object space conversion like a decoded one. */
+int aclo_decompress_blended_poses_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, uint32_t num_blend_clips, const uint32_t* blend_clip_indices, const float* blend_sample_times, const float* blend_weights,
+	int additive_format, const uint32_t* base_clip_indices, const float* base_sample_times,
+	const uint32_t* parent_indices, uint32_t num_transforms, float* out, uint64_t pose_stride_floats)
+{
+	uint32_t i, k;
+	const size_t pose_floats = (size_t)num_transforms * 12;
+	float* scratch;
+	int result = 0;
+	if (num_blend_clips < 2 || num_blend_clips > 8)
+		return -3;
+	scratch = (float*)malloc(pose_floats * sizeof(float) * (num_blend_clips + 1));
+	if (scratch == NULL)
+		return -1;
+	for (i = 0; i < count && result == 0; ++i)
+	{
+		float* pose = out + (uint64_t)i * pose_stride_floats;
+		const float* decoded[8];
+		for (k = 0; k < num_blend_clips && result == 0; ++k)
+		{
+			const uint32_t clip = k == 0 ? clip_indices[i] : blend_clip_indices[(uint64_t)i * (num_blend_clips - 1) + (k - 1)];
+			const float time = k == 0 ? sample_times[i] : blend_sample_times[(uint64_t)i * (num_blend_clips - 1) + (k - 1)];
+			if (aclo_num_tracks(blobs[clip]) != num_transforms)
+				result = -2;
+			else
+				result = aclo_decompress_tracks(blobs[clip], time, rounding_policy, options, scratch + pose_floats * k);
+			decoded[k] = scratch + pose_floats * k;
+		}
+		if (result == 0)
+			aclo_blend_poses(decoded, blend_weights + (uint64_t)i * num_blend_clips, num_blend_clips, num_transforms, pose);
+		if (result == 0 && additive_format != 0)
+		{
+			float* base_pose = scratch + pose_floats * num_blend_clips;
+			if (aclo_num_tracks(blobs[base_clip_indices[i]]) != num_transforms)
+				result = -2;
+			else
+				result = aclo_decompress_tracks(blobs[base_clip_indices[i]], base_sample_times[i], rounding_policy, options, base_pose);
+			if (result == 0)
+				aclo_apply_additive_to_base(additive_format, base_pose, pose, num_transforms, pose);
+		}
+		if (result == 0 && parent_indices != NULL)
+			aclo_local_to_object_space(parent_indices, pose, num_transforms, pose);
+	}
+	free(scratch);
+	return result;
+}
+
 /* ---- small utilities the reference's unit tests pin (tests/sources/core/test_time_utils.cpp, test_bit_manip_utils.cpp,
  * tests/sources/math/test_scalar_packing.cpp): exposed so that tests/test_oracle_kats.py can restate those tests ---- */
 

@@ -148,6 +148,12 @@ void aclo_local_to_object_space(const uint32_t* parent_indices, const float* loc
 int aclo_decompress_poses_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
 	int rounding_policy, const aclo_options* options, int additive_format, const uint32_t* base_clip_indices, const float* base_sample_times,
 	const uint32_t* parent_indices, uint32_t num_transforms, float* out, uint64_t pose_stride_floats);
+/* Blend of K local poses (no reference function; defined in acl_oracle.c next to its code, from math/quatf.h:170-211's building blocks) */
+void aclo_blend_poses(const float* const* poses, const float* weights, uint32_t num_poses, uint32_t num_transforms, float* out);
+int aclo_decompress_blended_poses_batch(const void* const* blobs, const uint32_t* clip_indices, const float* sample_times, uint32_t count,
+	int rounding_policy, const aclo_options* options, uint32_t num_blend_clips, const uint32_t* blend_clip_indices, const float* blend_sample_times, const float* blend_weights,
+	int additive_format, const uint32_t* base_clip_indices, const float* base_sample_times,
+	const uint32_t* parent_indices, uint32_t num_transforms, float* out, uint64_t pose_stride_floats);
 
 #ifdef __cplusplus
 }

@@ -254,6 +254,61 @@ def oracle_decompress_poses_batch(blobs, clip_indices, sample_times, num_transfo
     return out
 
 
+def oracle_blend_poses(poses, weights):
+    """aclo_blend_poses: poses [K, num_transforms, 12], weights [K] -> [num_transforms, 12]."""
+    lib = oracle()
+    poses = [np.ascontiguousarray(p, dtype=np.float32) for p in poses]
+    weights = np.ascontiguousarray(weights, dtype=np.float32)
+    num_transforms = poses[0].shape[0]
+    out = np.zeros((num_transforms, 12), dtype=np.float32)
+    pointers = (ctypes.c_void_p * len(poses))(*[p.ctypes.data for p in poses])
+    lib.aclo_blend_poses.restype = None
+    lib.aclo_blend_poses(pointers, ctypes.c_void_p(weights.ctypes.data), ctypes.c_uint32(len(poses)), ctypes.c_uint32(num_transforms), ctypes.c_void_p(out.ctypes.data))
+    return out
+
+
+def oracle_decompress_blended_poses_batch(blobs, clip_indices, sample_times, blend_clip_indices, blend_sample_times, blend_weights, num_transforms,
+                                          additive_format=0, base_clip_indices=None, base_sample_times=None, parent_indices=None, rounding=ROUND_NONE,
+                                          options=None, threads=None):
+    """decode K clips -> aclo_blend_poses -> apply_additive_to_base -> local_to_object_space for EVERY instance, split over host threads.
+    blend_clip_indices / blend_sample_times: [count, K - 1]; blend_weights: [count, K]. Returns [count, num_transforms, 12] float32."""
+    import concurrent.futures
+    lib = oracle()
+    lib.aclo_decompress_blended_poses_batch.restype = ctypes.c_int
+    count = int(len(clip_indices))
+    indices = np.ascontiguousarray(clip_indices, dtype=np.uint32)
+    times = np.ascontiguousarray(sample_times, dtype=np.float32)
+    weights = np.ascontiguousarray(blend_weights, dtype=np.float32).reshape(count, -1)
+    num_blend = weights.shape[1]
+    others = np.ascontiguousarray(blend_clip_indices, dtype=np.uint32).reshape(count, num_blend - 1)
+    other_times = np.ascontiguousarray(blend_sample_times, dtype=np.float32).reshape(count, num_blend - 1)
+    base_indices = np.ascontiguousarray(base_clip_indices if base_clip_indices is not None else np.zeros(count), dtype=np.uint32)
+    base_times = np.ascontiguousarray(base_sample_times if base_sample_times is not None else np.zeros(count), dtype=np.float32)
+    parents = None if parent_indices is None else np.ascontiguousarray(parent_indices, dtype=np.uint32)
+    out = np.zeros((count, num_transforms, 12), dtype=np.float32)
+    if options is None:
+        options = default_options()
+    blob_ptrs = (ctypes.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+    threads = _host_threads(threads)
+    piece = max(64, (count + threads - 1) // threads)
+
+    def run(first):
+        n = min(piece, count - first)
+        result = lib.aclo_decompress_blended_poses_batch(
+            blob_ptrs, ctypes.c_void_p(indices[first:].ctypes.data), ctypes.c_void_p(times[first:].ctypes.data), ctypes.c_uint32(n),
+            ctypes.c_int(rounding), ctypes.byref(options), ctypes.c_uint32(num_blend), ctypes.c_void_p(others[first:].ctypes.data),
+            ctypes.c_void_p(other_times[first:].ctypes.data), ctypes.c_void_p(weights[first:].ctypes.data), ctypes.c_int(int(additive_format)),
+            ctypes.c_void_p(base_indices[first:].ctypes.data), ctypes.c_void_p(base_times[first:].ctypes.data),
+            ctypes.c_void_p(parents.ctypes.data if parents is not None else None), ctypes.c_uint32(num_transforms),
+            ctypes.c_void_p(out[first:].ctypes.data), ctypes.c_uint64(num_transforms * 12))
+        if result != 0:
+            raise RuntimeError(f"aclo_decompress_blended_poses_batch failed: {result}")
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=threads) as pool:
+        list(pool.map(run, range(0, count, piece)))
+    return out
+
+
 def oracle_scalar_decompress_tracks_batch(blobs, clip_indices, sample_times, row_floats, rounding=ROUND_NONE, options=None, threads=None):
     """scalar decompress_tracks for EVERY instance (aclo_scalar_decompress_tracks_batch), split over host threads. Returns
     [count, row_floats] float32 (num_tracks * C values per instance, the rest of a row zero)."""

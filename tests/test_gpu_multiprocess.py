@@ -97,6 +97,7 @@ def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, insta
     assert "p2p_error" not in gather and "rccl_all_gather_error" not in gather, gather
     assert gather["p2p_to_rank0_ms"] > 0 and gather["rccl_all_gather_ms"] > 0
     assert gather["shard_bytes"] == instances * result["config"]["pose_bytes"]
+    assert result["checks"]["communicator_ranks"] == world_size and len(result["checks"]["kernel_ms_per_rank"]) == world_size
 
 
 def test_bench_at_8_ranks_covers_the_8_gpu_configs():
@@ -113,6 +114,15 @@ def test_bench_at_8_ranks_covers_the_8_gpu_configs():
     assert len(lines) == 1, completed.stdout[-2000:]
     result = json.loads(lines[0])
     assert result["n_gpus"] == world_size and result["gather"]["status"] == "done"
+    # what the line says about the job itself (bench.py: distributed_checks): the communicator counted every rank, every rank reported
+    # its device and its kernel time; the ranks of a dry run share one GPU, which the check of distinct devices is not applied to
+    checks = result["checks"]
+    assert checks["communicator_ranks"] == world_size and checks["n_gpus_claimed"] == world_size and checks["backend"] == "gloo"
+    assert len(checks["devices"]) == world_size and len(checks["peer_access"]) == world_size
+    assert len(checks["kernel_ms_per_rank"]) == world_size and all(value > 0 for value in checks["kernel_ms_per_rank"])
+    assert checks["kernel_ms_min"] == min(checks["kernel_ms_per_rank"]) and checks["kernel_ms_max"] == max(checks["kernel_ms_per_rank"])
+    assert result["roofline"]["kernel_ms_per_rank"] == checks["kernel_ms_per_rank"]
+    assert not any("ranks, not" in problem or "distinct GPUs" in problem for problem in checks["problems"]), checks
     workloads = {entry["workload"]: entry for entry in result["workloads"]}
     assert set(workloads) == {"cinematic", "database"}, result["workloads"]
     for name, instances in (("cinematic", 512), ("database", 256)):
