@@ -167,7 +167,7 @@ def test_pose_consumers_are_shaped_by_the_batch(setup):
     now the 100-bone batch in 4 800 byte rows decodes, and an instance of the asset in such rows is refused."""
     ctx, torch, device = setup
     character = _clip(41, 100)
-    asset = synth.build_clip(seed=42, num_tracks=3600, num_samples=4, sample_rate=30.0)
+    asset = synth.build_clip(seed=42, num_tracks=3600, num_samples=4, sample_rate=30.0, has_scale=1, scale_default=0.5)       # (with scale: 48 bytes per transform in LDS)
     h_character, h_asset = ctx.register_clip(character.blob), ctx.register_clip(asset.blob)
     parents = synth.humanoid_hierarchy(100)
     ctx.set_clip_hierarchy(h_character, parents)
