@@ -265,7 +265,9 @@ namespace
 		// one 3 500-bone asset in the registry does not take object space away from the 100-bone characters)
 		const uint32_t batch_quads = batch_pose_quads(context, ACLHIP_LAYOUT_QVV48, pose_stride_bytes);
 		const uint32_t image_quads = unit_scale ? batch_quads / 3 * 2 : batch_quads;
-		const uint32_t lds_quads_per_image = std::max<uint32_t>(align_to_u32(image_quads, 4), 4);		// (no row granularity here: every quad is addressed on its own)
+		// exactly the transforms a pose row holds (or the largest registered clip has), not a quad more: the kernel's "does the pose fit
+		// its image" test is also its "does the pose fit its row" test (every quad is addressed on its own: no granularity needed)
+		const uint32_t lds_quads_per_image = std::max<uint32_t>(image_quads, 1);
 		// additive0 / additive1 combine sub-track with sub-track: the base clip is decoded into the instance's image and the additive clip
 		// onto it by one wave; the relative format (a qvv_mul) needs both poses whole: a second wave, a second image
 		// (a blend accumulates its clips in the instance's image before anything else happens to it: its base clip gets a wave and an image of its own)

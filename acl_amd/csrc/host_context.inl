@@ -116,6 +116,8 @@ struct aclhip_context
 		size_t capacity = 0;						// words allocated
 		size_t zeroed_bins = 0;						// the counters | cursors layout (padded bins per half) the words were zeroed for; 0: not zeroed
 		uint32_t* barrier = nullptr;				// the one launch form's barrier words (order_control), zeroed when allocated
+		uint32_t* host_failed = nullptr;			// pinned, device visible: a kernel of the one launch form gave up at a barrier (order_grid_barrier)
+		bool one_launch_form_disabled = false;		// ... after which this stream orders with the three launch form
 	};
 	std::vector<order_scratch> order_scratches;
 	// aclhip_instance_list_*: instance lists kept in decode order (host_lists.inl)
@@ -894,6 +896,8 @@ extern "C" void aclhip_destroy(aclhip_context* context)
 		{
 			(void)hipFree(scratch.bins);
 			(void)hipFree(scratch.barrier);
+			if (scratch.host_failed != nullptr)
+				(void)hipHostFree(scratch.host_failed);
 		}
 	}
 	delete context;

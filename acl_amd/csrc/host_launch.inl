@@ -384,29 +384,65 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 	// ACLHIP_ORDER_LAUNCHES=3 forces the older form (three launches: LDS hash tables + device scope atomics), what clip tables of more
 	// than k_order_direct_bins entries take anyway
 	static const int forced_form = []() { const char* value = std::getenv("ACLHIP_ORDER_LAUNCHES"); return value != nullptr ? int(value[0] - '0') : 0; }();
-	if (num_bins <= k_order_direct_bins && forced_form != 3)
+	// A kernel of the one launch form gave up at a barrier since the last call on this stream (its workgroups did not all become
+	// resident within seconds: order_grid_barrier): the order it was to write is not there. Said loudly, once; the barrier words are
+	// reset and this stream orders with the three launch form -- whose workgroups never wait for one another -- from now on.
+	if (scratch->host_failed != nullptr && __atomic_load_n(scratch->host_failed, __ATOMIC_RELAXED) != 0)
 	{
-		// as many workgroups as keep the matrix small (every workgroup reads all of it), all of them resident at once
+		__atomic_store_n(scratch->host_failed, 0u, __ATOMIC_RELAXED);
+		scratch->one_launch_form_disabled = true;
+		(void)hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), stream);
+		return fail(context, ACLHIP_ERROR_DEVICE, "an earlier aclhip_order_instances_device on this stream did not complete (its workgroups could not all become resident "
+			"within seconds): the order it was to write is invalid. This stream orders with three launches from now on; order again");
+	}
+	if (num_bins <= k_order_direct_bins && forced_form != 3 && !scratch->one_launch_form_disabled)
+	{
+		// as many workgroups as keep the matrix small (every workgroup reads all of it), all of them resident at once: never more than
+		// an idle device holds together (occupancy query: one workgroup of 1 024 threads and 33 KB of LDS per CU at least)
 		static const uint32_t max_log2_blocks = []() { const char* value = std::getenv("ACLHIP_ORDER_GRID_LOG2_BLOCKS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_grid_max_log2_blocks; }();
+		static const int blocks_per_cu = []()
+		{
+			int blocks = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, reinterpret_cast<const void*>(order_instances_grid_kernel), int(k_order_direct_block_size), 0) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				blocks = 0;
+			}
+			return blocks;
+		}();
+		const uint64_t resident_blocks = uint64_t(std::max(blocks_per_cu, 0)) * context->num_compute_units;
 		uint32_t log2_blocks = 0;
 		while (log2_blocks < max_log2_blocks && (2u << log2_blocks) * k_order_direct_block_size <= num_instances
-			&& (size_t(num_bins) << (log2_blocks + 1)) <= k_order_grid_entries && (2u << log2_blocks) <= context->num_compute_units)
+			&& (size_t(num_bins) << (log2_blocks + 1)) <= k_order_grid_entries && (2u << log2_blocks) <= context->num_compute_units && (2u << log2_blocks) <= resident_blocks)
 			++log2_blocks;
-		const uint32_t num_blocks = 1u << log2_blocks;
-		const uint32_t instances_per_block = (num_instances + num_blocks - 1) / num_blocks;
-		const aclhip_status status = reserve(size_t(num_blocks) * num_bins + num_bins);		// the matrix | the bins' totals
-		if (status != ACLHIP_OK)
-			return status;
-		if (scratch->barrier == nullptr)
+		if (resident_blocks != 0)
 		{
-			ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->barrier), sizeof(order_control)));
-			ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), context->copy_stream));		// not the caller's stream: it may be capturing
-			ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
+			const uint32_t num_blocks = 1u << log2_blocks;
+			const uint32_t instances_per_block = (num_instances + num_blocks - 1) / num_blocks;
+			// the matrix | the bins' totals, at their LARGEST once and for all: 2^18 matrix entries (the loop above) + 8 192 totals, 1 MiB.
+			// The scratch of this form then never moves -- a captured hipGraph that holds its address stays valid whatever is registered
+			// later -- and no call after the first allocates. (Only registries beyond 8 192 clips, the three launch form, can outgrow it.)
+			constexpr size_t k_order_grid_scratch_words = std::max<size_t>(k_order_grid_entries / 2, k_order_direct_bins) + k_order_direct_bins;
+			const aclhip_status status = reserve(k_order_grid_scratch_words);
+			if (status != ACLHIP_OK)
+				return status;
+			if (scratch->barrier == nullptr)
+			{
+				ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->barrier), sizeof(order_control)));
+				ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), context->copy_stream));		// not the caller's stream: it may be capturing
+				ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
+				ACLHIP_CHECK_HIP(context, hipHostMalloc(reinterpret_cast<void**>(&scratch->host_failed), sizeof(uint32_t), hipHostMallocMapped));
+				*scratch->host_failed = 0;
+			}
+			scratch->zeroed_bins = 0;		// (the three launch form finds its counters dirty)
+			// testing aid: ACLHIP_ORDER_TEST_ABSENT_BLOCK=b keeps workgroup b away from the barriers, ACLHIP_ORDER_TEST_MAX_POLLS shortens the wait
+			static const uint32_t absent_block = []() { const char* value = std::getenv("ACLHIP_ORDER_TEST_ABSENT_BLOCK"); return value != nullptr ? uint32_t(std::atol(value)) : 0xFFFFFFFFu; }();
+			static const uint32_t max_polls = []() { const char* value = std::getenv("ACLHIP_ORDER_TEST_MAX_POLLS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_barrier_max_polls; }();
+			hipLaunchKernelGGL(order_instances_grid_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block,
+				num_bins, log2_blocks, scratch->bins, reinterpret_cast<order_control*>(scratch->barrier), scratch->host_failed, max_polls, absent_block, layout, out_order, out_clips, out_sample_times, out_positions);
+			ACLHIP_CHECK_HIP(context, hipGetLastError());
+			return ACLHIP_OK;
 		}
-		hipLaunchKernelGGL(order_instances_grid_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block,
-			num_bins, log2_blocks, scratch->bins, reinterpret_cast<order_control*>(scratch->barrier), layout, out_order, out_clips, out_sample_times, out_positions);
-		ACLHIP_CHECK_HIP(context, hipGetLastError());
-		return ACLHIP_OK;
 	}
 	const size_t padded_bins = (size_t(num_bins) + 4095) / 4096 * 4096;
 	{

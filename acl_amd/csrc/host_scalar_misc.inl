@@ -385,6 +385,8 @@ extern "C" aclhip_status aclhip_forget_stream(aclhip_context* context, void* str
 				(void)hipFree(context->order_scratches[i].bins);		// the stream is idle: nothing uses its scratch
 			if (context->order_scratches[i].barrier != nullptr)
 				(void)hipFree(context->order_scratches[i].barrier);
+			if (context->order_scratches[i].host_failed != nullptr)
+				(void)hipHostFree(context->order_scratches[i].host_failed);
 			context->order_scratches.erase(context->order_scratches.begin() + ptrdiff_t(i));
 			break;
 		}

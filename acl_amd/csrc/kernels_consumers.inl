@@ -282,10 +282,10 @@
 			// compiled without rtm::qvv_mul's matrix route -- registered behind a captured launch's back -- are refused here, not decoded wrongly.
 			constexpr bool multiplies_transforms = object_space || kBase == k_consumer_base_buffer || kBase == k_consumer_base_second_wave;
 			bool refused = clip_id >= num_clips || !is_transform_clip(clip.flags) || (object_space && clip.hierarchy == nullptr)
+				// (the image holds no more transforms than a pose row: launch_consumers sizes it from the stride -- one test for both)
 				|| clip.num_tracks * (unit_scale ? 2u : 3u) > lds_quads_per_image || (unit_scale && (clip.flags & k_clip_scaled) != 0)
-				|| uint64_t(clip.num_tracks) * 48u > pose_stride_bytes
 				|| (kBase == k_consumer_base_buffer && uint64_t(clip.num_tracks) * 48u > consumers.base_pose_stride_bytes)
-				|| (!kMirrored && multiplies_transforms && (clip.flags & k_clip_negative_scale) != 0);
+				|| (!kMirrored && multiplies_transforms && !base_is_clip && (clip.flags & k_clip_negative_scale) != 0);
 
 			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
@@ -297,7 +297,7 @@
 				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
 				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
-					|| (!kMirrored && multiplies_transforms && (base_clip.flags & k_clip_negative_scale) != 0);
+					|| (!kMirrored && multiplies_transforms && ((clip.flags | base_clip.flags) & k_clip_negative_scale) != 0);
 				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
 					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}

@@ -311,6 +311,8 @@
 		uint32_t generation;	// barriers passed: every workgroup reads it when it starts and waits for the next value (nothing
 								// a captured hipGraph would have to change between replays)
 		uint32_t more_padding[31];
+		uint32_t failed;		// != 0: a barrier of some launch did not open (see order_grid_barrier); the host resets the words and stops using this form on the stream
+		uint32_t last_padding[31];
 	};
 	constexpr uint32_t k_order_grid_entries = 1u << 19;			// bins x workgroups the one launch form takes
 	constexpr uint32_t k_order_grid_max_log2_blocks = 6;
@@ -328,10 +330,14 @@
 	// orderings in flight at once, tools/order_stress.py caught one wrong order in 640 000: an acknowledged write-through is not yet
 	// a visible one.)
 	// A barrier that does not open within seconds cannot open any more -- a fault in an earlier call left its words behind, or so many
-	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident -- and the kernel
-	// TRAPS: the launch fails loudly (the queue reports a hardware exception) instead of leaving a half written order behind for
-	// the decode that follows.
-	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t generation, uint32_t& passed)
+	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident (the grid is sized from
+	// the occupancy query to fit an otherwise idle device, order_instances_on_device). Round 3 TRAPPED there, which takes the whole
+	// process down with the queue. Now the workgroup gives up: it raises `failed` (device word) and `*host_failed` (pinned host memory
+	// the host looks at in its next ordering call on the stream, without synchronizing) and leaves WITHOUT placing anything -- the order
+	// buffers keep what they held, except in the one case that a barrier opens for some workgroups in the very poll in which others
+	// give up. The host then reports the failure, resets the barrier words and orders with the three launch form (no workgroup of
+	// which waits for another) on that stream from then on.
+	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t* host_failed, uint32_t generation, uint32_t max_polls, uint32_t& passed)
 	{
 		__builtin_amdgcn_s_waitcnt(0);		// (vmcnt 0: this wave's stores have reached the L2)
 		__syncthreads();
@@ -347,11 +353,14 @@
 			else
 			{
 				uint32_t polls = 0;
-				while (__hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation && ++polls < k_order_barrier_max_polls)
+				while (__hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation && ++polls < max_polls)
 					__builtin_amdgcn_s_sleep(k_order_barrier_poll_sleep);
-				open = polls < k_order_barrier_max_polls ? 1u : 0u;
+				open = polls < max_polls ? 1u : 0u;
 				if (open == 0)
-					__builtin_trap();
+				{
+					__hip_atomic_store(&control->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(host_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			passed = open;
@@ -369,7 +378,7 @@
 #endif
 
 	__global__ __launch_bounds__(k_order_direct_block_size) void order_instances_grid_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
-		uint32_t instances_per_block, uint32_t num_bins, uint32_t log2_blocks, uint32_t* histograms, order_control* control, order_layout layout_argument,
+		uint32_t instances_per_block, uint32_t num_bins, uint32_t log2_blocks, uint32_t* histograms, order_control* control, uint32_t* host_failed, uint32_t max_polls, uint32_t absent_block, order_layout layout_argument,
 		uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times, uint32_t* __restrict__ out_positions)
 	{
 		__shared__ uint32_t cursors[k_order_direct_bins];		// instances per bin of this workgroup, then their first positions
@@ -381,7 +390,15 @@
 		ACLHIP_ORDER_STAMP(0);
 		uint32_t generation = 0;
 		if (threadIdx.x == 0)
+		{
 			generation = __hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (before this workgroup arrives: the barrier cannot have opened yet)
+			// the words an earlier, failed launch left behind cannot be trusted (a replayed hipGraph runs before the host has seen the failure)
+			passed = __hip_atomic_load(&control->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1u : 0u;
+		}
+		__syncthreads();
+		// (absent_block: a test's stand-in for a workgroup that never becomes resident -- tests/test_gpu_order_device.py; no block has this index otherwise)
+		if (passed == 0 || blockIdx.x == absent_block)
+			return;
 		if (threadIdx.x < sizeof(order_layout) / 4)
 			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
 		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
@@ -396,7 +413,7 @@
 
 		// every column is written and visible
 		ACLHIP_ORDER_STAMP(1);
-		if (!order_grid_barrier(control, generation, passed))
+		if (!order_grid_barrier(control, host_failed, generation, max_polls, passed))
 			return;
 		ACLHIP_ORDER_STAMP(3);
 
@@ -430,7 +447,7 @@
 			}
 		}
 		ACLHIP_ORDER_STAMP(2);
-		if (!order_grid_barrier(control, generation + 1u, passed))
+		if (!order_grid_barrier(control, host_failed, generation + 1u, max_polls, passed))
 			return;
 		ACLHIP_ORDER_STAMP(4);
 

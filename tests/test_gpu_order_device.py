@@ -212,3 +212,52 @@ def test_orderings_of_several_processes_at_the_same_time():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     result = subprocess.run([sys.executable, os.path.join(root, "tools", "order_stress.py"), "6", "2", "6000"], capture_output=True, text=True, timeout=600)
     assert result.returncode == 0 and result.stdout.strip().endswith("ok"), result.stdout + result.stderr
+
+
+_FAILED_BARRIER_SCRIPT = r"""
+import numpy as np, torch
+from acl_amd import runtime, synth
+device = torch.device("cuda", 0)
+clips = [synth.build_clip(seed=500 + i, num_tracks=20 + i, num_samples=30) for i in range(12)]
+with runtime.Context(0) as context:
+    handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+    n = 16384
+    rng = np.random.default_rng(1)
+    which = rng.integers(0, len(clips), size=n)
+    d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+    d_times = torch.zeros(n, dtype=torch.float32, device=device)
+    d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+    torch.cuda.synchronize(device)
+    # workgroup 3 never reaches the barriers (ACLHIP_ORDER_TEST_ABSENT_BLOCK): the launch gives up instead of trapping ...
+    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+    torch.cuda.synchronize(device)                      # ... the process is alive, the queue healthy
+    assert np.all(d_order.cpu().numpy() == -1), "a launch that gave up placed instances"
+    # ... the next call on the stream says so, once ...
+    try:
+        context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+        raise SystemExit("the failed ordering was not reported")
+    except runtime.AclHipError as error:
+        assert "did not complete" in str(error), str(error)
+    # ... and from then on the stream orders with the form that needs no co-residency
+    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+    torch.cuda.synchronize(device)
+    order = d_order.cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(n)), "not a permutation"
+    sorted_clips = handles[which][order]
+    changes = int(np.count_nonzero(sorted_clips[1:] != sorted_clips[:-1]))
+    assert changes < 200, changes                       # bucketed by clip (a few runs per clip: the XCD interleave)
+print("FAILED_BARRIER_PATH_OK")
+"""
+
+
+def test_a_barrier_that_cannot_open_is_reported_not_trapped():
+    """Round 3's one launch form trapped when its workgroups could not all become resident (a queue exception takes the process down).
+    Now the launch gives up without placing anything, the next ordering call on the stream reports it and the stream falls back to the
+    three launch form. The absent workgroup is injected (ACLHIP_ORDER_TEST_ABSENT_BLOCK), the wait shortened."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ACLHIP_ORDER_TEST_ABSENT_BLOCK="3", ACLHIP_ORDER_TEST_MAX_POLLS="20000", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    completed = subprocess.run([sys.executable, "-c", _FAILED_BARRIER_SCRIPT], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert completed.returncode == 0 and "FAILED_BARRIER_PATH_OK" in completed.stdout, completed.stdout[-1500:] + completed.stderr[-3000:]
