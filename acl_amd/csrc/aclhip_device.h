@@ -756,15 +756,67 @@ namespace aclhip
 	// rtm::vector_lerp in its stable form: end * alpha + (start - start * alpha)
 	__device__ __forceinline__ float lerp_stable(float start, float end, float alpha) { return (end * alpha) + (start - (start * alpha)); }
 
+	// ---- ACLHIP_CONSUMERS_FAST (aclhip_pose_consumers::flags): the same formulas in the hardware's cheapest correct-to-an-ulp forms ----
+	// The default kernels follow the reference's x86 arithmetic one IEEE operation at a time and are bit exact with it; about half of a
+	// rotation's instructions are then the expansions of a correctly rounded square root and division, and the pose consumers are bound
+	// by instruction issue. Opt-in, per launch: v_sqrt_f32 / v_rsq_f32 (1 ulp) instead of the IEEE expansions, fused multiply-adds, and
+	// quat_mul_vector3 as two cross products. Every result stays within a few ulp of the default's (tests/test_gpu_consumers.py holds
+	// the poses to 2e-6 of the bit exact kernels and to the fp64 chain of test_pose_consumers_oracle.py).
+	__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+	__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+
+	__device__ __forceinline__ float quat_from_positive_w_fast(float x, float y, float z)
+	{
+		return fast_sqrt(fabsf(__builtin_fmaf(-z, z, __builtin_fmaf(-y, y, __builtin_fmaf(-x, x, 1.0f)))));
+	}
+
+	__device__ __forceinline__ float4 quat_normalize_fast(float4 q)
+	{
+		const float dot = __builtin_fmaf(q.w, q.w, __builtin_fmaf(q.z, q.z, __builtin_fmaf(q.y, q.y, q.x * q.x)));
+		const float inv_len = fast_rsqrt(dot);
+		return make_float4(q.x * inv_len, q.y * inv_len, q.z * inv_len, q.w * inv_len);
+	}
+
+	__device__ __forceinline__ float4 quat_lerp_no_normalization_fast(float4 q0, float4 q1, float alpha)
+	{
+		const float dot = __builtin_fmaf(q0.w, q1.w, __builtin_fmaf(q0.z, q1.z, __builtin_fmaf(q0.y, q1.y, q0.x * q1.x)));
+		const float signed_alpha = __uint_as_float(__float_as_uint(alpha) ^ (__float_as_uint(dot) & 0x80000000u));
+		const float beta = 1.0f - alpha;
+		return make_float4(__builtin_fmaf(q1.x, signed_alpha, q0.x * beta), __builtin_fmaf(q1.y, signed_alpha, q0.y * beta),
+			__builtin_fmaf(q1.z, signed_alpha, q0.z * beta), __builtin_fmaf(q1.w, signed_alpha, q0.w * beta));
+	}
+
+	// rtm::quat_mul's formula (lhs first, then rhs), one multiply and three fused multiply-adds per lane
+	__device__ __forceinline__ float4 quat_mul_fast(float4 l, float4 r)
+	{
+		float4 result;
+		result.x = __builtin_fmaf(r.w, l.x, __builtin_fmaf(r.x, l.w, __builtin_fmaf(r.y, l.z, -(r.z * l.y))));
+		result.y = __builtin_fmaf(r.w, l.y, __builtin_fmaf(-r.x, l.z, __builtin_fmaf(r.y, l.w, r.z * l.x)));
+		result.z = __builtin_fmaf(r.w, l.z, __builtin_fmaf(r.x, l.y, __builtin_fmaf(-r.y, l.x, r.z * l.w)));
+		result.w = __builtin_fmaf(r.w, l.w, __builtin_fmaf(-r.x, l.x, __builtin_fmaf(-r.y, l.y, -(r.z * l.z))));
+		return result;
+	}
+
+	// quat_mul_vector3(v, q) = conj(q) (v, 0) q, as v + w t + u x t with u = -q.xyz, t = 2 (u x v): two cross products instead of two
+	// quaternion products
+	__device__ __forceinline__ float4 quat_mul_vector3_fast(float4 v, float4 q)
+	{
+		const float ux = -q.x, uy = -q.y, uz = -q.z;
+		float tx = __builtin_fmaf(uy, v.z, -(uz * v.y)), ty = __builtin_fmaf(uz, v.x, -(ux * v.z)), tz = __builtin_fmaf(ux, v.y, -(uy * v.x));
+		tx += tx; ty += ty; tz += tz;
+		const float cx = __builtin_fmaf(uy, tz, -(uz * ty)), cy = __builtin_fmaf(uz, tx, -(ux * tz)), cz = __builtin_fmaf(ux, ty, -(uy * tx));
+		return make_float4(__builtin_fmaf(q.w, tx, v.x) + cx, __builtin_fmaf(q.w, ty, v.y) + cy, __builtin_fmaf(q.w, tz, v.z) + cz, 0.0f);
+	}
+
 	// Decodes one animated sub-track of one instance: both keyframes, range expansion, W reconstruction, interpolation.
 	// `policy` is the effective rounding policy of the track (none unless per track rounding is enabled);
 	// `lerp_alpha` the alpha handed to the interpolation.
 	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
-	template<bool kPolicies>
+	template<bool kPolicies, bool kFastMath = false>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
 		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples);
 
-	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false>
+	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false>
 	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
@@ -773,14 +825,30 @@ namespace aclhip
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
 			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
-		return interpolate_animated_samples<kPolicies>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples);
+		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples);
 	}
 
 	// What follows the unpack: W reconstruction, interpolation, normalization (rotations) / the stable lerp (translations, scales)
-	template<bool kPolicies>
+	template<bool kPolicies, bool kFastMath>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
 		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
 	{
+		if constexpr (kFastMath && !kPolicies)
+		{
+			// ACLHIP_CONSUMERS_FAST: the same formulas, 1 ulp square roots and fused multiply-adds (see quat_normalize_fast above)
+			if (is_rotation && __builtin_amdgcn_ballot_w64(is_rotation) != 0)
+			{
+				const float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w_fast(v0[0], v0[1], v0[2]));
+				const float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w_fast(v1[0], v1[1], v1[2]));
+				float4 result = quat_lerp_no_normalization_fast(q0, q1, lerp_alpha);
+				if (normalization >= 1)
+					result = quat_normalize_fast(result);
+				return result;
+			}
+			const float beta = 1.0f - lerp_alpha;
+			return make_float4(__builtin_fmaf(v1[0], lerp_alpha, v0[0] * beta), __builtin_fmaf(v1[1], lerp_alpha, v0[1] * beta), __builtin_fmaf(v1[2], lerp_alpha, v0[2] * beta), 0.0f);
+		}
+
 		// (the rotation arithmetic -- three square roots and a division, ~90 instructions -- sits behind a branch the WAVE takes: the
 		// compiler otherwise turns `if (is_rotation)` into selects, and a pass of translations and scales pays for rotations it does not have)
 		if (is_rotation && __builtin_amdgcn_ballot_w64(is_rotation) != 0)
@@ -1028,6 +1096,18 @@ namespace aclhip
 		result.rotation = quat_mul(lhs.rotation, rhs.rotation);
 		const float4 scaled = make_float4(lhs.translation.x * rhs.scale.x, lhs.translation.y * rhs.scale.y, lhs.translation.z * rhs.scale.z, 0.0f);
 		const float4 rotated = quat_mul_vector3(scaled, rhs.rotation);
+		result.translation = make_float4(rotated.x + rhs.translation.x, rotated.y + rhs.translation.y, rotated.z + rhs.translation.z, 0.0f);
+		result.scale = make_float4(lhs.scale.x * rhs.scale.x, lhs.scale.y * rhs.scale.y, lhs.scale.z * rhs.scale.z, 0.0f);
+		return result;
+	}
+
+	// the quaternion path of qvv_mul in ACLHIP_CONSUMERS_FAST arithmetic
+	__device__ __forceinline__ qvv qvv_mul_fast(const qvv& lhs, const qvv& rhs)
+	{
+		qvv result;
+		result.rotation = quat_mul_fast(lhs.rotation, rhs.rotation);
+		const float4 scaled = make_float4(lhs.translation.x * rhs.scale.x, lhs.translation.y * rhs.scale.y, lhs.translation.z * rhs.scale.z, 0.0f);
+		const float4 rotated = quat_mul_vector3_fast(scaled, rhs.rotation);
 		result.translation = make_float4(rotated.x + rhs.translation.x, rotated.y + rhs.translation.y, rotated.z + rhs.translation.z, 0.0f);
 		result.scale = make_float4(lhs.scale.x * rhs.scale.x, lhs.scale.y * rhs.scale.y, lhs.scale.z * rhs.scale.z, 0.0f);
 		return result;

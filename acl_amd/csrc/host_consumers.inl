@@ -244,6 +244,8 @@ namespace
 		if (has_base && !base_is_clip && (consumers.base_poses == nullptr || (consumers.base_pose_stride_bytes & 15u) != 0 || (reinterpret_cast<uintptr_t>(consumers.base_poses) & 15u) != 0))
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an additive format needs base clips or a 16 byte aligned base pose buffer");
 		const bool blend = consumers.num_blend_clips > 1;
+		if ((consumers.flags & ~ACLHIP_CONSUMERS_FAST) != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown pose consumer flags 0x%x", consumers.flags);
 		if (consumers.num_blend_clips > ACLHIP_MAX_BLEND_CLIPS)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "a blend of %u clips: at most %u", consumers.num_blend_clips, ACLHIP_MAX_BLEND_CLIPS);
 		if (blend && (consumers.blend_clips == nullptr || consumers.blend_sample_times == nullptr || consumers.blend_weights == nullptr))
@@ -340,7 +342,17 @@ namespace
 				  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, true, true> },
 			},
 		};
-		const consumer_kernel kernel = unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false>
+		// ACLHIP_CONSUMERS_FAST: object space launches without a blend, in the hardware's 1 ulp arithmetic (include/aclhip.h)
+		const bool fast = (consumers.flags & ACLHIP_CONSUMERS_FAST) != 0 && consumers.object_space != 0 && !blend;
+		static const consumer_kernel fast_kernels[2][4] =
+		{
+			{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, false, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, true, false, true>,
+			  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, false, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false, false, false, true> },
+			{ decompress_poses_consumer_kernel<true, k_consumer_base_none, false, true, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_buffer, false, true, false, true>,
+			  decompress_poses_consumer_kernel<true, k_consumer_base_second_wave, false, true, false, true>, decompress_poses_consumer_kernel<true, k_consumer_base_fused, false, true, false, true> },
+		};
+		const consumer_kernel kernel = fast ? (unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false, false, true> : fast_kernels[mirrored ? 1 : 0][base_kind])
+			: unit_scale ? decompress_poses_consumer_kernel<true, k_consumer_base_none, true, false>
 			: (blend ? blend_kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind] : kernels[mirrored ? 1 : 0][consumers.object_space != 0 ? 1 : 0][base_kind]);
 		if (lds_bytes > 64 * 1024 - 128)		// above the default limit
 			ACLHIP_CHECK_HIP(context, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int(k_lds_bytes)));

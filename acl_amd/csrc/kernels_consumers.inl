@@ -4,7 +4,7 @@
 	// ---- pose consumers -----------------------------------------------------------------------------------------------
 	// Decodes the whole local pose of one clip instance into an LDS image (image[0] = quad 0), window by window like the pose kernels
 	// but in ONE wave, because what follows needs every transform of the pose. Common-case settings only (see launch_consumers).
-	template<class image_writer_type>
+	template<bool kFastMath = false, class image_writer_type>
 	__device__ __forceinline__ void decode_animated_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
 		uint32_t lane, image_writer_type write_to_image)
 	{
@@ -13,7 +13,7 @@
 
 		const uint32_t num_quads = clip.num_tracks * 3u;
 		if (num_quads <= k_image_chunk_quads)
-			decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, lane, write_to_image);
+			decode_window_sub_tracks_into<false, false, kFastMath>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, lane, write_to_image);
 		else
 		{
 			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
@@ -21,11 +21,12 @@
 			{
 				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
 				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
-				decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, write_to_image);
+				decode_window_sub_tracks_into<false, false, kFastMath>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, write_to_image);
 			}
 		}
 	}
 
+	template<bool kFastMath = false>
 	__device__ __forceinline__ void decode_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
 		uint32_t lane, f32x4* image)
 	{
@@ -39,10 +40,11 @@
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
 		}
-		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0 });
+		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0 });
 	}
 
 	// The pose without its scales (every one of them is 1): rotation | translation, 32 bytes per transform, like the QV32 output layout
+	template<bool kFastMath = false>
 	__device__ __forceinline__ void decode_unit_scale_pose_into_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
 		uint32_t lane, f32x4* image)
 	{
@@ -55,16 +57,17 @@
 				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resolved + (piece >> 1) * 3u + (piece & 1u)),
 					(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 		}
-		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, compact_image_writer<ACLHIP_LAYOUT_QV32>{ reinterpret_cast<float*>(image), 0 });
+		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, compact_image_writer<ACLHIP_LAYOUT_QV32>{ reinterpret_cast<float*>(image), 0 });
 	}
 
 	// transform_add0 / transform_add1 (core/additive_utils.h:128-142) one sub-track at a time: unlike the relative format (a qvv_mul)
 	// they combine rotation with rotation, translation with translation and scale with scale. kind: 0 rotation, 1 translation, 2 scale
+	template<bool kFastMath = false>
 	__device__ __forceinline__ f32x4 apply_additive_sub_track(uint32_t additive_format, uint32_t kind, float4 additive, f32x4 base)
 	{
 		if (kind == 0)
 		{
-			const float4 rotation = quat_mul(additive, make_float4(base.x, base.y, base.z, base.w));
+			const float4 rotation = kFastMath ? quat_mul_fast(additive, make_float4(base.x, base.y, base.z, base.w)) : quat_mul(additive, make_float4(base.x, base.y, base.z, base.w));
 			return f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
 		}
 		if (kind == 1)
@@ -75,6 +78,7 @@
 	}
 
 	// A decoded sub-track of an additive clip goes ONTO the base pose the image already holds
+	template<bool kFastMath = false>
 	struct additive_image_writer
 	{
 		f32x4* image;
@@ -82,12 +86,13 @@
 		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
 		{
 			const uint32_t quad = entry.quad_index;
-			image[quad] = apply_additive_sub_track(additive_format, quad - entry.track_index * 3u, value, image[quad]);
+			image[quad] = apply_additive_sub_track<kFastMath>(additive_format, quad - entry.track_index * 3u, value, image[quad]);
 		}
 	};
 
 	// The additive clip applied onto the base pose in `image`, sub-track by sub-track: the constant and default ones from the clip's
 	// base pose table (defaults are the track_writer's own: what the pose consumers require), the animated ones as they are decoded.
+	template<bool kFastMath = false>
 	__device__ __forceinline__ void apply_additive_clip_onto_image(const device_clip& clip, float sample_time, uint32_t rounding_policy, const decode_params& params,
 		uint32_t additive_format, uint32_t lane, f32x4* image)
 	{
@@ -102,9 +107,9 @@
 					continue;
 				value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
 			}
-			image[quad] = apply_additive_sub_track(additive_format, quad - (quad / 3u) * 3u, value, image[quad]);
+			image[quad] = apply_additive_sub_track<kFastMath>(additive_format, quad - (quad / 3u) * 3u, value, image[quad]);
 		}
-		decode_animated_into_image(clip, sample_time, rounding_policy, params, lane, additive_image_writer{ image, additive_format });
+		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, additive_image_writer<kFastMath>{ image, additive_format });
 	}
 
 	// ---- blend of K clip instances (aclhip_pose_consumers::num_blend_clips; include/aclhip.h states the operation order) ----------------
@@ -225,7 +230,7 @@
 	//                  none can occur (scales that are sums and products of non negative values).
 	constexpr uint32_t k_consumer_base_none = 0, k_consumer_base_buffer = 1, k_consumer_base_second_wave = 2, k_consumer_base_fused = 3;
 
-	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored, bool kBlend = false>
+	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored, bool kBlend = false, bool kFast = false>
 	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
 		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t packed_block_shape,
@@ -240,6 +245,7 @@
 
 		static_assert(!kUnitScale || (kObjectSpace && kBase == k_consumer_base_none), "rotation | translation images: object space without a base");
 		static_assert(!kBlend || (!kUnitScale && kBase != k_consumer_base_fused), "a blend accumulates whole qvv images; a base clip is decoded by a second wave");
+		static_assert(!kFast || !kBlend, "ACLHIP_CONSUMERS_FAST: not instantiated for blends");
 		constexpr bool has_base = kBase != k_consumer_base_none;
 		constexpr bool base_is_clip = kBase == k_consumer_base_second_wave || kBase == k_consumer_base_fused;
 		// a base clip under additive0 / additive1: ONE wave decodes the base into the instance's image and the additive clip onto it
@@ -299,7 +305,7 @@
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
 					|| (!kMirrored && multiplies_transforms && ((clip.flags | base_clip.flags) & k_clip_negative_scale) != 0);
 				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
-					decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
+					decode_pose_into_image<kFast>(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}
 
 			if (kBlend && !refused)
@@ -326,14 +332,14 @@
 				{
 					if (fused_base)
 					{
-						decode_pose_into_image(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, image);
+						decode_pose_into_image<kFast>(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, image);
 						wave_lds_barrier();		// the base pose is complete (its DMA has landed)
-						apply_additive_clip_onto_image(clip, as_constant(sample_times)[instance], rounding_policy, params, consumers.additive_format, lane, image);
+						apply_additive_clip_onto_image<kFast>(clip, as_constant(sample_times)[instance], rounding_policy, params, consumers.additive_format, lane, image);
 					}
 					else if (unit_scale)
-						decode_unit_scale_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+						decode_unit_scale_pose_into_image<kFast>(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					else
-						decode_pose_into_image(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
+						decode_pose_into_image<kFast>(clip, as_constant(sample_times)[instance], rounding_policy, params, lane, image);
 					if constexpr (kBlend)
 					{
 						const uint32_t num_blend_clips = consumers.num_blend_clips;
@@ -444,8 +450,10 @@
 									const f32x4 child_rotation = slot_image[child_quad], child_translation = slot_image[child_quad + 1];
 									const f32x4 parent_rotation = slot_image[parent_quad], parent_translation = slot_image[parent_quad + 1];
 									const float4 parent_quat = make_float4(parent_rotation.x, parent_rotation.y, parent_rotation.z, parent_rotation.w);
-									const float4 rotation = quat_normalize(quat_mul(make_float4(child_rotation.x, child_rotation.y, child_rotation.z, child_rotation.w), parent_quat));
-									const float4 rotated = quat_mul_vector3(make_float4(child_translation.x, child_translation.y, child_translation.z, 0.0f), parent_quat);
+									const float4 child_quat = make_float4(child_rotation.x, child_rotation.y, child_rotation.z, child_rotation.w);
+									const float4 child_vector = make_float4(child_translation.x, child_translation.y, child_translation.z, 0.0f);
+									const float4 rotation = kFast ? quat_normalize_fast(quat_mul_fast(child_quat, parent_quat)) : quat_normalize(quat_mul(child_quat, parent_quat));
+									const float4 rotated = kFast ? quat_mul_vector3_fast(child_vector, parent_quat) : quat_mul_vector3(child_vector, parent_quat);
 									slot_image[child_quad] = f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
 									slot_image[child_quad + 1] = f32x4{ rotated.x + parent_translation.x, rotated.y + parent_translation.y, rotated.z + parent_translation.z, 0.0f };
 								}
@@ -458,7 +466,7 @@
 										const uint64_t mirrored = __ballot(qvv_mul_takes_matrix_path(child, parent));
 										if (mirrored != 0 && lane == uint32_t(__builtin_ctzll(mirrored)))
 											atomicAdd(rejected_count + 1, (unsigned long long)__builtin_popcountll(mirrored));
-										object = qvv_mul(child, parent);
+										object = kFast ? qvv_mul_fast(child, parent) : qvv_mul(child, parent);
 										if (mirrored != 0 && qvv_mul_takes_matrix_path(child, parent))
 											object = qvv_mul_through_matrices(child, parent);
 									}
@@ -466,9 +474,9 @@
 									{
 										// no registered clip can decode a negative scale and the base is a clip: products and sums of non
 										// negative scales -- nothing to count, nothing to route
-										object = qvv_mul(child, parent);
+										object = kFast ? qvv_mul_fast(child, parent) : qvv_mul(child, parent);
 									}
-									object.rotation = quat_normalize(object.rotation);
+									object.rotation = kFast ? quat_normalize_fast(object.rotation) : quat_normalize(object.rotation);
 									store_qvv(slot_image, pair & 0xFFFFu, object);
 								}
 							}

@@ -276,6 +276,7 @@
 
 	// Instance lists kept in decode order (aclhip_instance_list_update): instance instances[k] now plays clips[k]. It keeps its slot --
 	// a full re-order follows once enough of the list has changed (host_lists.inl) --, the clip handle the decode reads for that slot changes.
+	// (Two entries for one instance race on both arrays independently: the header forbids them. Handles are not checked: the decode does.)
 	__global__ __launch_bounds__(256) void update_instance_list_kernel(const uint32_t* __restrict__ instances, const uint32_t* __restrict__ new_clips, uint32_t count,
 		uint32_t num_instances, uint32_t* __restrict__ list_clips, const uint32_t* __restrict__ positions, uint32_t* __restrict__ ordered_clips)
 	{

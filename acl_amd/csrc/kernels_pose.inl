@@ -139,7 +139,7 @@
 		}
 	};
 
-	template<bool kPolicies, bool kWideKeyLoads = false, class image_writer_type>
+	template<bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false, class image_writer_type>
 	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image)
 	{
@@ -179,9 +179,9 @@
 
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 			else
-				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)

@@ -57,7 +57,7 @@ class PoseConsumers(ctypes.Structure):
     _fields_ = [
         ("additive_format", ctypes.c_uint32), ("object_space", ctypes.c_uint32),
         ("base_clips", ctypes.c_void_p), ("base_sample_times", ctypes.c_void_p), ("base_poses", ctypes.c_void_p), ("base_pose_stride_bytes", ctypes.c_uint64),
-        ("num_blend_clips", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+        ("num_blend_clips", ctypes.c_uint32), ("flags", ctypes.c_uint32),
         ("blend_clips", ctypes.c_void_p), ("blend_sample_times", ctypes.c_void_p), ("blend_weights", ctypes.c_void_p),
     ]
 
@@ -93,6 +93,7 @@ def relayout_pose(pose, layout, skip=(False, False, False), into=None):
 
 
 ADDITIVE_NONE, ADDITIVE_RELATIVE, ADDITIVE_ADDITIVE0, ADDITIVE_ADDITIVE1 = 0, 1, 2, 3  # aclhip_additive_format
+CONSUMERS_FAST = 1          # ACLHIP_CONSUMERS_FAST (aclhip_pose_consumers::flags)
 NO_PARENT = 0xFFFFFFFF
 
 
@@ -484,7 +485,7 @@ class Context:
         return ms.value
 
     def decompress_poses(self, clips, sample_times, additive_format=ADDITIVE_NONE, object_space=False, base_clips=None, base_sample_times=None, base_poses=None,
-                         params=None, num_tracks=None, out=None, instance_rounding=None, blend_clips=None, blend_sample_times=None, blend_weights=None):
+                         params=None, num_tracks=None, out=None, instance_rounding=None, blend_clips=None, blend_sample_times=None, blend_weights=None, flags=0):
         """Host arrays in, host poses out: float32 [n, num_tracks, 12] after the consumers. The base of an additive instance is either
         (base_clips[i], base_sample_times[i]) or base_poses[i] ([n, num_tracks, 12]). A blend of K clips per instance: blend_clips /
         blend_sample_times [n, K - 1] (the further clips), blend_weights [n, K]."""
@@ -502,6 +503,7 @@ class Context:
         consumers = PoseConsumers()
         consumers.additive_format = int(additive_format)
         consumers.object_space = 1 if object_space else 0
+        consumers.flags = int(flags)
         if base_clips is not None:
             base_clips = np.ascontiguousarray(base_clips, dtype=np.uint32)
             base_sample_times = np.ascontiguousarray(base_sample_times, dtype=np.float32)

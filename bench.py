@@ -45,6 +45,8 @@ WORKLOAD_TEXT = {
     "scalar": "64k instances per GPU of one 256-curve float1f track list (scalar tracks, SURVEY 8 f4)",
     "object_space": "the one_clip batch with local -> object space fused into the decode (pose consumers, SURVEY 8 f3)",
     "additive_object_space": "64k instances per GPU: an additive clip applied (additive1) onto a base clip instance decoded by the same wave, then local -> object space (SURVEY 8 f3)",
+    "object_space_fast": "object_space with ACLHIP_CONSUMERS_FAST: the opt-in 1 ulp arithmetic (poses within 2e-6 of the bit exact kernels')",
+    "additive_object_space_fast": "additive_object_space with ACLHIP_CONSUMERS_FAST",
     "blend_object_space": "64k instances per GPU, each the weighted blend of three clip instances (three 100-bone clips of one skeleton), then local -> object space (SURVEY 8 f3)",
     "one_clip_mixed_registry": "the one_clip batch (4 800 byte rows) while the context ALSO holds a 300-bone rig and a 551-bone clip: the launch is shaped by the batch, not by the registry",
     "track_requests": "4 M random (instance, bone) requests on the 100-bone clip: seek + decompress_track, one 48 byte qvv per request (SURVEY 8 a15)",
@@ -69,7 +71,7 @@ def _build_workload(name, rank, num_instances):
     from acl_amd import synth
 
     rng = np.random.default_rng(1000 + rank)
-    if name in ("one_clip", "object_space", "one_clip_mixed_registry", "track_requests"):
+    if name in ("one_clip", "object_space", "object_space_fast", "one_clip_mixed_registry", "track_requests"):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
         clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "blend_object_space":
@@ -78,7 +80,7 @@ def _build_workload(name, rank, num_instances):
                  synth.build_clip(seed=22, num_tracks=100, num_samples=241, sample_rate=30.0),
                  synth.build_clip(seed=23, num_tracks=100, num_samples=181, sample_rate=30.0)]
         clip_indices = np.zeros(num_instances, dtype=np.uint32)
-    elif name == "additive_object_space":
+    elif name in ("additive_object_space", "additive_object_space_fast"):
         # instance = additive clip 1 applied onto base clip 0 (instance i's base time is drawn in Job), then local -> object space
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0),
                  synth.build_clip(seed=12, num_tracks=100, num_samples=121, sample_rate=30.0, rotation_constant=0.5, translation_constant=0.8)]
@@ -240,13 +242,14 @@ class Job:
             self.d_tracks = torch.from_numpy(track_rng.integers(0, self.max_tracks, size=n).astype(np.int32)).to(self.device)
             self._launch = self.lib.aclhip_decompress_track_batch
             self._args = (handle, clips_ptr, times_ptr, self.d_tracks.data_ptr(), n, ctypes.byref(self.params), poses_ptr, stream_ptr)
-        elif name in ("object_space", "additive_object_space", "blend_object_space"):
+        elif name in ("object_space", "additive_object_space", "blend_object_space", "object_space_fast", "additive_object_space_fast"):
             parents = synth.humanoid_hierarchy(self.max_tracks)     # 13 depths, 4-18 transforms wide
             for clip_handle in self.handles:
                 context.set_clip_hierarchy(int(clip_handle), parents)
             self.consumers = runtime.PoseConsumers()
             self.consumers.object_space = 1
-            if name == "additive_object_space":
+            self.consumers.flags = runtime.CONSUMERS_FAST if name.endswith("_fast") else 0
+            if name.startswith("additive_object_space"):
                 base_rng = np.random.default_rng(2000 + rank)
                 self.d_base_clips = torch.full((n,), int(self.handles[0]), dtype=torch.int32, device=self.device)
                 self.d_base_times = torch.from_numpy(base_rng.uniform(0.0, self.clips[0].duration, size=n).astype(np.float32)).to(self.device)
@@ -351,7 +354,7 @@ class Job:
             return self.num_instances * (48 + 12) + read              # a 48 byte transform out, clip handle + sample time + track index in, the clip once
         if not self.is_scalar:
             written = written // 48 * self.runtime.LAYOUTS[self.layout][1]
-        if self.name == "additive_object_space":
+        if self.name.startswith("additive_object_space"):
             read += self.context.batch_algorithmic_bytes(self.handles[:1])[1]        # the base clip is read too; one pose per instance is written
         if self.name == "blend_object_space":
             read += self.context.batch_algorithmic_bytes(self.handles[1:])[1]        # the two other clips of every blend; one pose per instance is written
@@ -416,6 +419,8 @@ def default_run_specs():
         ("scalar", {}, 300),
         ("object_space", {}, 150),
         ("additive_object_space", {}, 100),
+        ("object_space_fast", {}, 150),                              # the same two with ACLHIP_CONSUMERS_FAST (opt-in arithmetic, <= 2e-6 from the default's poses)
+        ("additive_object_space_fast", {}, 100),
         ("blend_object_space", {}, 100),
         ("one_clip", {"layout": "qvv40"}, 300),
         ("one_clip", {"layout": "qv32"}, 300),

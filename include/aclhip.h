@@ -153,7 +153,7 @@ const char* aclhip_status_string(aclhip_status status);
 const char* aclhip_last_error_message(const aclhip_context* context);
 
 /* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks;
- * 4: aclhip_pose_consumers::num_blend_clips, blend_clips, blend_sample_times, blend_weights).
+ * 4: aclhip_pose_consumers::num_blend_clips, flags, blend_clips, blend_sample_times, blend_weights).
  * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
  * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
 #define ACLHIP_ABI_VERSION 4u
@@ -331,9 +331,11 @@ aclhip_status aclhip_pose_windows_of_launch(aclhip_context* context, uint32_t la
 
 /* The same order computed on the GPU for instance lists that live there (all pointers DEVICE pointers, stream ordered: ONE launch
  * on `stream` -- at most 64 workgroups that meet at barriers in global memory; three launches for registries of more than 8 192
- * clips --, scratch kept per stream by the context, no host synchronization). The one launch form needs all its workgroups resident
- * together: it is sized for that on a device the process has to itself or shares with a few others; a barrier that does not open
- * within seconds traps (the launch fails, the queue reports it) rather than leave a half written order behind. Writes the permutation to out_order and,
+ * clips --, scratch kept per stream by the context at a fixed size and address, no host synchronization). The one launch form needs all
+ * its workgroups resident together: its grid is sized from the occupancy query to fit an idle device many times over. Should a barrier
+ * not open within seconds all the same (dozens of such launches of other processes sharing the device), the launch GIVES UP without
+ * placing anything -- no trap, the queue stays healthy --, the next ordering call on the stream returns ACLHIP_ERROR_DEVICE (once: the
+ * order that launch was to write is invalid, order again) and the stream uses the three launch form from then on. Writes the permutation to out_order and,
  * when the pointers are not NULL, the permuted lists out_clips[k] = clips[out_order[k]], out_sample_times[k] =
  * sample_times[out_order[k]] (the arguments of the decode that follows on the same stream; rows = out_order puts the poses back
  * in the caller's rows). Which instance of a clip takes which of the clip's slots is decided by atomics: every call returns a valid
@@ -365,7 +367,8 @@ aclhip_status aclhip_order_instances_device_for_windows(aclhip_context* context,
  * All calls of one list must be made in stream order (one stream, or the caller's events between streams). WHEN a list is re-ordered
  * is decided on the host at the time of the call: a decode captured into a hipGraph replays what was decided when it was captured
  * (capture aclhip_order_instances_device + aclhip_decompress_tracks_batch instead when the order has to follow the replays' data).
- * An update that names an instance twice leaves either of the two clips. */
+ * An update must not name an instance twice: the two entries race, and the clip that plays until the next re-order need not be the one
+ * that plays after it (memory safe, but undefined which). Clip handles are not validated here: the decode refuses unknown ones (counted). */
 typedef uint32_t aclhip_instance_list;
 
 aclhip_status aclhip_instance_list_create(aclhip_context* context, uint32_t num_instances, aclhip_instance_list* out_list);
@@ -482,13 +485,24 @@ typedef struct aclhip_pose_consumers
 	 * The weights are the caller's (normally non negative with sum 1; they are not normalized here). The blended local pose then
 	 * takes the place of the decoded one: additive apply and object space follow as configured above. */
 	uint32_t num_blend_clips;			/* 0 or 1: no blend; 2 .. ACLHIP_MAX_BLEND_CLIPS */
-	uint32_t reserved0;
+	uint32_t flags;						/* ACLHIP_CONSUMERS_* */
 	const aclhip_clip* blend_clips;		/* DEVICE [num_instances * (K - 1)] */
 	const float* blend_sample_times;	/* DEVICE [num_instances * (K - 1)] */
 	const float* blend_weights;			/* DEVICE [num_instances * K] */
 } aclhip_pose_consumers;
 
 #define ACLHIP_MAX_BLEND_CLIPS 4u
+
+/* aclhip_pose_consumers::flags. By default the consumers' kernels follow the reference's x86 arithmetic one IEEE operation at a time
+ * (core/additive_utils.h:128-160 and compression/transform_pose_utils.h:35-50 through rtm::quat_mul / qvv_mul, math/quatf.h:135-211 for
+ * the decode) and are BIT EXACT with the oracle; about half of a rotation's instructions are then the expansions of correctly rounded
+ * square roots and divisions, and these kernels are bound by instruction issue. ACLHIP_CONSUMERS_FAST is the opt-in for callers who
+ * want the poses, not the bits: object space launches (object_space != 0, no blend) then compute the same formulas with the
+ * hardware's 1 ulp square root / reciprocal square root, fused multiply-adds and quat_mul_vector3 as two cross products -- in the
+ * decode of the instance and of its base, the fused additive apply and the walk. Rotations stay within 2e-6 of the default's per
+ * component, translations within 2e-6 of the pose's extent (tests/test_gpu_consumers.py; DESIGN.md 4.7 has the measured figures).
+ * Ignored (the default arithmetic runs) for local space output and for blends; mirrored transforms keep rtm's matrix route. */
+#define ACLHIP_CONSUMERS_FAST 1u
 
 /* aclhip_decompress_tracks_batch followed by the consumers, in one kernel. `params` as for aclhip_decompress_tracks_batch but
  * restricted to what a consumer can work with -- the track_writer's own default sub-track modes, no per track rounding,

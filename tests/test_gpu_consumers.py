@@ -468,3 +468,71 @@ def test_poses_without_scale_keep_no_scale_in_lds(num_tracks):
         context.unregister_clip(scaled_handle)
         assert helpers.exact(context.decompress_poses(clip_handles, times, object_space=True), expected)
         assert context.rejected_instance_count() == 0
+
+
+# ---- ACLHIP_CONSUMERS_FAST: the opt-in arithmetic (1 ulp square roots, fused multiply-adds) against the bit exact default -----------------
+FAST_ROTATION_TOLERANCE = 2.0e-6        # per component of a unit rotation
+FAST_TRANSLATION_TOLERANCE = 2.0e-6     # relative to max(1, largest |translation| of the pose)
+
+
+def assert_fast_close(fast, exact):
+    rotation = float(np.abs(fast[..., 0:4] - exact[..., 0:4]).max())
+    extent = max(1.0, float(np.abs(exact[..., 4:7]).max()))
+    translation = float(np.abs(fast[..., 4:7] - exact[..., 4:7]).max()) / extent
+    scale = float(np.abs(fast[..., 8:11] - exact[..., 8:11]).max()) / max(1.0, float(np.abs(exact[..., 8:11]).max()))
+    assert rotation <= FAST_ROTATION_TOLERANCE and translation <= FAST_TRANSLATION_TOLERANCE and scale <= FAST_TRANSLATION_TOLERANCE, (rotation, translation, scale)
+    assert np.all(fast[..., 7] == 0.0) and np.all(fast[..., 11] == 0.0)
+    return rotation, translation
+
+
+@pytest.mark.parametrize("name", ["small_scale", "window_boundary_107", "crowd_rig_1200", "stripped_wrap", "mostly_default"])
+def test_fast_arithmetic_stays_within_its_tolerance_of_the_bit_exact_kernels(name):
+    rng = np.random.default_rng(CLIP_SHAPES[name]["seed"] + 5)
+    spec = CLIP_SHAPES[name]
+    clips = [synth.build_clip(**spec), synth.build_clip(**dict(spec, seed=spec["seed"] + 1000, num_samples=spec["num_samples"] + 7))]
+    num_tracks = spec["num_tracks"]
+    parents = random_hierarchy(rng, num_tracks, parent_span=max(1, num_tracks // 8), extra_roots=2 if num_tracks > 8 else 0)
+    with runtime.Context(0) as context:
+        handles = [context.register_clip(c.blob) for c in clips]
+        for handle in handles:
+            context.set_clip_hierarchy(handle, parents)
+        n = 32 if num_tracks < 500 else 8
+        which, base_which = rng.integers(0, 2, size=n), rng.integers(0, 2, size=n)
+        times = np.array([rng.uniform(0.0, clips[c].duration) for c in which], dtype=np.float32)
+        base_times = np.array([rng.uniform(0.0, clips[c].duration) for c in base_which], dtype=np.float32)
+        clip_handles, base_handles = np.array([handles[c] for c in which], dtype=np.uint32), np.array([handles[c] for c in base_which], dtype=np.uint32)
+        base_poses = context.decompress_tracks(base_handles, base_times)
+        for additive_format, base_as_buffer in ((0, False), (1, False), (2, False), (3, False), (3, True)):
+            kwargs = dict(additive_format=additive_format, object_space=True)
+            if additive_format != 0 and base_as_buffer:
+                kwargs.update(base_poses=base_poses)
+            elif additive_format != 0:
+                kwargs.update(base_clips=base_handles, base_sample_times=base_times)
+            exact = context.decompress_poses(clip_handles, times, **kwargs)
+            fast = context.decompress_poses(clip_handles, times, flags=runtime.CONSUMERS_FAST, **kwargs)
+            assert_fast_close(fast, exact)
+            assert not helpers.exact(fast, exact) or num_tracks == 1            # (it IS another arithmetic)
+        # local space output ignores the flag: the default, bit exact kernels run
+        assert helpers.exact(context.decompress_poses(clip_handles, times, flags=runtime.CONSUMERS_FAST), context.decompress_poses(clip_handles, times))
+        assert context.rejected_instance_count() == 0
+
+
+def test_fast_object_space_of_the_humanoid_is_the_fp64_chain(context):
+    """the 100-bone character of the bench workloads (13 levels deep): fast object space against the fp64 product of the local matrices
+    down every bone's chain of parents, and against the bit exact kernel"""
+    clip = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)
+    handle = context.register_clip(clip.blob)
+    parents = synth.humanoid_hierarchy(100)
+    context.set_clip_hierarchy(handle, parents)
+    rng = np.random.default_rng(17)
+    n = 256
+    times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+    handles = np.full(n, handle, dtype=np.uint32)
+    exact = context.decompress_poses(handles, times, object_space=True)
+    fast = context.decompress_poses(handles, times, object_space=True, flags=runtime.CONSUMERS_FAST)
+    rotation, translation = assert_fast_close(fast, exact)
+    print(f"fast vs bit exact, 100-bone humanoid: rotations {rotation:.3e}, translations {translation:.3e} of the extent")
+    for i in range(0, n, 16):
+        assert_same_affine_maps(fast[i], parents, ob.oracle_decompress_tracks(clip.blob, float(times[i])), tolerance=2.0e-6)
+    assert np.abs(np.linalg.norm(fast[..., 0:4].astype(np.float64), axis=-1) - 1.0).max() <= 1.0e-6
+    context.unregister_clip(handle)
