@@ -765,9 +765,14 @@ namespace aclhip
 	__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 	__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 
+	// (1 - x^2 - y^2 - z^2 cancels badly for rotations near half a turn: W then moves by 1e-6 and more with the rounding of the
+	// squares, so those keep the reference's own operation order -- only the square root is the hardware's)
 	__device__ __forceinline__ float quat_from_positive_w_fast(float x, float y, float z)
 	{
-		return fast_sqrt(fabsf(__builtin_fmaf(-z, z, __builtin_fmaf(-y, y, __builtin_fmaf(-x, x, 1.0f)))));
+		float w_squared = 1.0f - (x * x);
+		w_squared = w_squared - (y * y);
+		w_squared = w_squared - (z * z);
+		return fast_sqrt(fabsf(w_squared));
 	}
 
 	__device__ __forceinline__ float4 quat_normalize_fast(float4 q)
@@ -797,11 +802,11 @@ namespace aclhip
 		return result;
 	}
 
-	// quat_mul_vector3(v, q) = conj(q) (v, 0) q, as v + w t + u x t with u = -q.xyz, t = 2 (u x v): two cross products instead of two
-	// quaternion products
+	// quat_mul_vector3(v, q) = quat_mul(quat_mul(conj(q), (v, 0)), q) -- in Hamilton's notation q (v, 0) q*, rtm::quat_mul(lhs, rhs)
+	// being rhs x lhs -- as v + w t + u x t with u = q.xyz, t = 2 (u x v): two cross products instead of two quaternion products
 	__device__ __forceinline__ float4 quat_mul_vector3_fast(float4 v, float4 q)
 	{
-		const float ux = -q.x, uy = -q.y, uz = -q.z;
+		const float ux = q.x, uy = q.y, uz = q.z;
 		float tx = __builtin_fmaf(uy, v.z, -(uz * v.y)), ty = __builtin_fmaf(uz, v.x, -(ux * v.z)), tz = __builtin_fmaf(ux, v.y, -(uy * v.x));
 		tx += tx; ty += ty; tz += tz;
 		const float cx = __builtin_fmaf(uy, tz, -(uz * ty)), cy = __builtin_fmaf(uz, tx, -(ux * tz)), cz = __builtin_fmaf(ux, ty, -(uy * tx));

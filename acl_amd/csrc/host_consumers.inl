@@ -275,7 +275,10 @@ namespace
 		// (a blend accumulates its clips in the instance's image before anything else happens to it: its base clip gets a wave and an image of its own)
 		const bool fused_base = base_is_clip && !blend && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
 		const bool two_waves = base_is_clip && !fused_base;
-		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1);
+		// (measurement knob: ACLHIP_CONSUMER_LDS_PAD bytes between the instances' images -- the walk's lanes touch the same quad of all of a
+		// workgroup's images at once, and images a multiple of 128 bytes apart put those on the same LDS banks)
+		static const size_t lds_pad = []() { const char* value = std::getenv("ACLHIP_CONSUMER_LDS_PAD"); return value != nullptr ? size_t(std::atol(value)) & ~size_t(15) : size_t(0); }();
+		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1) + lds_pad;
 		// a walk schedule of T transforms: 2 words + a step end per step + a pair per transform with a parent, at most 2 + 2 T words
 		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3)), 4), 4) : 0;
 		const size_t lds_schedule_bytes = size_t(lds_schedule_words) * sizeof(uint32_t);

@@ -419,10 +419,12 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 		{
 			const uint32_t num_blocks = 1u << log2_blocks;
 			const uint32_t instances_per_block = (num_instances + num_blocks - 1) / num_blocks;
-			// the matrix | the bins' totals, at their LARGEST once and for all: 2^18 matrix entries (the loop above) + 8 192 totals, 1 MiB.
+			// the matrix | the bins' totals, at their LARGEST once and for all: 2^19 matrix entries (the loop above) + 8 192 totals, 2 MiB.
 			// The scratch of this form then never moves -- a captured hipGraph that holds its address stays valid whatever is registered
 			// later -- and no call after the first allocates. (Only registries beyond 8 192 clips, the three launch form, can outgrow it.)
-			constexpr size_t k_order_grid_scratch_words = std::max<size_t>(k_order_grid_entries / 2, k_order_direct_bins) + k_order_direct_bins;
+			constexpr size_t k_order_grid_scratch_words = size_t(k_order_grid_entries) + k_order_direct_bins;
+			if ((size_t(num_bins) << log2_blocks) + num_bins > k_order_grid_scratch_words)
+				return fail(context, ACLHIP_ERROR_DEVICE, "internal: the ordering matrix outgrew its scratch (%u bins x %u workgroups)", num_bins, num_blocks);
 			const aclhip_status status = reserve(k_order_grid_scratch_words);
 			if (status != ACLHIP_OK)
 				return status;

@@ -241,11 +241,11 @@ with runtime.Context(0) as context:
     # ... and from then on the stream orders with the form that needs no co-residency
     context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
     torch.cuda.synchronize(device)
-    order = d_order.cpu().numpy()
-    assert np.array_equal(np.sort(order), np.arange(n)), "not a permutation"
-    sorted_clips = handles[which][order]
-    changes = int(np.count_nonzero(sorted_clips[1:] != sorted_clips[:-1]))
-    assert changes < 200, changes                       # bucketed by clip (a few runs per clip: the XCD interleave)
+    order = d_order.cpu().numpy().astype(np.uint32)
+    import os, sys
+    sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+    from test_order_instances import check_order
+    check_order(handles[which], order, 1, stable=False)  # a permutation, every clip on one XCD next to its other instances
 print("FAILED_BARRIER_PATH_OK")
 """
 

@@ -122,8 +122,9 @@ namespace
 			uint32_t turn_blocks = (num_blocks + turn_params.items_per_wave - 1) / turn_params.items_per_wave;
 			while ((uint64_t(turn_blocks) * k_waves_per_block) % windows_per_instance != 0)
 				turn_blocks++;
-			static const bool turn_wide = []() { const char* value = std::getenv("ACLHIP_ITEMS_PER_WAVE_WIDE"); return value != nullptr && value[0] == '1'; }();
-			hipLaunchKernelGGL(turn_wide ? decompress_tracks_in_turn_wide_loads_kernel : decompress_tracks_in_turn_kernel, dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,
+			// ACLHIP_ITEMS_PER_WAVE_WIDE = 1: 16 byte key reads at 8 waves per SIMD; 2 / 3: the same kernel with the registers of 7 / 6 waves per SIMD
+			static const int turn_wide = []() { const char* value = std::getenv("ACLHIP_ITEMS_PER_WAVE_WIDE"); return value != nullptr ? int(value[0] - '0') : 0; }();
+			hipLaunchKernelGGL(turn_wide == 1 ? decompress_tracks_in_turn_wide_loads_kernel : (turn_wide == 2 ? decompress_tracks_in_turn_wide_loads_7_kernel : (turn_wide == 3 ? decompress_tracks_in_turn_wide_loads_6_kernel : decompress_tracks_in_turn_kernel)), dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,
 				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, turn_params,
 				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 			ACLHIP_CHECK_HIP(context, hipGetLastError());

@@ -43,6 +43,18 @@
 		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
+	// round 4: the same with the register budget of 7 / 6 waves per SIMD (72 / 80 VGPRs): the loop around the 16 byte reads spills 25
+	// registers at 64 (the launch is LDS limited to 32 waves per CU anyway)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_wide_loads_7_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(6, 6))) void decompress_tracks_in_turn_wide_loads_6_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
 	// ---- decode waves hand their windows to a store wave ---------------------------------------------------------------------------------
 	// The common-case kernel above for poses of several windows (the 300-bone rig): a workgroup is kDecoders decode waves + ONE store
 	// wave. A decode wave does everything decompress_tracks_window does up to the finished LDS image, publishes it (a descriptor + a
