@@ -142,10 +142,11 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "transform %u has parent %u: transforms must be sorted parent first", misplaced, parent_indices[misplaced]);
 		const auto is_root = [&](uint32_t i) { return i == 0 || parent_indices[i] == ACLHIP_NO_PARENT; };
 
-		// [offset of the schedule for 1, 2, 4, 8 instances per workgroup] then per schedule:
+		// [{offset of the schedule, its steps, its words, 0} for 1, 2, 4, 8 instances per workgroup: one 16 byte scalar load tells a wave
+		// all it needs to request the copy] then per schedule, 16 byte aligned and padded to whole 16 byte pieces (it travels to LDS by DMA):
 		// num_steps | words of this schedule | step_end[num_steps] | transform | parent << 16, in step order (16 bits each: the
 		// consumers' LDS images end at about 3400 transforms; every word of the copy a wave keeps in LDS costs residency)
-		std::vector<uint32_t> image(4, 0);
+		std::vector<uint32_t> image(16, 0);
 		uint32_t max_schedule_words = 0;
 		for (uint32_t log2_instances = 0; log2_instances < 4; ++log2_instances)
 		{
@@ -156,9 +157,11 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 
 			const uint32_t num_steps = uint32_t(step_end.size());
 			const uint32_t header_words = 2 + num_steps;
-			const uint32_t schedule_words = header_words + uint32_t(pairs.size());
+			const uint32_t schedule_words = align_to_u32(header_words + uint32_t(pairs.size()), 4);
 			const uint32_t offset = uint32_t(image.size());
-			image[log2_instances] = offset;
+			image[log2_instances * 4 + 0] = offset;
+			image[log2_instances * 4 + 1] = num_steps;
+			image[log2_instances * 4 + 2] = schedule_words;
 			image.resize(size_t(offset) + schedule_words, 0);
 			image[offset + 0] = num_steps;
 			image[offset + 1] = schedule_words;
@@ -277,10 +280,12 @@ namespace
 		const bool two_waves = base_is_clip && !fused_base;
 		// (measurement knob: ACLHIP_CONSUMER_LDS_PAD bytes between the instances' images -- the walk's lanes touch the same quad of all of a
 		// workgroup's images at once, and images a multiple of 128 bytes apart put those on the same LDS banks)
-		static const size_t lds_pad = []() { const char* value = std::getenv("ACLHIP_CONSUMER_LDS_PAD"); return value != nullptr ? size_t(std::atol(value)) & ~size_t(15) : size_t(0); }();
+		// 16 bytes: the four images of a workgroup then start on different banks (round 4: 88.8 -> 86.9 us, 90.6 -> 83.7 us with ACLHIP_CONSUMERS_FAST;
+		// 32 the same, 64 less, 0 what rounds 2 and 3 measured)
+		static const size_t lds_pad = []() { const char* value = std::getenv("ACLHIP_CONSUMER_LDS_PAD"); return value != nullptr ? size_t(std::atol(value)) & ~size_t(15) : size_t(16); }();
 		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1) + lds_pad;
 		// a walk schedule of T transforms: 2 words + a step end per step + a pair per transform with a parent, at most 2 + 2 T words
-		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3)), 4), 4) : 0;
+		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3) + 3), 4), 4) : 0;
 		const size_t lds_schedule_bytes = size_t(lds_schedule_words) * sizeof(uint32_t);
 		constexpr size_t k_lds_bytes = 160 * 1024 - 128;		// the kernel's few static words
 		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)

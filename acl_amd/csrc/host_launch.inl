@@ -15,6 +15,8 @@ namespace
 		uint32_t windows_per_instance;		// waves per instance: pose windows of the largest pose the batch can hold
 		uint32_t lds_quads_per_wave;		// quads of LDS every wave gets for its window's image
 		bool wide_key_loads;				// poses of several windows read the bitstream with one aligned request per key (kernels_pose.inl)
+		uint32_t items_per_wave;			// poses of several windows, common case kernel: work items a wave takes in turn (1: the one-shot grid)
+		bool adjacent_items;				// ... consecutive instances instead of a sweep per turn
 	};
 
 	uint32_t batch_pose_quads(const aclhip_context* context, uint32_t layout, uint64_t pose_stride_bytes)
@@ -34,6 +36,11 @@ namespace
 		// ACLHIP_WIDE_KEY_LOADS=0 / 1 overrides the choice (measurements, parity runs of the other unpack)
 		static const int wide_override = []() { const char* value = std::getenv("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
 		shape.wide_key_loads = wide_override >= 0 ? wide_override != 0 : shape.windows_per_instance > 1;
+		// ACLHIP_IN_TURN_ITEMS = K (0 / 1: one-shot grid), ACLHIP_IN_TURN_ADJACENT = 0 / 1: measurement knobs
+		static const uint32_t in_turn_items = []() { const char* value = std::getenv("ACLHIP_IN_TURN_ITEMS"); return value != nullptr ? uint32_t(std::atol(value)) : 4u; }();
+		static const bool in_turn_adjacent = []() { const char* value = std::getenv("ACLHIP_IN_TURN_ADJACENT"); return value != nullptr && value[0] == '1'; }();
+		shape.items_per_wave = shape.windows_per_instance > 1 && shape.wide_key_loads ? std::min<uint32_t>(std::max<uint32_t>(in_turn_items, 1), 255) : 1;
+		shape.adjacent_items = in_turn_adjacent;
 		return shape;
 	}
 
@@ -55,6 +62,8 @@ namespace
 		else if (any_settings && compact) { kernel = decompress_tracks_any_settings_compact_kernel; name = "decompress_tracks_any_settings_compact_kernel"; }
 		else if (any_settings) { kernel = decompress_tracks_any_settings_kernel; name = "decompress_tracks_any_settings_kernel"; }
 		else if (compact) { kernel = decompress_tracks_compact_kernel; name = "decompress_tracks_compact_kernel"; }
+		else if (shape.wide_key_loads && shape.items_per_wave > 1 && shape.adjacent_items) { kernel = decompress_tracks_in_turn_adjacent_kernel; name = "decompress_tracks_in_turn_adjacent_kernel"; }
+		else if (shape.wide_key_loads && shape.items_per_wave > 1) { kernel = decompress_tracks_in_turn_kernel; name = "decompress_tracks_in_turn_kernel"; }
 		else if (shape.wide_key_loads) { kernel = decompress_tracks_wide_loads_kernel; name = "decompress_tracks_wide_loads_kernel"; }
 		else { kernel = decompress_tracks_kernel; name = "decompress_tracks_kernel"; }
 		if (out_name != nullptr)
@@ -96,7 +105,33 @@ namespace
 				return experiment_status;
 		}
 #endif
-		const pose_kernel kernel = pose_kernel_of(context, params, shape);
+		const char* kernel_name = nullptr;
+		const pose_kernel kernel = pose_kernel_of(context, params, shape, &kernel_name);
+		if (kernel == decompress_tracks_in_turn_kernel || kernel == decompress_tracks_in_turn_adjacent_kernel)
+		{
+			// every wave takes items_per_wave work items in turn (kernels_pose.inl): a K-th of the workgroups
+			decode_params turn_params = params;
+			turn_params.items_per_wave = uint8_t(shape.items_per_wave);
+			uint32_t turn_blocks;
+			if (shape.adjacent_items)
+			{
+				const uint64_t groups = (uint64_t(num_instances) + shape.items_per_wave - 1) / shape.items_per_wave;
+				turn_blocks = uint32_t((groups * windows_per_instance + k_waves_per_block - 1) / k_waves_per_block);
+			}
+			else
+			{
+				// a wave's items are gridDim * 4 work items apart: a multiple of the windows per instance keeps its window index (and with
+				// it the base pose window its LDS image holds) from turn to turn
+				turn_blocks = (num_blocks + shape.items_per_wave - 1) / shape.items_per_wave;
+				while ((uint64_t(turn_blocks) * k_waves_per_block) % windows_per_instance != 0)
+					turn_blocks++;
+			}
+			hipLaunchKernelGGL(kernel, dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,
+				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, turn_params,
+				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
+			ACLHIP_CHECK_HIP(context, hipGetLastError());
+			return ACLHIP_OK;
+		}
 		hipLaunchKernelGGL(kernel, dim3(num_blocks), dim3(k_block_size), lds_bytes, stream,
 			context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, params,
 			static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);

@@ -330,6 +330,30 @@
 				num_tracks = clip.num_tracks;
 				if (role == 0)
 				{
+					if (object_space)
+					{
+						// The walk schedule for this many instances per workgroup, requested BEFORE the decode (until round 4 behind it: three
+						// more dependent round trips -- offset, header, words -- at the end of every wave's chain, 1.7 of a decode's 6.3 us).
+						// One scalar load for the schedule's header (aclhip_set_clip_hierarchy: {offset, steps, words, 0} per workgroup size,
+						// in flight next to the seek's sample records), then the words travel global -> LDS by DMA while the pose is decoded:
+						//     num_steps | words | step_end[num_steps] | transform | parent << 16 in step order, padded to whole 16 byte pieces
+						// Every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then).
+						// A schedule longer than the launch reserved LDS for (a hierarchy set behind a captured launch's back) stays in
+						// global memory and the walk reads it there.
+						const u32x4 header = ((const ACLHIP_CONSTANT u32x4*)clip.hierarchy)[log2_instances_per_block];
+						schedule = clip.hierarchy + header.x;
+						num_levels = header.y;
+						const uint32_t num_words = header.z;
+						if (num_words <= (packed_block_shape >> 8))
+						{
+							for (uint32_t base = 0; base < num_words; base += k_wave_size * 4u)
+								if (base + lane * 4u < num_words)
+									__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(schedule + base + lane * 4u),
+										(__attribute__((address_space(3))) void*)(shared_schedule + base), 16, 0, 0);
+						}
+						else
+							num_levels |= 0x80000000u;
+					}
 					if (fused_base)
 					{
 						decode_pose_into_image<kFast>(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, image);
@@ -355,24 +379,6 @@
 						}
 						wave_lds_barrier();
 						blend_normalize_rotations(image, clip.num_tracks, lane);
-					}
-					if (object_space)
-					{
-						// the walk schedule for this many instances per workgroup (see aclhip_set_clip_hierarchy):
-						// num_steps | words | step_end[num_steps] | transform | parent << 16 in step order
-						schedule = clip.hierarchy + as_constant(clip.hierarchy)[log2_instances_per_block];
-						num_levels = as_constant(schedule)[0];
-						// every wave leaves its schedule in the shared copy: the same words when they share it (the copy is only used then).
-						// A schedule longer than the launch reserved LDS for (a hierarchy set behind a captured launch's back) stays in
-						// global memory and the walk reads it there.
-						const uint32_t num_words = as_constant(schedule)[1];
-						if (num_words <= (packed_block_shape >> 8))
-						{
-							for (uint32_t word = lane; word < num_words; word += k_wave_size)
-								shared_schedule[word] = schedule[word];
-						}
-						else
-							num_levels |= 0x80000000u;
 					}
 				}
 			}

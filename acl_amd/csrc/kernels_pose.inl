@@ -666,6 +666,45 @@
 		decompress_tracks_window<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
+	// Poses of several windows, since round 4: every wave takes params.items_per_wave work items IN TURN and keeps its LDS image from
+	// one to the next. A wave's items are the same window of different instances, so while the clip stays the same (a crowd of one
+	// rig: BASELINE.json configs[3]) the image already holds the clip's resolved pose window -- the animated quads are about to be
+	// overwritten, the others are this clip's constants -- and the base pose copy, the largest single item through the CU's texture
+	// unit (11 % of the launch, profiles/r03_experiments.md), is skipped from the second turn on. The next item's scalar seek also
+	// hides the store acknowledgement of the item before. With the 16 byte key reads the loop needs 71 registers: compiled for 7 waves
+	// per SIMD (at 64 it spills and loses 10 %; the launch is LDS limited to 32 waves per CU either way).
+	//   kAdjacentItems = false: item k of workgroup b is work item 4 (k gridDim + b) + wave -- every turn sweeps the batch front to back
+	//                           like the one-shot grid does (the host sizes the grid so that a wave keeps its window index);
+	//   kAdjacentItems = true:  wave g takes window g % W of instances (g / W) K .. (g / W) K + K - 1: consecutive instances, which in a
+	//                           list bucketed by clip are of one clip.
+	template<bool kAdjacentItems>
+	__device__ __forceinline__ void decompress_tracks_windows_in_turn(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t items_per_wave = params.items_per_wave;
+		uint32_t image_clip = 0xFFFFFFFFu;		// the clip whose base pose window the wave's LDS image holds
+		const uint32_t wave = blockIdx.x * k_waves_per_block + wave_in_block;
+		const uint32_t group = wave / windows_per_instance;
+		const uint32_t window = wave - group * windows_per_instance;
+		for (uint32_t turn = 0; turn < items_per_wave; ++turn)
+		{
+			const uint32_t work_item = kAdjacentItems ? (group * items_per_wave + turn) * windows_per_instance + window
+				: (turn * gridDim.x + blockIdx.x) * k_waves_per_block + wave_in_block;
+			decompress_tracks_window<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
+			// (the window's LDS reads completed before its stores were issued: the next turn's DMA may overwrite the image)
+		}
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<false>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<true>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
 	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{

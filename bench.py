@@ -48,6 +48,7 @@ WORKLOAD_TEXT = {
     "object_space_fast": "object_space with ACLHIP_CONSUMERS_FAST: the opt-in 1 ulp arithmetic (poses within 2e-6 of the bit exact kernels')",
     "additive_object_space_fast": "additive_object_space with ACLHIP_CONSUMERS_FAST",
     "blend_object_space": "64k instances per GPU, each the weighted blend of three clip instances (three 100-bone clips of one skeleton), then local -> object space (SURVEY 8 f3)",
+    "cinematic_16": "64k instances per GPU drawn from 16 distinct 300-bone rigs with scale (measurement aid: poses of several windows over several clips)",
     "one_clip_mixed_registry": "the one_clip batch (4 800 byte rows) while the context ALSO holds a 300-bone rig and a 551-bone clip: the launch is shaped by the batch, not by the registry",
     "track_requests": "4 M random (instance, bone) requests on the 100-bone clip: seek + decompress_track, one 48 byte qvv per request (SURVEY 8 a15)",
 }
@@ -102,6 +103,10 @@ def _build_workload(name, rank, num_instances):
         clips = [synth.build_clip(seed=4, num_tracks=300, num_samples=451, sample_rate=30.0, has_scale=1,
                                   scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8)]
         clip_indices = np.zeros(num_instances, dtype=np.uint32)
+    elif name == "cinematic_16":
+        clips = [synth.build_clip(seed=40 + i, num_tracks=300, num_samples=200 + 17 * i, sample_rate=30.0, has_scale=1,
+                                  scale_default=0.7, scale_constant=0.1, rotation_constant=0.45, translation_constant=0.8) for i in range(16)]
+        clip_indices = rng.integers(0, 16, size=num_instances).astype(np.uint32)
     elif name == "scalar":
         # 1 % of the curves at the raw bit rate: what the reference's compressor leaves for tracks it cannot quantize within precision
         clips = [synth.build_scalar_clip(seed=9, track_type=0, num_tracks=256, num_samples=120, sample_rate=60.0, raw_fraction=0.01)]

@@ -109,7 +109,7 @@ namespace
 				return ACLHIP_OK;
 			}
 		}
-		// several work items per wave, in turn (kernels_pose.inl: decompress_tracks_in_turn_kernel). Measurement knobs:
+		// several work items per wave, in turn (kernels_pose.inl: decompress_tracks_in_turn_r3_kernel). Measurement knobs:
 		// ACLHIP_ITEMS_PER_WAVE = K (0 / 1 = one-shot), ACLHIP_ITEMS_PER_WAVE_ALWAYS=1 also for one-window poses
 		static const uint32_t items_per_wave = []() { const char* value = std::getenv("ACLHIP_ITEMS_PER_WAVE"); return value != nullptr ? uint32_t(std::atol(value)) : k_default_items_per_wave; }();
 		static const bool items_per_wave_always = []() { const char* value = std::getenv("ACLHIP_ITEMS_PER_WAVE_ALWAYS"); return value != nullptr && value[0] == '1'; }();
@@ -124,7 +124,7 @@ namespace
 				turn_blocks++;
 			// ACLHIP_ITEMS_PER_WAVE_WIDE = 1: 16 byte key reads at 8 waves per SIMD; 2 / 3: the same kernel with the registers of 7 / 6 waves per SIMD
 			static const int turn_wide = []() { const char* value = std::getenv("ACLHIP_ITEMS_PER_WAVE_WIDE"); return value != nullptr ? int(value[0] - '0') : 0; }();
-			hipLaunchKernelGGL(turn_wide == 1 ? decompress_tracks_in_turn_wide_loads_kernel : (turn_wide == 2 ? decompress_tracks_in_turn_wide_loads_7_kernel : (turn_wide == 3 ? decompress_tracks_in_turn_wide_loads_6_kernel : decompress_tracks_in_turn_kernel)), dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,
+			hipLaunchKernelGGL(turn_wide == 1 ? decompress_tracks_in_turn_wide_loads_kernel : (turn_wide == 2 ? decompress_tracks_in_turn_wide_loads_7_kernel : (turn_wide == 3 ? decompress_tracks_in_turn_wide_loads_6_kernel : decompress_tracks_in_turn_r3_kernel)), dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,
 				context->d_clips, context->d_clips_capacity, clips, sample_times, num_instances, windows_per_instance, turn_params,
 				static_cast<uint8_t*>(poses), pose_stride_bytes, lds_quads_per_wave, context->d_rejected);
 			ACLHIP_CHECK_HIP(context, hipGetLastError());

@@ -3,7 +3,7 @@
 // measurements can be repeated; nothing here is reachable from a default build of libaclhip.so.
 //   decompress_tracks_handoff_kernel / _last_arriver_kernel   decode waves hand finished LDS windows to a store wave / the last arriver (one-shot grids)
 //   decompress_tracks_persistent_kernel                        a grid that fills the device once: looping decode waves + store waves around a pool of LDS images
-//   decompress_tracks_in_turn_kernel                           several work items per wave, the LDS image reused while the clip stays the same
+//   decompress_tracks_in_turn_r3_kernel                           several work items per wave, the LDS image reused while the clip stays the same
 //   decompress_tracks_staged_kernel                            keyframe bit runs staged through LDS, one base pose image per workgroup, merge on the way out
 
 #if !defined(ACLHIP_DEFAULT_ITEMS_PER_WAVE)
@@ -18,7 +18,7 @@
 	// 2 us of SCALAR loads (the seek; their counter is lgkmcnt), and by the time it first waits for a vector load the stores of the
 	// item before are long acknowledged. The hardware still balances the load: workgroups stay short (a few items) and plentiful.
 	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads>
-	__device__ __forceinline__ void decompress_tracks_windows_in_turn(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__device__ __forceinline__ void decompress_tracks_windows_in_turn_r3(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
 		const uint32_t items_per_wave = params.items_per_wave;
@@ -33,26 +33,26 @@
 		}
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_in_turn_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_in_turn_r3_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_windows_in_turn<false, false, false>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_windows_in_turn_r3<false, false, false>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_in_turn_wide_loads_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_windows_in_turn_r3<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// round 4: the same with the register budget of 7 / 6 waves per SIMD (72 / 80 VGPRs): the loop around the 16 byte reads spills 25
 	// registers at 64 (the launch is LDS limited to 32 waves per CU anyway)
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_wide_loads_7_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_windows_in_turn_r3<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(6, 6))) void decompress_tracks_in_turn_wide_loads_6_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_windows_in_turn<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
+		decompress_tracks_windows_in_turn_r3<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// ---- decode waves hand their windows to a store wave ---------------------------------------------------------------------------------
