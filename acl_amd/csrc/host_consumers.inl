@@ -181,12 +181,15 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 					parents[i] = ACLHIP_NO_PARENT;
 			return parents;
 		}();
+		// (first: what this recycles may be the very image looked for below -- its last user retired it a moment ago -- and recycling
+		// erases entries of the list the search walks. Round 3 searched first and could pick up a dangling entry: found by
+		// tests/test_gpu_lifetime.py once the timing of its launches changed)
+		collect_retired(context, false);
+
 		aclhip_context::hierarchy_image* shared = nullptr;
 		for (aclhip_context::hierarchy_image& candidate : context->hierarchies)
 			if (candidate.parents == canonical)
 				shared = &candidate;
-
-		collect_retired(context, false);
 		uint32_t* d_hierarchy = shared != nullptr ? shared->d_image : nullptr;
 		size_t staging_used = 0;
 		bool uploaded = true;

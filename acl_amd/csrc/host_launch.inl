@@ -122,8 +122,10 @@ namespace
 			{
 				// a wave's items are gridDim * 4 work items apart: a multiple of the windows per instance keeps its window index (and with
 				// it the base pose window its LDS image holds) from turn to turn
+				// ... and a multiple of the eight XCDs keeps every slot of the list on the XCD the one-shot grid runs it on (what the locality
+				// orders of host_launch.inl / kernels_misc.inl are made for)
 				turn_blocks = (num_blocks + shape.items_per_wave - 1) / shape.items_per_wave;
-				while ((uint64_t(turn_blocks) * k_waves_per_block) % windows_per_instance != 0)
+				while ((uint64_t(turn_blocks) * k_waves_per_block) % windows_per_instance != 0 || turn_blocks % k_num_xcds != 0)
 					turn_blocks++;
 			}
 			hipLaunchKernelGGL(kernel, dim3(turn_blocks), dim3(k_block_size), lds_bytes, stream,

@@ -151,6 +151,9 @@ def ref(asserting=False):
         lib.aclref_bench.restype = ctypes.c_double
         lib.aclref_bench_timed.argtypes = [vp, vp, vp, u32, u32, u32, ctypes.c_double, i32, vp]
         lib.aclref_bench_timed.restype = ctypes.c_double
+        if hasattr(lib, "aclref_bench_cold"):
+            lib.aclref_bench_cold.argtypes = [vp, u32, vp, u32, u32, u32, ctypes.c_uint64, ctypes.c_double]
+            lib.aclref_bench_cold.restype = ctypes.c_double
         _ref[key] = lib
     return _ref[key]
 

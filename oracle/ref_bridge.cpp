@@ -330,4 +330,55 @@ extern "C"
 		};
 		return bench_harness::run_timed(num_threads, seconds, pin != 0, make_worker, out_total_poses);
 	}
+
+	// The reference's OWN cold-cache protocol (tools/acl_decompressor/sources/benchmark.cpp:232-281), one thread like there: `num_copies`
+	// copies of the clip with a context each, a pose decoded from every copy in turn at one sample time, then the CPU caches flushed
+	// (a `flush_bytes` buffer rewritten) before the next sample time; only seek + decompress_tracks are timed, the flush is not.
+	// What the reference's published numbers are measured with (docs/decompression_performance.md); the warm, pinned sweep above is the
+	// figure that favours the CPU. Returns poses per second of that one thread.
+	double aclref_bench_cold(const void* blob, uint32_t blob_size, const float* sample_times, uint32_t num_sample_times, uint32_t max_tracks,
+		uint32_t num_copies, uint64_t flush_bytes, double seconds)
+	{
+		if (blob == nullptr || blob_size == 0 || num_sample_times == 0 || num_copies == 0)
+			return 0.0;
+		std::vector<std::vector<uint8_t>> storage(num_copies);
+		std::vector<const acl::compressed_tracks*> copies(num_copies);
+		std::vector<acl::decompression_context<benchmark_settings>> contexts(num_copies);
+		for (uint32_t c = 0; c < num_copies; ++c)
+		{
+			storage[c].resize(size_t(blob_size) + 64);
+			uint8_t* aligned = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(storage[c].data()) + 15) & ~uintptr_t(15));
+			std::memcpy(aligned, blob, blob_size);
+			copies[c] = reinterpret_cast<const acl::compressed_tracks*>(aligned);
+			contexts[c].initialize(*copies[c]);
+		}
+		std::vector<uint8_t> flush_buffer(flush_bytes);
+		std::vector<float> scratch(size_t(max_tracks) * 12);
+		uint8_t flush_value = 1;
+		std::memset(flush_buffer.data(), flush_value++, flush_buffer.size());
+		double timed_seconds = 0.0;
+		uint64_t poses = 0;
+		uint32_t sample = 0;
+		const auto wall_start = std::chrono::steady_clock::now();
+		while (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall_start).count() < seconds)
+		{
+			for (uint32_t c = 0; c < num_copies; ++c)
+			{
+				const auto start = std::chrono::steady_clock::now();
+				writer_identity writer;
+				writer.out = scratch.data();
+				writer.defaults = nullptr;
+				writer.per_track_policies = nullptr;
+				contexts[c].seek(sample_times[sample], acl::sample_rounding_policy::none);
+				contexts[c].decompress_tracks(writer);
+				timed_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+				poses++;
+			}
+			sample = sample + 1 == num_sample_times ? 0 : sample + 1;
+			std::memset(flush_buffer.data(), flush_value++, flush_buffer.size());
+			// (the compiler must not drop the rewrite of a buffer nobody reads)
+			asm volatile("" :: "r"(flush_buffer.data()) : "memory");
+		}
+		return timed_seconds > 0.0 ? double(poses) / timed_seconds : 0.0;
+	}
 }

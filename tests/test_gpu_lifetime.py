@@ -122,7 +122,10 @@ def test_clip_table_grows_in_place_past_its_first_pages():
         context.unregister_clip(first)
 
 
-def test_replacing_a_hierarchy_under_launches_in_flight():
+@pytest.mark.parametrize("drain_between_rounds", [False, True])
+def test_replacing_a_hierarchy_under_launches_in_flight(drain_between_rounds):
+    """(drain_between_rounds: the replaced hierarchy's image has been recycled by the time the same hierarchy is set again -- round 3
+    looked the shared image up BEFORE recycling and could hand the clip another skeleton's walk schedule)"""
     clip = synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)
     with runtime.Context(0) as context:
         handle = context.register_clip(clip.blob)
@@ -144,6 +147,9 @@ def test_replacing_a_hierarchy_under_launches_in_flight():
             context.set_clip_hierarchy(handle, parents)          # replaces the previous one while the last round's launches may still run
             for _ in range(4):
                 context.decompress_poses_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), 4800, consumers, stream=stream.cuda_stream)
+            if drain_between_rounds:
+                stream.synchronize()
+                assert helpers.bit_equal(d_poses.cpu().numpy(), ob.oracle_decompress_poses_batch([clip.blob], np.zeros(n, dtype=np.uint32), times, 100, parent_indices=parents)), round_index
         stream.synchronize()
         poses = d_poses.cpu().numpy()
         assert helpers.bit_equal(poses, ob.oracle_decompress_poses_batch([clip.blob], np.zeros(n, dtype=np.uint32), times, 100, parent_indices=hierarchies[1]))
