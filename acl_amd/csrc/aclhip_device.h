@@ -455,7 +455,7 @@ namespace aclhip
 	// Both keyframes of one animated sub-track, range expanded: the bit unpack of math/vector4_packing.h:921-1035 (quantized) and
 	// :479-599 (raw), then the segment and clip range expansion of animated_track_cache.transform.h:302-350,391-466,930-960.
 	// All four bitstream loads are issued before any of them is used. kHasRaw = false compiles the raw fix-up out.
-	template<bool kHasRaw, bool kFastMath = false>
+	template<bool kHasRaw>
 	__device__ __forceinline__ void unpack_animated_samples(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, float out_v0[3], float out_v1[3])
 	{
@@ -504,16 +504,11 @@ namespace aclhip
 			#pragma unroll
 			for (uint32_t c = 0; c < 3; ++c)
 			{
-				if constexpr (kFastMath)
-				{
-					// ACLHIP_CONSUMERS_FAST: both range expansions as fused multiply-adds
-					v[key][c] = __builtin_fmaf(__builtin_fmaf(quantized[c], plan.range_extent[c], plan.range_min[c]), clip_range.range_extent[c], clip_range.range_min[c]);
-				}
-				else
-				{
-					const float segment_value = (quantized[c] * plan.range_extent[c]) + plan.range_min[c];
-					v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
-				}
+				// (also under ACLHIP_CONSUMERS_FAST: a rotation's W = sqrt(1 - x^2 - y^2 - z^2) turns one ulp of x, y or z into 1e-5 of W
+				// for rotations near half a turn -- fusing these four operations, measured in round 4, moved rotations by up to 2.7e-5; the
+				// fast mode therefore keeps x, y, z bit identical to the default's and is cheaper only behind them)
+				const float segment_value = (quantized[c] * plan.range_extent[c]) + plan.range_min[c];
+				v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
 			}
 		}
 
@@ -837,7 +832,7 @@ namespace aclhip
 		if constexpr (kWideKeyLoads)
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
-			unpack_animated_samples<kHasRaw, kFastMath>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples);
 	}
 
