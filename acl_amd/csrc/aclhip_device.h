@@ -720,58 +720,13 @@ namespace aclhip
 	}
 #endif
 
-	// ---- correctly rounded square root and reciprocal in fewer instructions than the compiler's general expansions (round 4) ------------
-	// Every kernel but the headline's is bound by VALU issue, and a third of a rotation's ~100 instructions were the compiler's IEEE
-	// sqrtf (16: input scaling for tiny arguments, v_sqrt_f32, both neighbours tried against the residual, unscaling, a class test) and
-	// 1.0f / x (11: v_div_scale twice, v_rcp_f32, refinement, v_div_fmas, v_div_fixup). The arguments met here never need the scaling
-	// and special case parts: the same neighbour test on the bare v_sqrt_f32 (9 instructions) and two Newton steps on v_rcp_f32 (5)
-	// give the SAME BITS as sqrtf / 1.0f / x for every float in the ranges below -- checked exhaustively, all 2^32 bit patterns, on the
-	// device (tools/probes/exact_math_probe.hip; tests/test_gpu_exact_math.py runs it through aclhip_selftest_exact_math):
-	//   sqrt_rn_core   x == +0, or 2^-96 <= x <= +inf        (below 2^-96 the residuals underflow: why the compiler scales)
-	//   rcp_rn_core    2^-126 <= x <= 2^126                   (beyond, 1 / x is denormal or x is)
-	// A wave whose lanes are all inside the range takes the short form; any other wave (never, on real clips) the compiler's.
-	__device__ __forceinline__ float sqrt_rn_core(float x)
-	{
-		const float s = __builtin_amdgcn_sqrtf(x);		// within 1 ulp: the correctly rounded root is s or one of its neighbours
-		const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
-		const float residual_down = __builtin_fmaf(-down, s, x), residual_up = __builtin_fmaf(-up, s, x);
-		float result = residual_down <= 0.0f ? down : s;
-		result = residual_up > 0.0f ? up : result;
-		return result;
-	}
-
-	__device__ __forceinline__ float rcp_rn_core(float x)
-	{
-		const float r0 = __builtin_amdgcn_rcpf(x);
-		const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
-		return __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
-	}
-
-	__device__ __forceinline__ bool sqrt_rn_core_covers(float x) { return __float_as_uint(x) - 1u >= 0x0F800000u - 1u && __float_as_uint(x) <= 0x7F800000u; }		// +0 | [2^-96, +inf]
-	__device__ __forceinline__ bool rcp_rn_core_covers(float x) { return __float_as_uint(x) - 0x00800000u <= 0x7E800000u - 0x00800000u; }						// [2^-126, 2^126]
-
-	// sqrtf(x), 1.0f / x bit for bit (x >= +0 where it matters; anything else takes the compiler's form)
-	__device__ __forceinline__ float sqrt_rn(float x)
-	{
-		if (__builtin_expect(__builtin_amdgcn_ballot_w64(!sqrt_rn_core_covers(x)) != 0, 0))
-			return sqrtf(x);
-		return sqrt_rn_core(x);
-	}
-
-	__device__ __forceinline__ float rcp_rn(float x)
-	{
-		if (__builtin_expect(__builtin_amdgcn_ballot_w64(!rcp_rn_core_covers(x)) != 0, 0))
-			return 1.0f / x;
-		return rcp_rn_core(x);
-	}
-
 	// math/quatf.h:135-147
 	__device__ __forceinline__ float quat_from_positive_w(float x, float y, float z)
 	{
 		float w_squared = 1.0f - (x * x);
 		w_squared = w_squared - (y * y);
 		w_squared = w_squared - (z * z);
-		return sqrt_rn(fabsf(w_squared));
+		return sqrtf(fabsf(w_squared));
 	}
 
 	// math/quatf.h:200-211
@@ -781,7 +736,7 @@ namespace aclhip
 		dot = (q.y * q.y) + dot;
 		dot = (q.z * q.z) + dot;
 		dot = (q.w * q.w) + dot;
-		const float inv_len = rcp_rn(sqrt_rn(dot));
+		const float inv_len = 1.0f / sqrtf(dot);
 		return make_float4(q.x * inv_len, q.y * inv_len, q.z * inv_len, q.w * inv_len);
 	}
 

@@ -623,30 +623,6 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 	return ACLHIP_OK;
 }
 
-extern "C" aclhip_status aclhip_selftest_exact_math(aclhip_context* context, uint64_t* out_mismatches)
-{
-	if (context == nullptr || out_mismatches == nullptr)
-		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	device_guard guard(context->device);
-	unsigned long long* counters = nullptr;
-	ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&counters), 4 * sizeof(unsigned long long)));
-	hipError_t status = hipMemset(counters, 0, 4 * sizeof(unsigned long long));
-	if (status == hipSuccess)
-	{
-		hipLaunchKernelGGL(selftest_exact_math_kernel, dim3(context->num_compute_units * 32), dim3(256), 0, nullptr, counters);
-		status = hipGetLastError();
-	}
-	unsigned long long host[4] = { 0, 0, 0, 0 };
-	if (status == hipSuccess)
-		status = hipMemcpy(host, counters, sizeof(host), hipMemcpyDeviceToHost);
-	(void)hipFree(counters);
-	if (status != hipSuccess)
-		return fail(context, ACLHIP_ERROR_DEVICE, "the exact math self test failed to run: %s", hipGetErrorString(status));
-	for (uint32_t k = 0; k < 4; ++k)
-		out_mismatches[k] = host[k];
-	return ACLHIP_OK;
-}
-
 extern "C" aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buffer, uint64_t size_bytes, uint32_t repeats, void* stream, float* out_gb_per_second)
 {
 	if (context == nullptr || buffer == nullptr || out_gb_per_second == nullptr || repeats == 0 || size_bytes < 16 || (reinterpret_cast<uintptr_t>(buffer) & 15u) != 0)

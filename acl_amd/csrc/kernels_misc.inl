@@ -65,29 +65,6 @@
 		}
 	}
 
-	// Self test (aclhip_selftest_exact_math): the short correctly rounded square root and reciprocal of aclhip_device.h against the
-	// compiler's sqrtf / 1.0f / x on EVERY float bit pattern. out[0] / out[1]: patterns on which sqrt_rn / rcp_rn (what the kernels
-	// call: short form inside its range, the compiler's outside) differ from sqrtf / 1.0f / x; out[2] / out[3]: patterns INSIDE the
-	// ranges the short forms claim on which the bare short forms differ. Two NaNs count as equal whatever their payloads.
-	__global__ __launch_bounds__(256) void selftest_exact_math_kernel(unsigned long long* __restrict__ out)
-	{
-		const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
-		unsigned long long bad[4] = { 0, 0, 0, 0 };
-		const auto differ = [](float a, float b) { return __float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b); };
-		for (uint64_t bits = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; bits < (uint64_t(1) << 32); bits += stride)
-		{
-			const float x = __uint_as_float(uint32_t(bits));
-			const float root = sqrtf(x), reciprocal = 1.0f / x;
-			bad[0] += differ(sqrt_rn(x), root) ? 1u : 0u;
-			bad[1] += differ(rcp_rn(x), reciprocal) ? 1u : 0u;
-			bad[2] += sqrt_rn_core_covers(x) && differ(sqrt_rn_core(x), root) ? 1u : 0u;
-			bad[3] += rcp_rn_core_covers(x) && differ(rcp_rn_core(x), reciprocal) ? 1u : 0u;
-		}
-		for (uint32_t k = 0; k < 4; ++k)
-			if (bad[k] != 0)
-				atomicAdd(&out[k], bad[k]);
-	}
-
 	// Measurement aid: streams `num_quads` float4 to HBM, 16 bytes per lane, to find the write bandwidth a pose-shaped store
 	// stream can reach on this device (the decode kernel is a write streamer).
 	__global__ __launch_bounds__(k_block_size) void stream_write_kernel(float4* __restrict__ destination, uint64_t num_quads, float seed)

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
     "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
-    "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch", "aclhip_selftest_exact_math",
+    "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch",
 ]
 
 
@@ -217,7 +217,6 @@ def load_library():
     lib.aclhip_pose_windows_of_launch.argtypes = [vp, u32, u64, ctypes.POINTER(u32)]
     lib.aclhip_order_instances_device_for_windows.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
     lib.aclhip_describe_tracks_launch.argtypes = [vp, pparams, poutput, u64, ctypes.c_char_p, u32, ctypes.POINTER(u32)]
-    lib.aclhip_selftest_exact_math.argtypes = [vp, ctypes.POINTER(u64)]
     _lib = lib
     return lib
 
@@ -686,12 +685,6 @@ class Context:
             stride = int(pose_stride_bytes) if pose_stride_bytes is not None else 0xFFFFFFFFFFFFFFFF
             self._check(self._lib.aclhip_describe_tracks_launch(self._handle, ctypes.byref(params), ctypes.byref(output) if output is not None else None, stride, name, 128, None))
         return name.value.decode()
-
-    def selftest_exact_math(self):
-        """aclhip_selftest_exact_math: mismatches of (sqrt_rn, rcp_rn, sqrt_rn_core, rcp_rn_core) against sqrtf / 1.0f / x over all 2^32 floats"""
-        out = (ctypes.c_uint64 * 4)()
-        self._check(self._lib.aclhip_selftest_exact_math(self._handle, out))
-        return tuple(int(v) for v in out)
 
     def batch_algorithmic_bytes(self, clips):
         clips = np.ascontiguousarray(clips, dtype=np.uint32)

@@ -593,13 +593,6 @@ aclhip_status aclhip_measure_write_bandwidth(aclhip_context* context, void* buff
 aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* context, void* poses, uint64_t pose_stride_bytes, uint32_t num_instances, uint32_t num_tracks,
 	uint32_t repeats, void* stream, float* out_gb_per_second, uint32_t* out_waves_per_cu);
 
-/* Self test of the kernels' arithmetic: bit exactness with the reference rests on correctly rounded fp32 square roots and reciprocals
- * (math/quatf.h:135-211: sqrt in quat_from_positive_w, 1 / sqrt in quat_normalize). The kernels compute them in shorter instruction
- * sequences than the compiler's general sqrtf / 1.0f / x (aclhip_device.h: sqrt_rn, rcp_rn); this call compares the two on EVERY one
- * of the 2^32 float bit patterns on the device (a second or two). out_mismatches[0] / [1]: patterns on which sqrt_rn / rcp_rn differ
- * from sqrtf / 1.0f / x; [2] / [3]: the same for the bare short forms inside the ranges they are used in. All four must be 0. */
-aclhip_status aclhip_selftest_exact_math(aclhip_context* context, uint64_t* out_mismatches);
-
 /* Algorithmic bytes of one batch under the compulsory-HBM model of DESIGN.md: poses written plus each distinct
  * clip's touched bytes once. `clips` is a HOST pointer here. */
 aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* context, const aclhip_clip* clips, uint32_t num_instances,
