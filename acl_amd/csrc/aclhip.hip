@@ -4,12 +4,14 @@
 //
 // Kernels (device helpers in aclhip_device.h):
 //   decompress_tracks_kernel / decompress_tracks_any_settings_kernel
-//       one wave64 per (clip instance, window of 320 pose quads): scalar seek, base pose DMA'd global -> LDS, lanes <-> animated
+//       one wave64 per (clip instance, window of 312 pose quads = 104 tracks): scalar seek, base pose DMA'd global -> LDS, lanes <-> animated
 //       sub-tracks decode in place into the LDS image (bit unpack, segment + clip range, W, lerp, normalize), the window streams
 //       out 1 KiB per store instruction. The second entry point is the same body with per track rounding, the non default
-//       default sub-track modes and always-normalize compiled in.
-//   decompress_poses_consumer_kernel   the same decode, whole pose per wave, followed by what callers do next with a local pose -- apply
-//                                      an additive clip onto its base, local -> object space -- before the pose leaves LDS.
+//       default sub-track modes and always-normalize compiled in. Poses of several windows: decompress_tracks_in_turn_kernel (a wave
+//       takes four work items in turn and keeps its LDS image while the clip stays the same; one 16 byte read of the bitstream per key).
+//       Every launch is shaped by its batch (pose stride) and every kernel checks the clips it meets against that shape.
+//   decompress_poses_consumer_kernel   the same decode, whole pose per wave, followed by what callers do next with a local pose -- blend K
+//                                      clip instances, apply an additive clip onto its base, local -> object space -- before the pose leaves LDS.
 //   decompress_track_kernel            one thread per (instance, bone) request; the registration time plan replaces the
 //                                      reference's O(track index) skip over preceding widths.
 //   decompress_scalar_tracks_kernel    scalar track lists: one wave64 per (instance, 256 tracks), lanes <-> tracks.

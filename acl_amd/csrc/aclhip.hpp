@@ -454,6 +454,45 @@ namespace aclhip
 			return rejected_count() == before;
 		}
 
+		// The weighted blend of this context's pose (at its last seek()) with the poses of `num_others` further contexts of the same
+		// device (each at ITS last seek(); same number of tracks), then local -> object space on request: what an engine's locomotion
+		// blend does with K decompress_tracks results. weights[0] belongs to this context, weights[1 + k] to others[k]; used as given.
+		// The reference ships no blend function; the operation order is stated next to aclhip_pose_consumers::num_blend_clips
+		// (include/aclhip.h). False when nothing was written.
+		bool decompress_blended_pose(qvvf* out_pose, const decompression_context* const* others, uint32_t num_others, const float* weights, bool object_space)
+		{
+			if (!is_initialized() || m_info.track_type != 12 || m_info.num_tracks == 0 || m_sample_time < 0.0f || out_pose == nullptr
+				|| others == nullptr || weights == nullptr || num_others == 0 || num_others + 1 > ACLHIP_MAX_BLEND_CLIPS)
+				return false;
+			aclhip_clip other_clips[ACLHIP_MAX_BLEND_CLIPS];
+			float other_times[ACLHIP_MAX_BLEND_CLIPS];
+			for (uint32_t k = 0; k < num_others; ++k)
+			{
+				if (others[k] == nullptr || !others[k]->is_initialized() || others[k]->m_device != m_device || others[k]->m_sample_time < 0.0f)
+					return false;
+				other_clips[k] = others[k]->m_clip;
+				other_times[k] = others[k]->m_sample_time;
+			}
+
+			aclhip_decompress_params params;
+			aclhip_default_params(&params);
+			params.rounding_policy = static_cast<uint8_t>(m_rounding_policy);
+			params.looping_policy = static_cast<uint8_t>(m_looping_policy);
+			params.normalization = static_cast<uint8_t>(settings_type::get_rotation_normalization_policy());
+
+			aclhip_pose_consumers consumers = {};
+			consumers.object_space = object_space ? 1 : 0;
+			consumers.num_blend_clips = num_others + 1;
+			consumers.blend_clips = other_clips;
+			consumers.blend_sample_times = other_times;
+			consumers.blend_weights = weights;
+			const float sample_time = m_sample_time;
+			const uint64_t before = rejected_count();
+			if (aclhip_decompress_poses_host(m_device->get(), &m_clip, &sample_time, 1, &params, &consumers, out_pose, uint64_t(m_info.num_tracks) * sizeof(qvvf)) != ACLHIP_OK)
+				return false;
+			return rejected_count() == before;
+		}
+
 		// reference: decompress_tracks(track_writer_type&) (decompress.h:166)
 		template<class track_writer_type>
 		void decompress_tracks(track_writer_type& writer)

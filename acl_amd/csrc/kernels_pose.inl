@@ -50,6 +50,9 @@
 	{
 		const ACLHIP_CONSTANT u32x16* source = (const ACLHIP_CONSTANT u32x16*)(clips + clip_id);
 		struct { u32x16 lo, hi; } raw = { source[0], source[1] };
+		// (both halves are requested HERE, together: left alone the compiler sinks the load of the half that only the decode needs below
+		// the launch shape checks on the other -- one more dependent round trip in every wave's scalar prologue)
+		asm volatile("" : "+s"(raw.lo), "+s"(raw.hi));
 		device_clip clip;
 		__builtin_memcpy(&clip, &raw, sizeof(clip));
 		return clip;
@@ -246,6 +249,9 @@
 
 		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		// (kernel arguments beyond the 16 preloaded SGPRs -- the stride and the LDS slot size the launch shape checks need -- are fetched
+		// next to the instance's clip handle, not behind the clip record where the compiler would put them: one round trip less)
+		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));
 		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || !is_transform_clip(clip.flags)
@@ -563,6 +569,7 @@
 			return;
 
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));		// (see decompress_tracks_window)
 		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		if (clip_id >= num_clips || !is_transform_clip(clip.flags) || launch_refuses_clip(clip, windows_per_instance, lds_quads_per_wave, k_track_bytes, pose_stride_bytes))

@@ -2,7 +2,8 @@
 // decompress_pose, i.e. what a caller of the reference does with decompress_tracks + acl::apply_additive_to_base
 // (core/additive_utils.h:150) + acl::local_to_object_space (compression/transform_pose_utils.h:35).
 // argv: additive_clip base_clip parents(raw u32) times(text: "additive_time base_time" per line) output(raw floats)
-// output per time: for additive format 0..3: local pose [num_tracks x 12] then object space pose [num_tracks x 12]
+// output per time: for additive format 0..3: local pose [num_tracks x 12] then object space pose [num_tracks x 12];
+// then, once: the 0.25 / 0.75 blend of the two clips at the first pair of times, local and object space (decompress_blended_pose)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -94,6 +95,22 @@ int main(int argc, char** argv)
 					return 10;
 				std::fwrite(pose.data(), sizeof(aclhip::qvvf), pose.size(), out);
 			}
+		}
+	}
+	// the blend of the two clips' poses (weights 0.25 / 0.75), local and object space, at the first pair of times: appended to the output
+	{
+		additive.seek(times[0], aclhip::sample_rounding_policy::none);
+		base.seek(times[1], aclhip::sample_rounding_policy::none);
+		const context_type* others[1] = { &base };
+		const float weights[2] = { 0.25f, 0.75f };
+		if (additive.decompress_blended_pose(pose.data(), others, 0, weights, false) || additive.decompress_blended_pose(pose.data(), nullptr, 1, weights, false))
+			return 11;
+		for (int object_space = 0; object_space < 2; ++object_space)
+		{
+			std::memset(pose.data(), 0xCD, pose.size() * sizeof(aclhip::qvvf));
+			if (!additive.decompress_blended_pose(pose.data(), others, 1, weights, object_space != 0))
+				return 12;
+			std::fwrite(pose.data(), sizeof(aclhip::qvvf), pose.size(), out);
 		}
 	}
 	std::fclose(out);

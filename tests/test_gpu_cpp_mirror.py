@@ -152,7 +152,12 @@ def test_cpp_context_pose_consumers(pose_consumers_mirror_binary, tmp_path, name
     result = subprocess.run([pose_consumers_mirror_binary] + [str(paths[key]) for key in ("additive.acl", "base.acl", "parents.bin", "times.txt", "poses.bin")])
     assert result.returncode == 0
     num_tracks = case["parents"].size
-    poses = np.fromfile(paths["poses.bin"], dtype=np.float32).reshape(times.shape[0], 4, 2, num_tracks, 12)
+    everything = np.fromfile(paths["poses.bin"], dtype=np.float32)
+    poses = everything[: times.shape[0] * 8 * num_tracks * 12].reshape(times.shape[0], 4, 2, num_tracks, 12)
+    blended = everything[times.shape[0] * 8 * num_tracks * 12:].reshape(2, num_tracks, 12)
+    expected_blend = ob.oracle_blend_poses([ob.oracle_decompress_tracks(case["additive_blob"], float(times[0][0])), ob.oracle_decompress_tracks(case["base_blob"], float(times[0][1]))], [0.25, 0.75])
+    assert helpers.exact(blended[0], expected_blend)
+    assert helpers.exact(blended[1], ob.oracle_local_to_object_space(case["parents"], expected_blend))
     for i, (additive_time, base_time) in enumerate(times):
         additive_pose = ob.oracle_decompress_tracks(case["additive_blob"], float(additive_time))
         base_pose = ob.oracle_decompress_tracks(case["base_blob"], float(base_time))
