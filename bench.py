@@ -775,18 +775,12 @@ def measure_sharded_job(name, rank, world_size, device_index, dist, gather_mode,
 
 
 def device_pci_bus_id(torch, device_index):
-    """hipDeviceGetPCIBusId of the device, or None when neither the runtime nor torch tells"""
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        buffer = ctypes.create_string_buffer(64)
-        if hip.hipDeviceGetPCIBusId(buffer, 64, int(device_index)) == 0:
-            return buffer.value.decode()
-    except (OSError, AttributeError):
-        pass
+    """PCI address of the device (what hipDeviceGetPCIBusId prints), from the runtime torch already holds; None when it does not tell.
+    (No second copy of the HIP runtime is opened for this: two runtimes in one process do not see the same devices.)"""
     properties = torch.cuda.get_device_properties(device_index)
     if hasattr(properties, "pci_bus_id"):
         return f"{getattr(properties, 'pci_domain_id', 0):04x}:{properties.pci_bus_id:02x}:{getattr(properties, 'pci_device_id', 0):02x}"
-    return None
+    return getattr(properties, "uuid", None) and str(properties.uuid)
 
 
 def distributed_checks(torch, dist, rank, world_size, device_index, backend, kernel_ms):

@@ -261,3 +261,46 @@ def test_a_barrier_that_cannot_open_is_reported_not_trapped():
     env = dict(os.environ, ACLHIP_ORDER_TEST_ABSENT_BLOCK="3", ACLHIP_ORDER_TEST_MAX_POLLS="20000", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
     completed = subprocess.run([sys.executable, "-c", _FAILED_BARRIER_SCRIPT], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert completed.returncode == 0 and "FAILED_BARRIER_PATH_OK" in completed.stdout, completed.stdout[-1500:] + completed.stderr[-3000:]
+
+
+def test_order_for_the_windows_of_a_launch():
+    """aclhip_order_instances_device_for_windows + aclhip_pose_windows_of_launch: a batch of 100-bone characters in 4 800 byte rows is a
+    one-wave-per-pose launch whatever else is registered -- its order must be made for THAT shape (the registry's 300-bone rig would
+    give three waves per pose and another slot -> XCD map)."""
+    rng = np.random.default_rng(77)
+    clips = [synth.build_clip(seed=600 + i, num_tracks=100, num_samples=40 + i) for i in range(24)]
+    rig = synth.build_clip(seed=599, num_tracks=300, num_samples=30, has_scale=1)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        context.register_clip(rig.blob)
+        device = torch.device("cuda", 0)
+        n = 30000
+        which = rng.integers(0, len(clips), size=n)
+        times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+        assert context.pose_windows_of_launch(4800) == 1 and context.pose_windows_of_launch(14400) == 3
+        d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+        d_times = torch.from_numpy(times).to(device)
+        d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+        d_out_clips = torch.full((n,), -1, dtype=torch.int32, device=device)
+        d_out_times = torch.zeros((n,), dtype=torch.float32, device=device)
+        for windows in (1, 3):
+            context.order_instances_device_for_windows(windows, d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr(), d_out_times.data_ptr())
+            torch.cuda.synchronize(device)
+            order = d_order.cpu().numpy().astype(np.uint32)
+            check_order(handles[which], order, windows, stable=False)
+            assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), handles[which][order])
+        # the plain call orders for rows as wide as the largest registered clip: three waves per pose here
+        context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr(), d_out_times.data_ptr())
+        torch.cuda.synchronize(device)
+        check_order(handles[which], d_order.cpu().numpy().astype(np.uint32), 3, stable=False)
+        with pytest.raises(runtime.AclHipError):
+            context.order_instances_device_for_windows(0, d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+        # and the decode in the one-window order: every pose the oracle's
+        context.order_instances_device_for_windows(1, d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr(), d_out_times.data_ptr())
+        d_poses = torch.zeros((n, 100, 12), dtype=torch.float32, device=device)
+        context.decompress_tracks_batch(d_out_clips.data_ptr(), d_out_times.data_ptr(), n, d_poses.data_ptr(), 4800)
+        torch.cuda.synchronize(device)
+        order = d_order.cpu().numpy()
+        expected = ob.oracle_decompress_tracks_batch([c.blob for c in clips], which.astype(np.uint32), times, 100)
+        assert helpers.exact(d_poses.cpu().numpy(), expected[order])
+        assert context.rejected_instance_count() == 0
