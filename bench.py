@@ -461,7 +461,7 @@ def traffic_pass(device_index, manifest_path, steps=12):
     json.dump(manifest, open(manifest_path, "w"))
 
 
-def live_traffic(timeout_s=240):
+def live_traffic(timeout_s=90):
     """HBM bytes per launch of the decode kernel of EVERY spec of the default run, measured NOW: this same script in two rocprofv3
     --pmc passes of their own (traffic_pass above), FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of
     MI355X_MICROARCH.md), mean over the dispatches of the spec's decode kernel between two markers. Returns {workload key: bytes} --
