@@ -167,6 +167,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_database_samples = 1u << 7;		// bound to a database: `samples` holds database_sample_record (tier metadata copied per sample)
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_negative_scale = 1u << 11;			// some scale sub-track may decode a negative component: rtm::qvv_mul then composes matrices (pose consumers)
+	constexpr uint32_t k_clip_short_exact_math = 1u << 12;		// no animated rotation of the clip can hand the kernels a square root argument in (0, 2^-96): the short exact forms apply (host_clips.inl)
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)
@@ -631,23 +632,52 @@ namespace aclhip
 #include "../../tools/experiments/device_experiments.h"		// round 3's staged unpack: not part of a default build
 #endif
 
+	// ---- correctly rounded square root and reciprocal in fewer instructions than the compiler's general expansions (round 4) ------------
+	// Every kernel but the headline's is bound by VALU issue, and 59 of a rotation's ~100 instructions were the compiler's
+	// IEEE sqrtf (16 each: input scaling for tiny arguments, v_sqrt_f32, both neighbours tried against the residual, unscaling, a class
+	// test) and 1.0f / x (11: v_div_scale twice, v_rcp_f32, refinement, v_div_fmas, v_div_fixup). The same neighbour test on the bare
+	// v_sqrt_f32 (9 instructions) and two Newton steps on v_rcp_f32 (5) give the SAME BITS as sqrtf / 1.0f / x
+	//   sqrt_rn_short   for x == +0 and 2^-96 <= x <= +inf      (below 2^-96 the residuals underflow: why the compiler scales)
+	//   rcp_rn_short    for 2^-126 <= x <= 2^126                 (beyond, 1 / x is denormal or x is)
+	// -- checked on every one of the 2^32 float bit patterns on the device (tools/probes/exact_math_probe.hip). Which form a wave takes is
+	// a property of its CLIP, decided once at registration (k_clip_short_exact_math, host_clips.inl: no animated rotation of the clip can
+	// produce an argument outside those ranges) and read from the clip record: a scalar branch, no per lane test.
+	__device__ __forceinline__ float sqrt_rn_short(float x)
+	{
+		const float s = __builtin_amdgcn_sqrtf(x);		// within 1 ulp: the correctly rounded root is s or one of its neighbours
+		const float down = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+		const float residual_down = __builtin_fmaf(-down, s, x), residual_up = __builtin_fmaf(-up, s, x);
+		float result = residual_down <= 0.0f ? down : s;
+		result = residual_up > 0.0f ? up : result;
+		return result;
+	}
+
+	__device__ __forceinline__ float rcp_rn_short(float x)
+	{
+		const float r0 = __builtin_amdgcn_rcpf(x);
+		const float r1 = __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+		return __builtin_fmaf(__builtin_fmaf(-x, r1, 1.0f), r1, r1);
+	}
+
 	// math/quatf.h:135-147
+	template<bool kShortExact = false>
 	__device__ __forceinline__ float quat_from_positive_w(float x, float y, float z)
 	{
 		float w_squared = 1.0f - (x * x);
 		w_squared = w_squared - (y * y);
 		w_squared = w_squared - (z * z);
-		return sqrtf(fabsf(w_squared));
+		return kShortExact ? sqrt_rn_short(fabsf(w_squared)) : sqrtf(fabsf(w_squared));
 	}
 
 	// math/quatf.h:200-211
+	template<bool kShortExact = false>
 	__device__ __forceinline__ float4 quat_normalize(float4 q)
 	{
 		float dot = q.x * q.x;
 		dot = (q.y * q.y) + dot;
 		dot = (q.z * q.z) + dot;
 		dot = (q.w * q.w) + dot;
-		const float inv_len = 1.0f / sqrtf(dot);
+		const float inv_len = kShortExact ? rcp_rn_short(sqrt_rn_short(dot)) : 1.0f / sqrtf(dot);
 		return make_float4(q.x * inv_len, q.y * inv_len, q.z * inv_len, q.w * inv_len);
 	}
 
@@ -733,24 +763,58 @@ namespace aclhip
 	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
 	template<bool kPolicies, bool kFastMath = false>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
-		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples);
+		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math);
 
+	// short_exact_math (WAVE UNIFORM): the clip's k_clip_short_exact_math -- its rotations may take sqrt_rn_short / rcp_rn_short
 	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false>
 	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
-		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math = false)
 	{
 		float v0[3], v1[3];
 		if constexpr (kWideKeyLoads)
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
 			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
-		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples);
+		// (raw samples are any floats: a wave that meets one keeps the compiler's forms)
+		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples, !kHasRaw && short_exact_math);
 	}
 
 	// What follows the unpack: W reconstruction, interpolation, normalization (rotations) / the stable lerp (translations, scales)
+	// The rotation arithmetic of interpolate_animated_samples, with the compiler's or the short exact square roots / reciprocal
+	template<bool kPolicies, bool kShortExact>
+	__device__ __forceinline__ float4 interpolate_animated_rotation(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
+		uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+	{
+		float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w<kShortExact>(v0[0], v0[1], v0[2]));
+		float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w<kShortExact>(v1[0], v1[1], v1[2]));
+
+		// animated_track_cache.transform.h:1463-1473
+		if (kPolicies && normalize_samples)
+		{
+			q0 = quat_normalize<kShortExact>(q0);
+			q1 = quat_normalize<kShortExact>(q1);
+		}
+
+		if (kPolicies)
+		{
+			if (policy == k_round_floor)
+				return q0;
+			if (policy == k_round_ceil)
+				return q1;
+			if (policy == k_round_nearest)
+				return state.interpolation_alpha < 0.5f ? q0 : q1;
+		}
+
+		// :1604-1616
+		float4 result = quat_lerp_no_normalization(q0, q1, lerp_alpha);
+		if (normalization >= 1)
+			result = quat_normalize<kShortExact>(result);
+		return result;
+	}
+
 	template<bool kPolicies, bool kFastMath>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
-		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math)
 	{
 		if constexpr (kFastMath && !kPolicies)
 		{
@@ -772,31 +836,10 @@ namespace aclhip
 		// compiler otherwise turns `if (is_rotation)` into selects, and a pass of translations and scales pays for rotations it does not have)
 		if (is_rotation && __builtin_amdgcn_ballot_w64(is_rotation) != 0)
 		{
-			float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w(v0[0], v0[1], v0[2]));
-			float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w(v1[0], v1[1], v1[2]));
-
-			// animated_track_cache.transform.h:1463-1473
-			if (kPolicies && normalize_samples)
-			{
-				q0 = quat_normalize(q0);
-				q1 = quat_normalize(q1);
-			}
-
-			if (kPolicies)
-			{
-				if (policy == k_round_floor)
-					return q0;
-				if (policy == k_round_ceil)
-					return q1;
-				if (policy == k_round_nearest)
-					return state.interpolation_alpha < 0.5f ? q0 : q1;
-			}
-
-			// :1604-1616
-			float4 result = quat_lerp_no_normalization(q0, q1, lerp_alpha);
-			if (normalization >= 1)
-				result = quat_normalize(result);
-			return result;
+			// (a scalar branch: short_exact_math is the clip's flag, the same in every lane)
+			if (short_exact_math)
+				return interpolate_animated_rotation<kPolicies, true>(state, v0, v1, policy, lerp_alpha, normalization, normalize_samples);
+			return interpolate_animated_rotation<kPolicies, false>(state, v0, v1, policy, lerp_alpha, normalization, normalize_samples);
 		}
 
 		// unpack_translation_group / unpack_scale_group, animated_track_cache.transform.h:1774-1836,1896-1958

@@ -565,6 +565,90 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 	}
 
+	// ---- may the kernels use the SHORT correctly rounded square root / reciprocal on this clip's rotations? ----
+	// sqrt_rn_short / rcp_rn_short (aclhip_device.h) give the bits of sqrtf / 1.0f / x on x == 0 or x >= 2^-96, and on 2^-126 <= x <=
+	// 2^126 (checked on every float, tools/probes/exact_math_probe.hip); the compiler's general forms cost 16 / 11 instructions instead
+	// of 9 / 5 because they also cover what lies outside. Whether a clip can ever hand the kernels such an argument is decided HERE,
+	// once: W^2 = |((1 - x^2) - y^2) - z^2| lands in (0, 2^-96) only through exact cancellation followed by the square of a component
+	// below 2^-48 (a difference of two floats is a multiple of the smaller one's ulp) -- so a clip none of whose animated rotation
+	// components can decode to a NONZERO value below 2^-32 in magnitude, and whose values are bounded, is safe; the norms the
+	// normalize and the object space walk meet are then within [0.49, 2^41]. A component's decoded value is a monotone function of its
+	// quantized field (rounding is monotone, the extents are checked non negative), so the two field values next to its zero
+	// crossing decide: two binary searches per (segment, rotation, component). Rotations stored raw in some segment (any float),
+	// ranges that are negative, not finite or huge, and constant rotations beyond 2^20 make the clip "not provably safe": its waves take
+	// the compiler's forms. Either way the poses are bit identical to the reference's.
+	bool short_exact_math = true;
+	if (num_tracks != 0)
+	{
+		constexpr float k_tiny = 2.3283064365386963e-10f;		// 2^-32
+		constexpr float k_huge = 1048576.0f;					// 2^20
+		const auto decoded = [](const plan_entry& entry, const clip_range_entry& range, uint32_t c, uint32_t field)
+		{
+			// the kernels' own operations, in their order (unpack_animated_samples, aclhip_device.h)
+			const float quantized = float(field) * entry.inv_max_value;
+			const float segment_value = (quantized * entry.range_extent[c]) + entry.range_min[c];
+			return (segment_value * range.range_extent[c]) + range.range_min[c];
+		};
+		for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
+		{
+			const clip_range_entry& range = clip_ranges[a];
+			if (range.quad_index != range.track_index * 3)
+				continue;
+			for (uint32_t si = 0; si < num_segments && short_exact_math; ++si)
+			{
+				const plan_entry& entry = plan[size_t(si) * num_animated + a];
+				const uint32_t num_bits = entry.bit_offset_and_width >> 24;
+				if (num_bits == 32)
+				{
+					short_exact_math = false;
+					break;
+				}
+				const uint32_t max_field = num_bits == 0 ? 0u : (1u << num_bits) - 1u;
+				for (uint32_t c = 0; c < 3 && short_exact_math; ++c)
+				{
+					const bool ordered = entry.range_extent[c] >= 0.0f && range.range_extent[c] >= 0.0f && std::isfinite(entry.range_min[c]) && std::isfinite(range.range_min[c]);
+					const float lowest = decoded(entry, range, c, 0), highest = decoded(entry, range, c, max_field);
+					if (!ordered || !(std::fabs(lowest) <= k_huge) || !(std::fabs(highest) <= k_huge))
+					{
+						short_exact_math = false;
+						break;
+					}
+					// the smallest field that decodes to a value > 0 / >= 0 (max_field + 1: none)
+					const auto first_field = [&](bool strictly)
+					{
+						uint32_t low = 0, high = max_field + 1;
+						while (low < high)
+						{
+							const uint32_t middle = low + (high - low) / 2;
+							const float value = decoded(entry, range, c, middle);
+							if (strictly ? value > 0.0f : value >= 0.0f)
+								high = middle;
+							else
+								low = middle + 1;
+						}
+						return low;
+					};
+					const uint32_t first_positive = first_field(true), first_non_negative = first_field(false);
+					if (first_positive <= max_field && decoded(entry, range, c, first_positive) < k_tiny)
+						short_exact_math = false;
+					if (first_non_negative > 0 && decoded(entry, range, c, first_non_negative - 1) > -k_tiny)
+						short_exact_math = false;
+				}
+			}
+		}
+		for (uint32_t track = 0; track < num_tracks && short_exact_math; ++track)
+		{
+			const float* value = &base_pose[size_t(track * 3) * 4];
+			const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
+			if (int32_t(marker) >= 0)		// a constant rotation (W rebuilt above with the host's sqrtf)
+				short_exact_math = std::fabs(value[0]) <= k_huge && std::fabs(value[1]) <= k_huge && std::fabs(value[2]) <= k_huge;
+		}
+	}
+	// ACLHIP_SHORT_EXACT_MATH = 0: never (A/B measurements); 1: ALWAYS, whatever the analysis says (testing aid: shows the analysis has teeth)
+	static const int short_exact_override = []() { const char* value = std::getenv("ACLHIP_SHORT_EXACT_MATH"); return value != nullptr ? int(value[0] - '0') : -1; }();
+	if (short_exact_override == 0 || short_exact_override == 1)
+		short_exact_math = short_exact_override == 1;
+
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
 	const uint64_t base_pose_offset = blob_bytes;
@@ -684,6 +768,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.flags |= (header.version > k_version_first && header.is_wrap_optimized()) ? k_clip_wraps : 0u;
 		record.flags |= has_raw ? k_clip_has_raw : 0u;
 		record.flags |= negative_scale_possible ? k_clip_negative_scale : 0u;
+		record.flags |= short_exact_math ? k_clip_short_exact_math : 0u;
 		record.num_segments = num_segments;
 		record.num_animated = num_animated;
 		if (header.has_database())

@@ -242,6 +242,7 @@
 		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do; bit 31: its schedule is NOT in the shared LDS copy
 		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
 		__shared__ uint32_t walk_tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
+		__shared__ uint32_t walk_short_exact[k_consumer_max_instances];		// 1: every clip behind the instance's pose is k_clip_short_exact_math (or the slot has no work)
 
 		static_assert(!kUnitScale || (kObjectSpace && kBase == k_consumer_base_none), "rotation | translation images: object space without a base");
 		static_assert(!kBlend || (!kUnitScale && kBase != k_consumer_base_fused), "a blend accumulates whole qvv images; a base clip is decoded by a second wave");
@@ -274,6 +275,9 @@
 
 		uint32_t num_tracks = 0;		// stays 0 for a wave without work: past the batch, refused instance, empty track list
 		uint32_t num_levels = 0;
+		// the walk's normalize may take the short exact forms when every rotation it meets comes out of clips that are proven safe for
+		// them (norms near 1; a caller's base pose buffer holds anything)
+		uint32_t short_exact = kBase == k_consumer_base_buffer ? 0u : 1u;
 		if (instance < num_instances)
 		{
 			const uint32_t clip_id = as_constant(clip_ids)[instance];
@@ -297,6 +301,7 @@
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
 				: uint32_t(params.rounding_policy);
 
+			short_exact &= (clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
 			device_clip base_clip = clip;
 			if (base_is_clip)
 			{
@@ -304,6 +309,7 @@
 				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
 					|| (!kMirrored && multiplies_transforms && ((clip.flags | base_clip.flags) & k_clip_negative_scale) != 0);
+				short_exact &= (base_clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
 				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
 					decode_pose_into_image<kFast>(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}
@@ -317,6 +323,7 @@
 					const ACLHIP_CONSTANT device_clip* record = as_constant(clips) + (blend_clip_id < num_clips ? blend_clip_id : 0);
 					refused = refused || blend_clip_id >= num_clips || !is_transform_clip(record->flags) || record->num_tracks != clip.num_tracks
 						|| (!kMirrored && multiplies_transforms && (record->flags & k_clip_negative_scale) != 0);
+					short_exact &= (record->flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
 				}
 			}
 
@@ -415,6 +422,7 @@
 				walk_levels[slot] = num_levels;
 				walk_schedules[slot] = schedule;
 				walk_tracks[slot] = num_tracks;
+				walk_short_exact[slot] = num_tracks != 0 ? short_exact : 1u;
 			}
 			__syncthreads();
 			ACLHIP_PHASE_STAMP(1);
@@ -435,9 +443,10 @@
 				const bool slot_schedule_is_shared = (walk_levels[walk_slot] & 0x80000000u) == 0;
 				const uint32_t* slot_schedule = walk_schedules[walk_slot];
 
-				const auto walk = [&](const auto* schedule_words, auto scale_is_one)
+				const auto walk = [&](const auto* schedule_words, auto scale_is_one, auto short_exact_tag)
 				{
 					constexpr bool k_unit_scale = decltype(scale_is_one)::value;
+					constexpr bool k_short_exact = decltype(short_exact_tag)::value;		// sqrt_rn_short / rcp_rn_short in the normalize (aclhip_device.h)
 					const auto* pairs = schedule_words + 2u + slot_steps;
 					uint32_t step_start = 0;
 					for (uint32_t step = 0; __any(int(step < slot_steps)) != 0; ++step)
@@ -458,7 +467,7 @@
 									const float4 parent_quat = make_float4(parent_rotation.x, parent_rotation.y, parent_rotation.z, parent_rotation.w);
 									const float4 child_quat = make_float4(child_rotation.x, child_rotation.y, child_rotation.z, child_rotation.w);
 									const float4 child_vector = make_float4(child_translation.x, child_translation.y, child_translation.z, 0.0f);
-									const float4 rotation = kFast ? quat_normalize_fast(quat_mul_fast(child_quat, parent_quat)) : quat_normalize(quat_mul(child_quat, parent_quat));
+									const float4 rotation = kFast ? quat_normalize_fast(quat_mul_fast(child_quat, parent_quat)) : quat_normalize<k_short_exact>(quat_mul(child_quat, parent_quat));
 									const float4 rotated = kFast ? quat_mul_vector3_fast(child_vector, parent_quat) : quat_mul_vector3(child_vector, parent_quat);
 									slot_image[child_quad] = f32x4{ rotation.x, rotation.y, rotation.z, rotation.w };
 									slot_image[child_quad + 1] = f32x4{ rotated.x + parent_translation.x, rotated.y + parent_translation.y, rotated.z + parent_translation.z, 0.0f };
@@ -482,7 +491,7 @@
 										// negative scales -- nothing to count, nothing to route
 										object = kFast ? qvv_mul_fast(child, parent) : qvv_mul(child, parent);
 									}
-									object.rotation = kFast ? quat_normalize_fast(object.rotation) : quat_normalize(object.rotation);
+									object.rotation = kFast ? quat_normalize_fast(object.rotation) : quat_normalize<k_short_exact>(object.rotation);
 									store_qvv(slot_image, pair & 0xFFFFu, object);
 								}
 							}
@@ -503,17 +512,18 @@
 					const uint64_t mine = reinterpret_cast<uint64_t>(slot_schedule);
 					const uint64_t first_schedule = (uint64_t(__shfl(uint32_t(mine >> 32), int(leader))) << 32) | __shfl(uint32_t(mine), int(leader));
 					const bool shared_copy = __all(int(slot_steps == 0 || (mine == first_schedule && slot_schedule_is_shared))) != 0;
-					if (unit_scale)
+					const bool short_exact_walk = !kFast && __all(int(walk_short_exact[walk_slot] != 0)) != 0;
+					const auto walk_with = [&](auto scale_is_one, auto short_exact_tag)
 					{
 						if (shared_copy)
-							walk(static_cast<const uint32_t*>(shared_schedule), std::true_type());
+							walk(static_cast<const uint32_t*>(shared_schedule), scale_is_one, short_exact_tag);
 						else
-							walk(as_constant(slot_schedule), std::true_type());
-					}
-					else if (shared_copy)
-						walk(static_cast<const uint32_t*>(shared_schedule), std::false_type());
+							walk(as_constant(slot_schedule), scale_is_one, short_exact_tag);
+					};
+					if (short_exact_walk)
+						walk_with(std::integral_constant<bool, unit_scale>(), std::true_type());
 					else
-						walk(as_constant(slot_schedule), std::false_type());
+						walk_with(std::integral_constant<bool, unit_scale>(), std::false_type());
 				}
 				__builtin_amdgcn_s_setprio(0);
 			}

@@ -115,6 +115,7 @@
 		const plan_entry* plan;					// [num_segments][num_animated]
 		const clip_range_entry* clip_ranges;	// [num_animated]
 		uint32_t num_animated;
+		bool short_exact_math;					// k_clip_short_exact_math of the clip (wave uniform)
 	};
 
 	__device__ __forceinline__ window_tables window_tables_of(const device_clip& clip)
@@ -123,6 +124,7 @@
 		tables.plan = clip.plan;
 		tables.clip_ranges = clip.clip_ranges;
 		tables.num_animated = clip.num_animated;
+		tables.short_exact_math = (clip.flags & k_clip_short_exact_math) != 0;
 		return tables;
 	}
 
@@ -182,9 +184,9 @@
 
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples, tables.short_exact_math);
 			else
-				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples);
+				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples, tables.short_exact_math);
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)

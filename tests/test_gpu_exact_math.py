@@ -1,0 +1,70 @@
+"""The short correctly rounded square root / reciprocal of the rotation arithmetic (acl_amd/csrc/aclhip_device.h: sqrt_rn_short,
+rcp_rn_short) are bit identical to sqrtf / 1.0f / x only for arguments that are 0 or >= 2^-96 (all 2^32 floats checked:
+tools/probes/exact_math_probe.hip). Whether a clip's rotations can produce anything else is decided at registration
+(host_clips.inl: k_clip_short_exact_math). Here: a clip built to hit the gap -- a rotation component of exactly 1 next to one of 1e-20:
+W^2 = 1e-40 -- must be recognised (its poses stay bit identical to the oracle's, which computes with the C library's sqrtf), and the
+same clip with the analysis overruled (ACLHIP_SHORT_EXACT_MATH=1, a testing aid) must NOT be: the analysis is what keeps the bits.
+The reference's arithmetic: includes/acl/math/quatf.h:135-147,200-211. Needs a GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r"""
+import sys
+import numpy as np
+from acl_amd import runtime, synth
+from oracle import bindings as ob
+
+clip = synth.build_clip(seed=77, num_tracks=12, num_samples=20, rotation_default=0.0, rotation_constant=0.0, raw_fraction=0.0, width0_fraction=0.0)
+blob = clip.blob.copy()
+# transform_tracks_header at +32 (core/impl/compressed_headers.h:227-263): counts, then the offsets relative to the header itself
+header = np.frombuffer(blob[32:32 + 52].tobytes(), dtype=np.uint32)
+num_animated_rotations, clip_range_offset = int(header[2]), int(header[12])
+group = min(4, num_animated_rotations)
+base = 32 + clip_range_offset
+values = blob[base: base + 6 * group * 4].view(np.float32)
+# the first animated rotation: min = (1, 1e-20, 0), extent = 0: every key decodes to x = 1 exactly, y = 1e-20, z = 0
+values[0 * group], values[1 * group], values[2 * group] = 1.0, 1.0e-20, 0.0
+values[3 * group], values[4 * group], values[5 * group] = 0.0, 0.0, 0.0
+aligned = synth.aligned_bytes(blob.size)
+aligned[:] = blob
+
+with runtime.Context(0) as context:
+    handle = context.register_clip(aligned, check_hash=False)
+    times = np.linspace(0.0, clip.duration, 37, dtype=np.float32)
+    poses = context.decompress_tracks(np.full(times.size, handle, dtype=np.uint32), times)
+    exact = True
+    tiny_w = 0
+    for i, t in enumerate(times):
+        expected = ob.oracle_decompress_tracks(aligned, float(t))
+        exact = exact and np.array_equal(poses[i].view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]], expected.view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]])
+        tiny_w += int(np.any((np.abs(expected[:, 3]) > 0) & (np.abs(expected[:, 3]) < 1e-15)))
+    print("TINY_W", tiny_w, "EXACT", int(exact))
+"""
+
+
+def _run(extra_env):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **extra_env)
+    completed = subprocess.run([sys.executable, "-c", _SCRIPT], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert completed.returncode == 0, completed.stderr[-2000:]
+    line = next(l for l in completed.stdout.splitlines() if l.startswith("TINY_W"))
+    fields = line.split()
+    return int(fields[1]), int(fields[3])
+
+
+def test_a_clip_that_reaches_the_gap_of_the_short_forms_is_recognised():
+    tiny_w, exact = _run({})
+    assert tiny_w > 0                   # the clip does what it was built for: W = sqrt(1e-40)
+    assert exact == 1                   # ... and its poses are the oracle's bit for bit (the compiler's square root ran)
+
+
+def test_the_analysis_is_what_keeps_the_bits():
+    tiny_w, exact = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
+    assert tiny_w > 0 and exact == 0    # overruled: the short form meets an argument below 2^-96 and rounds it differently
