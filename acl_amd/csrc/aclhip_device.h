@@ -168,6 +168,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_components_shift = 8;				// scalar clips: floats per sample (1..4) in bits 8..10
 	constexpr uint32_t k_clip_negative_scale = 1u << 11;			// some scale sub-track may decode a negative component: rtm::qvv_mul then composes matrices (pose consumers)
 	constexpr uint32_t k_clip_short_exact_math = 1u << 12;		// no animated rotation of the clip can hand the kernels a square root argument in (0, 2^-96): the short exact forms apply (host_clips.inl)
+	constexpr uint32_t k_clip_raw_rotations = 1u << 13;			// some rotation sub-track is stored raw (fp32) in some segment
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)

@@ -574,10 +574,12 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	// components can decode to a NONZERO value below 2^-32 in magnitude, and whose values are bounded, is safe; the norms the
 	// normalize and the object space walk meet are then within [0.49, 2^41]. A component's decoded value is a monotone function of its
 	// quantized field (rounding is monotone, the extents are checked non negative), so the two field values next to its zero
-	// crossing decide: two binary searches per (segment, rotation, component). Rotations stored raw in some segment (any float),
-	// ranges that are negative, not finite or huge, and constant rotations beyond 2^20 make the clip "not provably safe": its waves take
-	// the compiler's forms. Either way the poses are bit identical to the reference's.
-	bool short_exact_math = true;
+	// crossing decide: two binary searches per (segment, rotation, component). Ranges that are negative, not finite or huge and
+	// constant rotations beyond 2^20 make the clip "not provably safe": its waves take the compiler's forms. Samples stored RAW (any
+	// float) are not judged here: a wave that meets one takes the compiler's forms anyway (kHasRaw), and k_clip_raw_rotations tells the
+	// object space walk that this clip's rotations are only as good as their normalization. Either way the poses are bit identical
+	// to the reference's.
+	bool short_exact_math = true, raw_rotations = false;
 	if (num_tracks != 0)
 	{
 		constexpr float k_tiny = 2.3283064365386963e-10f;		// 2^-32
@@ -600,8 +602,10 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 				const uint32_t num_bits = entry.bit_offset_and_width >> 24;
 				if (num_bits == 32)
 				{
-					short_exact_math = false;
-					break;
+					// any floats: a wave that meets a raw sample takes the compiler's forms (decode_animated_sub_track<kHasRaw = true>);
+					// the rest of the clip is judged on its quantized samples
+					raw_rotations = true;
+					continue;
 				}
 				const uint32_t max_field = num_bits == 0 ? 0u : (1u << num_bits) - 1u;
 				for (uint32_t c = 0; c < 3 && short_exact_math; ++c)
@@ -769,6 +773,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.flags |= has_raw ? k_clip_has_raw : 0u;
 		record.flags |= negative_scale_possible ? k_clip_negative_scale : 0u;
 		record.flags |= short_exact_math ? k_clip_short_exact_math : 0u;
+		record.flags |= raw_rotations ? k_clip_raw_rotations : 0u;
 		record.num_segments = num_segments;
 		record.num_animated = num_animated;
 		if (header.has_database())

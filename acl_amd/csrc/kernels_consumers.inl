@@ -182,6 +182,13 @@
 		}
 	}
 
+	// May the object space walk normalize this clip's rotations with the short exact forms (aclhip_device.h)? Its quantized rotations must
+	// be proven safe (k_clip_short_exact_math); raw ones are any floats, and only a normalizing decode brings those to a norm of 1
+	__device__ __forceinline__ uint32_t walk_may_use_short_exact_math(uint32_t clip_flags, uint32_t normalization)
+	{
+		return (clip_flags & k_clip_short_exact_math) != 0 && ((clip_flags & k_clip_raw_rotations) == 0 || normalization != ACLHIP_NORMALIZE_NEVER) ? 1u : 0u;
+	}
+
 	__device__ __forceinline__ void wave_lds_barrier()
 	{
 		__builtin_amdgcn_s_waitcnt(0);
@@ -301,7 +308,7 @@
 				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
 				: uint32_t(params.rounding_policy);
 
-			short_exact &= (clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
+			short_exact &= walk_may_use_short_exact_math(clip.flags, params.normalization);
 			device_clip base_clip = clip;
 			if (base_is_clip)
 			{
@@ -309,7 +316,7 @@
 				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
 					|| (!kMirrored && multiplies_transforms && ((clip.flags | base_clip.flags) & k_clip_negative_scale) != 0);
-				short_exact &= (base_clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
+				short_exact &= walk_may_use_short_exact_math(base_clip.flags, params.normalization);
 				if (!refused && two_waves && role == 1 && clip.num_tracks != 0)
 					decode_pose_into_image<kFast>(base_clip, as_constant(consumers.base_sample_times)[instance], rounding_policy, params, lane, base_image);
 			}
@@ -323,7 +330,7 @@
 					const ACLHIP_CONSTANT device_clip* record = as_constant(clips) + (blend_clip_id < num_clips ? blend_clip_id : 0);
 					refused = refused || blend_clip_id >= num_clips || !is_transform_clip(record->flags) || record->num_tracks != clip.num_tracks
 						|| (!kMirrored && multiplies_transforms && (record->flags & k_clip_negative_scale) != 0);
-					short_exact &= (record->flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
+					short_exact &= walk_may_use_short_exact_math(record->flags, params.normalization);
 				}
 			}
 
