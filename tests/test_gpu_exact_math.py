@@ -68,3 +68,35 @@ def test_a_clip_that_reaches_the_gap_of_the_short_forms_is_recognised():
 def test_the_analysis_is_what_keeps_the_bits():
     tiny_w, exact = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
     assert tiny_w > 0 and exact == 0    # overruled: the short form meets an argument below 2^-96 and rounds it differently
+
+
+@pytest.mark.parametrize("normalization", [0, 1])
+def test_raw_rotations_reach_the_walk_bit_exact(normalization):
+    """Half of the rotation sub-tracks stored raw: their waves decode with the compiler's forms, the others with the short ones, and
+    the object space walk takes the short normalize only when the decode normalized what it hands over (k_clip_raw_rotations,
+    kernels_consumers.inl: walk_may_use_short_exact_math). Bit identical to the oracle either way."""
+    from acl_amd import runtime, synth
+    from oracle import bindings as ob
+    import helpers
+    rng = np.random.default_rng(91 + normalization)
+    clips = [synth.build_clip(seed=610 + k, num_tracks=140, num_samples=30 + k, raw_fraction=0.5, has_scale=1, scale_default=0.6) for k in range(2)]
+    blobs = [c.blob for c in clips]
+    parents = np.zeros(140, dtype=np.uint32)
+    parents[0] = runtime.NO_PARENT
+    for i in range(1, 140):
+        parents[i] = rng.integers(max(0, i - 6), i)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(b) for b in blobs], dtype=np.uint32)
+        for handle in handles:
+            context.set_clip_hierarchy(int(handle), parents)
+        which = rng.integers(0, 2, size=48)
+        times = np.array([rng.uniform(0.0, clips[c].duration) for c in which], dtype=np.float32)
+        params = runtime.default_params(normalization=normalization)
+        options = ob.default_options(normalization=normalization)
+        got = context.decompress_poses(handles[which], times, object_space=True, params=params)
+        plain = context.decompress_tracks(handles[which], times, params=params)
+        for i in range(which.size):
+            local = ob.oracle_decompress_tracks(blobs[which[i]], float(times[i]), 0, options)
+            assert helpers.exact(plain[i], local), i
+            assert helpers.exact(got[i], ob.oracle_local_to_object_space(parents, local)), i
+        assert context.rejected_instance_count() == 0
