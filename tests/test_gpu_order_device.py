@@ -263,6 +263,42 @@ def test_a_barrier_that_cannot_open_is_reported_not_trapped():
     assert completed.returncode == 0 and "FAILED_BARRIER_PATH_OK" in completed.stdout, completed.stdout[-1500:] + completed.stderr[-3000:]
 
 
+def test_batches_of_few_clips_and_lists_that_start_anywhere():
+    """batches of one, two, three clips (every lane of a wave on one word of the LDS histogram), heavily skewed ones, sizes around
+    the workgroup boundaries, a clip list that starts 4 bytes into an allocation"""
+    clip = synth.build_clip(seed=5, num_tracks=3, num_samples=2)
+    with runtime.Context(0) as context:
+        handles = np.array([context.register_clip(clip.blob, check_hash=False) for _ in range(40)], dtype=np.uint32)
+        device = torch.device("cuda", 0)
+        rng = np.random.default_rng(2024)
+        for n in (3, 4, 5, 1023, 1025, 4099, 65536, 131072, 131073):
+            for distinct, skew in ((1, 0.0), (2, 0.0), (2, 0.97), (3, 0.0), (5, 0.9), (40, 0.0)):
+                which = rng.integers(0, distinct, size=n)
+                if skew > 0.0:
+                    which[rng.uniform(size=n) < skew] = 0
+                instance_clips = handles[which]
+                times = rng.uniform(0.0, 1.0, size=n).astype(np.float32)
+                _, _, d_order, d_out_clips, d_out_times = _order_on_device(context, device, instance_clips, times)
+                torch.cuda.synchronize(device)
+                order = d_order.cpu().numpy().astype(np.uint32)
+                check_order(instance_clips, order, 1, stable=False)
+                assert np.array_equal(d_out_clips.cpu().numpy().astype(np.uint32), instance_clips[order])
+                assert np.array_equal(d_out_times.cpu().numpy().view(np.uint32), times[order].view(np.uint32))
+        # a list that starts 4 bytes into an allocation
+        n = 50000
+        instance_clips = handles[rng.integers(0, handles.size, size=n)]
+        d_storage = torch.zeros((n + 1,), dtype=torch.int32, device=device)
+        d_storage[1:] = torch.from_numpy(instance_clips.astype(np.int32)).to(device)
+        d_times = torch.zeros((n,), dtype=torch.float32, device=device)
+        d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+        torch.cuda.synchronize(device)
+        context.order_instances_device(d_storage.data_ptr() + 4, d_times.data_ptr(), n, d_order.data_ptr())
+        torch.cuda.synchronize(device)
+        check_order(instance_clips, d_order.cpu().numpy().astype(np.uint32), 1, stable=False)
+        for handle in handles[::-1]:
+            context.unregister_clip(int(handle))
+
+
 def test_order_for_the_windows_of_a_launch():
     """aclhip_order_instances_device_for_windows + aclhip_pose_windows_of_launch: a batch of 100-bone characters in 4 800 byte rows is a
     one-wave-per-pose launch whatever else is registered -- its order must be made for THAT shape (the registry's 300-bone rig would
