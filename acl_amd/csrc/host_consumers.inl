@@ -290,7 +290,8 @@ namespace
 		// a walk schedule of T transforms: 2 words + a step end per step + a pair per transform with a parent, at most 2 + 2 T words
 		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3) + 3), 4), 4) : 0;
 		const size_t lds_schedule_bytes = size_t(lds_schedule_words) * sizeof(uint32_t);
-		constexpr size_t k_lds_bytes = 160 * 1024 - 256;		// the kernel's few static words (the walk's per instance arrays: 160 bytes)
+		// what a workgroup may ask for on top of the kernel's static words (consumer_walk_slots, kernels_consumers.inl)
+		constexpr size_t k_lds_bytes = 160 * 1024 - ((sizeof(consumer_walk_slots) + 127) / 128) * 128;
 		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "poses of %u transforms (the pose stride, the largest registered clip): too large for the pose consumers (%zu bytes of LDS per instance)", batch_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
 		uint32_t log2_instances_per_block = 2;

@@ -224,6 +224,15 @@
 	// HBM happens on the image the decode already holds.
 	// LDS per instance: [pose image | base image (base clips only) | hierarchy copy (object space only)].
 	constexpr uint32_t k_consumer_max_instances = 8;
+
+	// The kernel's static LDS: what the decoding waves leave behind for the walking wave, per instance of the workgroup
+	struct consumer_walk_slots
+	{
+		uint32_t levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do; bit 31: its schedule is NOT in the shared LDS copy
+		const uint32_t* schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
+		uint32_t tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
+		uint32_t short_exact[k_consumer_max_instances];			// 1: every clip behind the instance's pose is k_clip_short_exact_math (or the slot has no work)
+	};
 	constexpr uint32_t k_consumer_max_waves = k_consumer_max_instances * 2;
 
 	// Launch wide facts are template arguments (each instantiation keeps only its own path: registers, code size):
@@ -246,10 +255,11 @@
 		// packed_block_shape: log2 of the instances per workgroup (bits 0..7) | words of LDS reserved for the shared walk schedule (bits 8..31)
 		const uint32_t log2_instances_per_block = packed_block_shape & 0xFFu;
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
-		__shared__ uint32_t walk_levels[k_consumer_max_instances];				// steps to walk per instance of the workgroup; 0: nothing to do; bit 31: its schedule is NOT in the shared LDS copy
-		__shared__ const uint32_t* walk_schedules[k_consumer_max_instances];	// and the schedule to follow (global memory)
-		__shared__ uint32_t walk_tracks[k_consumer_max_instances];				// transforms of each instance's pose (0: nothing to store)
-		__shared__ uint32_t walk_short_exact[k_consumer_max_instances];		// 1: every clip behind the instance's pose is k_clip_short_exact_math (or the slot has no work)
+		__shared__ consumer_walk_slots walk;		// (what the host subtracts from the LDS it may ask for: host_consumers.inl)
+		uint32_t (&walk_levels)[k_consumer_max_instances] = walk.levels;
+		const uint32_t* (&walk_schedules)[k_consumer_max_instances] = walk.schedules;
+		uint32_t (&walk_tracks)[k_consumer_max_instances] = walk.tracks;
+		uint32_t (&walk_short_exact)[k_consumer_max_instances] = walk.short_exact;
 
 		static_assert(!kUnitScale || (kObjectSpace && kBase == k_consumer_base_none), "rotation | translation images: object space without a base");
 		static_assert(!kBlend || (!kUnitScale && kBase != k_consumer_base_fused), "a blend accumulates whole qvv images; a base clip is decoded by a second wave");

@@ -495,8 +495,9 @@ typedef struct aclhip_pose_consumers
 
 /* aclhip_pose_consumers::flags. By default the consumers' kernels follow the reference's x86 arithmetic one IEEE operation at a time
  * (core/additive_utils.h:128-160 and compression/transform_pose_utils.h:35-50 through rtm::quat_mul / qvv_mul, math/quatf.h:135-211 for
- * the decode) and are BIT EXACT with the oracle; about half of a rotation's instructions are then the expansions of correctly rounded
- * square roots and divisions, and these kernels are bound by instruction issue. ACLHIP_CONSUMERS_FAST is the opt-in for callers who
+ * the decode) and are BIT EXACT with the oracle; much of a rotation's arithmetic is then correctly rounded square roots and divisions
+ * (shorter exact forms of those run for clips whose registration proved them sufficient -- the bits do not change), and
+ * these kernels keep the vector ALUs busy. ACLHIP_CONSUMERS_FAST is the opt-in for callers who
  * want the poses, not the bits: object space launches (object_space != 0, no blend) then compute the same formulas with the
  * hardware's 1 ulp square root / reciprocal square root, fused multiply-adds and quat_mul_vector3 as two cross products -- in the
  * decode of the instance and of its base, the fused additive apply and the walk. Rotations stay within 2e-6 of the default's per
