@@ -196,8 +196,10 @@ namespace
 }
 
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
-	bool validate_only = false)
+	bool validate_only = false, uint32_t* out_facts = nullptr)
 {
+	if (out_facts != nullptr)
+		*out_facts = 0;
 	if (context == nullptr || out_clip == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 	*out_clip = ACLHIP_INVALID_HANDLE;
@@ -713,6 +715,10 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 #if defined(ACLHIP_EXPERIMENTS)
 	std::memcpy(staging.data() + window_spans_offset, window_spans.data(), window_spans.size() * sizeof(window_span_entry));
 #endif
+	// aclhip_analyze_clip: what registration derives about the clip's VALUES (the kernels' variants follow from these)
+	if (out_facts != nullptr)
+		*out_facts = (short_exact_math ? ACLHIP_CLIP_FACT_SHORT_EXACT_MATH : 0u) | (raw_rotations ? ACLHIP_CLIP_FACT_RAW_ROTATIONS : 0u)
+			| (negative_scale_possible ? ACLHIP_CLIP_FACT_NEGATIVE_SCALE : 0u);
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 

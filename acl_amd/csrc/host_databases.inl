@@ -222,6 +222,15 @@ extern "C" aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64
 	return report(scratch, guarded(&scratch, [&]() { return register_clip_impl(&scratch, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, &unused, true); }), out_message, capacity);
 }
 
+extern "C" aclhip_status aclhip_analyze_clip(const void* compressed_tracks, uint64_t size, int check_hash, uint32_t* out_facts)
+{
+	if (out_facts == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	aclhip_context scratch;		// no device is touched
+	aclhip_clip unused = ACLHIP_INVALID_HANDLE;
+	return guarded(&scratch, [&]() { return register_clip_impl(&scratch, compressed_tracks, size, check_hash, ACLHIP_INVALID_HANDLE, &unused, true, out_facts); });
+}
+
 extern "C" aclhip_status aclhip_check_database(const void* compressed_database, uint64_t size, const void* bulk_data_medium, const void* bulk_data_low,
 	int check_hash, char* out_message, uint32_t capacity)
 {

@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
     "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
-    "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch",
+    "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch", "aclhip_analyze_clip",
 ]
 
 
@@ -183,6 +183,7 @@ def load_library():
     lib.aclhip_database_stream_in.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_database_stream_out.argtypes = [vp, u32, u32, u32, vp, ctypes.POINTER(u32)]
     lib.aclhip_check_clip.argtypes = [vp, u64, i32, ctypes.c_char_p, u32]
+    lib.aclhip_analyze_clip.argtypes = [vp, u64, i32, ctypes.POINTER(ctypes.c_uint32)]
     lib.aclhip_check_database.argtypes = [vp, u64, vp, vp, i32, ctypes.c_char_p, u32]
     lib.aclhip_decompress_all_samples.argtypes = [vp, u32, pparams, vp, vp, u64, vp]
     lib.aclhip_all_gather_poses.argtypes = [vp, vp, vp, vp, u64, vp]
@@ -227,6 +228,19 @@ def check_clip(blob, check_hash=True):
     message = ctypes.create_string_buffer(512)
     status = load_library().aclhip_check_clip(array.ctypes.data, array.size, 1 if check_hash else 0, message, 512)
     return status, message.value.decode()
+
+
+CLIP_FACT_SHORT_EXACT_MATH, CLIP_FACT_RAW_ROTATIONS, CLIP_FACT_NEGATIVE_SCALE = 1, 2, 4
+
+
+def analyze_clip(blob, check_hash=True):
+    """Host only: what registration derives about the values a clip can decode to (aclhip_analyze_clip). Returns the CLIP_FACT_* bits."""
+    array = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob
+    facts = ctypes.c_uint32(0)
+    status = load_library().aclhip_analyze_clip(array.ctypes.data, array.size, 1 if check_hash else 0, ctypes.byref(facts))
+    if status != 0:
+        raise AclHipError(status, "aclhip_analyze_clip")
+    return int(facts.value)
 
 
 def check_database(database, bulk_data_medium=None, bulk_data_low=None, check_hash=True):

@@ -203,6 +203,20 @@ aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip cl
  * rest is here because the device reads through these offsets. */
 aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, int check_hash, char* out_message, uint32_t capacity);
 
+/* Host only, like aclhip_check_clip: what registration derives about the VALUES a (valid) clip can decode to, which decides the kernel
+ * variants its instances run -- for tools ("do my clips take the short arithmetic?") and tests. Bits of *out_facts:
+ *   ACLHIP_CLIP_FACT_SHORT_EXACT_MATH  no quantized rotation sample can hand the kernels a square root argument in (0, 2^-96) or a
+ *                                      norm outside [2^-126, 2^126]: the short correctly rounded square root / reciprocal run
+ *                                      (same bits, fewer instructions: DESIGN.md 4.1);
+ *   ACLHIP_CLIP_FACT_RAW_ROTATIONS     some rotation sub-track is stored raw (fp32) in some segment;
+ *   ACLHIP_CLIP_FACT_NEGATIVE_SCALE    some scale may decode to a negative component: the pose consumers compile rtm::qvv_mul's
+ *                                      matrix route in while such a clip is registered.
+ * Scalar track lists: 0. No reference counterpart (the reference has one code path). */
+#define ACLHIP_CLIP_FACT_SHORT_EXACT_MATH 1u
+#define ACLHIP_CLIP_FACT_RAW_ROTATIONS 2u
+#define ACLHIP_CLIP_FACT_NEGATIVE_SCALE 4u
+aclhip_status aclhip_analyze_clip(const void* compressed_tracks, uint64_t size, int check_hash, uint32_t* out_facts);
+
 /* Replaces decompression_context::is_bound_to(const compressed_tracks&) (decompress.h:138): true when `clip`
  * was registered from a blob with the same hash and size. */
 aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches);
