@@ -571,9 +571,11 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	// sqrt_rn_short / rcp_rn_short (aclhip_device.h) give the bits of sqrtf / 1.0f / x on x == 0 or x >= 2^-96, and on 2^-126 <= x <=
 	// 2^126 (checked on every float, tools/probes/exact_math_probe.hip); the compiler's general forms cost 16 / 11 instructions instead
 	// of 9 / 5 because they also cover what lies outside. Whether a clip can ever hand the kernels such an argument is decided HERE,
-	// once: W^2 = |((1 - x^2) - y^2) - z^2| lands in (0, 2^-96) only through exact cancellation followed by the square of a component
-	// below 2^-48 (a difference of two floats is a multiple of the smaller one's ulp) -- so a clip none of whose animated rotation
-	// components can decode to a NONZERO value below 2^-32 in magnitude, and whose values are bounded, is safe; the norms the
+	// once. With a = fl(1 - x^2), b = fl(a - y^2), c = fl(b - z^2), W^2 = |c|: a nonzero difference of two floats is a multiple of the
+	// smaller one's ulp, so a is 0 or >= 2^-24; b can only be small when a and y^2 nearly cancel (both >= 2^-24: |b| = 0 or >= 2^-48) or
+	// when a == 0 (b = -y^2); c likewise is 0, a multiple of an ulp >= 2^-72, or the plain sum -(|b| + z^2). So |c| lands in (0, 2^-96)
+	// only as the square of a component of magnitude below 2^-48 behind an EXACT cancellation in front of it -- a clip none of whose
+	// animated rotation components can decode to a NONZERO value below 2^-47 in magnitude, and whose values are bounded, is safe; the norms the
 	// normalize and the object space walk meet are then within [0.49, 2^41]. A component's decoded value is a monotone function of its
 	// quantized field (rounding is monotone, the extents are checked non negative), so the two field values next to its zero
 	// crossing decide: two binary searches per (segment, rotation, component). Ranges that are negative, not finite or huge and
@@ -584,7 +586,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	bool short_exact_math = true, raw_rotations = false;
 	if (num_tracks != 0)
 	{
-		constexpr float k_tiny = 2.3283064365386963e-10f;		// 2^-32
+		constexpr float k_tiny = 7.1054273576010019e-15f;		// 2^-47 (a binade above what the argument needs)
 		constexpr float k_huge = 1048576.0f;					// 2^20
 		const auto decoded = [](const plan_entry& entry, const clip_range_entry& range, uint32_t c, uint32_t field)
 		{

@@ -74,7 +74,7 @@ def test_clips_that_can_reach_the_gap_are_refused():
     assert runtime.analyze_clip(clip.blob) & runtime.CLIP_FACT_SHORT_EXACT_MATH
     cases = {
         "x = 1 next to y = 1e-20: W^2 = 1e-40": ((1.0, 1.0e-20, 0.0), (0.0, 0.0, 0.0)),
-        "a range that crosses zero in steps of 1e-12": ((-1.0e-9, 0.0, 0.0), (2.0e-9, 0.5, 0.5)),
+        "a range that crosses zero in steps of 6e-15 and less": ((-1.0e-13, 0.0, 0.0), (2.0e-13, 0.5, 0.5)),
         "a tiny negative value": ((0.1, -1.0e-15, 0.2), (0.0, 0.0, 0.0)),
         "a negative extent (the decoded values are no longer ordered)": ((0.5, 0.1, 0.1), (-0.25, 0.1, 0.1)),
         "a range that is not a number": ((np.nan, 0.0, 0.0), (0.1, 0.1, 0.1)),
@@ -88,7 +88,8 @@ def test_clips_that_can_reach_the_gap_are_refused():
         facts = runtime.analyze_clip(patched, check_hash=False)
         assert not facts & runtime.CLIP_FACT_SHORT_EXACT_MATH, name
     # ... while ranges that stay away from zero, or sit exactly on it, keep the fact
-    for name, (minimum, extent) in {"exact zeros": ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), "small but not tiny": ((1.0e-6, -1.0e-6, 0.3), (0.0, 0.0, 0.1))}.items():
+    for name, (minimum, extent) in {"exact zeros": ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), "small but not tiny": ((1.0e-6, -1.0e-6, 0.3), (0.0, 0.0, 0.1)),
+                                    "the noise of a hinge joint's idle axes: +- 1e-7 in steps of 1e-11 or so": ((-1.0000001e-7, -1.0000003e-7, -0.5), (2.0e-7, 2.0e-7, 1.0))}.items():
         facts = runtime.analyze_clip(_patched(clip, 1, minimum, extent), check_hash=False)
         assert facts & runtime.CLIP_FACT_SHORT_EXACT_MATH, name
 

@@ -31,7 +31,8 @@ group = min(4, num_animated_rotations)
 base = 32 + clip_range_offset
 values = blob[base: base + 6 * group * 4].view(np.float32)
 # the first animated rotation: min = (1, 1e-20, 0), extent = 0: every key decodes to x = 1 exactly, y = 1e-20, z = 0
-values[0 * group], values[1 * group], values[2 * group] = 1.0, 1.0e-20, 0.0
+import os
+values[0 * group], values[1 * group], values[2 * group] = 1.0, float(os.environ.get("ACLHIP_TEST_TINY_COMPONENT", "1.0e-20")), 0.0
 values[3 * group], values[4 * group], values[5 * group] = 0.0, 0.0, 0.0
 aligned = synth.aligned_bytes(blob.size)
 aligned[:] = blob
@@ -46,7 +47,7 @@ with runtime.Context(0) as context:
         expected = ob.oracle_decompress_tracks(aligned, float(t))
         exact = exact and np.array_equal(poses[i].view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]], expected.view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]])
         tiny_w += int(np.any((np.abs(expected[:, 3]) > 0) & (np.abs(expected[:, 3]) < 1e-15)))
-    print("TINY_W", tiny_w, "EXACT", int(exact))
+    print("TINY_W", tiny_w, "EXACT", int(exact), "SHORT", runtime.analyze_clip(aligned, check_hash=False) & runtime.CLIP_FACT_SHORT_EXACT_MATH)
 """
 
 
@@ -56,18 +57,26 @@ def _run(extra_env):
     assert completed.returncode == 0, completed.stderr[-2000:]
     line = next(l for l in completed.stdout.splitlines() if l.startswith("TINY_W"))
     fields = line.split()
-    return int(fields[1]), int(fields[3])
+    return int(fields[1]), int(fields[3]), int(fields[5])
 
 
 def test_a_clip_that_reaches_the_gap_of_the_short_forms_is_recognised():
-    tiny_w, exact = _run({})
+    tiny_w, exact, short = _run({})
     assert tiny_w > 0                   # the clip does what it was built for: W = sqrt(1e-40)
+    assert short == 0                   # ... registration sees it ...
     assert exact == 1                   # ... and its poses are the oracle's bit for bit (the compiler's square root ran)
 
 
 def test_the_analysis_is_what_keeps_the_bits():
-    tiny_w, exact = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
+    tiny_w, exact, _ = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
     assert tiny_w > 0 and exact == 0    # overruled: the short form meets an argument below 2^-96 and rounds it differently
+
+
+def test_the_smallest_components_the_analysis_lets_through_are_safe():
+    """x = 1 exactly next to y = 1e-14 (just above the 2^-47 the analysis asks of a nonzero component): W^2 = 1e-28 behind an exact
+    cancellation, still >= 2^-96 -- the clip keeps the short forms and its poses the oracle's bits"""
+    tiny_w, exact, short = _run({"ACLHIP_TEST_TINY_COMPONENT": "1.0e-14"})
+    assert tiny_w > 0 and short != 0 and exact == 1
 
 
 @pytest.mark.parametrize("normalization", [0, 1])
