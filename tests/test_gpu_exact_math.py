@@ -46,7 +46,7 @@ with runtime.Context(0) as context:
     for i, t in enumerate(times):
         expected = ob.oracle_decompress_tracks(aligned, float(t))
         exact = exact and np.array_equal(poses[i].view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]], expected.view(np.uint32)[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]])
-        tiny_w += int(np.any((np.abs(expected[:, 3]) > 0) & (np.abs(expected[:, 3]) < 1e-15)))
+        tiny_w += int(np.any((np.abs(expected[:, 3]) > 0) & (np.abs(expected[:, 3]) < 1e-13)))
     print("TINY_W", tiny_w, "EXACT", int(exact), "SHORT", runtime.analyze_clip(aligned, check_hash=False) & runtime.CLIP_FACT_SHORT_EXACT_MATH)
 """
 
