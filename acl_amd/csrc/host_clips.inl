@@ -583,7 +583,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	// float) are not judged here: a wave that meets one takes the compiler's forms anyway (kHasRaw), and k_clip_raw_rotations tells the
 	// object space walk that this clip's rotations are only as good as their normalization. Either way the poses are bit identical
 	// to the reference's.
-	bool short_exact_math = true, raw_rotations = false;
+	bool short_exact_math = true, raw_rotations = false, grid_has_tiny_values = false;
 	if (num_tracks != 0)
 	{
 		constexpr float k_tiny = 7.1054273576010019e-15f;		// 2^-47 (a binade above what the argument needs)
@@ -638,8 +638,55 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 					};
 					const uint32_t first_positive = first_field(true), first_non_negative = first_field(false);
 					if (first_positive <= max_field && decoded(entry, range, c, first_positive) < k_tiny)
-						short_exact_math = false;
+						grid_has_tiny_values = true;
 					if (first_non_negative > 0 && decoded(entry, range, c, first_non_negative - 1) > -k_tiny)
+						grid_has_tiny_values = true;
+				}
+			}
+		}
+		// The grid holds a value within 2^-47 of zero (the idle axes of a hinge joint: +-1e-7 of noise in steps of 1e-11): that no SAMPLE
+		// need ever take. The exact criterion then, on the key frames the clip actually stores: W^2 of every one of them, computed the way
+		// the kernels do, is 0 or >= 2^-96. (A millisecond for a 300-bone clip, paid only by clips the grid test refuses. Key frames that
+		// live in a database are not in this buffer: such clips stay refused.)
+		if (short_exact_math && grid_has_tiny_values)
+		{
+			short_exact_math = !header.has_database();
+			constexpr float k_gap = 1.2621774483536189e-29f;		// 2^-96
+			const auto read_field = [&](uint64_t bit, uint32_t num_bits) -> uint32_t
+			{
+				// num_bits <= 23 big endian bits at any bit address of the blob (bytes past its end read as zero)
+				uint64_t window = 0;
+				for (uint32_t i = 0; i < 5; ++i)
+				{
+					const uint64_t byte = (bit >> 3) + i;
+					window = (window << 8) | (byte < blob_size ? blob[byte] : 0u);
+				}
+				return uint32_t((window >> (40u - (bit & 7u) - num_bits)) & ((uint64_t(1) << num_bits) - 1u));
+			};
+			for (uint32_t sample = 0; sample < num_samples && short_exact_math; ++sample)
+			{
+				const sample_record& record = samples[sample];
+				const uint32_t si = record.segment_and_local >> 5, local = record.segment_and_local & 31u;
+				// (stripped key frames: bit `31 - local` of sample_indices says whether this one is stored, the ones in front of it where)
+				if ((record.sample_indices & (0x80000000u >> local)) == 0)
+					continue;
+				const uint32_t stored_ordinal = uint32_t(__builtin_popcount(record.sample_indices & ~(0xFFFFFFFFu >> local)));
+				const uint64_t key_frame_bit = uint64_t(record.animated_offset) * 8 + uint64_t(stored_ordinal) * record.pose_bit_size;
+				for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
+				{
+					const clip_range_entry& range = clip_ranges[a];
+					if (range.quad_index != range.track_index * 3)
+						continue;
+					const plan_entry& entry = plan[size_t(si) * num_animated + a];
+					const uint32_t num_bits = entry.bit_offset_and_width >> 24;
+					if (num_bits == 32)
+						continue;
+					float value[3];
+					for (uint32_t c = 0; c < 3; ++c)
+						value[c] = decoded(entry, range, c, num_bits == 0 ? 0u : read_field(key_frame_bit + (entry.bit_offset_and_width & 0x00FFFFFFu) + uint64_t(c) * num_bits, num_bits));
+					// quat_from_positive_w (math/quatf.h:135-147), one rounding per operation
+					const float w_squared = std::fabs(((1.0f - value[0] * value[0]) - value[1] * value[1]) - value[2] * value[2]);
+					if (w_squared > 0.0f && w_squared < k_gap)
 						short_exact_math = false;
 				}
 			}

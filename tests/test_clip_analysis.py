@@ -74,8 +74,7 @@ def test_clips_that_can_reach_the_gap_are_refused():
     assert runtime.analyze_clip(clip.blob) & runtime.CLIP_FACT_SHORT_EXACT_MATH
     cases = {
         "x = 1 next to y = 1e-20: W^2 = 1e-40": ((1.0, 1.0e-20, 0.0), (0.0, 0.0, 0.0)),
-        "a range that crosses zero in steps of 6e-15 and less": ((-1.0e-13, 0.0, 0.0), (2.0e-13, 0.5, 0.5)),
-        "a tiny negative value": ((0.1, -1.0e-15, 0.2), (0.0, 0.0, 0.0)),
+        "x = 1 next to z = 1e-16 behind y = 0: W^2 = 1e-32": ((1.0, 0.0, 1.0e-16), (0.0, 0.0, 0.0)),
         "a negative extent (the decoded values are no longer ordered)": ((0.5, 0.1, 0.1), (-0.25, 0.1, 0.1)),
         "a range that is not a number": ((np.nan, 0.0, 0.0), (0.1, 0.1, 0.1)),
         "an infinite extent": ((0.0, 0.0, 0.0), (np.inf, 0.1, 0.1)),
@@ -87,11 +86,35 @@ def test_clips_that_can_reach_the_gap_are_refused():
         assert status == 0, (name, message)
         facts = runtime.analyze_clip(patched, check_hash=False)
         assert not facts & runtime.CLIP_FACT_SHORT_EXACT_MATH, name
-    # ... while ranges that stay away from zero, or sit exactly on it, keep the fact
+    # ... while ranges that stay away from zero, or sit exactly on it, keep the fact -- and so do ranges whose GRID holds values next
+    # to zero as long as no stored key frame turns one into a square root argument in the gap (the second, exact test of registration)
     for name, (minimum, extent) in {"exact zeros": ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0)), "small but not tiny": ((1.0e-6, -1.0e-6, 0.3), (0.0, 0.0, 0.1)),
+                                    "a range that crosses zero in steps of 6e-15 and less": ((-1.0e-13, 0.0, 0.0), (2.0e-13, 0.5, 0.5)),
+                                    "a tiny negative value next to ordinary ones": ((0.1, -1.0e-15, 0.2), (0.0, 0.0, 0.0)),
                                     "the noise of a hinge joint's idle axes: +- 1e-7 in steps of 1e-11 or so": ((-1.0000001e-7, -1.0000003e-7, -0.5), (2.0e-7, 2.0e-7, 1.0))}.items():
         facts = runtime.analyze_clip(_patched(clip, 1, minimum, extent), check_hash=False)
         assert facts & runtime.CLIP_FACT_SHORT_EXACT_MATH, name
+
+
+@pytest.mark.parametrize("num_samples", [20, 100])
+def test_the_exact_test_agrees_with_brute_force_on_the_stored_key_frames(num_samples):
+    """Grids with values next to zero send registration to its second test: W^2 of every stored key frame. Same verdict as the oracle's
+    decode of every key frame (several segments at 100 samples)."""
+    clip = synth.build_clip(seed=78, num_tracks=9, num_samples=num_samples, rotation_default=0.0, rotation_constant=0.0, raw_fraction=0.0, width0_fraction=0.0)
+    one_below = float(np.nextafter(np.float32(1.0), np.float32(0.0)))
+    for minimum, extent in (((1.0, 0.0, 0.0), (0.0, 0.0, 1.0e-15)),            # z in [0, 1e-15] behind an exact cancellation: in the gap unless z == 0
+                            ((1.0, 0.0, 0.0), (0.0, 0.0, 0.0)),                # W^2 == 0
+                            ((one_below, 0.0, 0.0), (0.0, 0.0, 1.0e-15)),      # no cancellation: W^2 = 1.2e-7
+                            ((0.6, 0.8, 0.0), (0.0, 0.0, 1.0e-15)),            # fl(1 - 0.36) - 0.64 does not cancel exactly in fp32
+                            ((-1.0e-13, -1.0e-13, -1.0e-13), (2.0e-13, 2.0e-13, 2.0e-13))):
+        patched = _patched(clip, 2, minimum, extent)
+        facts = runtime.analyze_clip(patched, check_hash=False)
+
+        class Patched:
+            blob, spec, duration = patched, clip.spec, clip.duration
+        arguments = _square_root_arguments(Patched)
+        in_gap = bool(np.any((arguments > 0) & (arguments < GAP)))
+        assert bool(facts & runtime.CLIP_FACT_SHORT_EXACT_MATH) == (not in_gap), (minimum, extent, in_gap)
 
 
 def test_negative_scales_and_scalar_lists():

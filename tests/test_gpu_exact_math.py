@@ -32,7 +32,7 @@ base = 32 + clip_range_offset
 values = blob[base: base + 6 * group * 4].view(np.float32)
 # the first animated rotation: min = (1, 1e-20, 0), extent = 0: every key decodes to x = 1 exactly, y = 1e-20, z = 0
 import os
-values[0 * group], values[1 * group], values[2 * group] = 1.0, float(os.environ.get("ACLHIP_TEST_TINY_COMPONENT", "1.0e-20")), 0.0
+values[0 * group], values[1 * group], values[2 * group] = float(os.environ.get("ACLHIP_TEST_X", "1.0")), float(os.environ.get("ACLHIP_TEST_TINY_COMPONENT", "1.0e-20")), 0.0
 values[3 * group], values[4 * group], values[5 * group] = 0.0, 0.0, 0.0
 aligned = synth.aligned_bytes(blob.size)
 aligned[:] = blob
@@ -109,3 +109,11 @@ def test_raw_rotations_reach_the_walk_bit_exact(normalization):
             assert helpers.exact(plain[i], local), i
             assert helpers.exact(got[i], ob.oracle_local_to_object_space(parents, local)), i
         assert context.rejected_instance_count() == 0
+
+
+def test_a_grid_next_to_zero_whose_key_frames_stay_out_of_the_gap_keeps_the_short_forms():
+    """y = 1e-20 again, but next to x = 1 - 2^-24: no exact cancellation in front of it, W^2 = 1.2e-7. The grid test of registration
+    refuses (a value within 2^-47 of zero), its exact test on the stored key frames accepts -- and the poses are the oracle's bits"""
+    tiny_w, exact, short = _run({"ACLHIP_TEST_X": repr(float(np.nextafter(np.float32(1.0), np.float32(0.0))))})
+    assert short != 0 and exact == 1
+
