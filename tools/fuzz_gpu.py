@@ -97,8 +97,50 @@ def main():
                         print("CONSUMER MISMATCH", spec, "instance", i, kwargs["object_space"], additive_format, "rounding", rounding, "looping", looping, "normalization", normalization)
                         return 1
                 checks += n
+            # single bone requests (decompress_track): the whole pose's bits
+            if tracks > 0:
+                wanted = rng.integers(0, tracks, size=n)
+                single = context.decompress_track(handles[which], times, wanted, params=params)
+                for i in range(n):
+                    expected = ob.oracle_decompress_tracks(clips[which[i]].blob, float(times[i]), rounding, options)[wanted[i]]
+                    if not same(single[i], expected):
+                        print("TRACK MISMATCH", spec, "instance", i, "track", int(wanted[i]), "rounding", rounding, "looping", looping, "normalization", normalization)
+                        return 1
+                checks += n
+            # a blend of 2 .. 4 clip instances (both clips have the same tracks)
+            if normalization != 2 and tracks <= 700 and rng.uniform() < 0.5:
+                k = int(rng.integers(2, 5))
+                others = rng.integers(0, 2, size=(n, k - 1))
+                other_times = np.array([[rng.uniform(0.0, clips[w].duration) for w in row] for row in others], dtype=np.float32)
+                weights = rng.dirichlet(np.ones(k), size=n).astype(np.float32)
+                object_space = bool(rng.integers(0, 2))
+                got = context.decompress_poses(handles[which], times, params=params, object_space=object_space,
+                                               blend_clips=handles[others], blend_sample_times=other_times, blend_weights=weights)
+                expected = ob.oracle_decompress_blended_poses_batch([c.blob for c in clips], which, times, others, other_times, weights, tracks,
+                                                                    parent_indices=parents if object_space else None, rounding=rounding, options=options)
+                for i in range(n):
+                    if not same(got[i], expected[i]):
+                        print("BLEND MISMATCH", spec, "instance", i, "k", k, object_space, "rounding", rounding, "looping", looping, "normalization", normalization)
+                        return 1
+                checks += n
             for handle in handles:
                 context.unregister_clip(int(handle))
+            # a scalar track list now and then
+            if rng.uniform() < 0.3:
+                scalar_spec = dict(seed=int(rng.integers(1, 1 << 30)), track_type=int(rng.integers(0, 5)), num_tracks=int(rng.choice([1, 3, 64, 65, 256, 300, 1000])),
+                                   num_samples=int(rng.choice([1, 2, 30, 200])), raw_fraction=float(rng.choice([0.0, 0.05, 0.3])), wrap=int(rng.integers(0, 2)))
+                curves = synth.build_scalar_clip(**scalar_spec)
+                handle = context.register_clip(curves.blob)
+                count = int(rng.integers(1, 30))
+                curve_times = rng.uniform(-0.1, curves.duration + 0.1, size=count).astype(np.float32)
+                values = context.decompress_scalar_tracks(np.full(count, handle, dtype=np.uint32), curve_times, params=params)
+                for i in range(count):
+                    expected = ob.oracle_scalar_decompress_tracks(curves.blob, float(curve_times[i]), rounding, options)
+                    if not same(values[i, : curves.num_tracks], expected):
+                        print("SCALAR MISMATCH", scalar_spec, "instance", i, "time", curve_times[i], "rounding", rounding, "looping", looping)
+                        return 1
+                checks += count
+                context.unregister_clip(handle)
             rounds += 1
         print(f"fuzz ok: {rounds} clip pairs, {checks} poses checked, rejected {common.rejected_instance_count() + generic.rejected_instance_count()}")
     return 0
