@@ -193,6 +193,149 @@ namespace
 			return fail(context, ACLHIP_ERROR_DEVICE, "uploading a database's clip list failed");
 		return ACLHIP_OK;
 	}
+
+	// ---- What the VALUES of a clip's rotations allow the kernels: may they use the SHORT correctly rounded square root / reciprocal? ----
+	// sqrt_rn_short / rcp_rn_short (aclhip_device.h) give the bits of sqrtf / 1.0f / x on x == 0 or x >= 2^-96, and on 2^-126 <= x <=
+	// 2^126 (checked on every float, tools/probes/exact_math_probe.hip); the compiler's general forms cost 16 / 11 instructions instead
+	// of 9 / 5 because they also cover what lies outside. Whether a clip can ever hand the kernels such an argument is decided HERE,
+	// once. With a = fl(1 - x^2), b = fl(a - y^2), c = fl(b - z^2), W^2 = |c|: a nonzero difference of two floats is a multiple of the
+	// smaller one's ulp, so a is 0 or >= 2^-24; b can only be small when a and y^2 nearly cancel (both >= 2^-24: |b| = 0 or >= 2^-48) or
+	// when a == 0 (b = -y^2); c likewise is 0, a multiple of an ulp >= 2^-72, or the plain sum -(|b| + z^2). So |c| lands in (0, 2^-96)
+	// only as the square of a component of magnitude below 2^-48 behind an EXACT cancellation in front of it -- a clip none of whose
+	// animated rotation components can decode to a NONZERO value below 2^-47 in magnitude, and whose values are bounded, is safe; the norms the
+	// normalize and the object space walk meet are then within [0.49, 2^41]. A component's decoded value is a monotone function of its
+	// quantized field (rounding is monotone, the extents are checked non negative), so the two field values next to its zero
+	// crossing decide: two binary searches per (segment, rotation, component). Ranges that are negative, not finite or huge and
+	// constant rotations beyond 2^20 make the clip "not provably safe": its waves take the compiler's forms. Samples stored RAW (any
+	// float) are not judged here: a wave that meets one takes the compiler's forms anyway (kHasRaw), and k_clip_raw_rotations tells the
+	// object space walk that this clip's rotations are only as good as their normalization. Either way the poses are bit identical
+	// to the reference's.
+	struct rotation_value_facts
+	{
+		bool short_exact_math;		// -> k_clip_short_exact_math
+		bool raw_rotations;			// -> k_clip_raw_rotations
+	};
+	rotation_value_facts analyze_rotation_values(const uint8_t* blob, uint32_t blob_size, bool key_frames_in_a_database, uint32_t num_tracks, uint32_t num_samples, uint32_t num_segments,
+		uint32_t num_animated, const std::vector<plan_entry>& plan, const std::vector<clip_range_entry>& clip_ranges, const std::vector<sample_record>& samples, const std::vector<float>& base_pose)
+	{
+		bool short_exact_math = true, raw_rotations = false, grid_has_tiny_values = false;
+		if (num_tracks != 0)
+		{
+			constexpr float k_tiny = 7.1054273576010019e-15f;		// 2^-47 (a binade above what the argument needs)
+			constexpr float k_huge = 1048576.0f;					// 2^20
+			const auto decoded = [](const plan_entry& entry, const clip_range_entry& range, uint32_t c, uint32_t field)
+			{
+				// the kernels' own operations, in their order (unpack_animated_samples, aclhip_device.h)
+				const float quantized = float(field) * entry.inv_max_value;
+				const float segment_value = (quantized * entry.range_extent[c]) + entry.range_min[c];
+				return (segment_value * range.range_extent[c]) + range.range_min[c];
+			};
+			for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
+			{
+				const clip_range_entry& range = clip_ranges[a];
+				if (range.quad_index != range.track_index * 3)
+					continue;
+				for (uint32_t si = 0; si < num_segments && short_exact_math; ++si)
+				{
+					const plan_entry& entry = plan[size_t(si) * num_animated + a];
+					const uint32_t num_bits = entry.bit_offset_and_width >> 24;
+					if (num_bits == 32)
+					{
+						// any floats: a wave that meets a raw sample takes the compiler's forms (decode_animated_sub_track<kHasRaw = true>);
+						// the rest of the clip is judged on its quantized samples
+						raw_rotations = true;
+						continue;
+					}
+					const uint32_t max_field = num_bits == 0 ? 0u : (1u << num_bits) - 1u;
+					for (uint32_t c = 0; c < 3 && short_exact_math; ++c)
+					{
+						const bool ordered = entry.range_extent[c] >= 0.0f && range.range_extent[c] >= 0.0f && std::isfinite(entry.range_min[c]) && std::isfinite(range.range_min[c]);
+						const float lowest = decoded(entry, range, c, 0), highest = decoded(entry, range, c, max_field);
+						if (!ordered || !(std::fabs(lowest) <= k_huge) || !(std::fabs(highest) <= k_huge))
+						{
+							short_exact_math = false;
+							break;
+						}
+						// the smallest field that decodes to a value > 0 / >= 0 (max_field + 1: none)
+						const auto first_field = [&](bool strictly)
+						{
+							uint32_t low = 0, high = max_field + 1;
+							while (low < high)
+							{
+								const uint32_t middle = low + (high - low) / 2;
+								const float value = decoded(entry, range, c, middle);
+								if (strictly ? value > 0.0f : value >= 0.0f)
+									high = middle;
+								else
+									low = middle + 1;
+							}
+							return low;
+						};
+						const uint32_t first_positive = first_field(true), first_non_negative = first_field(false);
+						if (first_positive <= max_field && decoded(entry, range, c, first_positive) < k_tiny)
+							grid_has_tiny_values = true;
+						if (first_non_negative > 0 && decoded(entry, range, c, first_non_negative - 1) > -k_tiny)
+							grid_has_tiny_values = true;
+					}
+				}
+			}
+			// The grid holds a value within 2^-47 of zero (the idle axes of a hinge joint: +-1e-7 of noise in steps of 1e-11): that no SAMPLE
+			// need ever take. The exact criterion then, on the key frames the clip actually stores: W^2 of every one of them, computed the way
+			// the kernels do, is 0 or >= 2^-96. (A millisecond for a 300-bone clip, paid only by clips the grid test refuses. Key frames that
+			// live in a database are not in this buffer: such clips stay refused.)
+			if (short_exact_math && grid_has_tiny_values)
+			{
+				short_exact_math = !key_frames_in_a_database;
+				constexpr float k_gap = 1.2621774483536189e-29f;		// 2^-96
+				const auto read_field = [&](uint64_t bit, uint32_t num_bits) -> uint32_t
+				{
+					// num_bits <= 23 big endian bits at any bit address of the blob (bytes past its end read as zero)
+					uint64_t window = 0;
+					for (uint32_t i = 0; i < 5; ++i)
+					{
+						const uint64_t byte = (bit >> 3) + i;
+						window = (window << 8) | (byte < blob_size ? blob[byte] : 0u);
+					}
+					return uint32_t((window >> (40u - (bit & 7u) - num_bits)) & ((uint64_t(1) << num_bits) - 1u));
+				};
+				for (uint32_t sample = 0; sample < num_samples && short_exact_math; ++sample)
+				{
+					const sample_record& record = samples[sample];
+					const uint32_t si = record.segment_and_local >> 5, local = record.segment_and_local & 31u;
+					// (stripped key frames: bit `31 - local` of sample_indices says whether this one is stored, the ones in front of it where)
+					if ((record.sample_indices & (0x80000000u >> local)) == 0)
+						continue;
+					const uint32_t stored_ordinal = uint32_t(__builtin_popcount(record.sample_indices & ~(0xFFFFFFFFu >> local)));
+					const uint64_t key_frame_bit = uint64_t(record.animated_offset) * 8 + uint64_t(stored_ordinal) * record.pose_bit_size;
+					for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
+					{
+						const clip_range_entry& range = clip_ranges[a];
+						if (range.quad_index != range.track_index * 3)
+							continue;
+						const plan_entry& entry = plan[size_t(si) * num_animated + a];
+						const uint32_t num_bits = entry.bit_offset_and_width >> 24;
+						if (num_bits == 32)
+							continue;
+						float value[3];
+						for (uint32_t c = 0; c < 3; ++c)
+							value[c] = decoded(entry, range, c, num_bits == 0 ? 0u : read_field(key_frame_bit + (entry.bit_offset_and_width & 0x00FFFFFFu) + uint64_t(c) * num_bits, num_bits));
+						// quat_from_positive_w (math/quatf.h:135-147), one rounding per operation
+						const float w_squared = std::fabs(((1.0f - value[0] * value[0]) - value[1] * value[1]) - value[2] * value[2]);
+						if (w_squared > 0.0f && w_squared < k_gap)
+							short_exact_math = false;
+					}
+				}
+			}
+			for (uint32_t track = 0; track < num_tracks && short_exact_math; ++track)
+			{
+				const float* value = &base_pose[size_t(track * 3) * 4];
+				const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
+				if (int32_t(marker) >= 0)		// a constant rotation (W rebuilt above with the host's sqrtf)
+					short_exact_math = std::fabs(value[0]) <= k_huge && std::fabs(value[1]) <= k_huge && std::fabs(value[2]) <= k_huge;
+			}
+		}
+		return { short_exact_math, raw_rotations };
+	}
 }
 
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
@@ -567,138 +710,10 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 	}
 
-	// ---- may the kernels use the SHORT correctly rounded square root / reciprocal on this clip's rotations? ----
-	// sqrt_rn_short / rcp_rn_short (aclhip_device.h) give the bits of sqrtf / 1.0f / x on x == 0 or x >= 2^-96, and on 2^-126 <= x <=
-	// 2^126 (checked on every float, tools/probes/exact_math_probe.hip); the compiler's general forms cost 16 / 11 instructions instead
-	// of 9 / 5 because they also cover what lies outside. Whether a clip can ever hand the kernels such an argument is decided HERE,
-	// once. With a = fl(1 - x^2), b = fl(a - y^2), c = fl(b - z^2), W^2 = |c|: a nonzero difference of two floats is a multiple of the
-	// smaller one's ulp, so a is 0 or >= 2^-24; b can only be small when a and y^2 nearly cancel (both >= 2^-24: |b| = 0 or >= 2^-48) or
-	// when a == 0 (b = -y^2); c likewise is 0, a multiple of an ulp >= 2^-72, or the plain sum -(|b| + z^2). So |c| lands in (0, 2^-96)
-	// only as the square of a component of magnitude below 2^-48 behind an EXACT cancellation in front of it -- a clip none of whose
-	// animated rotation components can decode to a NONZERO value below 2^-47 in magnitude, and whose values are bounded, is safe; the norms the
-	// normalize and the object space walk meet are then within [0.49, 2^41]. A component's decoded value is a monotone function of its
-	// quantized field (rounding is monotone, the extents are checked non negative), so the two field values next to its zero
-	// crossing decide: two binary searches per (segment, rotation, component). Ranges that are negative, not finite or huge and
-	// constant rotations beyond 2^20 make the clip "not provably safe": its waves take the compiler's forms. Samples stored RAW (any
-	// float) are not judged here: a wave that meets one takes the compiler's forms anyway (kHasRaw), and k_clip_raw_rotations tells the
-	// object space walk that this clip's rotations are only as good as their normalization. Either way the poses are bit identical
-	// to the reference's.
-	bool short_exact_math = true, raw_rotations = false, grid_has_tiny_values = false;
-	if (num_tracks != 0)
-	{
-		constexpr float k_tiny = 7.1054273576010019e-15f;		// 2^-47 (a binade above what the argument needs)
-		constexpr float k_huge = 1048576.0f;					// 2^20
-		const auto decoded = [](const plan_entry& entry, const clip_range_entry& range, uint32_t c, uint32_t field)
-		{
-			// the kernels' own operations, in their order (unpack_animated_samples, aclhip_device.h)
-			const float quantized = float(field) * entry.inv_max_value;
-			const float segment_value = (quantized * entry.range_extent[c]) + entry.range_min[c];
-			return (segment_value * range.range_extent[c]) + range.range_min[c];
-		};
-		for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
-		{
-			const clip_range_entry& range = clip_ranges[a];
-			if (range.quad_index != range.track_index * 3)
-				continue;
-			for (uint32_t si = 0; si < num_segments && short_exact_math; ++si)
-			{
-				const plan_entry& entry = plan[size_t(si) * num_animated + a];
-				const uint32_t num_bits = entry.bit_offset_and_width >> 24;
-				if (num_bits == 32)
-				{
-					// any floats: a wave that meets a raw sample takes the compiler's forms (decode_animated_sub_track<kHasRaw = true>);
-					// the rest of the clip is judged on its quantized samples
-					raw_rotations = true;
-					continue;
-				}
-				const uint32_t max_field = num_bits == 0 ? 0u : (1u << num_bits) - 1u;
-				for (uint32_t c = 0; c < 3 && short_exact_math; ++c)
-				{
-					const bool ordered = entry.range_extent[c] >= 0.0f && range.range_extent[c] >= 0.0f && std::isfinite(entry.range_min[c]) && std::isfinite(range.range_min[c]);
-					const float lowest = decoded(entry, range, c, 0), highest = decoded(entry, range, c, max_field);
-					if (!ordered || !(std::fabs(lowest) <= k_huge) || !(std::fabs(highest) <= k_huge))
-					{
-						short_exact_math = false;
-						break;
-					}
-					// the smallest field that decodes to a value > 0 / >= 0 (max_field + 1: none)
-					const auto first_field = [&](bool strictly)
-					{
-						uint32_t low = 0, high = max_field + 1;
-						while (low < high)
-						{
-							const uint32_t middle = low + (high - low) / 2;
-							const float value = decoded(entry, range, c, middle);
-							if (strictly ? value > 0.0f : value >= 0.0f)
-								high = middle;
-							else
-								low = middle + 1;
-						}
-						return low;
-					};
-					const uint32_t first_positive = first_field(true), first_non_negative = first_field(false);
-					if (first_positive <= max_field && decoded(entry, range, c, first_positive) < k_tiny)
-						grid_has_tiny_values = true;
-					if (first_non_negative > 0 && decoded(entry, range, c, first_non_negative - 1) > -k_tiny)
-						grid_has_tiny_values = true;
-				}
-			}
-		}
-		// The grid holds a value within 2^-47 of zero (the idle axes of a hinge joint: +-1e-7 of noise in steps of 1e-11): that no SAMPLE
-		// need ever take. The exact criterion then, on the key frames the clip actually stores: W^2 of every one of them, computed the way
-		// the kernels do, is 0 or >= 2^-96. (A millisecond for a 300-bone clip, paid only by clips the grid test refuses. Key frames that
-		// live in a database are not in this buffer: such clips stay refused.)
-		if (short_exact_math && grid_has_tiny_values)
-		{
-			short_exact_math = !header.has_database();
-			constexpr float k_gap = 1.2621774483536189e-29f;		// 2^-96
-			const auto read_field = [&](uint64_t bit, uint32_t num_bits) -> uint32_t
-			{
-				// num_bits <= 23 big endian bits at any bit address of the blob (bytes past its end read as zero)
-				uint64_t window = 0;
-				for (uint32_t i = 0; i < 5; ++i)
-				{
-					const uint64_t byte = (bit >> 3) + i;
-					window = (window << 8) | (byte < blob_size ? blob[byte] : 0u);
-				}
-				return uint32_t((window >> (40u - (bit & 7u) - num_bits)) & ((uint64_t(1) << num_bits) - 1u));
-			};
-			for (uint32_t sample = 0; sample < num_samples && short_exact_math; ++sample)
-			{
-				const sample_record& record = samples[sample];
-				const uint32_t si = record.segment_and_local >> 5, local = record.segment_and_local & 31u;
-				// (stripped key frames: bit `31 - local` of sample_indices says whether this one is stored, the ones in front of it where)
-				if ((record.sample_indices & (0x80000000u >> local)) == 0)
-					continue;
-				const uint32_t stored_ordinal = uint32_t(__builtin_popcount(record.sample_indices & ~(0xFFFFFFFFu >> local)));
-				const uint64_t key_frame_bit = uint64_t(record.animated_offset) * 8 + uint64_t(stored_ordinal) * record.pose_bit_size;
-				for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
-				{
-					const clip_range_entry& range = clip_ranges[a];
-					if (range.quad_index != range.track_index * 3)
-						continue;
-					const plan_entry& entry = plan[size_t(si) * num_animated + a];
-					const uint32_t num_bits = entry.bit_offset_and_width >> 24;
-					if (num_bits == 32)
-						continue;
-					float value[3];
-					for (uint32_t c = 0; c < 3; ++c)
-						value[c] = decoded(entry, range, c, num_bits == 0 ? 0u : read_field(key_frame_bit + (entry.bit_offset_and_width & 0x00FFFFFFu) + uint64_t(c) * num_bits, num_bits));
-					// quat_from_positive_w (math/quatf.h:135-147), one rounding per operation
-					const float w_squared = std::fabs(((1.0f - value[0] * value[0]) - value[1] * value[1]) - value[2] * value[2]);
-					if (w_squared > 0.0f && w_squared < k_gap)
-						short_exact_math = false;
-				}
-			}
-		}
-		for (uint32_t track = 0; track < num_tracks && short_exact_math; ++track)
-		{
-			const float* value = &base_pose[size_t(track * 3) * 4];
-			const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
-			if (int32_t(marker) >= 0)		// a constant rotation (W rebuilt above with the host's sqrtf)
-				short_exact_math = std::fabs(value[0]) <= k_huge && std::fabs(value[1]) <= k_huge && std::fabs(value[2]) <= k_huge;
-		}
-	}
+	// ---- may the kernels use the SHORT correctly rounded square root / reciprocal on this clip's rotations? (analyze_rotation_values above) ----
+	const rotation_value_facts rotation_facts = analyze_rotation_values(blob, blob_size, header.has_database(), num_tracks, num_samples, num_segments, num_animated, plan, clip_ranges, samples, base_pose);
+	bool short_exact_math = rotation_facts.short_exact_math;
+	const bool raw_rotations = rotation_facts.raw_rotations;
 	// ACLHIP_SHORT_EXACT_MATH = 0: never (A/B measurements); 1: ALWAYS, whatever the analysis says (testing aid: shows the analysis has teeth)
 	static const int short_exact_override = []() { const char* value = std::getenv("ACLHIP_SHORT_EXACT_MATH"); return value != nullptr ? int(value[0] - '0') : -1; }();
 	if (short_exact_override == 0 || short_exact_override == 1)
