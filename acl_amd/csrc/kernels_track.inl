@@ -1,34 +1,76 @@
 // kernels_track.inl -- part of aclhip.hip (one translation unit; included there, in this order, not compiled on its own).
-// decompress_track_kernel: single (instance, bone) requests.
+// decompress_track_kernel: single (instance, bone) requests -- decompress_track_v0 (decompression/impl/decompression.transform.h:1753-2050).
+//
+// One wave64 takes 64 consecutive requests and works on them TOGETHER (round 5; until then one lane did one request start to end:
+// 41 vector loads per wave, most of them issued for a handful of active lanes, and three 16 byte stores 48 bytes apart per lane --
+// WRITE_SIZE 2.0 x the transforms, the texture unit 80 % busy, 226.6 us for 4 M requests, profiles/r04_track_requests_pmc_*.txt):
+//   1. lanes <-> requests: clip handle, sample time, track index in; when every request of the wave names the SAME clip -- a crowd of one
+//      rig, the bones of one character -- the clip record and everything derived from it live on the scalar unit (two s_loads instead of
+//      eight vector loads per lane); a wave of mixed clips reads its records per lane. The seek is per lane either way (sample times
+//      differ): two 16 byte sample records. The track's three base pose quads tell what each sub-track is: constant (the value itself),
+//      default, or animated (marker + ordinal).
+//   2. the wave's ANIMATED (request, kind) pairs -- about 0.4 per request on CMU-shaped clips, not 3 -- are counted with three ballots and
+//      packed into consecutive lanes (all rotations, then translations, then scales): lanes <-> animated sub-tracks, 64 per pass, usually
+//      ONE pass per wave instead of three sparse loops. A decode lane picks its request's seek result out of LDS, fetches its plan rows
+//      (one when both keys sit in one segment) and clip range, reads each key's bits with one aligned 16 byte load, and runs the same
+//      unpack / range / W / lerp / normalize as the pose kernels (aclhip_device.h: bit for bit the same values).
+//   3. decoded and constant quads meet in a 3 KiB LDS image of the wave's 64 transforms, which leaves as three 1 KiB contiguous
+//      streaming stores. Requests whose output is partly or wholly withheld (an unknown clip, a bad track index, default sub-tracks in
+//      the "skipped" mode, the tail of the batch) send their wave down the per lane store path instead.
+// The reference sums the widths of every preceding animated sub-track to find a track's bits (skip_*_groups +
+// count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192,1664-1707): O(track index). The registration time plan holds
+// that prefix sum.
 
-	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
-		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+	// what a decode lane needs to know about the request its sub-track belongs to: 64 bytes in LDS, as four 16 byte parts [part][request]
+	struct track_request_state
 	{
-		const uint32_t instance = blockIdx.x * k_block_size + threadIdx.x;
-		if (instance >= num_instances)
-			return;
+		const uint8_t* data[2];					// first stored keyframe of each key's data source (seek_state::animated_track_data)
+		const plan_entry* rows[2];				// the plan rows of the two keys' segments
+		const clip_range_entry* clip_ranges;
+		uint32_t bit_offsets[2];				// seek_state::key_frame_bit_offsets
+		float lerp_alpha;						// the interpolation alpha, per track rounding policy applied (decompression.transform.h:1975-1983)
+		uint32_t short_exact_math;				// the clip's k_clip_short_exact_math
+		uint32_t reserved[2];
+	};
+	static_assert(sizeof(track_request_state) == 64, "four 16 byte parts");
 
-		const uint32_t clip_id = clip_ids[instance];
-		if (clip_id >= num_clips || !is_transform_clip(clips[clip_id].flags))
-		{
-			atomicAdd(rejected_count, 1ull);
-			return;
-		}
+#if defined(ACLHIP_TRACK_NARROW_KEYS)
+	constexpr bool k_track_wide_key_loads = false;
+#else
+	constexpr bool k_track_wide_key_loads = true;
+#endif
+	constexpr uint32_t k_track_image_bytes = k_wave_size * 48;				// 64 transforms
+	constexpr uint32_t k_track_state_bytes = k_wave_size * 64;
+	constexpr uint32_t k_track_list_bytes = k_wave_size * 3 * 4;			// at most 192 animated (request, kind) pairs
+	constexpr uint32_t k_track_lds_bytes_per_wave = k_track_image_bytes + k_track_state_bytes + k_track_list_bytes;
 
-		const device_clip& clip = clips[clip_id];
-		const uint32_t track_index = track_indices[instance];
-		if (track_index >= clip.num_tracks)
-		{
-			// invalid track index (decompression.transform.h:1766-1768); an empty clip lands here as well
-			atomicAdd(rejected_count, 1ull);
-			return;
-		}
+	// all 128 bytes of a clip record, per lane; what the caller does not use is never loaded
+	__device__ __forceinline__ device_clip load_clip_per_lane(const device_clip* clips, uint32_t clip_id)
+	{
+		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(clips + clip_id);
+		u32x4 raw[8];
+		#pragma unroll
+		for (uint32_t i = 0; i < 8; ++i)
+			raw[i] = source[i];
+		device_clip clip;
+		__builtin_memcpy(&clip, raw, sizeof(clip));
+		return clip;
+	}
 
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[instance]) : uint32_t(params.rounding_policy);
+	// Step 1 for one lane's request against its clip record (in SGPRs when the wave shares the clip, in VGPRs otherwise): validation,
+	// seek, the track's three base pose quads. Returns false for a request that is refused (decompression.transform.h:1766-1768).
+	// out_animated: bit k = sub-track kind k is animated (out_ordinals[k] = its ordinal); the other kinds have their final value in
+	// out_quads[k] and whether it is stored at all in out_store[k].
+	__device__ __forceinline__ bool prepare_track_request(const device_clip& clip, float sample_time, uint32_t track_index, uint32_t rounding_policy,
+		const decode_params& params, track_request_state& out_state, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
+	{
+		out_animated = 0;
+		// invalid track index (decompression.transform.h:1766-1768); an empty clip lands here as well
+		if (!is_transform_clip(clip.flags) || track_index >= clip.num_tracks)
+			return false;
 
 		seek_state state;
-		seek(clip, sample_times[instance], rounding_policy, params.looping_policy, state);
+		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
 
 		// decompress_track_v0 folds a per track policy into the alpha and always interpolates (decompression.transform.h:1975-1983)
 		float lerp_alpha = state.interpolation_alpha;
@@ -40,32 +82,203 @@
 			lerp_alpha = apply_rounding_policy(lerp_alpha, policy);
 		}
 
-		// The reference sums the widths of every preceding animated sub-track to find this one's bits
-		// (skip_*_groups + count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192,1664-1707): O(track index).
-		// The registration time plan already holds that prefix sum.
-		const auto animated_lookup = [&](uint32_t ordinal)
-		{
-			const plan_entry plan0 = load_entry(clip.plan + size_t(state.segment_index[0]) * clip.num_animated, ordinal);
-			const plan_entry plan1 = load_entry(clip.plan + size_t(state.segment_index[1]) * clip.num_animated, ordinal);
-			const clip_range_entry clip_range = load_entry(clip.clip_ranges, ordinal);
-			return decode_animated_sub_track<true, false>(state, plan0, plan1, clip_range, is_rotation_entry(clip_range),
-				k_round_none, lerp_alpha, params.normalization, false);
-		};
+		out_state.data[0] = state.animated_track_data[0];
+		out_state.data[1] = state.animated_track_data[1];
+		out_state.rows[0] = clip.plan + size_t(state.segment_index[0]) * clip.num_animated;
+		out_state.rows[1] = clip.plan + size_t(state.segment_index[1]) * clip.num_animated;
+		out_state.clip_ranges = clip.clip_ranges;
+		out_state.bit_offsets[0] = state.key_frame_bit_offsets[0];
+		out_state.bit_offsets[1] = state.key_frame_bit_offsets[1];
+		out_state.lerp_alpha = lerp_alpha;
+		out_state.short_exact_math = (clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
+		out_state.reserved[0] = out_state.reserved[1] = 0;
 
+		// base pose quads: constant (real W), animated (marker + ordinal) or default (marker)
+		float4 quads[3];
+		#pragma unroll
+		for (uint32_t kind = 0; kind < 3; ++kind)
+			quads[kind] = load_quad(clip.base_pose, track_index * 3u + kind);
+
+		#pragma unroll
 		for (uint32_t kind = 0; kind < 3; ++kind)
 		{
-			const uint32_t quad = track_index * 3u + kind;
-			// base pose quad: constant (real W), animated (marker + ordinal) or default (marker)
-			float4 value = load_quad(clip.base_pose, quad);
+			float4 value = quads[kind];
 			const uint32_t marker = __float_as_uint(value.w);
 			bool store = true;
 			if (int32_t(marker) < 0 && (marker & k_quad_animated) != 0)
-				value = animated_lookup(marker & k_quad_ordinal_mask);
+			{
+				out_animated |= 1u << kind;
+				out_ordinals[kind] = marker & k_quad_ordinal_mask;
+			}
 			else if (int32_t(marker) < 0)
-				value = resolve_quad(params, value, quad, store);
+				value = resolve_quad(params, value, track_index * 3u + kind, store);
 			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
 				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
-			if (store)
-				store_streaming(&transforms[size_t(instance) * 3 + kind], f32x4{ value.x, value.y, value.z, value.w });
+			out_quads[kind] = value;
+			out_store[kind] = store;
+		}
+		return true;
+	}
+
+	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
+		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+	{
+		__shared__ __attribute__((aligned(16))) uint8_t track_lds[k_waves_per_block * k_track_lds_bytes_per_wave];
+
+		const uint32_t lane = threadIdx.x & (k_wave_size - 1);
+		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
+		const uint32_t first_instance = (blockIdx.x * k_waves_per_block + wave_in_block) * k_wave_size;		// wave uniform
+		if (first_instance >= num_instances)
+			return;
+		const uint32_t instance = first_instance + lane;
+		const bool in_batch = instance < num_instances;
+
+		uint8_t* wave_lds = track_lds + wave_in_block * k_track_lds_bytes_per_wave;
+		f32x4* image = reinterpret_cast<f32x4*>(wave_lds);												// [request * 3 + kind]
+		u32x4* state_parts = reinterpret_cast<u32x4*>(wave_lds + k_track_image_bytes);					// [part][request]
+		uint32_t* list = reinterpret_cast<uint32_t*>(wave_lds + k_track_image_bytes + k_track_state_bytes);
+
+		// ---- 1. lanes <-> requests ---------------------------------------------------------------------------------------------------
+		const uint32_t clamped_instance = in_batch ? instance : first_instance;
+		const uint32_t clip_id = clip_ids[clamped_instance];
+		const float sample_time = sample_times[clamped_instance];
+		const uint32_t track_index = track_indices[clamped_instance];
+		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[clamped_instance]) : uint32_t(params.rounding_policy);
+
+		const bool known_clip = in_batch && clip_id < num_clips;
+		const uint32_t first_clip_id = __builtin_amdgcn_readfirstlane(clip_id);			// lane 0 is always in the batch
+		const bool shared_clip = __builtin_amdgcn_ballot_w64(in_batch && clip_id != first_clip_id) == 0 && first_clip_id < num_clips;	// wave uniform
+
+		track_request_state state;
+		float4 quads[3];
+		bool store[3] = { false, false, false };
+		uint32_t animated = 0;
+		uint32_t ordinals[3] = { 0, 0, 0 };
+		bool accepted = false;
+		if (shared_clip)
+		{
+			const device_clip clip = load_clip(clips, first_clip_id);
+			if (in_batch)
+				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, quads, store, animated, ordinals);
+		}
+		else if (known_clip)
+		{
+			const device_clip clip = load_clip_per_lane(clips, clip_id);
+			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, quads, store, animated, ordinals);
+		}
+
+		// refused requests are counted, one atomic per wave
+		const uint64_t refused = __builtin_amdgcn_ballot_w64(in_batch && !accepted);
+		if (refused != 0 && lane == 0)
+			atomicAdd(rejected_count, (unsigned long long)__builtin_popcountll(refused));
+
+		// ---- 2. lanes <-> the wave's animated sub-tracks ------------------------------------------------------------------------------
+		const uint64_t animated_lanes[3] = { __builtin_amdgcn_ballot_w64((animated & 1u) != 0), __builtin_amdgcn_ballot_w64((animated & 2u) != 0), __builtin_amdgcn_ballot_w64((animated & 4u) != 0) };
+		const uint32_t num_animated[3] = { uint32_t(__builtin_popcountll(animated_lanes[0])), uint32_t(__builtin_popcountll(animated_lanes[1])), uint32_t(__builtin_popcountll(animated_lanes[2])) };
+		const uint32_t total_animated = num_animated[0] + num_animated[1] + num_animated[2];		// wave uniform
+
+		if (total_animated != 0)
+		{
+			uint32_t first_position = 0;
+			#pragma unroll
+			for (uint32_t kind = 0; kind < 3; ++kind)
+			{
+				if ((animated >> kind) & 1u)
+				{
+					const uint32_t position = first_position + __builtin_amdgcn_mbcnt_hi(uint32_t(animated_lanes[kind] >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(animated_lanes[kind]), 0u));
+					list[position] = lane | (kind << 6) | (ordinals[kind] << 8);
+				}
+				first_position += num_animated[kind];
+			}
+			if (animated != 0)
+			{
+				u32x4 parts[4];
+				__builtin_memcpy(parts, &state, sizeof(state));
+				#pragma unroll
+				for (uint32_t part = 0; part < 4; ++part)
+					state_parts[part * k_wave_size + lane] = parts[part];
+			}
+		}
+		// what is not animated is final already
+		#pragma unroll
+		for (uint32_t kind = 0; kind < 3; ++kind)
+			if (((animated >> kind) & 1u) == 0)
+				image[lane * 3u + kind] = f32x4{ quads[kind].x, quads[kind].y, quads[kind].z, quads[kind].w };
+
+		if (total_animated != 0)
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+			for (uint32_t base = 0; base < total_animated; base += k_wave_size)
+			{
+				const bool valid = base + lane < total_animated;
+				const uint32_t entry = list[min(base + lane, total_animated - 1)];
+				const uint32_t source_lane = entry & 63u;
+				const uint32_t kind = (entry >> 6) & 3u;
+				const uint32_t ordinal = entry >> 8;
+
+				u32x4 parts[4];
+				#pragma unroll
+				for (uint32_t part = 0; part < 4; ++part)
+					parts[part] = state_parts[part * k_wave_size + source_lane];
+				track_request_state request;
+				__builtin_memcpy(&request, parts, sizeof(request));
+
+				const plan_entry plan0 = load_entry(request.rows[0], ordinal);
+				const plan_entry plan1 = request.rows[1] == request.rows[0] ? plan0 : load_entry(request.rows[1], ordinal);
+				const clip_range_entry clip_range = load_entry(request.clip_ranges, ordinal);
+
+				seek_state key_state;
+				key_state.animated_track_data[0] = request.data[0];
+				key_state.animated_track_data[1] = request.data[1];
+				key_state.segment_index[0] = key_state.segment_index[1] = 0;		// (the rows are resolved already)
+				key_state.key_frame_bit_offsets[0] = request.bit_offsets[0];
+				key_state.key_frame_bit_offsets[1] = request.bit_offsets[1];
+				key_state.interpolation_alpha = request.lerp_alpha;
+				key_state.uses_single_segment = false;
+
+				// the raw bit rate is rare: only a wave that actually meets one pays for its code path
+				const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+				const bool short_exact_math = request.short_exact_math != 0;
+				float4 value;
+				if (!has_raw)
+					value = decode_animated_sub_track<false, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request.lerp_alpha, params.normalization, false, short_exact_math);
+				else
+					value = decode_animated_sub_track<true, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request.lerp_alpha, params.normalization, false, false);
+				if (valid)
+					image[source_lane * 3u + kind] = f32x4{ value.x, value.y, value.z, value.w };
+			}
+		}
+
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// ---- 3. the wave's 64 transforms leave -----------------------------------------------------------------------------------------
+		const bool stores_all = accepted && store[0] && store[1] && store[2];
+		if (__builtin_amdgcn_ballot_w64(stores_all) == ~0ull)
+		{
+			// three 1 KiB contiguous stores
+			f32x4 staged[3];
+			#pragma unroll
+			for (uint32_t row = 0; row < 3; ++row)
+				staged[row] = image[row * k_wave_size + lane];
+			float4* out = transforms + size_t(first_instance) * 3u + lane;
+			#pragma unroll
+			for (uint32_t row = 0; row < 3; ++row)
+				store_streaming(out + row * k_wave_size, staged[row]);
+			return;
+		}
+
+		// a request that is refused, or whose default sub-tracks are skipped, leaves (part of) its transform as the caller had it
+		if (accepted)
+		{
+			#pragma unroll
+			for (uint32_t kind = 0; kind < 3; ++kind)
+				if (store[kind])
+					store_streaming(&transforms[size_t(instance) * 3u + kind], image[lane * 3u + kind]);
 		}
 	}
