@@ -39,14 +39,29 @@ def build_synth(force=False):
     return target
 
 
+def _hip_sources():
+    # one translation unit: aclhip.hip includes its parts (*.inl)
+    sources = [os.path.join(CSRC, f) for f in ("aclhip.hip", "aclhip_device.h", "acl_format.h")] + [os.path.join(ROOT, "include", "aclhip.h")]
+    return sources + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inl"))
+
+
 def build_hip(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libaclhip.so")
-    # one translation unit: aclhip.hip includes its parts (*.inl)
-    sources = [os.path.join(CSRC, f) for f in ("aclhip.hip", "aclhip_device.h", "acl_format.h")] + [os.path.join(ROOT, "include", "aclhip.h")]
-    sources += sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inl"))
+    sources = _hip_sources()
     if force or _newer(target, sources):
         _run([HIPCC] + HIP_FLAGS + [sources[0], "-o", target])
+    return target
+
+
+def build_hip_lab(force=False):
+    """libaclhip_lab.so: the same library with -DACLHIP_LAB_KNOBS -- it reads the measurement knobs and ACLHIP_SHORT_EXACT_MATH=1
+    (host_context.inl: lab_knob), which the shipped library ignores. Tests that need such a knob and tools/ point ACLHIP_LIBRARY at it."""
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libaclhip_lab.so")
+    sources = _hip_sources()
+    if force or _newer(target, sources):
+        _run([HIPCC] + HIP_FLAGS + ["-DACLHIP_LAB_KNOBS", sources[0], "-o", target])
     return target
 
 
@@ -59,7 +74,13 @@ def build_oracle(force=False):
 
 
 def build_all(force=False):
-    return {"synth": build_synth(force), "hip": build_hip(force), "oracle": build_oracle(force)}
+    # the two builds of the HIP library (half a minute each) side by side
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        lab = pool.submit(build_hip_lab, force)
+        hip = build_hip(force)
+        lab = lab.result()
+    return {"synth": build_synth(force), "hip": hip, "hip_lab": lab, "oracle": build_oracle(force)}
 
 
 if __name__ == "__main__":

@@ -714,10 +714,15 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	const rotation_value_facts rotation_facts = analyze_rotation_values(blob, blob_size, header.has_database(), num_tracks, num_samples, num_segments, num_animated, plan, clip_ranges, samples, base_pose);
 	bool short_exact_math = rotation_facts.short_exact_math;
 	const bool raw_rotations = rotation_facts.raw_rotations;
-	// ACLHIP_SHORT_EXACT_MATH = 0: never (A/B measurements); 1: ALWAYS, whatever the analysis says (testing aid: shows the analysis has teeth)
-	static const int short_exact_override = []() { const char* value = std::getenv("ACLHIP_SHORT_EXACT_MATH"); return value != nullptr ? int(value[0] - '0') : -1; }();
-	if (short_exact_override == 0 || short_exact_override == 1)
-		short_exact_math = short_exact_override == 1;
+	// ACLHIP_SHORT_EXACT_MATH = 0: never (A/B measurements; harmless: the compiler's forms are exact everywhere). = 1: ALWAYS, whatever
+	// the analysis says -- it BREAKS bit exactness on the clips the analysis exists for, so only a lab build (-DACLHIP_LAB_KNOBS:
+	// libaclhip_lab.so, what tests/test_gpu_exact_math.py uses to show the analysis has teeth) listens to it.
+	static const int short_exact_off = []() { const char* value = path_knob("ACLHIP_SHORT_EXACT_MATH"); return value != nullptr && value[0] == '0' ? 1 : 0; }();
+	static const int short_exact_forced = []() { const char* value = lab_knob("ACLHIP_SHORT_EXACT_MATH"); return value != nullptr && value[0] == '1' ? 1 : 0; }();
+	if (short_exact_off != 0)
+		short_exact_math = false;
+	if (short_exact_forced != 0)
+		short_exact_math = true;
 
 	// ---- one device allocation: blob (+ zeroed tail padding) | base pose | segments | plan | clip ranges | sample -> segment ----
 	const uint64_t blob_bytes = align_to_u32(blob_size, 16) + 64;		// windows of up to 16 bytes are read: keep well past the reference's 15 bytes of slack
@@ -781,7 +786,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 #endif
 	// aclhip_analyze_clip: what registration derives about the clip's VALUES (the kernels' variants follow from these)
 	if (out_facts != nullptr)
-		*out_facts = (short_exact_math ? ACLHIP_CLIP_FACT_SHORT_EXACT_MATH : 0u) | (raw_rotations ? ACLHIP_CLIP_FACT_RAW_ROTATIONS : 0u)
+		*out_facts = (rotation_facts.short_exact_math ? ACLHIP_CLIP_FACT_SHORT_EXACT_MATH : 0u) | (raw_rotations ? ACLHIP_CLIP_FACT_RAW_ROTATIONS : 0u)		// (the analysis, not what a knob made of it)
 			| (negative_scale_possible ? ACLHIP_CLIP_FACT_NEGATIVE_SCALE : 0u);
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work

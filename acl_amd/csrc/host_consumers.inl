@@ -268,7 +268,7 @@ namespace
 		// No clip with a scale other than 1 registered, no base to combine with: every scale of every pose is 1, in local and in object
 		// space -- the LDS images hold rotation | translation (32 of a transform's 48 bytes: half as many poses again per CU) and the
 		// scales are written on the way out
-		const bool unit_scale = !has_base && !blend && consumers.object_space != 0 && context->num_scaled_clips == 0 && std::getenv("ACLHIP_CONSUMER_KEEP_SCALE") == nullptr;
+		const bool unit_scale = !has_base && !blend && consumers.object_space != 0 && context->num_scaled_clips == 0 && path_knob("ACLHIP_CONSUMER_KEEP_SCALE") == nullptr;
 		// (sized for the BATCH like every pose launch: no pose of it is larger than its row, pose_launch_shape_of in host_launch.inl --
 		// one 3 500-bone asset in the registry does not take object space away from the 100-bone characters)
 		const uint32_t batch_quads = batch_pose_quads(context, ACLHIP_LAYOUT_QVV48, pose_stride_bytes);
@@ -279,13 +279,13 @@ namespace
 		// additive0 / additive1 combine sub-track with sub-track: the base clip is decoded into the instance's image and the additive clip
 		// onto it by one wave; the relative format (a qvv_mul) needs both poses whole: a second wave, a second image
 		// (a blend accumulates its clips in the instance's image before anything else happens to it: its base clip gets a wave and an image of its own)
-		const bool fused_base = base_is_clip && !blend && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && std::getenv("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
+		const bool fused_base = base_is_clip && !blend && consumers.additive_format != ACLHIP_ADDITIVE_RELATIVE && lab_knob("ACLHIP_CONSUMER_TWO_IMAGES") == nullptr;
 		const bool two_waves = base_is_clip && !fused_base;
 		// (measurement knob: ACLHIP_CONSUMER_LDS_PAD bytes between the instances' images -- the walk's lanes touch the same quad of all of a
 		// workgroup's images at once, and images a multiple of 128 bytes apart put those on the same LDS banks)
 		// 16 bytes: the four images of a workgroup then start on different banks (round 4: 88.8 -> 86.9 us, 90.6 -> 83.7 us with ACLHIP_CONSUMERS_FAST;
 		// 32 the same, 64 less, 0 what rounds 2 and 3 measured)
-		static const size_t lds_pad = []() { const char* value = std::getenv("ACLHIP_CONSUMER_LDS_PAD"); return value != nullptr ? size_t(std::atol(value)) & ~size_t(15) : size_t(16); }();
+		static const size_t lds_pad = []() { const char* value = lab_knob("ACLHIP_CONSUMER_LDS_PAD"); return value != nullptr ? size_t(std::atol(value)) & ~size_t(15) : size_t(16); }();
 		const size_t lds_bytes_per_instance = size_t(lds_quads_per_image) * 16 * (two_waves ? 2 : 1) + lds_pad;
 		// a walk schedule of T transforms: 2 words + a step end per step + a pair per transform with a parent, at most 2 + 2 T words
 		const uint32_t lds_schedule_words = consumers.object_space != 0 ? align_to_u32(std::max<uint32_t>(std::min<uint32_t>(context->max_hierarchy_words, 2 + 2 * (batch_quads / 3) + 3), 4), 4) : 0;
@@ -295,7 +295,7 @@ namespace
 		if (lds_bytes_per_instance + lds_schedule_bytes > k_lds_bytes)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "poses of %u transforms (the pose stride, the largest registered clip): too large for the pose consumers (%zu bytes of LDS per instance)", batch_quads / 3, lds_bytes_per_instance + lds_schedule_bytes);
 		uint32_t log2_instances_per_block = 2;
-		if (const char* forced = std::getenv("ACLHIP_CONSUMER_LOG2_INSTANCES"))
+		if (const char* forced = lab_knob("ACLHIP_CONSUMER_LOG2_INSTANCES"))
 			log2_instances_per_block = std::min<uint32_t>(uint32_t(forced[0] - '0'), 3);
 		while (log2_instances_per_block != 0 && (lds_bytes_per_instance << log2_instances_per_block) + lds_schedule_bytes > k_lds_bytes / 3)
 			log2_instances_per_block--;

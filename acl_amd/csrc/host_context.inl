@@ -153,6 +153,24 @@ struct aclhip_context
 
 namespace
 {
+	// Environment knobs, all of them, go through these two (INTEGRATION.md 9 lists them).
+	//   path_knob: selects between code paths that are EACH held to the oracle bit for bit by tests/ (the other kernel family, the other
+	//              key read width, clip slabs off, the three launch ordering, ...) and the test aids of the ordering barrier. Harmless in a
+	//              shipped library: whatever they are set to, results are the reference's.
+	//   lab_knob:  measurement knobs (LDS padding, occupancy, re-order thresholds) and the one that can break bit exactness
+	//              (ACLHIP_SHORT_EXACT_MATH=1). A default build does not read them at all; -DACLHIP_LAB_KNOBS (libaclhip_lab.so,
+	//              acl_amd/build.py; implied by -DACLHIP_EXPERIMENTS) does.
+	inline const char* path_knob(const char* name) { return std::getenv(name); }
+	inline const char* lab_knob(const char* name)
+	{
+#if defined(ACLHIP_LAB_KNOBS) || defined(ACLHIP_EXPERIMENTS)
+		return std::getenv(name);
+#else
+		(void)name;
+		return nullptr;
+#endif
+	}
+
 	constexpr size_t k_slab_bytes = size_t(32) << 20;
 	constexpr size_t k_slab_alignment = 256;
 
@@ -160,7 +178,7 @@ namespace
 	uint8_t* allocate_clip_memory(aclhip_context* context, size_t bytes)
 	{
 		bytes = (bytes + k_slab_alignment - 1) & ~(k_slab_alignment - 1);
-		static const bool use_slabs = []() { const char* value = std::getenv("ACLHIP_CLIP_SLABS"); return value == nullptr || value[0] != '0'; }();
+		static const bool use_slabs = []() { const char* value = path_knob("ACLHIP_CLIP_SLABS"); return value == nullptr || value[0] != '0'; }();
 		if (!use_slabs)
 		{
 			aclhip_context::clip_slab slab;
@@ -644,7 +662,7 @@ namespace
 			properties.location.id = context->device;
 			size_t granularity = 0;
 			void* range = nullptr;
-			static const bool allow_virtual = []() { const char* value = std::getenv("ACLHIP_VIRTUAL_CLIP_TABLE"); return value == nullptr || value[0] != '0'; }();
+			static const bool allow_virtual = []() { const char* value = path_knob("ACLHIP_VIRTUAL_CLIP_TABLE"); return value == nullptr || value[0] != '0'; }();
 			if (allow_virtual && hipMemGetAllocationGranularity(&granularity, &properties, hipMemAllocationGranularityRecommended) == hipSuccess && granularity != 0
 				&& hipMemAddressReserve(&range, size_t(k_reserved_table_entries) * sizeof(device_clip), granularity, nullptr, 0) == hipSuccess && range != nullptr)
 			{
@@ -803,7 +821,7 @@ extern "C" aclhip_status aclhip_create(int device_index, aclhip_context** out_co
 		return ACLHIP_ERROR_OUT_OF_MEMORY;
 	context->device = device_index;
 	{
-		const char* force_generic = std::getenv("ACLHIP_FORCE_GENERIC_KERNEL");
+		const char* force_generic = path_knob("ACLHIP_FORCE_GENERIC_KERNEL");
 		context->force_generic_kernel = force_generic != nullptr && force_generic[0] == '1';
 	}
 

@@ -34,11 +34,11 @@ namespace
 		shape.windows_per_instance = std::max<uint32_t>((quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
 		shape.lds_quads_per_wave = std::min<uint32_t>(std::max<uint32_t>(align_to_u32(quads, 64), 64), k_image_chunk_quads);
 		// ACLHIP_WIDE_KEY_LOADS=0 / 1 overrides the choice (measurements, parity runs of the other unpack)
-		static const int wide_override = []() { const char* value = std::getenv("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
+		static const int wide_override = []() { const char* value = path_knob("ACLHIP_WIDE_KEY_LOADS"); return value != nullptr ? int(value[0] - '0') : -1; }();
 		shape.wide_key_loads = wide_override >= 0 ? wide_override != 0 : shape.windows_per_instance > 1;
 		// ACLHIP_IN_TURN_ITEMS = K (0 / 1: one-shot grid), ACLHIP_IN_TURN_ADJACENT = 0 / 1: measurement knobs
-		static const uint32_t in_turn_items = []() { const char* value = std::getenv("ACLHIP_IN_TURN_ITEMS"); return value != nullptr ? uint32_t(std::atol(value)) : 4u; }();
-		static const bool in_turn_adjacent = []() { const char* value = std::getenv("ACLHIP_IN_TURN_ADJACENT"); return value != nullptr && value[0] == '1'; }();
+		static const uint32_t in_turn_items = []() { const char* value = path_knob("ACLHIP_IN_TURN_ITEMS"); return value != nullptr ? uint32_t(std::atol(value)) : 4u; }();
+		static const bool in_turn_adjacent = []() { const char* value = path_knob("ACLHIP_IN_TURN_ADJACENT"); return value != nullptr && value[0] == '1'; }();
 		shape.items_per_wave = shape.windows_per_instance > 1 && shape.wide_key_loads ? std::min<uint32_t>(std::max<uint32_t>(in_turn_items, 1), 255) : 1;
 		shape.adjacent_items = in_turn_adjacent;
 		return shape;
@@ -90,7 +90,7 @@ namespace
 		size_t lds_bytes = size_t(lds_quads_per_wave) * 16 * k_waves_per_block;
 		{
 			// measurement aid: ACLHIP_EXTRA_LDS_BYTES inflates a workgroup's LDS so that fewer workgroups fit a CU (occupancy experiments)
-			static const size_t extra_lds = []() { const char* value = std::getenv("ACLHIP_EXTRA_LDS_BYTES"); return value != nullptr ? size_t(std::atol(value)) : size_t(0); }();
+			static const size_t extra_lds = []() { const char* value = lab_knob("ACLHIP_EXTRA_LDS_BYTES"); return value != nullptr ? size_t(std::atol(value)) : size_t(0); }();
 			lds_bytes += extra_lds;
 		}
 #if defined(ACLHIP_EXPERIMENTS)
@@ -420,7 +420,7 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 
 	// ACLHIP_ORDER_LAUNCHES=3 forces the older form (three launches: LDS hash tables + device scope atomics), what clip tables of more
 	// than k_order_direct_bins entries take anyway
-	static const int forced_form = []() { const char* value = std::getenv("ACLHIP_ORDER_LAUNCHES"); return value != nullptr ? int(value[0] - '0') : 0; }();
+	static const int forced_form = []() { const char* value = path_knob("ACLHIP_ORDER_LAUNCHES"); return value != nullptr ? int(value[0] - '0') : 0; }();
 	// A kernel of the one launch form gave up at a barrier since the last call on this stream (its workgroups did not all become
 	// resident within seconds: order_grid_barrier): the order it was to write is not there. Said loudly, once; the barrier words are
 	// reset and this stream orders with the three launch form -- whose workgroups never wait for one another -- from now on.
@@ -436,7 +436,7 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 	{
 		// as many workgroups as keep the matrix small (every workgroup reads all of it), all of them resident at once: never more than
 		// an idle device holds together (occupancy query: one workgroup of 1 024 threads and 33 KB of LDS per CU at least)
-		static const uint32_t max_log2_blocks = []() { const char* value = std::getenv("ACLHIP_ORDER_GRID_LOG2_BLOCKS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_grid_max_log2_blocks; }();
+		static const uint32_t max_log2_blocks = []() { const char* value = lab_knob("ACLHIP_ORDER_GRID_LOG2_BLOCKS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_grid_max_log2_blocks; }();
 		static const int blocks_per_cu = []()
 		{
 			int blocks = 0;
@@ -465,18 +465,30 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 			const aclhip_status status = reserve(k_order_grid_scratch_words);
 			if (status != ACLHIP_OK)
 				return status;
-			if (scratch->barrier == nullptr)
+			// (each on its own: a call that fails half way must not leave the next one a barrier without its host word)
+			if (scratch->host_failed == nullptr)
 			{
-				ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&scratch->barrier), sizeof(order_control)));
-				ACLHIP_CHECK_HIP(context, hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), context->copy_stream));		// not the caller's stream: it may be capturing
-				ACLHIP_CHECK_HIP(context, hipStreamSynchronize(context->copy_stream));
 				ACLHIP_CHECK_HIP(context, hipHostMalloc(reinterpret_cast<void**>(&scratch->host_failed), sizeof(uint32_t), hipHostMallocMapped));
 				*scratch->host_failed = 0;
 			}
+			if (scratch->barrier == nullptr)
+			{
+				void* barrier = nullptr;
+				ACLHIP_CHECK_HIP(context, hipMalloc(&barrier, sizeof(order_control)));
+				hipError_t zeroed = hipMemsetAsync(barrier, 0, sizeof(order_control), context->copy_stream);		// not the caller's stream: it may be capturing
+				if (zeroed == hipSuccess)
+					zeroed = hipStreamSynchronize(context->copy_stream);
+				if (zeroed != hipSuccess)
+				{
+					(void)hipFree(barrier);
+					ACLHIP_CHECK_HIP(context, zeroed);
+				}
+				scratch->barrier = static_cast<decltype(scratch->barrier)>(barrier);
+			}
 			scratch->zeroed_bins = 0;		// (the three launch form finds its counters dirty)
 			// testing aid: ACLHIP_ORDER_TEST_ABSENT_BLOCK=b keeps workgroup b away from the barriers, ACLHIP_ORDER_TEST_MAX_POLLS shortens the wait
-			static const uint32_t absent_block = []() { const char* value = std::getenv("ACLHIP_ORDER_TEST_ABSENT_BLOCK"); return value != nullptr ? uint32_t(std::atol(value)) : 0xFFFFFFFFu; }();
-			static const uint32_t max_polls = []() { const char* value = std::getenv("ACLHIP_ORDER_TEST_MAX_POLLS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_barrier_max_polls; }();
+			static const uint32_t absent_block = []() { const char* value = path_knob("ACLHIP_ORDER_TEST_ABSENT_BLOCK"); return value != nullptr ? uint32_t(std::atol(value)) : 0xFFFFFFFFu; }();
+			static const uint32_t max_polls = []() { const char* value = path_knob("ACLHIP_ORDER_TEST_MAX_POLLS"); return value != nullptr ? uint32_t(std::atol(value)) : k_order_barrier_max_polls; }();
 			hipLaunchKernelGGL(order_instances_grid_kernel, dim3(num_blocks), dim3(k_order_direct_block_size), 0, stream, clips, sample_times, num_instances, instances_per_block,
 				num_bins, log2_blocks, scratch->bins, reinterpret_cast<order_control*>(scratch->barrier), scratch->host_failed, max_polls, absent_block, layout, out_order, out_clips, out_sample_times, out_positions);
 			ACLHIP_CHECK_HIP(context, hipGetLastError());

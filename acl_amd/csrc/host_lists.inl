@@ -34,17 +34,15 @@ namespace
 		return list < context->instance_lists.size() && context->instance_lists[list].in_use ? &context->instance_lists[list] : nullptr;
 	}
 
-	aclhip_status order_list(aclhip_context* context, aclhip_context::instance_list& list, uint32_t windows_per_instance, void* stream)
+	// An ordering kernel of the one launch form gave up on this stream and the host has not reported it yet (order_grid_barrier,
+	// kernels_misc.inl: every ordering queued on the stream since then wrote the identity order -- valid and consistent, without
+	// locality). A peek at pinned host memory, no synchronization. (the caller holds the registry lock)
+	bool ordering_gave_up_on(const aclhip_context* context, hipStream_t stream)
 	{
-		const aclhip_status status = order_instances_on_device(context, windows_per_instance, list.clips(), nullptr, list.num_instances, list.order(), list.ordered_clips(), nullptr, list.positions(), stream);
-		if (status == ACLHIP_OK)
-		{
-			list.ordered = true;
-			list.ordered_for_windows = windows_per_instance;
-			list.changed_since_ordered = 0;
-			list.num_orderings++;
-		}
-		return status;
+		for (const aclhip_context::order_scratch& scratch : context->order_scratches)
+			if (scratch.stream == stream && scratch.host_failed != nullptr && __atomic_load_n(scratch.host_failed, __ATOMIC_RELAXED) != 0)
+				return true;
+		return false;
 	}
 }
 
@@ -112,7 +110,10 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 	ACLHIP_CHECK_HIP(context, hipMemcpyAsync(snapshot.clips(), clips, size_t(snapshot.num_instances) * sizeof(uint32_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
 	// (the shape of the decodes to come is not known yet: ordered for the largest registered clip, again by the first decode whose pose
 	// stride says otherwise)
-	const aclhip_status status = order_list(context, snapshot, 0, stream);		// (takes the context's lock itself)
+	// (what "the largest registered clip" means is settled HERE: a clip registered or unregistered before the first decode must not
+	// make that decode mistake the order for one of its own shape)
+	const uint32_t registry_windows = windows_per_instance_of(context);		// (takes the context's lock itself)
+	const aclhip_status status = order_instances_on_device(context, registry_windows, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);		// (takes the context's lock itself)
 	if (status != ACLHIP_OK)
 		return status;
 	std::lock_guard<std::mutex> lock(context->mutex);
@@ -120,7 +121,7 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 	if (list != nullptr && list->d_memory == snapshot.d_memory)
 	{
 		list->ordered = true;
-		list->ordered_for_windows = 0;
+		list->ordered_for_windows = registry_windows;
 		list->changed_since_ordered = 0;
 		list->num_orderings++;
 	}
@@ -167,7 +168,8 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 
 	aclhip_context::instance_list snapshot;
 	bool reorder = false;
-	uint32_t windows_per_instance = 1, registry_windows = 1;
+	uint32_t windows_per_instance = 1;
+	bool ordering_gave_up = false;
 	{
 		std::lock_guard<std::mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
@@ -177,7 +179,11 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_set_clips comes first");
 		snapshot = *list;
 		windows_per_instance = pose_launch_shape_of(context, device_params.layout, pose_stride_bytes).windows_per_instance;
-		registry_windows = std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
+		ordering_gave_up = ordering_gave_up_on(context, static_cast<hipStream_t>(stream));
+		// an ordering on this stream gave up: this list's order may be the identity. The ordering below reports it (once, and this decode
+		// is refused with it); the decode after that orders the list again, with the form that cannot give up
+		if (ordering_gave_up)
+			list->changed_since_ordered = list->num_instances;
 	}
 	status = check_batch_arguments(context, snapshot.clips(), sample_times, snapshot.num_instances, poses, pose_stride_bytes);
 	if (status != ACLHIP_OK)
@@ -185,9 +191,8 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 
 	// enough of the list plays other clips than when it was ordered, or it was ordered for launches of another shape (which slot of a
 	// launch runs on which XCD follows from the waves a pose takes): order it again, in front of this decode
-	static const uint32_t reorder_divisor = []() { const char* value = std::getenv("ACLHIP_LIST_REORDER_DIVISOR"); return value != nullptr ? uint32_t(std::max(1L, std::atol(value))) : 8u; }();		// (measurement knob)
-	const uint32_t ordered_for = snapshot.ordered_for_windows != 0 ? snapshot.ordered_for_windows : registry_windows;
-	reorder = uint64_t(snapshot.changed_since_ordered) * reorder_divisor >= snapshot.num_instances || ordered_for != windows_per_instance;
+	static const uint32_t reorder_divisor = []() { const char* value = lab_knob("ACLHIP_LIST_REORDER_DIVISOR"); return value != nullptr ? uint32_t(std::max(1L, std::atol(value))) : 8u; }();		// (measurement knob)
+	reorder = ordering_gave_up || uint64_t(snapshot.changed_since_ordered) * reorder_divisor >= snapshot.num_instances || snapshot.ordered_for_windows != windows_per_instance;
 
 	device_params.time_indices = snapshot.order();
 	device_params.instance_rows = poses_in_instance_order != 0 ? snapshot.order() : nullptr;

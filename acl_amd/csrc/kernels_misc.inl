@@ -334,40 +334,75 @@
 	// ordering launches of OTHER processes share the device that none of them gets all its workgroups resident (the grid is sized from
 	// the occupancy query to fit an otherwise idle device, order_instances_on_device). Round 3 TRAPPED there, which takes the whole
 	// process down with the queue. Now the workgroup gives up: it raises `failed` (device word) and `*host_failed` (pinned host memory
-	// the host looks at in its next ordering call on the stream, without synchronizing) and leaves WITHOUT placing anything -- the order
-	// buffers keep what they held, except in the one case that a barrier opens for some workgroups in the very poll in which others
-	// give up. The host then reports the failure, resets the barrier words and orders with the three launch form (no workgroup of
-	// which waits for another) on that stream from then on.
+	// the host looks at in its next ordering / list call on the stream, without synchronizing), and so does every other workgroup of
+	// the launch: each writes the identity order for its share of the instances (order_write_identity below). The host then reports
+	// the failure, resets the barrier words and orders with the three launch form (no workgroup of which waits for another) on that
+	// stream from then on.
+	constexpr uint32_t k_order_generation_given_up = 0x80000000u;	// in control->generation: some workgroup gave up on this barrier, nobody passes it any more
+
 	__device__ __forceinline__ bool order_grid_barrier(order_control* control, uint32_t* host_failed, uint32_t generation, uint32_t max_polls, uint32_t& passed)
 	{
 		__builtin_amdgcn_s_waitcnt(0);		// (vmcnt 0: this wave's stores have reached the L2)
 		__syncthreads();
 		if (threadIdx.x == 0)
 		{
-			uint32_t open = 1;
+			// The barrier opens for ALL workgroups or for none: opening it and giving up on it are both a compare-and-swap of the
+			// generation word away from `generation`, and only one of them can win (until round 5 a barrier that opened in the very
+			// poll in which another workgroup gave up left an order that was half placed, half not).
+			uint32_t open;
 			if (__hip_atomic_fetch_add(&control->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1)
 			{
 				__hip_atomic_store(&control->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				__builtin_amdgcn_s_waitcnt(0);		// (arrived is back to 0 before anybody passes)
-				__hip_atomic_store(&control->generation, generation + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				uint32_t expected = generation;
+				open = __hip_atomic_compare_exchange_strong(&control->generation, &expected, (generation + 1u) & ~k_order_generation_given_up, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
 			}
 			else
 			{
 				uint32_t polls = 0;
-				while (__hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == generation && ++polls < max_polls)
+				uint32_t seen = generation;
+				while ((seen = __hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == generation && ++polls < max_polls)
 					__builtin_amdgcn_s_sleep(k_order_barrier_poll_sleep);
-				open = polls < max_polls ? 1u : 0u;
-				if (open == 0)
+				if (seen == generation)
 				{
-					__hip_atomic_store(&control->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(host_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					// out of patience: close the barrier for everybody -- unless it opened this very moment
+					uint32_t expected = generation;
+					if (__hip_atomic_compare_exchange_strong(&control->generation, &expected, generation | k_order_generation_given_up, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+						seen = generation | k_order_generation_given_up;
+					else
+						seen = expected;
 				}
+				open = (seen & k_order_generation_given_up) == 0 ? 1u : 0u;
+			}
+			if (open == 0)
+			{
+				__hip_atomic_store(&control->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(host_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			passed = open;
 		}
 		__syncthreads();
 		return passed != 0;
+	}
+
+	// What a workgroup that gives up leaves behind for its share of the instances: the IDENTITY order -- slot i holds instance i. Every
+	// workgroup of a launch gives up or none does (order_grid_barrier), so a failed ordering is still a valid one, without locality:
+	// a decode that was enqueued behind it reads and writes in bounds, and an instance list stays consistent (order, positions and
+	// ordered clips agree). The host still reports the failure at its next call on the stream.
+	__device__ __forceinline__ void order_write_identity(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t first, uint32_t end,
+		uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times, uint32_t* __restrict__ out_positions)
+	{
+		for (uint32_t instance = first + threadIdx.x; instance < end; instance += blockDim.x)
+		{
+			out_order[instance] = instance;
+			if (out_clip_ids != nullptr)
+				out_clip_ids[instance] = clip_ids[instance];
+			if (out_sample_times != nullptr)
+				out_sample_times[instance] = sample_times[instance];
+			if (out_positions != nullptr)
+				out_positions[instance] = instance;
+		}
 	}
 
 #if defined(ACLHIP_EXPERIMENTS)
@@ -394,18 +429,22 @@
 		{
 			generation = __hip_atomic_load(&control->generation, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (before this workgroup arrives: the barrier cannot have opened yet)
 			// the words an earlier, failed launch left behind cannot be trusted (a replayed hipGraph runs before the host has seen the failure)
-			passed = __hip_atomic_load(&control->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1u : 0u;
+			passed = __hip_atomic_load(&control->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && (generation & k_order_generation_given_up) == 0 ? 1u : 0u;
 		}
 		__syncthreads();
-		// (absent_block: a test's stand-in for a workgroup that never becomes resident -- tests/test_gpu_order_device.py; no block has this index otherwise)
+		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
+		// (absent_block: a test's stand-in for a workgroup that becomes resident too late -- tests/test_gpu_order_device.py; no block has
+		// this index otherwise. By the time such a workgroup runs the others have given up: it finds `failed` raised and does what they did)
 		if (passed == 0 || blockIdx.x == absent_block)
+		{
+			order_write_identity(clip_ids, sample_times, first, end, out_order, out_clip_ids, out_sample_times, out_positions);
 			return;
+		}
 		if (threadIdx.x < sizeof(order_layout) / 4)
 			reinterpret_cast<uint32_t*>(&layout)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&layout_argument)[threadIdx.x];
 		for (uint32_t bin = threadIdx.x; bin < num_bins; bin += k_order_direct_block_size)
 			cursors[bin] = 0;
 		__syncthreads();
-		const uint32_t first = blockIdx.x * instances_per_block, end = min(first + instances_per_block, num_instances);
 		for (uint32_t instance = first + threadIdx.x; instance < end; instance += k_order_direct_block_size)
 			atomicAdd(&cursors[min(clip_ids[instance], num_bins - 1)], 1u);
 		__syncthreads();
@@ -415,7 +454,10 @@
 		// every column is written and visible
 		ACLHIP_ORDER_STAMP(1);
 		if (!order_grid_barrier(control, host_failed, generation, max_polls, passed))
+		{
+			order_write_identity(clip_ids, sample_times, first, end, out_order, out_clip_ids, out_sample_times, out_positions);
 			return;
+		}
 		ACLHIP_ORDER_STAMP(3);
 
 		// Every workgroup turns the rows of ITS share of the bins into "instances in the workgroups in front" (in place) and the
@@ -448,8 +490,11 @@
 			}
 		}
 		ACLHIP_ORDER_STAMP(2);
-		if (!order_grid_barrier(control, host_failed, generation + 1u, max_polls, passed))
+		if (!order_grid_barrier(control, host_failed, (generation + 1u) & ~k_order_generation_given_up, max_polls, passed))
+		{
+			order_write_identity(clip_ids, sample_times, first, end, out_order, out_clip_ids, out_sample_times, out_positions);
 			return;
+		}
 		ACLHIP_ORDER_STAMP(4);
 
 		// first position of a bin = instances of the bins in front of it; this workgroup starts behind the ones in front of it.

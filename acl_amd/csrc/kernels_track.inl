@@ -21,28 +21,32 @@
 // count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192,1664-1707): O(track index). The registration time plan holds
 // that prefix sum.
 
-	// what a decode lane needs to know about the request its sub-track belongs to: 64 bytes in LDS, as four 16 byte parts [part][request]
+	// what a decode lane needs to know about the request its sub-track belongs to: 32 bytes in LDS, as two 16 byte parts [part][request]
+	// (the interpolation alpha comes over ds_bpermute, the clip's tables from the scalar clip record or -- waves of mixed clips -- from
+	// the clip handle, over ds_bpermute as well: 5 KiB of LDS per wave all told, so that registers, not LDS, decide how many waves a
+	// CU holds. Measured, 4 M requests on one clip: 64 bytes of state per request and the list beside the image (7.75 KiB, 20 waves per
+	// CU) 74.3 us; this form at 70 registers = 7 waves per SIMD 64.3 us; squeezed into 64 registers for 8 (15 spilled) 85.4 us.)
 	struct track_request_state
 	{
 		const uint8_t* data[2];					// first stored keyframe of each key's data source (seek_state::animated_track_data)
-		const plan_entry* rows[2];				// the plan rows of the two keys' segments
-		const clip_range_entry* clip_ranges;
+		uint32_t rows[2];						// first plan entry of each key's segment (segment index x animated sub-tracks); bit 31 of rows[0]: the clip's k_clip_short_exact_math
 		uint32_t bit_offsets[2];				// seek_state::key_frame_bit_offsets
-		float lerp_alpha;						// the interpolation alpha, per track rounding policy applied (decompression.transform.h:1975-1983)
-		uint32_t short_exact_math;				// the clip's k_clip_short_exact_math
-		uint32_t reserved[2];
 	};
-	static_assert(sizeof(track_request_state) == 64, "four 16 byte parts");
+	static_assert(sizeof(track_request_state) == 32, "two 16 byte parts");
+	constexpr uint32_t k_track_row_short_exact_math = 0x80000000u;
 
+#if !defined(ACLHIP_TRACK_WAVES_PER_EU)
+	#define ACLHIP_TRACK_WAVES_PER_EU 7
+#endif
 #if defined(ACLHIP_TRACK_NARROW_KEYS)
 	constexpr bool k_track_wide_key_loads = false;
 #else
 	constexpr bool k_track_wide_key_loads = true;
 #endif
-	constexpr uint32_t k_track_image_bytes = k_wave_size * 48;				// 64 transforms
-	constexpr uint32_t k_track_state_bytes = k_wave_size * 64;
-	constexpr uint32_t k_track_list_bytes = k_wave_size * 3 * 4;			// at most 192 animated (request, kind) pairs
-	constexpr uint32_t k_track_lds_bytes_per_wave = k_track_image_bytes + k_track_state_bytes + k_track_list_bytes;
+	constexpr uint32_t k_track_image_bytes = k_wave_size * 48;				// 64 transforms; before that the list of the wave's animated (request, kind) pairs, 4 bytes each
+	constexpr uint32_t k_track_state_bytes = k_wave_size * 32;
+	constexpr uint32_t k_track_lds_bytes_per_wave = k_track_image_bytes + k_track_state_bytes;
+	static_assert(k_wave_size * 3 * 4 <= k_track_image_bytes, "the list fits where the image will be");
 
 	// all 128 bytes of a clip record, per lane; what the caller does not use is never loaded
 	__device__ __forceinline__ device_clip load_clip_per_lane(const device_clip* clips, uint32_t clip_id)
@@ -62,7 +66,7 @@
 	// out_animated: bit k = sub-track kind k is animated (out_ordinals[k] = its ordinal); the other kinds have their final value in
 	// out_quads[k] and whether it is stored at all in out_store[k].
 	__device__ __forceinline__ bool prepare_track_request(const device_clip& clip, float sample_time, uint32_t track_index, uint32_t rounding_policy,
-		const decode_params& params, track_request_state& out_state, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
+		const decode_params& params, track_request_state& out_state, float& out_lerp_alpha, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
 	{
 		out_animated = 0;
 		// invalid track index (decompression.transform.h:1766-1768); an empty clip lands here as well
@@ -81,17 +85,14 @@
 				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
 			lerp_alpha = apply_rounding_policy(lerp_alpha, policy);
 		}
+		out_lerp_alpha = lerp_alpha;
 
 		out_state.data[0] = state.animated_track_data[0];
 		out_state.data[1] = state.animated_track_data[1];
-		out_state.rows[0] = clip.plan + size_t(state.segment_index[0]) * clip.num_animated;
-		out_state.rows[1] = clip.plan + size_t(state.segment_index[1]) * clip.num_animated;
-		out_state.clip_ranges = clip.clip_ranges;
+		out_state.rows[0] = (state.segment_index[0] * clip.num_animated) | ((clip.flags & k_clip_short_exact_math) != 0 ? k_track_row_short_exact_math : 0u);
+		out_state.rows[1] = state.segment_index[1] * clip.num_animated;
 		out_state.bit_offsets[0] = state.key_frame_bit_offsets[0];
 		out_state.bit_offsets[1] = state.key_frame_bit_offsets[1];
-		out_state.lerp_alpha = lerp_alpha;
-		out_state.short_exact_math = (clip.flags & k_clip_short_exact_math) != 0 ? 1u : 0u;
-		out_state.reserved[0] = out_state.reserved[1] = 0;
 
 		// base pose quads: constant (real W), animated (marker + ordinal) or default (marker)
 		float4 quads[3];
@@ -120,7 +121,14 @@
 		return true;
 	}
 
-	__global__ __launch_bounds__(k_block_size) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+	__device__ __forceinline__ void track_wave_barrier()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_TRACK_WAVES_PER_EU, ACLHIP_TRACK_WAVES_PER_EU))) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
 		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
 	{
@@ -136,8 +144,8 @@
 
 		uint8_t* wave_lds = track_lds + wave_in_block * k_track_lds_bytes_per_wave;
 		f32x4* image = reinterpret_cast<f32x4*>(wave_lds);												// [request * 3 + kind]
+		uint32_t* list = reinterpret_cast<uint32_t*>(wave_lds);											// (read into registers before the image takes its place)
 		u32x4* state_parts = reinterpret_cast<u32x4*>(wave_lds + k_track_image_bytes);					// [part][request]
-		uint32_t* list = reinterpret_cast<uint32_t*>(wave_lds + k_track_image_bytes + k_track_state_bytes);
 
 		// ---- 1. lanes <-> requests ---------------------------------------------------------------------------------------------------
 		const uint32_t clamped_instance = in_batch ? instance : first_instance;
@@ -151,21 +159,27 @@
 		const bool shared_clip = __builtin_amdgcn_ballot_w64(in_batch && clip_id != first_clip_id) == 0 && first_clip_id < num_clips;	// wave uniform
 
 		track_request_state state;
+		float lerp_alpha = 0.0f;
 		float4 quads[3];
 		bool store[3] = { false, false, false };
 		uint32_t animated = 0;
 		uint32_t ordinals[3] = { 0, 0, 0 };
 		bool accepted = false;
+		// the tables of the shared clip, for the decode lanes (wave uniform)
+		const plan_entry* shared_plan = nullptr;
+		const clip_range_entry* shared_clip_ranges = nullptr;
 		if (shared_clip)
 		{
 			const device_clip clip = load_clip(clips, first_clip_id);
+			shared_plan = clip.plan;
+			shared_clip_ranges = clip.clip_ranges;
 			if (in_batch)
-				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, quads, store, animated, ordinals);
+				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 		else if (known_clip)
 		{
 			const device_clip clip = load_clip_per_lane(clips, clip_id);
-			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, quads, store, animated, ordinals);
+			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 
 		// refused requests are counted, one atomic per wave
@@ -176,8 +190,9 @@
 		// ---- 2. lanes <-> the wave's animated sub-tracks ------------------------------------------------------------------------------
 		const uint64_t animated_lanes[3] = { __builtin_amdgcn_ballot_w64((animated & 1u) != 0), __builtin_amdgcn_ballot_w64((animated & 2u) != 0), __builtin_amdgcn_ballot_w64((animated & 4u) != 0) };
 		const uint32_t num_animated[3] = { uint32_t(__builtin_popcountll(animated_lanes[0])), uint32_t(__builtin_popcountll(animated_lanes[1])), uint32_t(__builtin_popcountll(animated_lanes[2])) };
-		const uint32_t total_animated = num_animated[0] + num_animated[1] + num_animated[2];		// wave uniform
+		const uint32_t total_animated = num_animated[0] + num_animated[1] + num_animated[2];		// wave uniform, at most 192: three passes
 
+		uint32_t entries[3] = { 0, 0, 0 };
 		if (total_animated != 0)
 		{
 			uint32_t first_position = 0;
@@ -193,69 +208,79 @@
 			}
 			if (animated != 0)
 			{
-				u32x4 parts[4];
+				u32x4 parts[2];
 				__builtin_memcpy(parts, &state, sizeof(state));
-				#pragma unroll
-				for (uint32_t part = 0; part < 4; ++part)
-					state_parts[part * k_wave_size + lane] = parts[part];
+				state_parts[lane] = parts[0];
+				state_parts[k_wave_size + lane] = parts[1];
 			}
+			track_wave_barrier();
+			entries[0] = list[min(lane, total_animated - 1)];
+			if (total_animated > k_wave_size)
+			{
+				entries[1] = list[min(k_wave_size + lane, total_animated - 1)];
+				entries[2] = list[min(2 * k_wave_size + lane, total_animated - 1)];
+			}
+			track_wave_barrier();		// the list is in registers: its place is the image's now
 		}
+
 		// what is not animated is final already
 		#pragma unroll
 		for (uint32_t kind = 0; kind < 3; ++kind)
 			if (((animated >> kind) & 1u) == 0)
 				image[lane * 3u + kind] = f32x4{ quads[kind].x, quads[kind].y, quads[kind].z, quads[kind].w };
 
-		if (total_animated != 0)
+		#pragma unroll 1
+		for (uint32_t pass = 0; pass * k_wave_size < total_animated; ++pass)
 		{
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const bool valid = pass * k_wave_size + lane < total_animated;
+			const uint32_t entry = pass == 0 ? entries[0] : (pass == 1 ? entries[1] : entries[2]);
+			const uint32_t source_lane = entry & 63u;
+			const uint32_t kind = (entry >> 6) & 3u;
+			const uint32_t ordinal = entry >> 8;
 
-			for (uint32_t base = 0; base < total_animated; base += k_wave_size)
+			u32x4 parts[2] = { state_parts[source_lane], state_parts[k_wave_size + source_lane] };
+			track_request_state request;
+			__builtin_memcpy(&request, parts, sizeof(request));
+			const float request_alpha = __uint_as_float(uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(__float_as_uint(lerp_alpha)))));
+
+			// the clip's tables: the wave's one clip, or -- a wave of mixed clips -- each request's own
+			const plan_entry* plan = shared_plan;
+			const clip_range_entry* clip_ranges = shared_clip_ranges;
+			if (!shared_clip)
 			{
-				const bool valid = base + lane < total_animated;
-				const uint32_t entry = list[min(base + lane, total_animated - 1)];
-				const uint32_t source_lane = entry & 63u;
-				const uint32_t kind = (entry >> 6) & 3u;
-				const uint32_t ordinal = entry >> 8;
-
-				u32x4 parts[4];
-				#pragma unroll
-				for (uint32_t part = 0; part < 4; ++part)
-					parts[part] = state_parts[part * k_wave_size + source_lane];
-				track_request_state request;
-				__builtin_memcpy(&request, parts, sizeof(request));
-
-				const plan_entry plan0 = load_entry(request.rows[0], ordinal);
-				const plan_entry plan1 = request.rows[1] == request.rows[0] ? plan0 : load_entry(request.rows[1], ordinal);
-				const clip_range_entry clip_range = load_entry(request.clip_ranges, ordinal);
-
-				seek_state key_state;
-				key_state.animated_track_data[0] = request.data[0];
-				key_state.animated_track_data[1] = request.data[1];
-				key_state.segment_index[0] = key_state.segment_index[1] = 0;		// (the rows are resolved already)
-				key_state.key_frame_bit_offsets[0] = request.bit_offsets[0];
-				key_state.key_frame_bit_offsets[1] = request.bit_offsets[1];
-				key_state.interpolation_alpha = request.lerp_alpha;
-				key_state.uses_single_segment = false;
-
-				// the raw bit rate is rare: only a wave that actually meets one pays for its code path
-				const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
-				const bool short_exact_math = request.short_exact_math != 0;
-				float4 value;
-				if (!has_raw)
-					value = decode_animated_sub_track<false, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request.lerp_alpha, params.normalization, false, short_exact_math);
-				else
-					value = decode_animated_sub_track<true, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request.lerp_alpha, params.normalization, false, false);
-				if (valid)
-					image[source_lane * 3u + kind] = f32x4{ value.x, value.y, value.z, value.w };
+				const uint32_t request_clip_id = uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(clip_id)));
+				const device_clip clip = load_clip_per_lane(clips, request_clip_id);		// (an accepted request's: a known clip)
+				plan = clip.plan;
+				clip_ranges = clip.clip_ranges;
 			}
+
+			const uint32_t row0 = request.rows[0] & ~k_track_row_short_exact_math, row1 = request.rows[1];
+			const plan_entry plan0 = load_entry(plan, row0 + ordinal);
+			const plan_entry plan1 = row1 == row0 ? plan0 : load_entry(plan, row1 + ordinal);
+			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
+
+			seek_state key_state;
+			key_state.animated_track_data[0] = request.data[0];
+			key_state.animated_track_data[1] = request.data[1];
+			key_state.segment_index[0] = key_state.segment_index[1] = 0;		// (the rows are resolved already)
+			key_state.key_frame_bit_offsets[0] = request.bit_offsets[0];
+			key_state.key_frame_bit_offsets[1] = request.bit_offsets[1];
+			key_state.interpolation_alpha = request_alpha;
+			key_state.uses_single_segment = false;
+
+			// the raw bit rate is rare: only a wave that actually meets one pays for its code path
+			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+			const bool short_exact_math = (request.rows[0] & k_track_row_short_exact_math) != 0;
+			float4 value;
+			if (!has_raw)
+				value = decode_animated_sub_track<false, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request_alpha, params.normalization, false, short_exact_math);
+			else
+				value = decode_animated_sub_track<true, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request_alpha, params.normalization, false, false);
+			if (valid)
+				image[source_lane * 3u + kind] = f32x4{ value.x, value.y, value.z, value.w };
 		}
 
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		track_wave_barrier();
 
 		// ---- 3. the wave's 64 transforms leave -----------------------------------------------------------------------------------------
 		const bool stores_all = accepted && store[0] && store[1] && store[2];

@@ -3,7 +3,9 @@ rcp_rn_short) are bit identical to sqrtf / 1.0f / x only for arguments that are 
 tools/probes/exact_math_probe.hip). Whether a clip's rotations can produce anything else is decided at registration
 (host_clips.inl: k_clip_short_exact_math). Here: a clip built to hit the gap -- a rotation component of exactly 1 next to one of 1e-20:
 W^2 = 1e-40 -- must be recognised (its poses stay bit identical to the oracle's, which computes with the C library's sqrtf), and the
-same clip with the analysis overruled (ACLHIP_SHORT_EXACT_MATH=1, a testing aid) must NOT be: the analysis is what keeps the bits.
+same clip with the analysis overruled (ACLHIP_SHORT_EXACT_MATH=1, which only the lab build of the library -- libaclhip_lab.so,
+-DACLHIP_LAB_KNOBS -- listens to: a shipped library cannot be talked out of bit exactness by an environment variable) must NOT be: the
+analysis is what keeps the bits.
 The reference's arithmetic: includes/acl/math/quatf.h:135-147,200-211. Needs a GPU."""
 import os
 import subprocess
@@ -68,8 +70,16 @@ def test_a_clip_that_reaches_the_gap_of_the_short_forms_is_recognised():
 
 
 def test_the_analysis_is_what_keeps_the_bits():
-    tiny_w, exact, _ = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
+    lab_library = os.path.join(ROOT, "acl_amd", "lib", "libaclhip_lab.so")
+    assert os.path.exists(lab_library), "acl_amd/build.py builds it (build_hip_lab)"
+    tiny_w, exact, short = _run({"ACLHIP_SHORT_EXACT_MATH": "1", "ACLHIP_LIBRARY": lab_library})
     assert tiny_w > 0 and exact == 0    # overruled: the short form meets an argument below 2^-96 and rounds it differently
+    assert short == 0                   # aclhip_analyze_clip still reports the analysis, not the override
+
+
+def test_the_shipped_library_does_not_listen_to_the_override():
+    tiny_w, exact, short = _run({"ACLHIP_SHORT_EXACT_MATH": "1"})
+    assert tiny_w > 0 and exact == 1 and short == 0
 
 
 def test_the_smallest_components_the_analysis_lets_through_are_safe():

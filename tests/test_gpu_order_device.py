@@ -215,6 +215,7 @@ def test_orderings_of_several_processes_at_the_same_time():
 
 
 _FAILED_BARRIER_SCRIPT = r"""
+import ctypes
 import numpy as np, torch
 from acl_amd import runtime, synth
 device = torch.device("cuda", 0)
@@ -225,35 +226,63 @@ with runtime.Context(0) as context:
     rng = np.random.default_rng(1)
     which = rng.integers(0, len(clips), size=n)
     d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
-    d_times = torch.zeros(n, dtype=torch.float32, device=device)
+    times = rng.uniform(0.0, 0.9, size=n).astype(np.float32)
+    d_times = torch.from_numpy(times).to(device)
     d_order = torch.full((n,), -1, dtype=torch.int32, device=device)
+    d_out_clips = torch.full((n,), -1, dtype=torch.int32, device=device)
+    stride = 31 * 48
+    d_expected = torch.zeros((n, stride // 4), dtype=torch.float32, device=device)
+    context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_expected.data_ptr(), stride)
     torch.cuda.synchronize(device)
-    # workgroup 3 never reaches the barriers (ACLHIP_ORDER_TEST_ABSENT_BLOCK): the launch gives up instead of trapping ...
-    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+
+    # An instance list whose FIRST ordering gives up (workgroup 3 never reaches the barriers: ACLHIP_ORDER_TEST_ABSENT_BLOCK). The launch
+    # gives up instead of trapping, as a whole, and leaves the identity order: the list is consistent, a decode queued behind it in bounds
+    instance_list = context.instance_list_create(n)
+    context.instance_list_set_clips(instance_list, d_clips.data_ptr())
     torch.cuda.synchronize(device)                      # ... the process is alive, the queue healthy
-    assert np.all(d_order.cpu().numpy() == -1), "a launch that gave up placed instances"
-    # ... the next call on the stream says so, once ...
+    order_address, _ = context.instance_list_order(instance_list)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    def read_list():
+        words = np.zeros((4, n), dtype=np.uint32)           # the list's memory: clips | order | positions | ordered clips
+        assert hip.hipMemcpy(words.ctypes.data, order_address - 4 * n, 4 * 4 * n, 2) == 0      # hipMemcpyDeviceToHost
+        return words
+    list_words = read_list()
+    assert np.array_equal(list_words[1], np.arange(n)), "a launch that gave up did not leave the identity order"
+    assert np.array_equal(list_words[2], np.arange(n)) and np.array_equal(list_words[3], list_words[0]), "the list is not consistent"
+    # ... the next list decode on the stream says so, once, and is refused ...
+    d_poses = torch.zeros((n, stride // 4), dtype=torch.float32, device=device)
     try:
-        context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+        context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_poses.data_ptr(), stride, poses_in_instance_order=True)
         raise SystemExit("the failed ordering was not reported")
     except runtime.AclHipError as error:
         assert "did not complete" in str(error), str(error)
-    # ... and from then on the stream orders with the form that needs no co-residency
-    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr())
+    # ... and the one after that orders the list again, with the form that needs no co-residency, and decodes it
+    _, orderings_before = context.instance_list_order(instance_list)
+    context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_poses.data_ptr(), stride, poses_in_instance_order=True)
     torch.cuda.synchronize(device)
-    order = d_order.cpu().numpy().astype(np.uint32)
+    _, orderings_after = context.instance_list_order(instance_list)
+    assert orderings_after == orderings_before + 1, (orderings_before, orderings_after)
+    assert torch.equal(d_poses.view(torch.int32), d_expected.view(torch.int32)), "the re-ordered list decodes other poses"
+    list_words = read_list()
     import os, sys
     sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
     from test_order_instances import check_order
-    check_order(handles[which], order, 1, stable=False)  # a permutation, every clip on one XCD next to its other instances
+    check_order(handles[which], list_words[1].copy(), 1, stable=False)  # a permutation, every clip on one XCD next to its other instances
+    # the plain ordering call on that stream takes the three launch form as well
+    context.order_instances_device(d_clips.data_ptr(), d_times.data_ptr(), n, d_order.data_ptr(), d_out_clips.data_ptr())
+    torch.cuda.synchronize(device)
+    check_order(handles[which], d_order.cpu().numpy().astype(np.uint32), 1, stable=False)
 print("FAILED_BARRIER_PATH_OK")
 """
 
 
 def test_a_barrier_that_cannot_open_is_reported_not_trapped():
     """Round 3's one launch form trapped when its workgroups could not all become resident (a queue exception takes the process down).
-    Now the launch gives up without placing anything, the next ordering call on the stream reports it and the stream falls back to the
-    three launch form. The absent workgroup is injected (ACLHIP_ORDER_TEST_ABSENT_BLOCK), the wait shortened."""
+    Round 4 gave up without placing anything -- which left an instance list whose first ordering gave up with order, positions and
+    ordered clips in un-initialised memory, and a decode behind it reading out of bounds. Now every workgroup of the launch gives up
+    or none does, a launch that gives up writes the identity order, the next ordering / list decode on the stream reports it (once)
+    and the stream falls back to the three launch form. The absent workgroup is injected (ACLHIP_ORDER_TEST_ABSENT_BLOCK), the wait shortened."""
     import os
     import subprocess
     import sys

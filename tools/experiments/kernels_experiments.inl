@@ -554,7 +554,7 @@
 				unpack_staged_samples<false>(key_bytes0, key_bytes1, position0, position1, plan0, plan1, current_range, is_rotation, v0, v1);
 			else
 				unpack_staged_samples<true>(key_bytes0, key_bytes1, position0, position1, plan0, plan1, current_range, is_rotation, v0, v1);
-			const float4 value = interpolate_animated_samples<false>(state, v0, v1, is_rotation, k_round_none, state.interpolation_alpha, normalization, false);
+			const float4 value = interpolate_animated_samples<false>(state, v0, v1, is_rotation, k_round_none, state.interpolation_alpha, normalization, false, false);
 
 			if (valid)
 				decoded[current_ordinal - first_ordinal] = f32x4{ value.x, value.y, value.z, value.w };
