@@ -197,6 +197,13 @@ namespace aclhip
 		const uint32_t* instance_rows;	// pose kernels: row of the pose buffer each instance writes, or null (row = instance index)
 		const uint32_t* time_indices;	// pose kernels: entry of sample_times each instance reads, or null (its own): instance lists kept in decode order
 		const uint8_t* skip_tracks;		// compact pose kernels: per track, bit k set = its sub-track of kind k is not stored (aclhip_output_desc::skip_tracks), or null
+		// per instance writer decisions (aclhip_output_desc, ABI 5) and looping policies; every per instance array is indexed by the
+		// CALLER's instance index (caller_instance_of below)
+		const uint8_t* mask_table;					// skip masks, mask_stride bytes each, or null
+		const uint8_t* instance_masks;				// mask of every instance, or null
+		const uint32_t* instance_track_counts;		// tracks every instance stores (its first K), or null
+		const uint8_t* instance_looping_policies;	// or null
+		uint32_t mask_stride;
 		uint8_t rounding_policy;
 		uint8_t looping_policy;
 		uint8_t normalization;
@@ -208,6 +215,19 @@ namespace aclhip
 		uint8_t skip_mask;				// bit k: sub-tracks of kind k (rotation / translation / scale) are not stored
 		uint8_t items_per_wave;			// decompress_tracks_in_turn_kernel: work items a wave takes in turn
 	};
+
+	// Per instance settings. `caller_instance`: the instance's index in the CALLER's lists -- instance lists decode in slot order and find
+	// it in their order (decode_params::time_indices), everything else decodes instance i at slot i.
+	__device__ __forceinline__ uint32_t instance_rounding_policy_of(const decode_params& params, uint32_t caller_instance)
+	{
+		return params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[caller_instance]) : uint32_t(params.rounding_policy);
+	}
+
+	// decompression_context::set_looping_policy (decompress.h:149) belongs to one context = one instance
+	__device__ __forceinline__ uint32_t instance_looping_policy_of(const decode_params& params, uint32_t caller_instance)
+	{
+		return params.instance_looping_policies != nullptr ? uint32_t(params.instance_looping_policies[caller_instance]) : uint32_t(params.looping_policy);
+	}
 
 	// What happens to a decoded (local space) pose before it is stored (aclhip_pose_consumers resolved to device pointers)
 	struct consumer_params

@@ -466,6 +466,20 @@ namespace
 			if (ok && output->skip_tracks != nullptr)
 				ok = upload(output->skip_tracks, std::max<uint32_t>(max_tracks, 1), &d_skip_tracks);
 			local_output.skip_tracks = static_cast<const uint8_t*>(d_skip_tracks);
+			// per instance writer decisions: the masks the instances name (as many as the largest index says), their track counts
+			void* d_instance_masks = nullptr; void* d_mask_table = nullptr; void* d_track_counts = nullptr;
+			if (ok && output->instance_masks != nullptr && output->mask_table != nullptr)
+			{
+				uint32_t num_masks = 0;
+				for (uint32_t i = 0; i < num_instances; ++i)
+					num_masks = std::max<uint32_t>(num_masks, uint32_t(output->instance_masks[i]) + 1);
+				ok = upload(output->instance_masks, num_instances, &d_instance_masks) && upload(output->mask_table, size_t(num_masks) * output->mask_stride, &d_mask_table);
+			}
+			if (ok && output->instance_track_counts != nullptr)
+				ok = upload(output->instance_track_counts, sizeof(uint32_t) * num_instances, &d_track_counts);
+			local_output.instance_masks = output->instance_masks != nullptr ? static_cast<const uint8_t*>(d_instance_masks) : nullptr;
+			local_output.mask_table = output->mask_table != nullptr ? static_cast<const uint8_t*>(d_mask_table) : nullptr;
+			local_output.instance_track_counts = static_cast<const uint32_t*>(d_track_counts);
 		}
 		if (ok && local.default_values != nullptr)
 			ok = upload(local.default_values, size_t(std::max<uint32_t>(default_values_count, 1)) * 48, &d_defaults);
@@ -473,6 +487,9 @@ namespace
 			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
 		if (ok && local.instance_rounding_policies != nullptr)
 			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+		void* d_instance_looping = nullptr;
+		if (ok && local.instance_looping_policies != nullptr)
+			ok = upload(local.instance_looping_policies, num_instances, &d_instance_looping);
 
 		aclhip_pose_consumers local_consumers = {};
 		if (consumers != nullptr)
@@ -527,6 +544,7 @@ namespace
 		local.default_values = static_cast<const float*>(d_defaults);
 		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
 		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+		local.instance_looping_policies = static_cast<const uint8_t*>(d_instance_looping);
 
 		aclhip_status status;
 		if (single_track)

@@ -742,6 +742,11 @@ namespace
 		out.instance_rows = nullptr;
 		out.time_indices = nullptr;
 		out.skip_tracks = nullptr;
+		out.mask_table = nullptr;
+		out.instance_masks = nullptr;
+		out.instance_track_counts = nullptr;
+		out.instance_looping_policies = params->instance_looping_policies;
+		out.mask_stride = 0;
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;
 		out.items_per_wave = 1;

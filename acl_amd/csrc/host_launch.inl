@@ -52,9 +52,9 @@ namespace
 		// the common case (track_writer defaults, no per track rounding, normalization != always) copies a resolved pose image
 		const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
 		// an output descriptor that changes nothing (QVV48, nothing skipped) takes the plain kernels
-		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
+		const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr || params.instance_masks != nullptr;
 		// the compact layouts with nothing else skipped have kernels that build the LDS image in the output layout (kernels_pose.inl)
-		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && params.skip_tracks == nullptr;
+		const bool native_layout = !any_settings && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && params.skip_tracks == nullptr && params.instance_masks == nullptr;
 		const char* name;
 		pose_kernel kernel;
 		if (native_layout && params.layout == ACLHIP_LAYOUT_QV32) { kernel = decompress_tracks_qv32_kernel; name = "decompress_tracks_qv32_kernel"; }
@@ -97,7 +97,7 @@ namespace
 		{
 			// round 3's slower kernel variants, selected by environment knobs (tools/experiments/host_experiments.inl)
 			const bool any_settings = params.standard_defaults == 0 || params.per_track_rounding != 0 || context->force_generic_kernel;
-			const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr;
+			const bool compact = params.layout != ACLHIP_LAYOUT_QVV48 || params.skip_mask != 0 || params.skip_tracks != nullptr || params.instance_masks != nullptr;
 			bool launched = false;
 			const aclhip_status experiment_status = launch_experimental_tracks(context, clips, sample_times, num_instances, params, poses, pose_stride_bytes, stream,
 				windows_per_instance, num_waves, num_blocks, any_settings, compact, lds_quads_per_wave, lds_bytes, launched);
@@ -205,6 +205,17 @@ namespace
 			params.skip_mask |= 4u;
 		params.instance_rows = output->rows;
 		params.skip_tracks = output->skip_tracks;
+		// per instance writer decisions (track_writer::skip_track_*(track_index) of ONE pose, core/track_writer.h:189-191; the first K tracks)
+		if ((output->instance_masks != nullptr) != (output->mask_table != nullptr))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "instance_masks and mask_table come together");
+		if (output->instance_masks != nullptr && output->mask_stride == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "mask_stride: the bytes of one mask of mask_table (at least the tracks of the largest clip of the batch)");
+		if (output->instance_masks != nullptr)
+			params.skip_tracks = nullptr;		// (overridden, as the header says)
+		params.mask_table = output->mask_table;
+		params.instance_masks = output->instance_masks;
+		params.mask_stride = output->mask_stride;
+		params.instance_track_counts = output->instance_track_counts;
 		return ACLHIP_OK;
 	}
 }

@@ -145,6 +145,9 @@ namespace
 			ok = upload(local.track_rounding_policies, std::max<uint32_t>(max_tracks, 1), &d_track_policies);
 		if (ok && local.instance_rounding_policies != nullptr)
 			ok = upload(local.instance_rounding_policies, num_instances, &d_instance_policies);
+		void* d_instance_looping = nullptr;
+		if (ok && local.instance_looping_policies != nullptr)
+			ok = upload(local.instance_looping_policies, num_instances, &d_instance_looping);
 
 		if (!ok)
 		{
@@ -153,6 +156,7 @@ namespace
 		}
 		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
 		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
+		local.instance_looping_policies = static_cast<const uint8_t*>(d_instance_looping);
 
 		aclhip_status status = launch_scalar(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks),
 			num_instances, &local, d_out, out_stride_bytes, work_stream);
@@ -220,6 +224,7 @@ extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, 
 	if (params != nullptr) local = *params; else aclhip_default_params(&local);
 	local.rounding_policy = ACLHIP_ROUND_NEAREST;		// convert.impl.h:166
 	local.instance_rounding_policies = nullptr;
+	local.instance_looping_policies = nullptr;
 
 	// the duration the reference's loop clamps to is the one of the looping policy in effect (convert.impl.h:139)
 	float duration = info.duration;

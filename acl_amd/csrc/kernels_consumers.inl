@@ -40,7 +40,7 @@
 						(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 			}
 		}
-		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0 });
+		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, qvv48_image_writer{ image, 0, 0xFFFFFFFFu });
 	}
 
 	// The pose without its scales (every one of them is 1): rotation | translation, 32 bytes per transform, like the QV32 output layout
@@ -57,7 +57,7 @@
 				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(resolved + (piece >> 1) * 3u + (piece & 1u)),
 					(__attribute__((address_space(3))) void*)(image + base), 16, 0, 0);
 		}
-		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, compact_image_writer<ACLHIP_LAYOUT_QV32>{ reinterpret_cast<float*>(image), 0 });
+		decode_animated_into_image<kFastMath>(clip, sample_time, rounding_policy, params, lane, compact_image_writer<ACLHIP_LAYOUT_QV32>{ reinterpret_cast<float*>(image), 0, 0xFFFFFFFFu });
 	}
 
 	// transform_add0 / transform_add1 (core/additive_utils.h:128-142) one sub-track at a time: unlike the relative format (a qvv_mul)
@@ -248,7 +248,7 @@
 
 	template<bool kObjectSpace, uint32_t kBase, bool kUnitScale, bool kMirrored, bool kBlend = false, bool kFast = false>
 	__global__ __launch_bounds__(k_consumer_max_waves * k_wave_size) void decompress_poses_consumer_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params params, consumer_params consumers,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, decode_params launch_params, consumer_params consumers,
 		uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_image, uint32_t lds_bytes_per_instance, uint32_t packed_block_shape,
 		unsigned long long* __restrict__ rejected_count)
 	{
@@ -314,9 +314,10 @@
 				|| (kBase == k_consumer_base_buffer && uint64_t(clip.num_tracks) * 48u > consumers.base_pose_stride_bytes)
 				|| (!kMirrored && multiplies_transforms && !base_is_clip && (clip.flags & k_clip_negative_scale) != 0);
 
-			const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-				: uint32_t(params.rounding_policy);
+			const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(launch_params, instance));
+			// the instance's own looping policy (decompress.h:149) goes for every clip decoded on its behalf -- its base, its blend partners
+			decode_params params = launch_params;
+			params.looping_policy = uint8_t(__builtin_amdgcn_readfirstlane(instance_looping_policy_of(launch_params, instance)));
 
 			short_exact &= walk_may_use_short_exact_math(clip.flags, params.normalization);
 			device_clip base_clip = clip;

@@ -87,11 +87,18 @@
 		return layout == ACLHIP_LAYOUT_QVV48 ? 48u : (layout == ACLHIP_LAYOUT_QVV40 ? 40u : 32u);
 	}
 
-	__device__ __forceinline__ bool launch_refuses_clip(const device_clip& clip, uint32_t windows_per_instance, uint32_t lds_quads_per_wave, uint32_t bytes_per_track, uint64_t pose_stride_bytes)
+	// num_tracks: the tracks of the clip this instance stores -- all of them, or its first K (aclhip_output_desc::instance_track_counts)
+	__device__ __forceinline__ bool launch_refuses_clip(uint32_t num_tracks, uint32_t windows_per_instance, uint32_t lds_quads_per_wave, uint32_t bytes_per_track, uint64_t pose_stride_bytes)
 	{
-		return num_pose_windows(clip.num_tracks) > windows_per_instance
-			|| min(clip.num_tracks * 3u, k_image_chunk_quads) > lds_quads_per_wave
-			|| uint64_t(clip.num_tracks) * bytes_per_track > pose_stride_bytes;
+		return num_pose_windows(num_tracks) > windows_per_instance
+			|| min(num_tracks * 3u, k_image_chunk_quads) > lds_quads_per_wave
+			|| uint64_t(num_tracks) * bytes_per_track > pose_stride_bytes;
+	}
+
+	// the tracks of its clip an instance stores: aclhip_output_desc::instance_track_counts (wave uniform)
+	__device__ __forceinline__ uint32_t stored_tracks_of(const decode_params& params, uint32_t caller_instance, uint32_t clip_tracks)
+	{
+		return params.instance_track_counts != nullptr ? min(clip_tracks, as_constant(params.instance_track_counts)[caller_instance]) : clip_tracks;
 	}
 
 	// What the any-settings pose kernel stores for a quad of the LDS image: default sub-tracks -- still tagged in their W lane, every
@@ -138,9 +145,11 @@
 	{
 		f32x4* image;
 		uint32_t first_quad;
+		uint32_t window_quads;		// (an instance that stores its first K tracks only has a shorter window than its clip: what lies beyond is dropped)
 		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
 		{
-			image[entry.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
+			if (entry.quad_index - first_quad < window_quads)
+				image[entry.quad_index - first_quad] = f32x4{ value.x, value.y, value.z, value.w };
 		}
 	};
 
@@ -205,9 +214,9 @@
 
 	template<bool kAnySettings, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
-		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t lane, f32x4* image)
+		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t window_quads, uint32_t lane, f32x4* image)
 	{
-		const qvv48_image_writer writer = { image, first_quad };
+		const qvv48_image_writer writer = { image, first_quad, window_quads };
 		if (kAnySettings && params.per_track_rounding != 0)
 			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 		else
@@ -254,10 +263,14 @@
 		// (kernel arguments beyond the 16 preloaded SGPRs -- the stride and the LDS slot size the launch shape checks need -- are fetched
 		// next to the instance's clip handle, not behind the clip record where the compiler would put them: one round trip less)
 		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));
-		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
+		// (instance lists decode in slot order: the caller's index of this slot's instance is in their order)
+		const uint32_t caller_instance = params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance;
+		const float sample_time = as_constant(sample_times)[caller_instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+		// the tracks this instance stores: all of its clip's, or its first K (aclhip_output_desc::instance_track_counts: a per character LOD)
+		const uint32_t stored_tracks = stored_tracks_of(params, caller_instance, clip.num_tracks);
 		if (clip_id >= num_clips || !is_transform_clip(clip.flags)
-			|| launch_refuses_clip(clip, windows_per_instance, lds_quads_per_wave, kCompactOutput ? layout_bytes_per_track(params.layout) : 48u, pose_stride_bytes))
+			|| launch_refuses_clip(stored_tracks, windows_per_instance, lds_quads_per_wave, kCompactOutput ? layout_bytes_per_track(params.layout) : 48u, pose_stride_bytes))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -265,7 +278,7 @@
 		}
 
 		// an empty track list (decompression.transform.h:1531-1533) or a pose that ends before this window
-		const uint32_t num_quads = clip.num_tracks * 3u;
+		const uint32_t num_quads = stored_tracks * 3u;
 		const uint32_t first_quad = window * k_image_chunk_quads;
 		if (first_quad >= num_quads)
 			return;
@@ -273,7 +286,7 @@
 
 		// the window's animated sub-tracks: image_chunks[window] .. image_chunks[window + 1]
 		uint32_t first_ordinal = 0, end_ordinal = clip.num_animated;
-		if (num_quads > k_image_chunk_quads)
+		if (clip.num_tracks * 3u > k_image_chunk_quads)
 		{
 			first_ordinal = as_constant(clip.image_chunks)[window];
 			end_ordinal = as_constant(clip.image_chunks)[window + 1];
@@ -290,7 +303,8 @@
 			const ACLHIP_CONSTANT f32x4* source = (const ACLHIP_CONSTANT f32x4*)(resolve_defaults ? clip.base_pose : clip.resolved_pose) + first_quad;
 			// (in-turn kernel: the image still holds this clip's window from the wave's previous item -- every animated quad is about to be
 			// overwritten, the others are this clip's constants already)
-			const bool image_is_current = image_clip != nullptr && *image_clip == clip_id;
+			// (with per instance track counts the image of the previous item may hold fewer quads than this one needs: no reuse)
+			const bool image_is_current = image_clip != nullptr && *image_clip == clip_id && params.instance_track_counts == nullptr;
 			if (image_clip != nullptr)
 				*image_clip = clip_id;
 			if (!image_is_current)
@@ -304,13 +318,12 @@
 			}
 		}
 
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
+		const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, caller_instance));
+		const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, caller_instance));
 		const uint32_t normalization = params.normalization;
 
 		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
 #if defined(ACLHIP_EXP_PHASE_TIMES)
 		asm volatile("" :: "s"(state.key_frame_bit_offsets[0]), "s"(state.key_frame_bit_offsets[1]));		// the seek's loads have arrived
 		ACLHIP_WAVE0_STAMP(1);
@@ -340,7 +353,7 @@
 		// lanes <-> animated sub-tracks of this window
 		// (decoded quads are written after the DMA has delivered their slots: a wave's memory operations return in order, and the
 		// keyframe loads every decoded value waits for were issued after the DMA)
-		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -349,7 +362,13 @@
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		ACLHIP_WAVE0_STAMP(2);
 
-		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults && params.skip_tracks == nullptr)
+		// track_writer::skip_track_rotation / _translation / _scale(track_index) (core/track_writer.h:189-191): one mask for the launch, or
+		// this instance's own out of the caller's table (aclhip_output_desc::mask_table, instance_masks)
+		const uint8_t* skip_tracks = params.skip_tracks;
+		if (kCompactOutput && params.instance_masks != nullptr)
+			skip_tracks = params.mask_table + size_t(as_constant(params.instance_masks)[caller_instance]) * params.mask_stride;
+
+		if (kCompactOutput && params.layout != ACLHIP_LAYOUT_QVV48 && (params.skip_mask & ~(params.layout == ACLHIP_LAYOUT_QV32 ? 4u : 0u)) == 0 && !resolve_defaults && skip_tracks == nullptr)
 		{
 			// Compact layouts, nothing else skipped (the common use): the window is RE-TILED on its way out -- lanes <-> consecutive 16 byte
 			// pieces of the OUTPUT, gathered from the QVV48 image in LDS -- so that every store instruction still writes 1 KiB of
@@ -471,9 +490,8 @@
 				// span of the pose, minus the dropped pieces.
 				const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
 				store = store && ((params.skip_mask >> kind) & 1u) == 0;
-				// track_writer::skip_track_rotation / _translation / _scale(track_index) (core/track_writer.h:189-191), launch wide
-				if (params.skip_tracks != nullptr && store)
-					store = ((params.skip_tracks[track_index] >> kind) & 1u) == 0;
+				if (skip_tracks != nullptr && store)
+					store = ((skip_tracks[track_index] >> kind) & 1u) == 0;
 				if (params.layout == ACLHIP_LAYOUT_QVV48)
 				{
 					if (store)
@@ -516,11 +534,14 @@
 	{
 		float* image;
 		uint32_t first_track;
+		uint32_t window_tracks;		// (see qvv48_image_writer)
 		__device__ __forceinline__ void operator()(const clip_range_entry& entry, float4 value) const
 		{
 			typedef float f32x2 __attribute__((ext_vector_type(2)));
 			const uint32_t kind = entry.quad_index - entry.track_index * 3u;
 			const uint32_t track = entry.track_index - first_track;
+			if (track >= window_tracks)
+				return;
 			if (kLayout == ACLHIP_LAYOUT_QV32)
 			{
 				if (kind != 2)
@@ -572,9 +593,11 @@
 
 		const uint32_t clip_id = as_constant(clip_ids)[instance];
 		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));		// (see decompress_tracks_window)
-		const float sample_time = as_constant(sample_times)[params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance];
+		const uint32_t caller_instance = params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance;
+		const float sample_time = as_constant(sample_times)[caller_instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
-		if (clip_id >= num_clips || !is_transform_clip(clip.flags) || launch_refuses_clip(clip, windows_per_instance, lds_quads_per_wave, k_track_bytes, pose_stride_bytes))
+		const uint32_t stored_tracks = stored_tracks_of(params, caller_instance, clip.num_tracks);		// (see decompress_tracks_window)
+		if (clip_id >= num_clips || !is_transform_clip(clip.flags) || launch_refuses_clip(stored_tracks, windows_per_instance, lds_quads_per_wave, k_track_bytes, pose_stride_bytes))
 		{
 			if (lane == 0 && window == 0)
 				atomicAdd(rejected_count, 1ull);
@@ -582,9 +605,9 @@
 		}
 
 		const uint32_t first_track = window * k_window_tracks;
-		if (first_track >= clip.num_tracks)
+		if (first_track >= stored_tracks)
 			return;
-		const uint32_t window_tracks = min(clip.num_tracks - first_track, k_window_tracks);
+		const uint32_t window_tracks = min(stored_tracks - first_track, k_window_tracks);
 		const uint32_t window_bytes = window_tracks * k_track_bytes;
 		const uint32_t window_pieces = (window_bytes + 15u) / 16u;		// QVV40 with an odd number of tracks ends on half a piece
 
@@ -612,16 +635,15 @@
 			}
 		}
 
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
+		const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, caller_instance));
+		const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, caller_instance));
 
 		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
 
 		// the base pose must be in the image before decoded sub-tracks take their places in it (the QVV40 pieces of a decoded sub-track
 		// and of its constant neighbours share 16 byte units: DMA first, then the decode's own writes)
-		const compact_image_writer<kLayout> writer = { reinterpret_cast<float*>(image), first_track };
+		const compact_image_writer<kLayout> writer = { reinterpret_cast<float*>(image), first_track, window_tracks };
 		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer);
 
 		__builtin_amdgcn_s_waitcnt(0);
@@ -686,7 +708,7 @@
 	//                           like the one-shot grid does (the host sizes the grid so that a wave keeps its window index);
 	//   kAdjacentItems = true:  wave g takes window g % W of instances (g / W) K .. (g / W) K + K - 1: consecutive instances, which in a
 	//                           list bucketed by clip are of one clip.
-	template<bool kAdjacentItems>
+	template<bool kAdjacentItems, bool kWideKeyLoads = true>
 	__device__ __forceinline__ void decompress_tracks_windows_in_turn(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
@@ -699,7 +721,7 @@
 		{
 			const uint32_t work_item = kAdjacentItems ? (group * items_per_wave + turn) * windows_per_instance + window
 				: (turn * gridDim.x + blockIdx.x) * k_waves_per_block + wave_in_block;
-			decompress_tracks_window<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
+			decompress_tracks_window<false, false, kWideKeyLoads>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
 			// (the window's LDS reads completed before its stores were issued: the next turn's DMA may overwrite the image)
 		}
 	}
@@ -713,6 +735,11 @@
 	{
 		decompress_tracks_windows_in_turn<true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
+
+	// (One-window poses gain nothing from taking items in turn -- measured in round 5 with the byte-window key reads of the one-shot kernel,
+	// 2 / 3 / 4 items per wave: headline 48.8 -> 53.7 / 56.2 / 57.3 us, 256 clips as drawn 62.0 -> 64.6 / 66.0 / 66.8, in locality order
+	// 50.7 -> 54.1 / - / 55.7: at 8 waves per SIMD the one-shot grid already overlaps one wave's chain with the stores of seven others, and a
+	// 100 bone pose pulls its base pose window out of the L2 either way. profiles/r05_experiments.md)
 
 	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)

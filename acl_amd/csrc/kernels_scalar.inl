@@ -264,14 +264,13 @@
 		if (first_track >= clip.num_tracks || clip.num_samples == 0)
 			return;		// past the end of this clip's track list / empty track list (:185-186,246-248)
 
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr
-			? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[instance]))
-			: uint32_t(params.rounding_policy);
+		const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, instance));
+		const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, instance));
 
 		// seek_v0 (:182-240): a frame is num_bits_per_frame bits
 		uint32_t key_frame0, key_frame1;
 		float seek_alpha;
-		find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_time, rounding_policy, params.looping_policy,
+		find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_time, rounding_policy, looping_policy,
 			key_frame0, key_frame1, seek_alpha);
 
 		const uint32_t num_components = (clip.flags >> k_clip_components_shift) & 7u;
@@ -448,11 +447,10 @@
 		#pragma unroll
 		for (uint32_t k = 0; k < k_scalar_group; ++k)
 		{
-			rounding_policies[k] = params.instance_rounding_policies != nullptr
-				? __builtin_amdgcn_readfirstlane(uint32_t(params.instance_rounding_policies[first_instance + min(k, count - 1)]))
-				: uint32_t(params.rounding_policy);
+			rounding_policies[k] = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, first_instance + min(k, count - 1)));
+			const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, first_instance + min(k, count - 1)));
 			uint32_t key_frame0, key_frame1;
-			find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, times[k], rounding_policies[k], params.looping_policy,
+			find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, times[k], rounding_policies[k], looping_policy,
 				key_frame0, key_frame1, alphas[k]);
 			frames[k] = scalar_frames();
 			frames[k].blob = clip.blob;
@@ -546,10 +544,10 @@
 		if (clip.num_samples == 0)
 			return;
 
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[instance]) : uint32_t(params.rounding_policy);
+		const uint32_t rounding_policy = instance_rounding_policy_of(params, instance);
 		uint32_t key_frame0, key_frame1;
 		float alpha;
-		find_key_frames(flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_times[instance], rounding_policy, params.looping_policy,
+		find_key_frames(flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, sample_times[instance], rounding_policy, instance_looping_policy_of(params, instance),
 			key_frame0, key_frame1, alpha);
 		if (params.per_track_rounding != 0)
 		{

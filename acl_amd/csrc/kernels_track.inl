@@ -65,7 +65,7 @@
 	// seek, the track's three base pose quads. Returns false for a request that is refused (decompression.transform.h:1766-1768).
 	// out_animated: bit k = sub-track kind k is animated (out_ordinals[k] = its ordinal); the other kinds have their final value in
 	// out_quads[k] and whether it is stored at all in out_store[k].
-	__device__ __forceinline__ bool prepare_track_request(const device_clip& clip, float sample_time, uint32_t track_index, uint32_t rounding_policy,
+	__device__ __forceinline__ bool prepare_track_request(const device_clip& clip, float sample_time, uint32_t track_index, uint32_t rounding_policy, uint32_t looping_policy,
 		const decode_params& params, track_request_state& out_state, float& out_lerp_alpha, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
 	{
 		out_animated = 0;
@@ -74,7 +74,7 @@
 			return false;
 
 		seek_state state;
-		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
 
 		// decompress_track_v0 folds a per track policy into the alpha and always interpolates (decompression.transform.h:1975-1983)
 		float lerp_alpha = state.interpolation_alpha;
@@ -152,7 +152,8 @@
 		const uint32_t clip_id = clip_ids[clamped_instance];
 		const float sample_time = sample_times[clamped_instance];
 		const uint32_t track_index = track_indices[clamped_instance];
-		const uint32_t rounding_policy = params.instance_rounding_policies != nullptr ? uint32_t(params.instance_rounding_policies[clamped_instance]) : uint32_t(params.rounding_policy);
+		const uint32_t rounding_policy = instance_rounding_policy_of(params, clamped_instance);
+		const uint32_t looping_policy = instance_looping_policy_of(params, clamped_instance);
 
 		const bool known_clip = in_batch && clip_id < num_clips;
 		const uint32_t first_clip_id = __builtin_amdgcn_readfirstlane(clip_id);			// lane 0 is always in the batch
@@ -174,12 +175,12 @@
 			shared_plan = clip.plan;
 			shared_clip_ranges = clip.clip_ranges;
 			if (in_batch)
-				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
+				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 		else if (known_clip)
 		{
 			const device_clip clip = load_clip_per_lane(clips, clip_id);
-			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
+			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 
 		// refused requests are counted, one atomic per wave

@@ -49,6 +49,7 @@ class DecompressParams(ctypes.Structure):
         ("rounding_policy", ctypes.c_uint8), ("looping_policy", ctypes.c_uint8), ("normalization", ctypes.c_uint8), ("per_track_rounding", ctypes.c_uint8),
         ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("default_values", ctypes.c_void_p), ("track_rounding_policies", ctypes.c_void_p), ("instance_rounding_policies", ctypes.c_void_p),
+        ("instance_looping_policies", ctypes.c_void_p),
     ]
 
 
@@ -67,10 +68,11 @@ class OutputDesc(ctypes.Structure):
     _fields_ = [
         ("layout", ctypes.c_uint32), ("skip_rotations", ctypes.c_uint8), ("skip_translations", ctypes.c_uint8), ("skip_scales", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("rows", ctypes.c_void_p), ("skip_tracks", ctypes.c_void_p),
+        ("mask_table", ctypes.c_void_p), ("instance_masks", ctypes.c_void_p), ("instance_track_counts", ctypes.c_void_p), ("mask_stride", ctypes.c_uint32), ("reserved1", ctypes.c_uint32),
     ]
 
 
-ABI_VERSION = 4             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
+ABI_VERSION = 5             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
 PEER_HANDLE_BYTES = 72      # ACLHIP_PEER_HANDLE_BYTES
 LAYOUT_QVV48, LAYOUT_QVV40, LAYOUT_QV32 = 0, 1, 2  # aclhip_pose_layout
 LAYOUTS = {"qvv48": (LAYOUT_QVV48, 48), "qvv40": (LAYOUT_QVV40, 40), "qv32": (LAYOUT_QV32, 32)}     # name -> (aclhip_pose_layout, bytes per track)

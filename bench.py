@@ -51,7 +51,10 @@ WORKLOAD_TEXT = {
     "cinematic_16": "64k instances per GPU drawn from 16 distinct 300-bone rigs with scale (measurement aid: poses of several windows over several clips)",
     "one_clip_mixed_registry": "the one_clip batch (4 800 byte rows) while the context ALSO holds a 300-bone rig and a 551-bone clip: the launch is shaped by the batch, not by the registry",
     "track_requests": "4 M random (instance, bone) requests on the 100-bone clip: seek + decompress_track, one 48 byte qvv per request (SURVEY 8 a15)",
+    "one_clip_lods": "the one_clip batch with a per character LOD: every instance stores its first 100 / 60 / 30 bones (a third of the crowd each, "
+                     "aclhip_output_desc::instance_track_counts): one launch, 63 % of the bytes",
 }
+LOD_TRACK_COUNTS = (100, 60, 30)
 TRACK_REQUESTS = 1 << 22
 
 
@@ -72,7 +75,7 @@ def _build_workload(name, rank, num_instances):
     from acl_amd import synth
 
     rng = np.random.default_rng(1000 + rank)
-    if name in ("one_clip", "object_space", "object_space_fast", "one_clip_mixed_registry", "track_requests"):
+    if name in ("one_clip", "object_space", "object_space_fast", "one_clip_mixed_registry", "track_requests", "one_clip_lods"):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0)]
         clip_indices = np.zeros(num_instances, dtype=np.uint32)
     elif name == "blend_object_space":
@@ -274,11 +277,17 @@ class Job:
                 self.consumers.blend_clips, self.consumers.blend_sample_times, self.consumers.blend_weights = self.d_blend_clips.data_ptr(), self.d_blend_times.data_ptr(), self.d_blend_weights.data_ptr()
             self._launch = self.lib.aclhip_decompress_poses_batch
             self._args = (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), ctypes.byref(self.consumers), poses_ptr, self.pose_stride, stream_ptr)
-        elif layout != "qvv48" or self.d_rows is not None:
+        elif layout != "qvv48" or self.d_rows is not None or name == "one_clip_lods":
             self.output = runtime.OutputDesc()
             self.output.layout = runtime.LAYOUTS[layout][0]
             if self.d_rows is not None:
                 self.output.rows = self.d_rows.data_ptr()
+            if name == "one_clip_lods":
+                # the writer of every pose keeps its first K bones (track_writer::skip_track_*(track_index), core/track_writer.h:189-191, per character)
+                lod_rng = np.random.default_rng(6000 + rank)
+                self.track_counts = lod_rng.choice(np.array(LOD_TRACK_COUNTS, dtype=np.int32), size=n)
+                self.d_track_counts = torch.from_numpy(self.track_counts).to(self.device)
+                self.output.instance_track_counts = self.d_track_counts.data_ptr()
             self._launch = self.lib.aclhip_decompress_tracks_batch_out
             self._args = (handle, clips_ptr, times_ptr, n, ctypes.byref(self.params), ctypes.byref(self.output), poses_ptr, self.pose_stride, stream_ptr)
         else:
@@ -359,6 +368,8 @@ class Job:
             return self.num_instances * (48 + 12) + read              # a 48 byte transform out, clip handle + sample time + track index in, the clip once
         if not self.is_scalar:
             written = written // 48 * self.runtime.LAYOUTS[self.layout][1]
+        if self.name == "one_clip_lods":
+            written = int(np.minimum(self.track_counts, self.max_tracks).sum()) * self.runtime.LAYOUTS[self.layout][1]       # what the writers keep
         if self.name.startswith("additive_object_space"):
             read += self.context.batch_algorithmic_bytes(self.handles[:1])[1]        # the base clip is read too; one pose per instance is written
         if self.name == "blend_object_space":
@@ -411,6 +422,7 @@ def default_run_specs():
     return [
         ("one_clip", {}, 300),                                      # the headline batch again (its traffic goes to roofline.traffic)
         ("one_clip_mixed_registry", {}, 300),                       # ... while the context also holds a 300-bone rig and a 551-bone clip
+        ("one_clip_lods", {}, 300),                                 # ... with per instance track counts (100 / 60 / 30 bones): poses/s follow the bytes written
         ("256_clips", {}, 300),
         ("256_clips", {"order": "locality"}, 300),
         ("256_clips", {"order": "device"}, 300),                    # ordered on the GPU in front of every launch: the ordering is in kernel_ms

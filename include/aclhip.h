@@ -98,6 +98,8 @@ typedef struct aclhip_decompress_params
 	const float* default_values;			/* DEVICE pointer or NULL. CONSTANT: 12 floats; VARIABLE: max num_tracks * 12 floats (qvv per track) */
 	const uint8_t* track_rounding_policies;	/* DEVICE pointer or NULL: track_writer::get_rounding_policy() per track, used when seeking with PER_TRACK */
 	const uint8_t* instance_rounding_policies;	/* DEVICE pointer or NULL: one aclhip_rounding_policy per instance, overrides rounding_policy */
+	const uint8_t* instance_looping_policies;	/* DEVICE pointer or NULL: one aclhip_looping_policy per instance, overrides looping_policy --
+												 * decompression_context::set_looping_policy() belongs to ONE context = one instance (decompress.h:149) */
 } aclhip_decompress_params;
 
 /* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
@@ -125,6 +127,22 @@ typedef struct aclhip_output_desc
 											 * (core/track_writer.h:189-191) for the whole launch: one byte per track (as many as the largest clip of
 											 * the batch has tracks), bit 0 / 1 / 2 set = the track's rotation / translation / scale is skipped -- not
 											 * written, its bytes in the pose buffer are left untouched (an LOD that drops finger bones) */
+	/* Per INSTANCE writer decisions (ABI 5). In the reference the track_writer belongs to ONE decompress_tracks call, i.e. to one pose:
+	 * skip_track_rotation / _translation / _scale(track_index) (core/track_writer.h:189-191) are per character. A crowd with per
+	 * character LODs is ONE launch here:
+	 *   mask_table + instance_masks   M skip masks of mask_stride bytes each (a mask = what skip_tracks is: one byte per track, bit 0 / 1 / 2 =
+	 *                                 rotation / translation / scale skipped); instance i uses mask instance_masks[i] (< M, not checked: the
+	 *                                 caller's table). Overrides skip_tracks.
+	 *   instance_track_counts         instance i stores only its first instance_track_counts[i] tracks (the LOD most engines use: bones are
+	 *                                 ordered by importance); nothing beyond is decoded, DMA'd or written -- on a kernel bound by its
+	 *                                 writes, bytes not written are poses per second. A count above the clip's track count changes nothing.
+	 * Every per instance array of this struct and of aclhip_decompress_params is indexed by the CALLER's instance index (instance lists:
+	 * the index in the list handed to aclhip_instance_list_set_clips, whatever order the library decodes in). */
+	const uint8_t* mask_table;				/* DEVICE pointer or NULL */
+	const uint8_t* instance_masks;			/* DEVICE pointer or NULL: one mask index per instance; needs mask_table */
+	const uint32_t* instance_track_counts;	/* DEVICE pointer or NULL */
+	uint32_t mask_stride;					/* bytes from one mask of mask_table to the next (>= tracks of the largest clip of the batch) */
+	uint32_t reserved1;
 } aclhip_output_desc;
 
 typedef struct aclhip_clip_info
@@ -153,10 +171,11 @@ const char* aclhip_status_string(aclhip_status status);
 const char* aclhip_last_error_message(const aclhip_context* context);
 
 /* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks;
- * 4: aclhip_pose_consumers::num_blend_clips, flags, blend_clips, blend_sample_times, blend_weights).
+ * 4: aclhip_pose_consumers::num_blend_clips, flags, blend_clips, blend_sample_times, blend_weights;
+ * 5: aclhip_decompress_params::instance_looping_policies, aclhip_output_desc::mask_table, instance_masks, instance_track_counts, mask_stride).
  * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
  * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
-#define ACLHIP_ABI_VERSION 4u
+#define ACLHIP_ABI_VERSION 5u
 uint32_t aclhip_abi_version(void);
 
 /* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are

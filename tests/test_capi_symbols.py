@@ -105,6 +105,8 @@ def test_header_library_and_binding_agree_on_the_abi_version():
     declared = int(re.search(r"#define\s+ACLHIP_ABI_VERSION\s+(\d+)u", header).group(1))
     lib = runtime.load_library()
     assert lib.aclhip_abi_version() == declared == runtime.ABI_VERSION
-    # the binding's mirror of the struct that changed last: layout u32 | 3 skip bytes + 1 reserved | rows | skip_tracks
-    assert ctypes.sizeof(runtime.OutputDesc) == 24
-    assert runtime.OutputDesc.skip_tracks.offset == 16
+    # the binding's mirrors of the structs that changed last (ABI 5): layout u32 | 3 skip bytes + 1 reserved | rows | skip_tracks |
+    # mask_table | instance_masks | instance_track_counts | mask_stride u32 + 1 reserved; ... | instance_looping_policies
+    assert ctypes.sizeof(runtime.OutputDesc) == 56
+    assert runtime.OutputDesc.skip_tracks.offset == 16 and runtime.OutputDesc.mask_table.offset == 24 and runtime.OutputDesc.mask_stride.offset == 48
+    assert ctypes.sizeof(runtime.DecompressParams) == 40 and runtime.DecompressParams.instance_looping_policies.offset == 32

@@ -238,7 +238,7 @@
 		seek_state state;
 		seek(clip, sample_time, rounding_policy, params.looping_policy, state);
 
-		decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+		decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
 
 		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
 		publish(window_quads, uint64_t(row) * pose_stride_bytes + uint64_t(first_quad) * 16u);
@@ -438,7 +438,7 @@
 			stamp_items++;
 #endif
 
-			decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, first_quad, lane, image);
+			decode_window_sub_tracks<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
 
 			const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
 			const uint64_t pose_offset = uint64_t(row) * pose_stride_bytes + uint64_t(first_quad) * 16u;
