@@ -214,6 +214,7 @@ namespace aclhip
 		uint8_t layout;					// aclhip_pose_layout (aclhip_output_desc)
 		uint8_t skip_mask;				// bit k: sub-tracks of kind k (rotation / translation / scale) are not stored
 		uint8_t items_per_wave;			// decompress_tracks_in_turn_kernel: work items a wave takes in turn
+		uint8_t clips_by_caller_instance;	// pose kernels: 1 when the clip list is in the CALLER's instance order although the launch decodes in slot order (attached instance lists: clip = clips[time_indices[slot]])
 	};
 
 	// Per instance settings. `caller_instance`: the instance's index in the CALLER's lists -- instance lists decode in slot order and find

@@ -750,6 +750,7 @@ namespace
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;
 		out.items_per_wave = 1;
+		out.clips_by_caller_instance = 0;
 		out.rounding_policy = params->rounding_policy;
 		out.looping_policy = params->looping_policy;
 		out.normalization = params->normalization;

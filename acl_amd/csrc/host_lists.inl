@@ -12,6 +12,7 @@ struct aclhip_context::instance_list
 	bool ordered = false;
 	uint32_t ordered_for_windows = 0;		// waves per pose of the launch shape the order was made for (the slot -> XCD map depends on it); 0: the registry's at that time
 	uint64_t num_orderings = 0;
+	const uint32_t* attached_clips = nullptr;	// aclhip_instance_list_attach: the caller's clip array (instance order) the list decodes, or null (the list's own copy)
 
 	uint32_t* clips() const { return d_memory; }
 	uint32_t* order() const { return d_memory + num_instances; }
@@ -104,6 +105,7 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 		// the clips are about to be overwritten: whatever order the list had describes them no longer. It counts as ordered again
 		// only once the new order has been enqueued (a failure below leaves a list that refuses decodes, not one that decodes a stale assignment)
 		list->ordered = false;
+		list->attached_clips = nullptr;
 		snapshot = *list;
 	}
 	device_guard guard(context->device);
@@ -128,6 +130,55 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 	return ACLHIP_OK;
 }
 
+extern "C" aclhip_status aclhip_instance_list_attach(aclhip_context* context, aclhip_instance_list handle, const aclhip_clip* caller_clips, void* stream)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (caller_clips == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null clip list");
+	aclhip_context::instance_list snapshot;
+	{
+		std::lock_guard<std::mutex> lock(context->mutex);
+		aclhip_context::instance_list* list = find_list(context, handle);
+		if (list == nullptr)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+		list->ordered = false;		// (see aclhip_instance_list_set_clips)
+		list->attached_clips = nullptr;
+		snapshot = *list;
+	}
+	device_guard guard(context->device);
+	const uint32_t registry_windows = windows_per_instance_of(context);		// (takes the context's lock itself)
+	// the order of the caller's array as it is now; no copy of the clips, no slot-order copy, no positions: the decode reads the caller's array through the order
+	const aclhip_status status = order_instances_on_device(context, registry_windows, caller_clips, nullptr, snapshot.num_instances, snapshot.order(), nullptr, nullptr, nullptr, stream);
+	if (status != ACLHIP_OK)
+		return status;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list != nullptr && list->d_memory == snapshot.d_memory)
+	{
+		list->ordered = true;
+		list->attached_clips = caller_clips;
+		list->ordered_for_windows = registry_windows;
+		list->changed_since_ordered = 0;
+		list->num_orderings++;
+	}
+	return ACLHIP_OK;
+}
+
+extern "C" aclhip_status aclhip_instance_list_note_changes(aclhip_context* context, aclhip_instance_list handle, uint32_t count)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::mutex> lock(context->mutex);
+	aclhip_context::instance_list* list = find_list(context, handle);
+	if (list == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
+	if (!list->ordered || list->attached_clips == nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_attach comes first");
+	list->changed_since_ordered = uint32_t(std::min<uint64_t>(uint64_t(list->changed_since_ordered) + count, 0xFFFFFFFFull));
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_instance_list_update(aclhip_context* context, aclhip_instance_list handle, const uint32_t* instances, const aclhip_clip* clips, uint32_t count, void* stream)
 {
 	if (context == nullptr)
@@ -142,6 +193,8 @@ extern "C" aclhip_status aclhip_instance_list_update(aclhip_context* context, ac
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
 	if (!list->ordered)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "aclhip_instance_list_set_clips comes first");
+	if (list->attached_clips != nullptr)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "an attached list decodes the caller's own clip array: write the changes there and call aclhip_instance_list_note_changes");
 	device_guard guard(context->device);
 	note_launch_stream(context, static_cast<hipStream_t>(stream));
 	hipLaunchKernelGGL(update_instance_list_kernel, dim3((count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -185,6 +238,7 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 		if (ordering_gave_up)
 			list->changed_since_ordered = list->num_instances;
 	}
+	const bool attached = snapshot.attached_clips != nullptr;
 	status = check_batch_arguments(context, snapshot.clips(), sample_times, snapshot.num_instances, poses, pose_stride_bytes);
 	if (status != ACLHIP_OK)
 		return status;
@@ -196,11 +250,15 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 
 	device_params.time_indices = snapshot.order();
 	device_params.instance_rows = poses_in_instance_order != 0 ? snapshot.order() : nullptr;
+	device_params.clips_by_caller_instance = attached ? 1 : 0;
 
 	device_guard guard(context->device);
 	if (reorder)
 	{
-		status = order_instances_on_device(context, windows_per_instance, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
+		if (attached)
+			status = order_instances_on_device(context, windows_per_instance, snapshot.attached_clips, nullptr, snapshot.num_instances, snapshot.order(), nullptr, nullptr, nullptr, stream);
+		else
+			status = order_instances_on_device(context, windows_per_instance, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
 		if (status != ACLHIP_OK)
 			return status;
 		std::lock_guard<std::mutex> lock(context->mutex);
@@ -213,7 +271,7 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 			list->num_orderings++;
 		}
 	}
-	return launch_tracks(context, snapshot.ordered_clips(), sample_times, snapshot.num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
+	return launch_tracks(context, attached ? snapshot.attached_clips : snapshot.ordered_clips(), sample_times, snapshot.num_instances, device_params, poses, pose_stride_bytes, static_cast<hipStream_t>(stream));
 }
 
 extern "C" aclhip_status aclhip_instance_list_get_order(aclhip_context* context, aclhip_instance_list handle, const uint32_t** out_order, uint64_t* out_num_orderings)

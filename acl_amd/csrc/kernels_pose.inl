@@ -259,12 +259,16 @@
 			return;
 
 		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
-		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		uint32_t clip_id = as_constant(clip_ids)[instance];
 		// (kernel arguments beyond the 16 preloaded SGPRs -- the stride and the LDS slot size the launch shape checks need -- are fetched
 		// next to the instance's clip handle, not behind the clip record where the compiler would put them: one round trip less)
 		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));
 		// (instance lists decode in slot order: the caller's index of this slot's instance is in their order)
 		const uint32_t caller_instance = params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance;
+		// an attached instance list: the clip list is the caller's own array, in the caller's order (one more dependent scalar load, for
+		// these launches only; what was read above is thrown away)
+		if (params.clips_by_caller_instance != 0)
+			clip_id = as_constant(clip_ids)[caller_instance];
 		const float sample_time = as_constant(sample_times)[caller_instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		// the tracks this instance stores: all of its clip's, or its first K (aclhip_output_desc::instance_track_counts: a per character LOD)
@@ -591,9 +595,11 @@
 		if (instance >= num_instances)
 			return;
 
-		const uint32_t clip_id = as_constant(clip_ids)[instance];
+		uint32_t clip_id = as_constant(clip_ids)[instance];
 		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));		// (see decompress_tracks_window)
 		const uint32_t caller_instance = params.time_indices != nullptr ? as_constant(params.time_indices)[instance] : instance;
+		if (params.clips_by_caller_instance != 0)
+			clip_id = as_constant(clip_ids)[caller_instance];
 		const float sample_time = as_constant(sample_times)[caller_instance];
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 		const uint32_t stored_tracks = stored_tracks_of(params, caller_instance, clip.num_tracks);		// (see decompress_tracks_window)

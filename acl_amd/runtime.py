@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
-    "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order",
+    "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order", "aclhip_instance_list_attach", "aclhip_instance_list_note_changes",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
     "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch", "aclhip_analyze_clip",
 ]
@@ -363,6 +363,13 @@ class Context:
     def instance_list_update(self, instance_list, instances_ptr, clips_ptr, count, stream=None):
         self._check(self._lib.aclhip_instance_list_update(self._handle, ctypes.c_uint32(instance_list), ctypes.c_void_p(instances_ptr), ctypes.c_void_p(clips_ptr),
                                                           ctypes.c_uint32(count), ctypes.c_void_p(stream)))
+
+    def instance_list_attach(self, instance_list, caller_clips_ptr, stream=None):
+        """aclhip_instance_list_attach: the list decodes the caller's own device clip array (kept alive and in place by the caller)"""
+        self._check(self._lib.aclhip_instance_list_attach(self._handle, ctypes.c_uint32(instance_list), ctypes.c_void_p(caller_clips_ptr), ctypes.c_void_p(stream)))
+
+    def instance_list_note_changes(self, instance_list, count):
+        self._check(self._lib.aclhip_instance_list_note_changes(self._handle, ctypes.c_uint32(instance_list), ctypes.c_uint32(count)))
 
     def decompress_tracks_list(self, instance_list, times_ptr, poses_ptr, pose_stride_bytes, params=None, output=None, poses_in_instance_order=False, stream=None):
         params = params if params is not None else default_params()

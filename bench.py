@@ -169,7 +169,10 @@ class Job:
     "device" (aclhip_order_instances_device in front of EVERY launch, on the launch stream: the ordering is part of the step),
     "list" (a persistent aclhip_instance_list: ordered once at setup; EVERY step 1 % of the instances change clip through
     aclhip_instance_list_update and the list is decoded with aclhip_decompress_tracks_list -- the library re-orders it when an
-    eighth of it has changed: update, decode and the re-orders that fall into the timed steps are all part of the step).
+    eighth of it has changed: update, decode and the re-orders that fall into the timed steps are all part of the step),
+    "attached" (the same frame loop with aclhip_instance_list_attach: the list decodes the CALLER's clip array; EVERY step a caller side
+    kernel -- torch's index_copy_, standing in for the animation graph -- writes the 1 % changes into that array on the decode stream,
+    aclhip_instance_list_note_changes counts them, the list is decoded: the caller's kernel, the decode and the re-orders are all part of the step).
     layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
     def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48"):
@@ -296,7 +299,7 @@ class Job:
         if order == "device":
             self._order_args = (handle, self.d_source_clips.data_ptr(), self.d_source_times.data_ptr(), n, self.d_order.data_ptr(), clips_ptr, times_ptr, stream_ptr)
         self.instance_list = None
-        if order == "list":
+        if order in ("list", "attached"):
             # 16 pre-drawn update sets (1 % of the instances each, new clips drawn like the old ones), cycled through by the steps
             update_rng = np.random.default_rng(3000 + rank)
             count = max(1, n // 100)
@@ -307,7 +310,11 @@ class Job:
                 self._updates.append((torch.from_numpy(instances).to(self.device), torch.from_numpy(new_clips).to(self.device), count))
             self._update_index = 0
             self.instance_list = context.instance_list_create(n)
-            context.instance_list_set_clips(self.instance_list, clips_ptr, stream=stream_ptr)
+            if order == "attached":
+                self._updates = [(instances.long(), new_clips, count) for instances, new_clips, count in self._updates]       # (index_copy_ takes 64 bit indices)
+                context.instance_list_attach(self.instance_list, clips_ptr, stream=stream_ptr)
+            else:
+                context.instance_list_set_clips(self.instance_list, clips_ptr, stream=stream_ptr)
             self.stream.synchronize()
 
     def order_step(self):
@@ -319,7 +326,11 @@ class Job:
         if self.instance_list is not None:
             instances, new_clips, count = self._updates[self._update_index % len(self._updates)]
             self._update_index += 1
-            self.context.instance_list_update(self.instance_list, instances.data_ptr(), new_clips.data_ptr(), count, stream=self.stream.cuda_stream)
+            if self.order == "attached":
+                self.caller_update(instances, new_clips)
+                self.context.instance_list_note_changes(self.instance_list, count)
+            else:
+                self.context.instance_list_update(self.instance_list, instances.data_ptr(), new_clips.data_ptr(), count, stream=self.stream.cuda_stream)
             self.context.decompress_tracks_list(self.instance_list, self.d_times.data_ptr(), self.d_poses.data_ptr(), self.pose_stride, params=self.params, stream=self.stream.cuda_stream)
             return
         if self._order_args is not None:
@@ -327,6 +338,20 @@ class Job:
         status = self._launch(*self._args)
         if status != 0:
             raise SystemExit(f"the batch launch failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
+
+    def caller_update(self, instances, new_clips):
+        """the caller's side of an attached list: its own kernel writes the clip changes into its own array, on the decode stream"""
+        self.d_clips.index_copy_(0, instances, new_clips)
+
+    def caller_update_ms(self, repeats):
+        start, stop = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        start.record(self.stream)
+        for k in range(repeats):
+            instances, new_clips, _ = self._updates[k % len(self._updates)]
+            self.caller_update(instances, new_clips)
+        stop.record(self.stream)
+        stop.synchronize()
+        return float(start.elapsed_time(stop)) / repeats
 
     def prewarm(self, seconds):
         """Device pre-warm (setup, not one of the W warm-up steps): an idle MI355X needs a few ms of work before its clocks settle.
@@ -427,6 +452,7 @@ def default_run_specs():
         ("256_clips", {"order": "locality"}, 300),
         ("256_clips", {"order": "device"}, 300),                    # ordered on the GPU in front of every launch: the ordering is in kernel_ms
         ("256_clips", {"order": "list"}, 300),                      # persistent instance list: 1 % of the instances change clip per step, inside the step
+        ("256_clips", {"order": "attached"}, 300),                  # ... attached to the caller's clip array: the caller's own kernel writes the 1 %, no update launch
         ("cinematic", {}, 150),
         ("database", {}, 300),
         ("database", {"order": "locality"}, 300),                   # the same instances laid out in aclhip_order_instances_for_locality order
@@ -592,6 +618,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
             "kernel_ms_order_reused": decode_ms_order_reused,  # the decode alone in that order (an instance list ordered once, sample times refreshed per frame)
+            "caller_update_ms": job.caller_update_ms(repeats) if job.order == "attached" else None,      # order "attached": the caller's kernel alone (inside kernel_ms)
             "list_orderings": None if job.instance_list is None else int(job.context.instance_list_order(job.instance_list)[1]),     # order "list": times the library (re-)ordered the list, setup included
             "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload for all of the workload's clips (setup)
             "launches_timed": repeats,
@@ -842,7 +869,7 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=sorted(WORKLOAD_TEXT))
     parser.add_argument("--instances", type=int, default=INSTANCES_PER_GPU, help="instances per GPU")
-    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "list"],
+    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "list", "attached"],
                         help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup); "
                              "aclhip_order_instances_device in front of every launch (part of the step)")
     parser.add_argument("--no-live-traffic", action="store_true", help="default run: keep roofline.traffic from profiles/traffic.json instead of measuring it with two rocprofv3 --pmc passes")
@@ -946,7 +973,8 @@ def main():
         if args.order != "random":
             workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order",
                               "device": ", ordered by aclhip_order_instances_device in front of every launch (inside the step)",
-                              "list": ", kept in a persistent aclhip_instance_list: 1 % of the instances change clip in every step (inside the step), the library re-orders when 1/8 has changed"}[args.order]
+                              "list": ", kept in a persistent aclhip_instance_list: 1 % of the instances change clip in every step (inside the step), the library re-orders when 1/8 has changed",
+                              "attached": ", kept in an aclhip_instance_list ATTACHED to the caller's clip array: every step a caller side kernel (torch index_copy_) writes 1 % of the clips there (inside the step), no update launch, the library re-orders when 1/8 has changed"}[args.order]
             workload_text += ", poses scattered back to their original rows" if args.keep_rows else ""
         result = {
             "metric": "poses/sec (whole node), 64k clip instances x 100 bones per GPU, seek + decompress_tracks",

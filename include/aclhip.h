@@ -395,6 +395,16 @@ aclhip_status aclhip_order_instances_device_for_windows(aclhip_context* context,
  *                                    aclhip_instance_list_get_order) -- 1 KiB stores to consecutive rows, what the write path likes -- or,
  *                                    with poses_in_instance_order != 0, in row i for instance i (scattered rows: measured 20 % slower).
  *                                    `output` as in aclhip_decompress_tracks_batch_out (its `rows` must be NULL), or NULL.
+ *   aclhip_instance_list_attach      instead of set_clips + update: the list decodes the CALLER's own clip array (device, `num_instances`
+ *                                    entries in the caller's instance order, valid and in place for as long as the list is attached to
+ *                                    it). The caller's animation graph writes clip changes straight into that array -- no update launch,
+ *                                    no copy: a decode reads caller_clips[order[j]] for slot j (round 4 measured the library's own update
+ *                                    launch at 5.3 us per frame for 655 changed instances; the extra dependent load this form costs a
+ *                                    wavefront is hidden). An instance that changed clip is still decoded correctly, just no longer next
+ *                                    to its clip's other instances;
+ *   aclhip_instance_list_note_changes  tells an attached list that `count` of its instances changed clip since the last call (a host
+ *                                    side number, nothing is read): once an eighth of the list has changed, the next decode re-orders it
+ *                                    from the caller's array as it is then.
  * A list is ordered for the shape of the launches that decode it (wavefronts per pose: aclhip_pose_windows_of_launch); a decode whose pose
  * stride gives another shape than the list was last ordered for re-orders it first.
  * All calls of one list must be made in stream order (one stream, or the caller's events between streams). WHEN a list is re-ordered
@@ -408,6 +418,8 @@ aclhip_status aclhip_instance_list_create(aclhip_context* context, uint32_t num_
 aclhip_status aclhip_instance_list_destroy(aclhip_context* context, aclhip_instance_list list);
 aclhip_status aclhip_instance_list_set_clips(aclhip_context* context, aclhip_instance_list list, const aclhip_clip* clips, void* stream);
 aclhip_status aclhip_instance_list_update(aclhip_context* context, aclhip_instance_list list, const uint32_t* instances, const aclhip_clip* clips, uint32_t count, void* stream);
+aclhip_status aclhip_instance_list_attach(aclhip_context* context, aclhip_instance_list list, const aclhip_clip* caller_clips, void* stream);
+aclhip_status aclhip_instance_list_note_changes(aclhip_context* context, aclhip_instance_list list, uint32_t count);
 aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, aclhip_instance_list list, const float* sample_times, const aclhip_decompress_params* params,
 	const aclhip_output_desc* output, int poses_in_instance_order, void* poses, uint64_t pose_stride_bytes, void* stream);
 /* the list's order, slot -> instance (device pointer, num_instances entries; contents change when the list is re-ordered, stream

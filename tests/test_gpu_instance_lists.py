@@ -196,3 +196,51 @@ def test_a_captured_list_decode_replays_with_new_sample_times():
             assert helpers.bit_equal(d_rows.cpu().numpy(), expected), replay
         del graph
         context.instance_list_destroy(instance_list)
+
+
+def test_an_attached_list_decodes_the_callers_own_clip_array():
+    """aclhip_instance_list_attach: no copy of the clips, no update launch -- the caller writes clip changes into its own device array,
+    tells the list how many (aclhip_instance_list_note_changes) and every decode follows the array as it is THEN, in the list's order
+    or in the caller's rows; the list re-orders itself from the array once an eighth has changed"""
+    rng = np.random.default_rng(21)
+    with runtime.Context(0) as context:
+        clips = [synth.build_clip(seed=800 + i, num_tracks=int(rng.integers(20, 101)), num_samples=int(rng.integers(2, 90))) for i in range(23)]
+        handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+        durations = np.array([c.duration for c in clips], dtype=np.float32)
+        max_tracks = 100
+        n = 9000
+        device = torch.device("cuda", 0)
+        which = rng.integers(0, len(clips), size=n)
+        d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)          # the CALLER's array: the list keeps reading it
+        instance_list = context.instance_list_create(n)
+        context.instance_list_attach(instance_list, d_clips.data_ptr())
+        order_address, orderings = context.instance_list_order(instance_list)
+        assert orderings == 1
+        with pytest.raises(runtime.AclHipError):                                        # an attached list has no update call
+            context.instance_list_update(instance_list, d_clips.data_ptr(), d_clips.data_ptr(), 1)
+        for frame in range(10):
+            count = n // 100 if frame != 5 else n // 5
+            changed = rng.choice(n, size=count, replace=False)
+            which[changed] = rng.integers(0, len(clips), size=count)
+            d_clips.index_copy_(0, torch.from_numpy(changed).to(device), torch.from_numpy(handles[which[changed]].astype(np.int32)).to(device))      # the caller's kernel
+            context.instance_list_note_changes(instance_list, count)
+            times = (rng.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+            d_times = torch.from_numpy(times).to(device)
+            expected = ob.oracle_decompress_tracks_batch([c.blob for c in clips], which, times, max_tracks)
+            d_rows = torch.zeros((n, max_tracks, 12), dtype=torch.float32, device=device)
+            d_slots = torch.zeros((n, max_tracks, 12), dtype=torch.float32, device=device)
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_rows.data_ptr(), max_tracks * 48, poses_in_instance_order=True)
+            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_slots.data_ptr(), max_tracks * 48)
+            torch.cuda.synchronize(device)
+            order = _read_order(order_address, n)
+            assert helpers.bit_equal(d_rows.cpu().numpy(), expected), frame
+            assert helpers.bit_equal(d_slots.cpu().numpy(), expected[order]), frame
+        _, orderings = context.instance_list_order(instance_list)
+        assert 2 <= orderings <= 4, orderings          # re-ordered when a fifth changed at once, not every frame
+        # back to a list of its own: set_clips detaches
+        context.instance_list_set_clips(instance_list, d_clips.data_ptr())
+        context.instance_list_update(instance_list, torch.zeros(1, dtype=torch.int32, device=device).data_ptr(), d_clips.data_ptr(), 1)
+        with pytest.raises(runtime.AclHipError):
+            context.instance_list_note_changes(instance_list, 1)
+        assert context.rejected_instance_count() == 0
+        context.instance_list_destroy(instance_list)
