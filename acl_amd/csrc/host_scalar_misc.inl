@@ -250,6 +250,80 @@ extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, 
 
 // ---- multi-GPU gather ------------------------------------------------------------------------------------------------
 
+namespace
+{
+	// RCCL is only ever touched by callers that gather; decoding never loads it. The communicator a caller hands over was made by the
+	// RCCL of ITS process, so that is the library whose ncclAllGather must run: a symbol that is already visible wins, then a library
+	// that is already loaded under RCCL's soname (RTLD_NOLOAD: PyTorch loads its bundled librccl privately), and only then a fresh load.
+	struct rccl_entry_points
+	{
+		void* library = nullptr;
+		int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;		// ncclAllGather (rccl.h:678)
+		int (*get_version)(int*) = nullptr;															// ncclGetVersion
+		const char* how = "";
+	};
+
+	const rccl_entry_points& rccl()
+	{
+		static const rccl_entry_points entry_points = []()
+		{
+			rccl_entry_points found;
+			void* all_gather = dlsym(RTLD_DEFAULT, "ncclAllGather");
+			void* get_version = dlsym(RTLD_DEFAULT, "ncclGetVersion");
+			found.how = "already visible in the process";
+			if (all_gather == nullptr)
+			{
+				static const char* const names[] = { "librccl.so.1", "librccl.so" };
+				for (int pass = 0; pass < 2 && found.library == nullptr; ++pass)
+					for (const char* name : names)
+					{
+						found.library = dlopen(name, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+						if (found.library != nullptr)
+						{
+							found.how = pass == 0 ? "already loaded (found by its soname)" : "loaded by this library";
+							break;
+						}
+					}
+				if (found.library != nullptr)
+				{
+					all_gather = dlsym(found.library, "ncclAllGather");
+					get_version = dlsym(found.library, "ncclGetVersion");
+				}
+			}
+			found.all_gather = reinterpret_cast<decltype(found.all_gather)>(all_gather);
+			found.get_version = reinterpret_cast<decltype(found.get_version)>(get_version);
+			return found;
+		}();
+		return entry_points;
+	}
+}
+
+// What aclhip_all_gather_poses would call, without a communicator: resolves ncclAllGather and ncclGetVersion the same way, calls the
+// latter. For a check BEFORE a multi-GPU job is leased (tests/test_gpu_all_gather.py): a missing soname or symbol shows here.
+// out_version: RCCL's version code (e.g. 22606); out_path: the file the symbol lives in (dladdr), out_how: how it was found.
+extern "C" aclhip_status aclhip_probe_rccl(int* out_version, char* out_path, uint32_t path_capacity, char* out_how, uint32_t how_capacity)
+{
+	const rccl_entry_points& entry_points = rccl();
+	if (out_version != nullptr)
+		*out_version = 0;
+	if (out_path != nullptr && path_capacity != 0)
+		out_path[0] = 0;
+	if (out_how != nullptr && how_capacity != 0)
+		std::snprintf(out_how, how_capacity, "%s", entry_points.how);
+	if (entry_points.all_gather == nullptr || entry_points.get_version == nullptr)
+		return fail(static_cast<aclhip_context*>(nullptr), ACLHIP_ERROR_DEVICE, "RCCL is not available: %s", entry_points.library == nullptr ? "librccl.so.1 / librccl.so could not be loaded" : "the library has no ncclAllGather / ncclGetVersion");
+	int version = 0;
+	const int result = entry_points.get_version(&version);
+	if (result != 0)
+		return fail(static_cast<aclhip_context*>(nullptr), ACLHIP_ERROR_DEVICE, "ncclGetVersion failed: ncclResult_t %d", result);
+	if (out_version != nullptr)
+		*out_version = version;
+	Dl_info info;
+	if (out_path != nullptr && path_capacity != 0 && dladdr(reinterpret_cast<void*>(entry_points.all_gather), &info) != 0 && info.dli_fname != nullptr)
+		std::snprintf(out_path, path_capacity, "%s", info.dli_fname);
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream)
 {
 	if (context == nullptr)
@@ -259,28 +333,13 @@ extern "C" aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* 
 	if (shard_bytes == 0)
 		return ACLHIP_OK;
 
-	// ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream)
-	// (rccl.h:678); the library is only loaded by callers that gather, decoding never touches it
-	typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
-	static all_gather_fn all_gather = nullptr;
-	{
-		std::lock_guard<std::mutex> lock(context->mutex);
-		if (all_gather == nullptr)
-		{
-			void* library = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-			if (library == nullptr)
-				library = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-			if (library == nullptr)
-				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 could not be loaded: %s", dlerror());
-			all_gather = reinterpret_cast<all_gather_fn>(dlsym(library, "ncclAllGather"));
-			if (all_gather == nullptr)
-				return fail(context, ACLHIP_ERROR_DEVICE, "librccl.so.1 has no ncclAllGather");
-		}
-	}
+	const rccl_entry_points& entry_points = rccl();
+	if (entry_points.all_gather == nullptr)
+		return fail(context, ACLHIP_ERROR_DEVICE, "RCCL is not available: %s", entry_points.library == nullptr ? "librccl.so.1 / librccl.so could not be loaded" : "the library has no ncclAllGather");
 
 	device_guard guard(context->device);
 	constexpr int k_nccl_uint8 = 1;		// ncclUint8 (rccl.h:460)
-	const int result = all_gather(shard_poses, all_poses, size_t(shard_bytes), k_nccl_uint8, rccl_comm, static_cast<hipStream_t>(stream));
+	const int result = entry_points.all_gather(shard_poses, all_poses, size_t(shard_bytes), k_nccl_uint8, rccl_comm, static_cast<hipStream_t>(stream));
 	if (result != 0)
 		return fail(context, ACLHIP_ERROR_DEVICE, "ncclAllGather failed: ncclResult_t %d", result);
 	return ACLHIP_OK;

@@ -383,6 +383,10 @@
 	// (28.0 -> 25.8 us for 64k x 256 float1f curves, 25.0 with 16 byte stores: what remains is the decode's own arithmetic, about 140
 	// VALU instructions per instance and 256 curves = 17 us of issue per SIMD; groups of 2 / 8: 28.4 / 32.6 us; capping the registers
 	// for 6 / 8 waves per SIMD: 22.7 / 42 us on this shape, slower on 1024 curves). Groups of mixed clips fall back to one instance after the other.
+	// (Round 5 let a wave take several groups IN TURN, keeping a float1f launch's tables in registers from turn to turn, to break the
+	// lock step of two rounds of waves: 2 / 4 turns at full residency 26.6 / 29.7 us against 25.3 us for this one-shot form on the same
+	// box, groups of 2 or 1 instance worse still -- profiles/r05_experiments.md 5; the launch's own instruction count is 19.7 us of vector
+	// issue at the PEAK clock under a 22 - 23 us launch.)
 	constexpr uint32_t k_scalar_group = 4;
 
 	template<uint32_t kRows, bool kPolicies, uint32_t kComponents>

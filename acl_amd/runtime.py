@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_measure_write_bandwidth", "aclhip_measure_pose_store_bandwidth", "aclhip_describe_tracks_kernel",
     "aclhip_register_database", "aclhip_unregister_database", "aclhip_get_database_info", "aclhip_register_clip_with_database",
     "aclhip_database_stream_in", "aclhip_database_stream_out",
-    "aclhip_all_gather_poses", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
+    "aclhip_all_gather_poses", "aclhip_probe_rccl", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
     "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
@@ -222,6 +222,16 @@ def load_library():
     lib.aclhip_describe_tracks_launch.argtypes = [vp, pparams, poutput, u64, ctypes.c_char_p, u32, ctypes.POINTER(u32)]
     _lib = lib
     return lib
+
+
+def probe_rccl():
+    """aclhip_probe_rccl: (version code, path of the library, how it was found) of the RCCL aclhip_all_gather_poses would call; raises AclHipError when there is none"""
+    lib = load_library()
+    version, path, how = ctypes.c_int(0), ctypes.create_string_buffer(512), ctypes.create_string_buffer(128)
+    status = lib.aclhip_probe_rccl(ctypes.byref(version), path, 512, how, 128)
+    if status != 0:
+        raise AclHipError(status, lib.aclhip_last_error_message(None).decode())
+    return version.value, path.value.decode(), how.value.decode()
 
 
 def check_clip(blob, check_hash=True):

@@ -175,7 +175,7 @@ class Job:
     aclhip_instance_list_note_changes counts them, the list is decoded: the caller's kernel, the decode and the re-orders are all part of the step).
     layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
-    def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48"):
+    def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48", paging="decode_stream"):
         import torch
         from acl_amd import runtime, synth
 
@@ -239,6 +239,10 @@ class Job:
                 self.d_rows = self.d_order
         self.d_poses = torch.empty((self.num_instances, self.pose_stride // 4), dtype=torch.float32, device=self.device)
         self.stream = torch.cuda.current_stream(self.device)
+        # database workload: the stream the tiers are paged in on -- the decode stream (every copy between two launches) or a second one
+        # (copies overlap the launches: database_streamer.h:87-93 lets a stream-in run concurrently with decompression)
+        self.paging = paging
+        self.paging_stream = torch.cuda.Stream(self.device) if paging == "second_stream" else self.stream
         self.params = runtime.default_params()
         self.consumers = None
         self.output = None
@@ -479,7 +483,7 @@ def run_steps(job, steps):
     schedule = job.stream_schedule(steps)
     for i in range(steps):
         if i in schedule:
-            job.context.database_stream_in(job.database, schedule[i][0], schedule[i][1], stream=job.stream.cuda_stream)
+            job.context.database_stream_in(job.database, schedule[i][0], schedule[i][1], stream=job.paging_stream.cuda_stream)
         job.step()
 
 
@@ -499,11 +503,12 @@ def traffic_pass(device_index, manifest_path, steps=12):
     json.dump(manifest, open(manifest_path, "w"))
 
 
-def live_traffic(timeout_s=90):
-    """HBM bytes per launch of the decode kernel of EVERY spec of the default run, measured NOW: this same script in two rocprofv3
-    --pmc passes of their own (traffic_pass above), FETCH_SIZE and WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md), mean over the dispatches of the spec's decode kernel between two markers. Returns {workload key: bytes} --
-    empty when rocprofv3 is not there, a profiler is already attached or a pass fails (the committed profiles/traffic.json stays)."""
+def live_traffic(timeout_s=120):
+    """HBM bytes and VALU instructions per launch of the decode kernel of EVERY spec of the default run, measured NOW: this same script
+    in three rocprofv3 --pmc passes of their own (traffic_pass above) -- FETCH_SIZE, WRITE_SIZE (KiB; FETCH_SIZE doubled per the gfx950
+    note of MI355X_MICROARCH.md) and SQ_INSTS_VALU --, mean over the dispatches of the spec's decode kernel between two markers. Returns
+    {workload key: {"traffic": bytes, "valu_instructions": count}} -- empty when rocprofv3 is not there, a profiler is already attached
+    or a pass fails (the committed profiles/traffic.json stays)."""
     import csv
     import glob
     import shutil
@@ -516,7 +521,7 @@ def live_traffic(timeout_s=90):
     if any(name.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for name in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return {}
     means = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         directory = tempfile.mkdtemp(prefix="aclhip_pmc_", dir="/tmp")
         try:
             manifest_path = os.path.join(directory, "manifest.json")
@@ -539,16 +544,19 @@ def live_traffic(timeout_s=90):
                     in_marker = False
                     current.append((kernel, value))
             if len(groups) != len(manifest):
-                return {}
+                raise ValueError("the counter pass saw other launches than its manifest lists")
             for entry, group in zip(manifest, groups):
                 values = [value for kernel, value in group if entry["kernel"] in kernel]
                 if values:
                     means.setdefault(entry["workload"], {})[counter] = sum(values) / len(values)
         except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-            return {}
+            if counter != "SQ_INSTS_VALU":       # (the HBM passes are what "traffic" needs; the instruction count is an extra)
+                return {}
         finally:
             shutil.rmtree(directory, ignore_errors=True)
-    return {key: int((2.0 * value["FETCH_SIZE"] + value["WRITE_SIZE"]) * 1024.0) for key, value in means.items() if len(value) == 2}
+    # SQ_INSTS_VALU: vector ALU instructions the decode kernel issues per launch (all waves) -- the VALU issue floor of the entry
+    return {key: {"traffic": int((2.0 * value["FETCH_SIZE"] + value["WRITE_SIZE"]) * 1024.0), "valu_instructions": value.get("SQ_INSTS_VALU")}
+            for key, value in means.items() if "FETCH_SIZE" in value and "WRITE_SIZE" in value}
 
 
 def traffic_key_of(workload, order, layout, keep_rows=False):
@@ -618,6 +626,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
             "kernel_ms_order_reused": decode_ms_order_reused,  # the decode alone in that order (an instance list ordered once, sample times refreshed per frame)
+            **bound_of(kernel_ms, int(algorithmic), None),      # (the instruction floor arrives with the live counter passes of the default run)
             "caller_update_ms": job.caller_update_ms(repeats) if job.order == "attached" else None,      # order "attached": the caller's kernel alone (inside kernel_ms)
             "list_orderings": None if job.instance_list is None else int(job.context.instance_list_order(job.instance_list)[1]),     # order "list": times the library (re-)ordered the list, setup included
             "registration_ms_total": round(job.registration_ms, 3),      # validate + derive tables + upload for all of the workload's clips (setup)
@@ -625,6 +634,126 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
         }
     finally:
         job.close()
+
+
+NUM_SIMDS = 256 * 4             # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+PEAK_CLOCK_HZ = 2.4e9           # the peak engine clock: a floor computed with it is a floor at any clock the device really ran at
+
+
+def bound_of(kernel_ms, algorithmic_bytes, valu_instructions):
+    """Which resource binds an entry, and how close to THAT bound it runs. Two floors under a launch: its algorithmic bytes at the HBM
+    specification rate, and its vector ALU instructions (SQ_INSTS_VALU of this run's counter pass) issued at one wave64 instruction per
+    four cycles per SIMD on all 1 024 SIMDs at the peak clock -- optimistic on purpose (no transcendental quarter rates, no dependent
+    issue stalls, every SIMD busy from the first to the last cycle), so that frac_of_bound never flatters. The HBM fraction of a kernel
+    whose instruction floor is the higher one says little about the kernel; this field says which one to read."""
+    hbm_floor_ms = algorithmic_bytes / (HBM_PEAK_GBPS * 1e9) * 1e3
+    valu_floor_ms = None if not valu_instructions else valu_instructions * 4.0 / (NUM_SIMDS * PEAK_CLOCK_HZ) * 1e3
+    bound = "valu" if valu_floor_ms is not None and valu_floor_ms > hbm_floor_ms else "hbm"
+    floor = max(hbm_floor_ms, valu_floor_ms or 0.0)
+    return {"bound": bound, "valu_instructions": None if not valu_instructions else int(valu_instructions), "valu_issue_floor_ms": valu_floor_ms, "hbm_floor_ms": hbm_floor_ms,
+            "frac_of_bound": floor / kernel_ms}
+
+
+def measure_database_paging(rank, device_index, repeats=300):
+    """The database workload with its tiers paged in on a SECOND stream while the batches run (BASELINE.json configs[4]: "paged from host
+    DRAM via pinned hipMemcpyAsync"; the reference lets a stream-in run next to decompression, database_streamer.impl.h:60-136), beside
+    the same schedule issued on the decode stream and the decode alone in the two end states. Every figure is the decode stream's own
+    time per launch (HIP events on it). The pose buffer after the paged run must equal the one of a decode with everything resident."""
+    job = Job("database", rank, device_index, paging="second_stream")
+    torch, context, database = job.torch, job.context, job.database
+    try:
+        def timed(paging_stream):
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            job.paging_stream = paging_stream
+            torch.cuda.synchronize(job.device)
+            start.record(job.stream)
+            run_steps(job, repeats)
+            stop.record(job.stream)
+            torch.cuda.synchronize(job.device)
+            return float(start.elapsed_time(stop)) / repeats
+
+        def everything_out():
+            for tier in (job.runtime.TIER_MEDIUM_IMPORTANCE, job.runtime.TIER_LOWEST_IMPORTANCE):
+                context.database_stream_out(database, tier, stream=job.stream.cuda_stream)
+            torch.cuda.synchronize(job.device)
+
+        second_stream = job.paging_stream
+        job.prewarm(0.05)
+        # (a stream's first use creates its hardware queue, milliseconds: the second stream pages everything in and out once before anything is timed)
+        for tier in (job.runtime.TIER_MEDIUM_IMPORTANCE, job.runtime.TIER_LOWEST_IMPORTANCE):
+            context.database_stream_in(database, tier, stream=second_stream.cuda_stream)
+        second_stream.synchronize()
+        everything_out()
+        nothing_streamed_ms = job.kernel_ms(repeats)
+        same_stream_ms = timed(job.stream)
+        everything_out()
+        second_stream_ms = timed(second_stream)
+        paged_poses = job.d_poses.clone()
+        everything_streamed_ms = job.kernel_ms(repeats)
+        torch.cuda.synchronize(job.device)
+        same_poses = bool(torch.equal(paged_poses.view(torch.int32), job.d_poses.view(torch.int32)))
+        # the copies alone: everything out, then in again back to back on the second stream
+        everything_out()
+        info = context.database_info(database)
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(second_stream)
+        for tier in (job.runtime.TIER_MEDIUM_IMPORTANCE, job.runtime.TIER_LOWEST_IMPORTANCE):
+            context.database_stream_in(database, tier, stream=second_stream.cuda_stream)
+        stop.record(second_stream)
+        stop.synchronize()
+        copy_ms = float(start.elapsed_time(stop))
+        paged_bytes = int(sum(info.bulk_data_size))
+        algorithmic = job.algorithmic_bytes()
+        return {
+            "workload": "database, paged on a second stream",
+            "config": WORKLOAD_TEXT["database"].replace("on the decode stream", "on a second stream"),
+            "instances": job.num_instances, "kernel": job.kernel_name(), "launches_timed": repeats,
+            "kernel_ms": second_stream_ms,                                  # decode stream time per launch while the tiers arrive on the other stream
+            "kernel_ms_paged_on_the_decode_stream": same_stream_ms,         # round 4's protocol: every copy between two launches
+            "kernel_ms_nothing_streamed": nothing_streamed_ms,              # the decode alone, before any tier has arrived ...
+            "kernel_ms_everything_streamed": everything_streamed_ms,       # ... and after all of them have
+            "paging_overhead": second_stream_ms / (0.5 * (nothing_streamed_ms + everything_streamed_ms)) - 1.0,     # against the mean of the two end states the paged run passes through
+            "poses_equal_everything_resident": same_poses,
+            "paged_bytes": paged_bytes, "paged_chunks": int(sum(info.num_chunks)), "h2d_ms_back_to_back": copy_ms,
+            "h2d_gbps": None if copy_ms <= 0 else paged_bytes / (copy_ms * 1e-3) / 1e9,
+            "algorithmic_bytes": int(algorithmic), "achieved": algorithmic / (second_stream_ms * 1e-3) / 1e9, "frac": algorithmic / (second_stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None, "traffic_source": None,
+        }
+    finally:
+        job.paging_stream = job.stream
+        job.close()
+
+
+def self_check(job, count=256):
+    """After the timed region: `count` random rows of the pose buffer the LAST timed launch wrote, against the CPU oracle for the same
+    (clip, sample time) -- the driver's number certifies itself (the reference's harness validates before it times,
+    tools/acl_compressor/sources/validate_tracks.cpp:92-260). Pose batches in a caller-visible row order, single track requests and scalar
+    lists; None for what has no oracle on this side (database tiers, consumers) or no fixed rows (device / list orders)."""
+    from oracle import bindings as ob      # the checker, never the thing measured
+    if job.database is not None or job.consumers is not None or job.order in ("device", "list", "attached") or job.d_rows is not None or job.name == "one_clip_lods":
+        return None
+    torch = job.torch
+    torch.cuda.synchronize(job.device)
+    rng = np.random.default_rng(12345)
+    rows = np.sort(rng.choice(job.num_instances, size=min(count, job.num_instances), replace=False))
+    got = job.d_poses[torch.from_numpy(rows).to(job.device)].cpu().numpy()
+    blobs = [c.blob for c in job.clips]
+    which, times = job.clip_indices[rows].astype(np.uint32), job.times[rows]
+    if job.is_scalar:
+        expected = ob.oracle_scalar_decompress_tracks_batch(blobs, which, times, got.shape[1])
+    elif job.track_requests:
+        tracks = job.d_tracks.cpu().numpy()[rows]
+        expected = np.stack([ob.oracle_decompress_track(blobs[int(c)], float(t), int(b)) for c, t, b in zip(which, times, tracks)])
+    else:
+        full = ob.oracle_decompress_tracks_batch(blobs, which, times, job.max_tracks)
+        layout_id, bytes_per_track = job.runtime.LAYOUTS[job.layout]
+        expected = job.runtime.relayout_pose(full, layout_id).reshape(rows.size, -1)
+        got = got[:, : job.max_tracks * bytes_per_track // 4]
+    got = got.reshape(expected.shape)
+    finite = np.isfinite(expected) & np.isfinite(got)
+    return {"instances": int(rows.size), "max_abs_err": float(np.abs(got[finite] - expected[finite]).max()) if finite.any() else 0.0,
+            "bit_exact": bool(np.array_equal(got.view(np.uint32), expected.view(np.uint32))),
+            "against": "oracle/acl_oracle.c (held to the reference's own headers bit for bit by tests/test_oracle_vs_reference.py), rows of the last timed launch"}
 
 
 # ---- CPU baseline -----------------------------------------------------------------------------------------------------------
@@ -641,6 +770,31 @@ def cgroup_cpu_max():
         return f"{quota} {period}"
     except OSError:
         return None
+
+
+def cpu_topology():
+    """(sockets, cores per socket, threads per core) of the host from /proc/cpuinfo and sysfs -- what lscpu prints; Nones when unreadable"""
+    try:
+        physical, cores = set(), {}
+        package = None
+        for line in open("/proc/cpuinfo"):
+            key, _, value = line.partition(":")
+            key, value = key.strip(), value.strip()
+            if key == "physical id":
+                package = int(value)
+                physical.add(package)
+            elif key == "cpu cores" and package is not None:
+                cores[package] = int(value)
+        sockets = len(physical)
+        cores_per_socket = max(cores.values()) if cores else None
+        siblings = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        threads_per_core = len(siblings.replace("-", ",").split(",")) if "," in siblings or "-" in siblings else 1
+        if "-" in siblings and "," not in siblings:
+            low, high = siblings.split("-")
+            threads_per_core = int(high) - int(low) + 1
+        return (sockets or None), cores_per_socket, threads_per_core
+    except (OSError, ValueError):
+        return None, None, None
 
 
 def cpu_baseline(clips, clip_indices, times, row_units, is_scalar):
@@ -664,7 +818,10 @@ def cpu_baseline(clips, clip_indices, times, row_units, is_scalar):
         points = sorted({t for t in (1, 8, 32, 64, 128, 256) if t < nproc} | {nproc})
         sweep = {}
         for threads in points:
-            sweep[str(threads)] = bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, row_units, threads, seconds, 1, None)
+            # the single-thread point carries the extrapolation below: best of three windows (round 4's driver run had ONE one-second
+            # window land below the cold-cache figure -- a neighbour on the box, not physics)
+            windows = 3 if threads == points[0] else 1
+            sweep[str(threads)] = max(bench(blob_ptrs, indices.ctypes.data, sample_times.ctypes.data, sample, row_units, threads, seconds, 1, None) for _ in range(windows))
         best_threads = max(sweep, key=lambda k: sweep[k])
         # the reference's OWN benchmark protocol next to the warm sweep (tools/acl_decompressor/sources/benchmark.cpp:232-281): one thread, 220
         # copies of the clip decoded in turn, the CPU caches flushed between sample times -- what its published numbers are measured with
@@ -674,11 +831,19 @@ def cpu_baseline(clips, clip_indices, times, row_units, is_scalar):
             cold_times = np.ascontiguousarray(sample_times[:100], dtype=np.float32)
             cold = lib.aclref_bench_cold(blob.ctypes.data, blob.size, cold_times.ctypes.data, cold_times.size, row_units, 220, 128 << 20, seconds)
         per_thread = sweep[str(points[0])] / points[0]
+        sockets, cores_per_socket, threads_per_core = cpu_topology()
+        physical_cores = sockets * cores_per_socket if sockets and cores_per_socket else None
+        # one thread at its best: the warm loop or the reference's own cold-cache protocol, whichever is faster on this box
+        best_1t = max(per_thread, cold or 0.0)
         description.update({
             "cold_cache_1t": cold,                               # poses/s of ONE thread under the reference's cold-cache protocol (first clip of the list)
-            # what this host would reach if every one of its `nproc` logical CPUs ran at the measured single-thread rate (an upper bound: SMT
-            # siblings and memory bandwidth are ignored) -- next to `value`, which is what the container's CPU quota really gives
-            "extrapolated_all_cpus": per_thread * nproc,
+            "sockets": sockets, "cores_per_socket": cores_per_socket, "threads_per_core": threads_per_core, "physical_cores": physical_cores,       # lscpu style, beside `nproc` logical CPUs
+            # what this host would reach if every one of its `nproc` logical CPUs ran at the best single-thread rate measured (an upper bound: SMT
+            # siblings share a core, memory bandwidth is ignored) -- next to `value`, which is what the container's CPU quota really gives;
+            # the same per PHYSICAL core is the fairer figure for an SMT host
+            "extrapolated_all_cpus": best_1t * nproc,
+            "extrapolated_physical_cores": None if physical_cores is None else best_1t * physical_cores,
+            "extrapolated_from": "max(per_thread_1t: best of three windows, cold_cache_1t)",
             "value": sweep[best_threads], "cores": int(best_threads), "threads_at_best": int(best_threads), "kind": "reference",
             "per_thread_1t": per_thread, "sweep": sweep,
             "sample": f"{sample} instances of the same list statically partitioned over the threads, seek + decompress_tracks, reference headers "
@@ -939,7 +1104,7 @@ def main():
     start_mark.record(job.stream)
     for i in range(args.steps):
         if i in stream_schedule:
-            job.context.database_stream_in(job.database, stream_schedule[i][0], stream_schedule[i][1], stream=job.stream.cuda_stream)
+            job.context.database_stream_in(job.database, stream_schedule[i][0], stream_schedule[i][1], stream=job.paging_stream.cuda_stream)
         job.step()
     stop_mark.record(job.stream)
     torch.cuda.synchronize(device)
@@ -951,6 +1116,14 @@ def main():
         elapsed_tensor = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(elapsed_tensor, op=dist.ReduceOp.MAX)
         elapsed = float(elapsed_tensor.item())
+
+    # the rows the LAST TIMED launch wrote, against the oracle -- before anything else touches the pose buffer, outside every timed region
+    checked = None
+    if rank == 0 and not profiling:
+        try:
+            checked = self_check(job)
+        except Exception as error:      # noqa: BLE001 -- reported in the line, the timing stands on its own
+            checked = {"error": repr(error)[:300]}
 
     # Roofline of the decode kernel: device time per launch from the HIP events of the timed region
     kernel_ms = float(start_mark.elapsed_time(stop_mark)) / args.steps
@@ -1048,6 +1221,8 @@ def main():
         gather.update(measure_gather(job, dist, rank, world_size, args.gather))
         gather["status"] = "done"
 
+    if rank == 0:
+        result["self_check"] = checked
     headline = (job.clips, job.clip_indices, job.times, job.pose_stride // 4 if job.is_scalar else job.max_tracks, job.is_scalar, job.database is not None, job.consumers is not None)
     job.close()
 
@@ -1072,6 +1247,7 @@ def main():
         # the other north-star configs, measured in this process outside the timed region (about 0.2 s of launches each)
         specs = default_run_specs()
         entries = [measure_job(name, rank, device_index, repeats=repeats, **options) for name, options, repeats in specs]
+        paging_entry = measure_database_paging(rank, device_index)
         result["roofline"]["traffic_source"] = "profiles/traffic.json (committed rocprofv3 --pmc passes)"
         if not args.no_live_traffic:
             # EVERY entry's HBM traffic measured by THIS run (two counter passes of a few launches of every spec, after the timed regions)
@@ -1080,11 +1256,15 @@ def main():
             source = "this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of 12 launches of every workload, FETCH_SIZE x 2 (gfx950)"
             for entry in entries:
                 if entry["workload"] in measured:
-                    entry["traffic_committed"], entry["traffic"], entry["traffic_source"] = entry["traffic"], measured[entry["workload"]], source
+                    entry["traffic_committed"], entry["traffic"], entry["traffic_source"] = entry["traffic"], measured[entry["workload"]]["traffic"], source
+                    entry.update(bound_of(entry["kernel_ms"], entry["algorithmic_bytes"], measured[entry["workload"]]["valu_instructions"]))
             if "one_clip" in measured:
-                result["roofline"]["traffic_committed"], result["roofline"]["traffic"], result["roofline"]["traffic_source"] = result["roofline"]["traffic"], measured["one_clip"], source
+                result["roofline"]["traffic_committed"], result["roofline"]["traffic"], result["roofline"]["traffic_source"] = result["roofline"]["traffic"], measured["one_clip"]["traffic"], source
+                floors = bound_of(kernel_ms, int(algorithmic_bytes), measured["one_clip"]["valu_instructions"])
+                result["roofline"].update({key: floors[key] for key in ("valu_instructions", "valu_issue_floor_ms", "hbm_floor_ms", "frac_of_bound")})
+                result["roofline"]["bound"] = floors["bound"]
         layout_entries = [entries[0]] + [e for e in entries if e["workload"] in ("one_clip, qvv40", "one_clip, qv32")]
-        result["workloads"] = [e for e in entries[1:] if e not in layout_entries]
+        result["workloads"] = [e for e in entries[1:] if e not in layout_entries] + [paging_entry]
         result["layouts"] = [{key: entry[key] for key in ("layout", "pose_bytes", "kernel", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes", "traffic", "traffic_source")} for entry in layout_entries]
         result["footprint_sweep"] = [
             {key: entry[key] for key in ("instances", "kernel_ms", "poses_per_s", "achieved", "frac", "algorithmic_bytes")}
@@ -1102,6 +1282,8 @@ def main():
             result["cpu_baseline"]["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
             if result["cpu_baseline"].get("extrapolated_all_cpus"):
                 result["cpu_baseline"]["gpu_over_cpu_extrapolated"] = result["value"] / result["cpu_baseline"]["extrapolated_all_cpus"]
+            if result["cpu_baseline"].get("extrapolated_physical_cores"):
+                result["cpu_baseline"]["gpu_over_cpu_extrapolated_physical_cores"] = result["value"] / result["cpu_baseline"]["extrapolated_physical_cores"]
         print(json.dumps(result))
 
     if distributed:

@@ -576,6 +576,13 @@ aclhip_status aclhip_decompress_poses_host(aclhip_context* context, const aclhip
  * DEVICE pointers; asynchronous on `stream`. librccl.so.1 is loaded on first use: ACLHIP_ERROR_DEVICE when it is absent. */
 aclhip_status aclhip_all_gather_poses(aclhip_context* context, void* rccl_comm, const void* shard_poses, void* all_poses, uint64_t shard_bytes, void* stream);
 
+/* The RCCL aclhip_all_gather_poses would call, found the same way -- a ncclAllGather already visible in the process, else a library
+ * already loaded under RCCL's soname, else a fresh load of librccl.so.1 / librccl.so (the communicator was made by the RCCL of the
+ * caller's process: that one must run) -- and asked for its version, without a communicator. A check to run BEFORE a multi-GPU job:
+ * out_version RCCL's version code (22606 = 2.26.6), out_path the file the entry point lives in, out_how how it was found (any of the
+ * three may be NULL). ACLHIP_ERROR_DEVICE when RCCL or one of the two symbols is missing. No reference counterpart. */
+aclhip_status aclhip_probe_rccl(int* out_version, char* out_path, uint32_t path_capacity, char* out_how, uint32_t how_capacity);
+
 /* Peer gather: when ONE GPU wants every pose (the one that renders), each other GPU pushes its shard straight into that GPU's
  * buffer over its own xGMI link -- the destination's seven links work concurrently and no shard travels twice -- instead of a ring
  * collective that also gives every rank every shard. One process per GPU:

@@ -57,3 +57,20 @@ def test_single_rank_all_gather_copies_the_shard():
         context.all_gather_poses(None, shard.data_ptr(), gathered.data_ptr(), 16)
     assert rccl.ncclCommDestroy(comm) == 0
     context.close()
+
+
+def test_rccl_is_found_and_answers_without_a_communicator():
+    """what the first N > 1 run on a real node would otherwise be the first to find out: the RCCL the library would call -- the one of
+    THIS process (PyTorch's bundled librccl when torch.distributed made the communicator) -- is there, exports ncclAllGather and
+    ncclGetVersion, and the version is one torch.distributed itself reports"""
+    import torch
+    version, path, how = runtime.probe_rccl()
+    assert version >= 20000, version                 # RCCL 2.x (22606 = 2.26.6 on ROCm 7)
+    assert "rccl" in os.path.basename(path), path
+    print(f"RCCL {version} from {path} ({how})")
+    reported = torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else None
+    if reported:
+        major, minor, patch = reported[:3]
+        # one RCCL per process: when torch has loaded its own, the probe must have found THAT one (same version), not a second library
+        if "torch" in path or how != "loaded by this library":
+            assert version == major * 10000 + minor * 100 + patch, (version, reported, path)
