@@ -579,6 +579,7 @@
 	{
 		static_assert(kLayout == ACLHIP_LAYOUT_QV32 || kLayout == ACLHIP_LAYOUT_QVV40, "compact layouts");
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
+		ACLHIP_WAVE0_STAMP(0);
 		constexpr uint32_t k_window_tracks = k_image_chunk_quads / 3u;
 		constexpr uint32_t k_track_bytes = kLayout == ACLHIP_LAYOUT_QV32 ? 32u : 40u;
 
@@ -646,6 +647,10 @@
 
 		seek_state state;
 		seek(clip, sample_time, rounding_policy, looping_policy, state);
+#if defined(ACLHIP_EXP_PHASE_TIMES)
+		asm volatile("" :: "s"(state.key_frame_bit_offsets[0]), "s"(state.key_frame_bit_offsets[1]));		// the seek's loads have arrived
+		ACLHIP_WAVE0_STAMP(1);
+#endif
 
 		// the base pose must be in the image before decoded sub-tracks take their places in it (the QVV40 pieces of a decoded sub-track
 		// and of its constant neighbours share 16 byte units: DMA first, then the decode's own writes)
@@ -657,6 +662,7 @@
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+		ACLHIP_WAVE0_STAMP(2);
 		constexpr uint32_t k_rows = (k_window_tracks * k_track_bytes / 16u + k_wave_size - 1) / k_wave_size;
 		f32x4 staged[k_rows];
 		#pragma unroll
@@ -678,6 +684,7 @@
 				store_streaming_floats<2>(reinterpret_cast<float*>(out + size_t(piece) * 16), half);
 			}
 		}
+		ACLHIP_WAVE0_STAMP(3);
 	}
 
 	#define ACLHIP_POSE_KERNEL_ARGUMENTS const device_clip* __restrict__ clips, uint32_t num_clips, \

@@ -134,3 +134,22 @@ def test_bench_at_8_ranks_covers_the_8_gpu_configs():
         assert gather["p2p_to_rank0_ms"] > 0 and gather["rccl_all_gather_ms"] > 0 and gather["shard_bytes"] == instances * entry["pose_bytes"]
     assert workloads["cinematic"]["bones"] == 300
     assert workloads["database"]["database_chunks_streamed_in_together"] > 0
+
+
+def test_a_gather_that_does_not_come_back_still_leaves_the_decode_line():
+    """the first real N > 1 run must report its decode whatever a collective or a peer mapping does on a node this code has never run on:
+    with the gather watchdog set to fire at once, the line still arrives -- the communicator's rank count, every rank's kernel time,
+    the whole-job rate -- and says that the gather timed out"""
+    world_size = 2
+    env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_GATHER_TIMEOUT="0.0001")
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--instances", "8192", "--no-extras", "--gather", "both"]
+    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, completed.stdout[-2000:] + completed.stderr[-2000:]
+    result = json.loads(lines[0])
+    assert result["gather"]["status"] == "timed out"
+    assert result["n_gpus"] == world_size and result["value"] > 0 and result["roofline"]["kernel_ms"] > 0
+    checks = result["checks"]
+    assert checks["communicator_ranks"] == world_size and len(checks["kernel_ms_per_rank"]) == world_size and all(value > 0 for value in checks["kernel_ms_per_rank"])
+    assert result["self_check"]["bit_exact"] is True

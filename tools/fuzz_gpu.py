@@ -72,6 +72,34 @@ def main():
                     print("POSE MISMATCH", spec, "instance", i, "time", times[i], "rounding", rounding, "looping", looping, "normalization", normalization)
                     return 1
             checks += n
+            # every instance with a looping policy and a writer of its own (ABI 5): its first K tracks through one of three skip masks
+            if rng.uniform() < 0.5:
+                import ctypes
+                instance_looping = rng.integers(0, 3, size=n).astype(np.uint8)
+                counts = rng.integers(0, tracks + 2, size=n).astype(np.uint32)
+                mask_table = rng.integers(0, 8, size=(3, tracks)).astype(np.uint8)
+                mask_table[0] = 0
+                instance_masks = rng.integers(0, 3, size=n).astype(np.uint8)
+                writer_params = runtime.default_params(rounding_policy=rounding, looping_policy=looping, normalization=normalization)
+                writer_params.instance_looping_policies = instance_looping.ctypes.data
+                output = runtime.OutputDesc()
+                output.mask_table, output.mask_stride, output.instance_masks, output.instance_track_counts = mask_table.ctypes.data, tracks, instance_masks.ctypes.data, counts.ctypes.data
+                fill = np.float32(7.0)
+                got = np.full((n, tracks, 12), fill, dtype=np.float32)
+                instance_handles = np.ascontiguousarray(handles[which])
+                context._check(context._lib.aclhip_decompress_tracks_host_out(context._handle, instance_handles.ctypes.data, times.ctypes.data, n, ctypes.byref(writer_params), 0,
+                                                                              ctypes.byref(output), got.ctypes.data, tracks * 48))
+                for i in range(n):
+                    expected = np.full((tracks, 12), fill, dtype=np.float32)
+                    full = ob.oracle_decompress_tracks(clips[which[i]].blob, float(times[i]), rounding, ob.default_options(looping_policy=int(instance_looping[i]), normalization=normalization))
+                    kept = min(int(counts[i]), tracks)
+                    expected[:kept] = full[:kept]
+                    for kind in range(3):
+                        expected[((mask_table[instance_masks[i]] >> kind) & 1) == 1, kind * 4: kind * 4 + 4] = fill
+                    if not same(got[i], expected):
+                        print("WRITER MISMATCH", spec, "instance", i, "time", times[i], "count", int(counts[i]), "mask", int(instance_masks[i]), "looping", int(instance_looping[i]), "rounding", rounding, "normalization", normalization)
+                        return 1
+                checks += n
             # object space + additive, when the consumers take these settings
             if normalization != 2 and tracks <= 700:
                 parents = np.zeros(tracks, dtype=np.uint32)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measurement aid (needs a library built with -DACLHIP_EXP_PHASE_TIMES, ACLHIP_LIBRARY pointing at it): wall clock stamps, 100 MHz clock, of
 the pose consumer kernel's phases per workgroup (entry, poses decoded, walk done, stores issued) or of the pose kernel's phases for the
-first wave of the first 16384 workgroups (entry, seek done, window decoded into LDS, stores issued). usage: phase_times.py <workload>"""
+first wave of the first 16384 workgroups (entry, seek done, window decoded into LDS, stores issued). usage: phase_times.py <workload> [layout]"""
 import ctypes
 import os
 import sys
@@ -14,7 +14,8 @@ import bench
 
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "object_space"
-    job = bench.Job(workload, 0, 0)
+    layout = sys.argv[2] if len(sys.argv) > 2 else "qvv48"
+    job = bench.Job(workload, 0, 0, layout=layout)
     job.prewarm(0.05)
     for _ in range(20):
         job.step()
@@ -26,7 +27,7 @@ def main():
     stamps = stamps.reshape(blocks, 4).astype(np.int64)
     stamps = stamps[stamps[:, 0] != 0]
     t = (stamps - stamps[:, 0].min()) * 0.01        # us
-    print(workload, "workgroups", t.shape[0], "kernel span %.1f us" % (t[:, 3].max()))
+    print(workload, layout, "workgroups", t.shape[0], "kernel span %.1f us" % (t[:, 3].max()))
     consumer = workload in ("object_space", "additive_object_space")
     names = ("decode", "walk", "store issue") if consumer else ("seek", "tables + keyframes + unpack", "store issue")
     for name, a, b in ((names[0], 0, 1), (names[1], 1, 2), (names[2], 2, 3), ("life", 0, 3)):
