@@ -1194,6 +1194,8 @@ def main():
                 "frac_of_best_store_only": None if not achievable_gbps else achieved_gbps / achievable_gbps,
             },
         }
+    if rank == 0:
+        result["self_check"] = checked
     if rank == 0 and checks is not None:
         result["checks"] = checks
         result["roofline"]["kernel_ms_per_rank"] = checks.get("kernel_ms_per_rank")
@@ -1221,8 +1223,6 @@ def main():
         gather.update(measure_gather(job, dist, rank, world_size, args.gather))
         gather["status"] = "done"
 
-    if rank == 0:
-        result["self_check"] = checked
     headline = (job.clips, job.clip_indices, job.times, job.pose_stride // 4 if job.is_scalar else job.max_tracks, job.is_scalar, job.database is not None, job.consumers is not None)
     job.close()
 

@@ -28,6 +28,7 @@ def main():
     parser.add_argument("--repeats", type=int, default=400)
     parser.add_argument("--workloads", default="cinematic")
     parser.add_argument("--order", default=None)
+    parser.add_argument("--layout", default=None)
     parser.add_argument("variants", nargs="+")
     args = parser.parse_args()
 
@@ -43,6 +44,8 @@ def main():
             options = {}
             if args.order:
                 options["order"] = args.order
+            if args.layout:
+                options["layout"] = args.layout
             code = RUNNER % {"root": ROOT, "workload": workload, "repeats": args.repeats, "options": options}
             try:
                 proc = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240, cwd=ROOT)
