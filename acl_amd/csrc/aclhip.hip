@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <unordered_set>

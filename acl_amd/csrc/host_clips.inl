@@ -83,7 +83,7 @@ static aclhip_status register_scalar_clip(aclhip_context* context, const uint8_t
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	device_guard guard(context->device);
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
@@ -791,7 +791,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	device_guard guard(context->device);
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
@@ -1026,7 +1026,7 @@ extern "C" aclhip_status aclhip_unregister_clip(aclhip_context* context, aclhip_
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	if (clip >= context->clips.size() || !context->clips[clip].in_use)
 		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 

@@ -125,7 +125,7 @@ extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclh
 
 	return guarded(context, [&]() -> aclhip_status
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		if (clip >= context->clips.size() || !context->clips[clip].in_use)
 			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 		host_clip& entry = context->clips[clip];
@@ -260,7 +260,7 @@ namespace
 		if (params.standard_defaults == 0 || params.per_track_rounding != 0)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding, normalization != always");
 
-		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+		std::shared_lock<std::shared_mutex> lock(context->mutex);		// see launch_tracks
 		note_launch_stream(context, stream);
 
 		// one wave per instance, the whole pose (its base, its hierarchy) in LDS; as many instances per workgroup (a power of two, at
@@ -420,7 +420,7 @@ namespace
 
 		uint32_t max_tracks = 0;
 		{
-			std::lock_guard<std::mutex> lock(context->mutex);
+			std::lock_guard<std::shared_mutex> lock(context->mutex);
 			for (uint32_t i = 0; i < num_instances; ++i)
 				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
 					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);

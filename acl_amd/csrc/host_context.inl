@@ -58,7 +58,12 @@ namespace
 struct aclhip_context
 {
 	int device = 0;
-	std::mutex mutex;
+	// The registry lock. Everything that registers, retires, orders or changes a list holds it exclusively; the LAUNCHES (pose, track,
+	// scalar, consumer batches) hold it SHARED across their enqueue: decoding threads of one context no longer serialize on it (until
+	// round 5 they did), while an unregistration still cannot record its "everything enqueued so far" events in the middle of a launch
+	// that has noted its stream but not yet enqueued its kernel.
+	std::shared_mutex mutex;
+	std::mutex streams_mutex;				// launch_streams, among launching threads (they only hold `mutex` shared)
 	std::vector<host_clip> clips;
 	std::vector<uint32_t> free_slots;
 	std::vector<host_database> databases;
@@ -299,6 +304,8 @@ namespace
 	// record on it fails from then on and the stream is dropped from the list.)
 	void note_launch_stream(aclhip_context* context, hipStream_t stream)
 	{
+		// (callers hold context->mutex, shared or exclusive; readers of the list hold it exclusively: no launch is inside this function then)
+		std::lock_guard<std::mutex> lock(context->streams_mutex);
 		for (hipStream_t known : context->launch_streams)
 			if (known == stream)
 				return;

@@ -145,7 +145,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_database: everything above is host work
 
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	device_guard guard(context->device);
 	if (!guard.ok)
 		return fail(context, ACLHIP_ERROR_DEVICE, "hipSetDevice(%d) failed", context->device);
@@ -329,7 +329,7 @@ extern "C" aclhip_status aclhip_unregister_database(aclhip_context* context, acl
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	if (database >= context->databases.size() || !context->databases[database].in_use)
 		return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
 	if (context->databases[database].num_bound_clips != 0)
@@ -357,7 +357,7 @@ extern "C" aclhip_status aclhip_get_database_info(const aclhip_context* context,
 {
 	if (context == nullptr || out_info == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
 	if (database >= context->databases.size() || !context->databases[database].in_use)
 		return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
 	*out_info = context->databases[database].info;
@@ -449,7 +449,7 @@ namespace
 			return ACLHIP_ERROR_INVALID_ARGUMENT;
 		if (out_num_chunks != nullptr)
 			*out_num_chunks = 0;
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		if (database >= context->databases.size() || !context->databases[database].in_use)
 			return fail(context, ACLHIP_ERROR_UNKNOWN_DATABASE, "unknown database handle %u", database);
 		if (tier != 1 && tier != 2)
@@ -571,7 +571,7 @@ extern "C" aclhip_status aclhip_get_clip_info(const aclhip_context* context, acl
 {
 	if (context == nullptr || out_info == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
 	if (clip >= context->clips.size() || !context->clips[clip].in_use)
 		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 	*out_info = context->clips[clip].info;
@@ -582,7 +582,7 @@ extern "C" aclhip_status aclhip_clip_matches(const aclhip_context* context, aclh
 {
 	if (context == nullptr || compressed_tracks == nullptr || out_matches == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
 	if (clip >= context->clips.size() || !context->clips[clip].in_use)
 		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 	// is_bound_to_v0 compares pointer and hash (decompression.transform.h:159-169); there is no shared pointer here: hash + size

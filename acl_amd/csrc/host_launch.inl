@@ -75,7 +75,7 @@ namespace
 		const decode_params& params, void* poses, uint64_t pose_stride_bytes, hipStream_t stream)
 	{
 		// launches read the registry's maxima and are noted (note_launch_stream) under the registry lock; the clip table itself never moves
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::shared_lock<std::shared_mutex> lock(context->mutex);
 		note_launch_stream(context, stream);
 
 		// one wave per (instance, pose window)
@@ -255,7 +255,7 @@ namespace
 	{
 		if (context == nullptr)
 			return 1;
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		return std::max<uint32_t>((context->max_pose_quads + k_image_chunk_quads - 1) / k_image_chunk_quads, 1);
 	}
 
@@ -377,7 +377,7 @@ extern "C" aclhip_status aclhip_pose_windows_of_launch(aclhip_context* context, 
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 	if (aclhip_layout_bytes_per_track(layout) == 0)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown pose layout %u", layout);
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	*out_windows_per_instance = pose_launch_shape_of(context, layout, pose_stride_bytes).windows_per_instance;
 	return ACLHIP_OK;
 }
@@ -398,7 +398,7 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 	const order_layout layout = make_order_layout(num_instances, windows_per_instance != 0 ? windows_per_instance : windows_per_instance_of(context));
 
 	device_guard guard(context->device);
-	std::lock_guard<std::mutex> lock(context->mutex);		// the scratch of a stream is handed to one call at a time, in stream order
+	std::lock_guard<std::shared_mutex> lock(context->mutex);		// the scratch of a stream is handed to one call at a time, in stream order
 	const uint32_t num_bins = uint32_t(context->clips.size()) + 1;		// handles are slots of the registry; the last bin takes everything else
 	note_launch_stream(context, stream);
 	aclhip_context::order_scratch* scratch = nullptr;
@@ -545,7 +545,7 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 	if (status != ACLHIP_OK)
 		return status;
 
-	std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+	std::shared_lock<std::shared_mutex> lock(context->mutex);		// see launch_tracks
 	device_guard guard(context->device);
 	note_launch_stream(context, static_cast<hipStream_t>(stream));
 	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;

@@ -58,7 +58,7 @@ extern "C" aclhip_status aclhip_instance_list_create(aclhip_context* context, ui
 	uint32_t* memory = nullptr;
 	ACLHIP_CHECK_HIP(context, hipMalloc(reinterpret_cast<void**>(&memory), size_t(num_instances) * 4 * sizeof(uint32_t)));
 
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	uint32_t slot = 0;
 	while (slot < context->instance_lists.size() && context->instance_lists[slot].in_use)
 		slot++;
@@ -77,7 +77,7 @@ extern "C" aclhip_status aclhip_instance_list_destroy(aclhip_context* context, a
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list == nullptr)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -98,7 +98,7 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null clip list");
 	aclhip_context::instance_list snapshot;
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
 		if (list == nullptr)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -118,7 +118,7 @@ extern "C" aclhip_status aclhip_instance_list_set_clips(aclhip_context* context,
 	const aclhip_status status = order_instances_on_device(context, registry_windows, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);		// (takes the context's lock itself)
 	if (status != ACLHIP_OK)
 		return status;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list != nullptr && list->d_memory == snapshot.d_memory)
 	{
@@ -138,7 +138,7 @@ extern "C" aclhip_status aclhip_instance_list_attach(aclhip_context* context, ac
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null clip list");
 	aclhip_context::instance_list snapshot;
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
 		if (list == nullptr)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -152,7 +152,7 @@ extern "C" aclhip_status aclhip_instance_list_attach(aclhip_context* context, ac
 	const aclhip_status status = order_instances_on_device(context, registry_windows, caller_clips, nullptr, snapshot.num_instances, snapshot.order(), nullptr, nullptr, nullptr, stream);
 	if (status != ACLHIP_OK)
 		return status;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list != nullptr && list->d_memory == snapshot.d_memory)
 	{
@@ -169,7 +169,7 @@ extern "C" aclhip_status aclhip_instance_list_note_changes(aclhip_context* conte
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list == nullptr)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -187,7 +187,7 @@ extern "C" aclhip_status aclhip_instance_list_update(aclhip_context* context, ac
 		return ACLHIP_OK;
 	if (instances == nullptr || clips == nullptr)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null update lists");
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list == nullptr)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -224,7 +224,7 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 	uint32_t windows_per_instance = 1;
 	bool ordering_gave_up = false;
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
 		if (list == nullptr)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);
@@ -261,7 +261,7 @@ extern "C" aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, 
 			status = order_instances_on_device(context, windows_per_instance, snapshot.clips(), nullptr, snapshot.num_instances, snapshot.order(), snapshot.ordered_clips(), nullptr, snapshot.positions(), stream);
 		if (status != ACLHIP_OK)
 			return status;
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		aclhip_context::instance_list* list = find_list(context, handle);
 		if (list != nullptr && list->d_memory == snapshot.d_memory)
 		{
@@ -278,7 +278,7 @@ extern "C" aclhip_status aclhip_instance_list_get_order(aclhip_context* context,
 {
 	if (context == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	aclhip_context::instance_list* list = find_list(context, handle);
 	if (list == nullptr)
 		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown instance list %u", handle);

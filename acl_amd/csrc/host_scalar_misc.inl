@@ -22,7 +22,7 @@ namespace
 		if (status != ACLHIP_OK)
 			return status;
 
-		std::lock_guard<std::mutex> lock(context->mutex);		// see launch_tracks
+		std::shared_lock<std::shared_mutex> lock(context->mutex);		// see launch_tracks
 		device_guard guard(context->device);
 		note_launch_stream(context, static_cast<hipStream_t>(stream));
 		if (track_indices != nullptr)
@@ -110,7 +110,7 @@ namespace
 
 		uint32_t max_tracks = 0;
 		{
-			std::lock_guard<std::mutex> lock(context->mutex);
+			std::lock_guard<std::shared_mutex> lock(context->mutex);
 			for (uint32_t i = 0; i < num_instances; ++i)
 				if (clips[i] < context->clips.size() && context->clips[clips[i]].in_use)
 					max_tracks = std::max(max_tracks, context->clips[clips[i]].info.num_tracks);
@@ -210,7 +210,7 @@ extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, 
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 	aclhip_clip_info info;
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		if (clip >= context->clips.size() || !context->clips[clip].in_use)
 			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
 		info = context->clips[clip].info;
@@ -383,7 +383,7 @@ extern "C" aclhip_status aclhip_peer_open_buffer(aclhip_context* context, const 
 	std::memcpy(&offset, handle + sizeof(ipc_handle), sizeof(offset));
 	void* base = nullptr;
 	ACLHIP_CHECK_HIP(context, hipIpcOpenMemHandle(&base, ipc_handle, hipIpcMemLazyEnablePeerAccess));
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	context->peer_mappings.push_back({ static_cast<uint8_t*>(base) + offset, base });
 	*out_device_buffer = static_cast<uint8_t*>(base) + offset;
 	return ACLHIP_OK;
@@ -397,7 +397,7 @@ extern "C" aclhip_status aclhip_peer_close_buffer(aclhip_context* context, void*
 		return ACLHIP_OK;
 	void* base = nullptr;
 	{
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		for (size_t i = 0; i < context->peer_mappings.size(); ++i)
 			if (context->peer_mappings[i].buffer == device_buffer)
 			{
@@ -435,7 +435,7 @@ extern "C" aclhip_status aclhip_forget_stream(aclhip_context* context, void* str
 	device_guard guard(context->device);
 	// (outside the lock: other threads keep registering and launching while this stream drains)
 	ACLHIP_CHECK_HIP(context, hipStreamSynchronize(hip_stream));
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	for (size_t i = 0; i < context->launch_streams.size(); ++i)
 		if (context->launch_streams[i] == hip_stream)
 		{
@@ -462,7 +462,7 @@ extern "C" aclhip_status aclhip_get_lifetime_stats(aclhip_context* context, uint
 {
 	if (context == nullptr || out_stats == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	device_guard guard(context->device);
 	collect_retired(context, false);
 	out_stats[0] = context->clips_registered;
@@ -577,7 +577,7 @@ extern "C" aclhip_status aclhip_describe_tracks_launch(aclhip_context* context, 
 		return status;
 	// the very functions launch_tracks asks (shape from the batch's stride, kernel from shape and settings: ACLHIP_WIDE_KEY_LOADS and
 	// ACLHIP_FORCE_GENERIC_KERNEL included)
-	std::lock_guard<std::mutex> lock(context->mutex);
+	std::lock_guard<std::shared_mutex> lock(context->mutex);
 	const pose_launch_shape shape = pose_launch_shape_of(context, device_params.layout, pose_stride_bytes);
 	const char* name = "";
 	(void)pose_kernel_of(context, device_params, shape, &name);
@@ -626,7 +626,7 @@ extern "C" aclhip_status aclhip_measure_pose_store_bandwidth(aclhip_context* con
 	const hipEvent_t start = resources.start, stop = resources.stop;
 	{
 		// the probe launches on the caller's stream like any decode: the context has to know the stream (retired clips wait for it)
-		std::lock_guard<std::mutex> lock(context->mutex);
+		std::lock_guard<std::shared_mutex> lock(context->mutex);
 		note_launch_stream(context, hip_stream);
 	}
 	// workgroups of 4 waves per CU by the LDS a workgroup asks for: 20 KB -> 8 (32 waves), 40 KB -> 4, 52 KB -> 3, 80 KB -> 2 (8 waves);
@@ -719,7 +719,7 @@ extern "C" aclhip_status aclhip_batch_algorithmic_bytes(const aclhip_context* co
 	if (context == nullptr || (num_instances != 0 && clips == nullptr) || out_bytes_written == nullptr || out_distinct_clip_bytes == nullptr)
 		return ACLHIP_ERROR_INVALID_ARGUMENT;
 
-	std::lock_guard<std::mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
 	std::unordered_set<uint32_t> distinct;
 	uint64_t written = 0, read = 0;
 	for (uint32_t i = 0; i < num_instances; ++i)

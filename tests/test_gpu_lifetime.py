@@ -198,3 +198,88 @@ def test_decodes_enqueued_before_an_unregistration_still_decode_the_clip():
         context.forget_stream(stream.cuda_stream)
         assert context.lifetime_stats()["launch_streams"] == 0
         context.unregister_clip(filler_handle)
+
+
+def test_several_threads_launch_on_their_own_streams_next_to_a_churning_registry():
+    """Launches hold the registry lock SHARED (round 5): four threads, each with its own stream, buffers and kind of batch -- whole poses,
+    single bone requests, a compact layout, an instance list -- decode side by side while a fifth registers and unregisters clips
+    (exclusive). Every result is the oracle's; a clip unregistered while the others launch is never decoded after its memory is gone
+    (the unregistration's events cannot slip between a launch's noting its stream and enqueueing its kernel)."""
+    rng = np.random.default_rng(5)
+    resident = [synth.build_clip(seed=900 + i, num_tracks=100, num_samples=int(rng.integers(20, 200))) for i in range(6)]
+    churn = [synth.build_clip(seed=950 + i, num_tracks=int(rng.integers(3, 130)), num_samples=int(rng.integers(2, 60))) for i in range(24)]
+    with runtime.Context(0) as context:
+        device = torch.device("cuda", 0)
+        handles = np.array([context.register_clip(c.blob) for c in resident], dtype=np.uint32)
+        durations = np.array([c.duration for c in resident], dtype=np.float32)
+        n = 4096
+        stop = threading.Event()
+        failures = []
+        rounds = [0, 0, 0, 0]
+
+        def worker(kind):
+            try:
+                local = np.random.default_rng(100 + kind)
+                which = local.integers(0, len(resident), size=n)
+                times = (local.uniform(0.0, 1.0, size=n).astype(np.float32) * durations[which]).astype(np.float32)
+                full = ob.oracle_decompress_tracks_batch([c.blob for c in resident], which, times, 100)
+                stream = torch.cuda.Stream(device)
+                with torch.cuda.stream(stream):
+                    d_clips = torch.from_numpy(handles[which].astype(np.int32)).to(device)
+                    d_times = torch.from_numpy(times).to(device)
+                    tracks = local.integers(0, 100, size=n)
+                    d_tracks = torch.from_numpy(tracks.astype(np.int32)).to(device)
+                    width = {0: 1200, 1: 12, 2: 800, 3: 1200}[kind]
+                    d_out = torch.zeros((n, width), dtype=torch.float32, device=device)
+                stream.synchronize()
+                expected = {0: full.reshape(n, 1200), 1: full[np.arange(n), tracks], 2: runtime.relayout_pose(full, runtime.LAYOUT_QV32).reshape(n, 800), 3: full.reshape(n, 1200)}[kind]
+                output = runtime.OutputDesc()
+                output.layout = runtime.LAYOUT_QV32
+                instance_list = None
+                if kind == 3:
+                    instance_list = context.instance_list_create(n)
+                    context.instance_list_set_clips(instance_list, d_clips.data_ptr(), stream=stream.cuda_stream)
+                while not stop.is_set():
+                    for _ in range(6):
+                        if kind == 0:
+                            context.decompress_tracks_batch(d_clips.data_ptr(), d_times.data_ptr(), n, d_out.data_ptr(), 4800, stream=stream.cuda_stream)
+                        elif kind == 1:
+                            context.decompress_track_batch(d_clips.data_ptr(), d_times.data_ptr(), d_tracks.data_ptr(), n, d_out.data_ptr(), stream=stream.cuda_stream)
+                        elif kind == 2:
+                            context.decompress_tracks_batch_out(d_clips.data_ptr(), d_times.data_ptr(), n, d_out.data_ptr(), 3200, output, stream=stream.cuda_stream)
+                        else:
+                            context.decompress_tracks_list(instance_list, d_times.data_ptr(), d_out.data_ptr(), 4800, poses_in_instance_order=True, stream=stream.cuda_stream)
+                    stream.synchronize()
+                    got = d_out.cpu().numpy()
+                    if not np.array_equal(got.view(np.uint32), expected.view(np.uint32)):
+                        failures.append(f"thread {kind}: poses differ from the oracle")
+                        return
+                    rounds[kind] += 1
+                    with torch.cuda.stream(stream):
+                        d_out.zero_()
+                if instance_list is not None:
+                    context.instance_list_destroy(instance_list)
+            except Exception as error:      # noqa: BLE001 -- reported by the main thread
+                failures.append(f"thread {kind}: {error!r}")
+
+        threads = [threading.Thread(target=worker, args=(kind,)) for kind in range(4)]
+        for thread in threads:
+            thread.start()
+        live = []
+        deadline = time.perf_counter() + 4.0
+        registered = 0
+        while time.perf_counter() < deadline and not failures:
+            live.append(context.register_clip(churn[registered % len(churn)].blob, check_hash=False))
+            registered += 1
+            if len(live) >= 16:
+                for index in sorted(rng.choice(len(live), size=12, replace=False), reverse=True):
+                    context.unregister_clip(live.pop(int(index)))
+        stop.set()
+        for thread in threads:
+            thread.join()
+        for clip in live:
+            context.unregister_clip(clip)
+        assert not failures, failures
+        assert all(count > 0 for count in rounds), rounds
+        assert context.rejected_instance_count() == 0
+        print(f"\n{registered} clips registered next to {rounds} verified rounds of 6 launches per thread")
