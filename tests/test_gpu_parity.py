@@ -252,3 +252,42 @@ def test_context_is_usable_from_several_host_threads(context):
         thread.join(timeout=120)
     assert not any(thread.is_alive() for thread in threads)
     assert errors == []
+
+
+@pytest.mark.parametrize("num_requests", [1, 63, 64, 65, 1000, 4097])
+def test_track_requests_with_refused_and_skipped_lanes_inside_full_waves(context, num_requests):
+    """decompress_track_kernel works on 64 requests per wave (round 5): a wave that holds a refused request -- an unknown or scalar clip,
+    a track index past the clip's end -- or a request whose default sub-tracks are skipped leaves those bytes as the caller had them and
+    still decodes its other lanes to the oracle's bits; waves of one clip and waves of mixed clips; batch sizes around the wave size."""
+    rng = np.random.default_rng(num_requests)
+    clips = [synth.build_clip(**CLIP_SPECS["cmu_100"]), synth.build_clip(**CLIP_SPECS["scale_37"]), synth.build_clip(**CLIP_SPECS["all_default"])]
+    curves = synth.build_scalar_clip(seed=3, track_type=0, num_tracks=10, num_samples=20)
+    handles = [context.register_clip(c.blob) for c in clips]
+    scalar_handle = context.register_clip(curves.blob)
+    for mixed in (False, True):
+        which = rng.integers(0, len(clips), size=num_requests) if mixed else np.zeros(num_requests, dtype=np.int64)
+        clip_ids = np.array([handles[w] for w in which], dtype=np.uint32)
+        times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+        tracks = np.array([rng.integers(0, clips[w].num_tracks) for w in which], dtype=np.uint32)
+        # a tenth of the requests is refused, one way or another
+        refused = rng.uniform(size=num_requests) < 0.1
+        kinds = rng.integers(0, 3, size=num_requests)
+        clip_ids[refused & (kinds == 0)] = 54321
+        clip_ids[refused & (kinds == 1)] = scalar_handle
+        tracks[refused & (kinds == 2)] = 5000
+        for default_mode in (ob.DEFAULT_CONSTANT, ob.DEFAULT_SKIPPED):
+            modes = dict(default_rotation_mode=default_mode, default_translation_mode=default_mode, default_scale_mode=default_mode if default_mode == ob.DEFAULT_SKIPPED else ob.DEFAULT_LEGACY)
+            params = runtime.default_params(**modes)
+            options = ob.default_options(**modes)
+            before = context.rejected_instance_count()
+            fill = np.float32(-7.5)
+            got = context.decompress_track(clip_ids, times, tracks, params=params, out=np.full((num_requests, 12), fill, dtype=np.float32))
+            expected = np.full((num_requests, 12), fill, dtype=np.float32)
+            for i in range(num_requests):
+                if not refused[i]:
+                    pose = ob.oracle_decompress_tracks(clips[which[i]].blob, float(times[i]), options=options, out=np.full((clips[which[i]].num_tracks, 12), fill, dtype=np.float32))
+                    expected[i] = pose[tracks[i]]
+            assert helpers.bit_equal(got, expected), (num_requests, mixed, default_mode)
+            assert context.rejected_instance_count() == before + int(refused.sum())
+    for handle in handles + [scalar_handle]:
+        context.unregister_clip(handle)
