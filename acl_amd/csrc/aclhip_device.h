@@ -270,9 +270,12 @@ namespace aclhip
 	typedef float f32x3_store __attribute__((ext_vector_type(3)));
 	typedef float f32x2_store __attribute__((ext_vector_type(2)));
 
+#if !defined(ACLHIP_STORE_MODIFIERS)
+	#define ACLHIP_STORE_MODIFIERS "sc0 sc1 nt"
+#endif
 	__device__ __forceinline__ void store_streaming(void* address, f32x4_store value)
 	{
-		asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt\n\ts_nop 1" :: "v"(address), "v"(value) : "memory");
+		asm volatile("global_store_dwordx4 %0, %1, off " ACLHIP_STORE_MODIFIERS "\n\ts_nop 1" :: "v"(address), "v"(value) : "memory");
 	}
 
 	// C packed floats (4 byte aligned)
