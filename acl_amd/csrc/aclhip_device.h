@@ -203,6 +203,9 @@ namespace aclhip
 		const uint8_t* instance_masks;				// mask of every instance, or null
 		const uint32_t* instance_track_counts;		// tracks every instance stores (its first K), or null
 		const uint8_t* instance_looping_policies;	// or null
+		const uint8_t* track_rounding_table;		// per instance writers' track rounding policies: tables of track_rounding_stride bytes, or null
+		const uint8_t* instance_rounding_tables;	// table of every instance, or null
+		uint32_t track_rounding_stride;
 		uint32_t mask_stride;
 		uint8_t rounding_policy;
 		uint8_t looping_policy;
@@ -228,6 +231,15 @@ namespace aclhip
 	__device__ __forceinline__ uint32_t instance_looping_policy_of(const decode_params& params, uint32_t caller_instance)
 	{
 		return params.instance_looping_policies != nullptr ? uint32_t(params.instance_looping_policies[caller_instance]) : uint32_t(params.looping_policy);
+	}
+
+	// track_writer::get_rounding_policy(policy, track_index) (core/track_writer.h:97) belongs to the writer of ONE pose: the instance's own
+	// table of per track policies, or the launch's
+	__device__ __forceinline__ const uint8_t* instance_track_rounding_of(const decode_params& params, uint32_t caller_instance)
+	{
+		return params.instance_rounding_tables != nullptr
+			? params.track_rounding_table + size_t(params.instance_rounding_tables[caller_instance]) * params.track_rounding_stride
+			: params.track_rounding_policies;
 	}
 
 	// What happens to a decoded (local space) pose before it is stored (aclhip_pose_consumers resolved to device pointers)

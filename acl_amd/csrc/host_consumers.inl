@@ -490,6 +490,15 @@ namespace
 		void* d_instance_looping = nullptr;
 		if (ok && local.instance_looping_policies != nullptr)
 			ok = upload(local.instance_looping_policies, num_instances, &d_instance_looping);
+		// per instance writers' track rounding tables: as many tables as the largest index names
+		void* d_rounding_table = nullptr; void* d_rounding_tables_of = nullptr;
+		if (ok && local.track_rounding_table != nullptr && local.instance_rounding_tables != nullptr)
+		{
+			uint32_t num_tables = 0;
+			for (uint32_t i = 0; i < num_instances; ++i)
+				num_tables = std::max<uint32_t>(num_tables, uint32_t(local.instance_rounding_tables[i]) + 1);
+			ok = upload(local.instance_rounding_tables, num_instances, &d_rounding_tables_of) && upload(local.track_rounding_table, size_t(num_tables) * local.track_rounding_stride, &d_rounding_table);
+		}
 
 		aclhip_pose_consumers local_consumers = {};
 		if (consumers != nullptr)
@@ -545,6 +554,11 @@ namespace
 		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
 		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
 		local.instance_looping_policies = static_cast<const uint8_t*>(d_instance_looping);
+		if (local.track_rounding_table != nullptr && local.instance_rounding_tables != nullptr)
+		{
+			local.track_rounding_table = static_cast<const uint8_t*>(d_rounding_table);
+			local.instance_rounding_tables = static_cast<const uint8_t*>(d_rounding_tables_of);
+		}
 
 		aclhip_status status;
 		if (single_track)
@@ -586,7 +600,7 @@ extern "C" aclhip_status aclhip_decompress_poses_host(aclhip_context* context, c
 {
 	if (consumers == nullptr)
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "null consumers") : ACLHIP_ERROR_INVALID_ARGUMENT;
-	if (params != nullptr && (params->default_values != nullptr || params->track_rounding_policies != nullptr))
+	if (params != nullptr && (params->default_values != nullptr || params->track_rounding_policies != nullptr || params->track_rounding_table != nullptr))
 		return context != nullptr ? fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "pose consumers take the track_writer's default sub-track modes, no per track rounding") : ACLHIP_ERROR_INVALID_ARGUMENT;
 	return decompress_host(context, clips, sample_times, nullptr, num_instances, params, 0, poses, pose_stride_bytes, 0, consumers);
 }

@@ -753,6 +753,13 @@ namespace
 		out.instance_masks = nullptr;
 		out.instance_track_counts = nullptr;
 		out.instance_looping_policies = params->instance_looping_policies;
+		if ((params->track_rounding_table != nullptr) != (params->instance_rounding_tables != nullptr))
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "track_rounding_table and instance_rounding_tables come together");
+		if (params->track_rounding_table != nullptr && params->track_rounding_stride == 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "track_rounding_stride: the bytes of one table of track_rounding_table (at least the tracks of the largest clip of the batch)");
+		out.track_rounding_table = params->track_rounding_table;
+		out.instance_rounding_tables = params->instance_rounding_tables;
+		out.track_rounding_stride = params->track_rounding_stride;
 		out.mask_stride = 0;
 		out.layout = ACLHIP_LAYOUT_QVV48;
 		out.skip_mask = 0;

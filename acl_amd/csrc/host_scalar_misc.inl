@@ -148,6 +148,15 @@ namespace
 		void* d_instance_looping = nullptr;
 		if (ok && local.instance_looping_policies != nullptr)
 			ok = upload(local.instance_looping_policies, num_instances, &d_instance_looping);
+		// per instance writers' track rounding tables: as many tables as the largest index names
+		void* d_rounding_table = nullptr; void* d_rounding_tables_of = nullptr;
+		if (ok && local.track_rounding_table != nullptr && local.instance_rounding_tables != nullptr)
+		{
+			uint32_t num_tables = 0;
+			for (uint32_t i = 0; i < num_instances; ++i)
+				num_tables = std::max<uint32_t>(num_tables, uint32_t(local.instance_rounding_tables[i]) + 1);
+			ok = upload(local.instance_rounding_tables, num_instances, &d_rounding_tables_of) && upload(local.track_rounding_table, size_t(num_tables) * local.track_rounding_stride, &d_rounding_table);
+		}
 
 		if (!ok)
 		{
@@ -157,6 +166,11 @@ namespace
 		local.track_rounding_policies = static_cast<const uint8_t*>(d_track_policies);
 		local.instance_rounding_policies = static_cast<const uint8_t*>(d_instance_policies);
 		local.instance_looping_policies = static_cast<const uint8_t*>(d_instance_looping);
+		if (local.track_rounding_table != nullptr && local.instance_rounding_tables != nullptr)
+		{
+			local.track_rounding_table = static_cast<const uint8_t*>(d_rounding_table);
+			local.instance_rounding_tables = static_cast<const uint8_t*>(d_rounding_tables_of);
+		}
 
 		aclhip_status status = launch_scalar(context, static_cast<const aclhip_clip*>(d_clip_ids), static_cast<const float*>(d_times), static_cast<const uint32_t*>(d_tracks),
 			num_instances, &local, d_out, out_stride_bytes, work_stream);
@@ -225,6 +239,8 @@ extern "C" aclhip_status aclhip_decompress_all_samples(aclhip_context* context, 
 	local.rounding_policy = ACLHIP_ROUND_NEAREST;		// convert.impl.h:166
 	local.instance_rounding_policies = nullptr;
 	local.instance_looping_policies = nullptr;
+	local.track_rounding_table = nullptr;
+	local.instance_rounding_tables = nullptr;
 
 	// the duration the reference's loop clamps to is the one of the looping policy in effect (convert.impl.h:139)
 	float duration = info.duration;

@@ -357,7 +357,15 @@
 		// lanes <-> animated sub-tracks of this window
 		// (decoded quads are written after the DMA has delivered their slots: a wave's memory operations return in order, and the
 		// keyframe loads every decoded value waits for were issued after the DMA)
-		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
+		if (kAnySettings && params.instance_rounding_tables != nullptr)
+		{
+			// the instance's own writer: its table of per track rounding policies (wave uniform)
+			decode_params instance_params = params;
+			instance_params.track_rounding_policies = params.track_rounding_table + size_t(as_constant(params.instance_rounding_tables)[caller_instance]) * params.track_rounding_stride;
+			decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, instance_params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
+		}
+		else
+			decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);

@@ -310,7 +310,7 @@
 		const scalar_track_header* const headers = reinterpret_cast<const scalar_track_header*>(clip.plan);
 		const float* const ranges = reinterpret_cast<const float*>(clip.clip_ranges);
 		const uint32_t num_tracks = clip.num_tracks;
-		const uint8_t* const track_rounding_policies = params.track_rounding_policies;
+		const uint8_t* const track_rounding_policies = instance_track_rounding_of(params, instance);		// (wave uniform)
 
 		// Every lane takes kRows tracks, 64 apart. The component count is wave uniform: one specialised loop runs.
 		const auto decode_tracks = [=](auto components)
@@ -487,8 +487,6 @@
 		const scalar_track_header* const headers = reinterpret_cast<const scalar_track_header*>(clip.plan);
 		const float* const ranges = reinterpret_cast<const float*>(clip.clip_ranges);
 		const uint32_t num_tracks = clip.num_tracks;
-		const uint8_t* const track_rounding_policies = params.track_rounding_policies;
-
 		const auto decode_tracks = [&](auto components)
 		{
 			constexpr uint32_t C = decltype(components)::value;
@@ -504,7 +502,8 @@
 				if (k >= count)
 					break;
 				float* row = reinterpret_cast<float*>(out + uint64_t(first_instance + k) * out_stride_bytes);
-				decode_and_store_lane_tracks<C, kRows, true, kPolicies>(frames[k], tables, alphas[k], rounding_policies[k], track_rounding_policies, first_track, num_tracks, lane, row);
+				decode_and_store_lane_tracks<C, kRows, true, kPolicies>(frames[k], tables, alphas[k], rounding_policies[k], kPolicies ? instance_track_rounding_of(params, first_instance + k) : nullptr,
+					first_track, num_tracks, lane, row);
 			}
 		};
 		if constexpr (kComponents == 1)
@@ -557,7 +556,10 @@
 		{
 			uint32_t policy = rounding_policy;
 			if (rounding_policy == k_round_per_track)
-				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
+			{
+				const uint8_t* track_policies = instance_track_rounding_of(params, instance);
+				policy = track_policies != nullptr ? track_policies[track_index] : k_round_none;
+			}
 			alpha = apply_rounding_policy(alpha, policy);
 		}
 

@@ -66,7 +66,7 @@
 	// out_animated: bit k = sub-track kind k is animated (out_ordinals[k] = its ordinal); the other kinds have their final value in
 	// out_quads[k] and whether it is stored at all in out_store[k].
 	__device__ __forceinline__ bool prepare_track_request(const device_clip& clip, float sample_time, uint32_t track_index, uint32_t rounding_policy, uint32_t looping_policy,
-		const decode_params& params, track_request_state& out_state, float& out_lerp_alpha, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
+		const uint8_t* track_rounding_policies, const decode_params& params, track_request_state& out_state, float& out_lerp_alpha, float4 (&out_quads)[3], bool (&out_store)[3], uint32_t& out_animated, uint32_t (&out_ordinals)[3])
 	{
 		out_animated = 0;
 		// invalid track index (decompression.transform.h:1766-1768); an empty clip lands here as well
@@ -82,7 +82,7 @@
 		{
 			uint32_t policy = rounding_policy;
 			if (rounding_policy == k_round_per_track)
-				policy = params.track_rounding_policies != nullptr ? params.track_rounding_policies[track_index] : k_round_none;
+				policy = track_rounding_policies != nullptr ? track_rounding_policies[track_index] : k_round_none;
 			lerp_alpha = apply_rounding_policy(lerp_alpha, policy);
 		}
 		out_lerp_alpha = lerp_alpha;
@@ -154,6 +154,7 @@
 		const uint32_t track_index = track_indices[clamped_instance];
 		const uint32_t rounding_policy = instance_rounding_policy_of(params, clamped_instance);
 		const uint32_t looping_policy = instance_looping_policy_of(params, clamped_instance);
+		const uint8_t* track_rounding_policies = params.per_track_rounding != 0 ? instance_track_rounding_of(params, clamped_instance) : nullptr;
 
 		const bool known_clip = in_batch && clip_id < num_clips;
 		const uint32_t first_clip_id = __builtin_amdgcn_readfirstlane(clip_id);			// lane 0 is always in the batch
@@ -175,12 +176,12 @@
 			shared_plan = clip.plan;
 			shared_clip_ranges = clip.clip_ranges;
 			if (in_batch)
-				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
+				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 		else if (known_clip)
 		{
 			const device_clip clip = load_clip_per_lane(clips, clip_id);
-			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, params, state, lerp_alpha, quads, store, animated, ordinals);
+			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 
 		// refused requests are counted, one atomic per wave

