@@ -51,6 +51,31 @@ int integration_example(const void* tracks, uint64_t tracks_size, const void* co
 		s = aclhip_decompress_tracks_list(gpu, characters, d_times, NULL, NULL, 0, d_poses, (uint64_t)max_tracks * 48, hip_stream);
 		s = aclhip_decompress_tracks_list(gpu, characters, d_times, &params, &output, 1, d_poses, (uint64_t)max_tracks * 48, hip_stream);
 		s = aclhip_instance_list_get_order(gpu, characters, &d_order, &orderings);
+		{
+			/* per character writers and contexts (ABI 5): LODs, skip masks, looping policies and per track rounding tables per instance; a list
+			 * attached to the engine's own clip array */
+			aclhip_output_desc writers = { 0 };
+			aclhip_decompress_params per_character = params;
+			writers.instance_track_counts = d_rows;
+			writers.mask_table = (const uint8_t*)d_bones;
+			writers.mask_stride = max_tracks;
+			writers.instance_masks = (const uint8_t*)d_bones;
+			per_character.instance_looping_policies = (const uint8_t*)d_bones;
+			per_character.per_track_rounding = 1;
+			per_character.rounding_policy = ACLHIP_ROUND_PER_TRACK;
+			per_character.track_rounding_table = (const uint8_t*)d_bones;
+			per_character.track_rounding_stride = max_tracks;
+			per_character.instance_rounding_tables = (const uint8_t*)d_bones;
+			s = aclhip_decompress_tracks_batch_out(gpu, d_clips, d_times, num_instances, &per_character, &writers, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+			s = aclhip_instance_list_attach(gpu, characters, d_clips, hip_stream);
+			s = aclhip_instance_list_note_changes(gpu, characters, 3);
+			s = aclhip_decompress_tracks_list(gpu, characters, d_times, &per_character, &writers, 0, d_poses, (uint64_t)max_tracks * 48, hip_stream);
+		}
+		{
+			int rccl_version = 0;
+			char rccl_path[256], rccl_how[64];
+			s = aclhip_probe_rccl(&rccl_version, rccl_path, sizeof(rccl_path), rccl_how, sizeof(rccl_how));
+		}
 		s = aclhip_instance_list_destroy(gpu, characters);
 		s = aclhip_forget_stream(gpu, hip_stream);
 		if (aclhip_abi_version() != ACLHIP_ABI_VERSION)

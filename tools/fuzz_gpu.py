@@ -100,6 +100,25 @@ def main():
                         print("WRITER MISMATCH", spec, "instance", i, "time", times[i], "count", int(counts[i]), "mask", int(instance_masks[i]), "looping", int(instance_looping[i]), "rounding", rounding, "normalization", normalization)
                         return 1
                 checks += n
+            # every instance with its own table of per track rounding policies (track_writer::get_rounding_policy per pose), poses and single tracks
+            if tracks > 0 and rng.uniform() < 0.3:
+                tables = rng.integers(0, 4, size=(3, tracks)).astype(np.uint8)
+                table_of = rng.integers(0, 3, size=n).astype(np.uint8)
+                table_params = runtime.default_params(rounding_policy=runtime.ROUND_PER_TRACK, per_track_rounding=1, looping_policy=looping, normalization=normalization)
+                table_params.track_rounding_table, table_params.track_rounding_stride, table_params.instance_rounding_tables = tables.ctypes.data, tracks, table_of.ctypes.data
+                got = context.decompress_tracks(handles[which], times, params=table_params)
+                wanted = rng.integers(0, tracks, size=n)
+                single = context.decompress_track(handles[which], times, wanted, params=table_params)
+                for i in range(n):
+                    table_options = ob.default_options(looping_policy=looping, normalization=normalization, per_track_rounding=1)
+                    row = np.ascontiguousarray(tables[table_of[i]])
+                    table_options.track_rounding = row.ctypes.data
+                    expected = ob.oracle_decompress_tracks(clips[which[i]].blob, float(times[i]), ob.ROUND_PER_TRACK, table_options)
+                    expected_single = ob.oracle_decompress_track(clips[which[i]].blob, float(times[i]), int(wanted[i]), rounding=ob.ROUND_PER_TRACK, options=table_options)
+                    if not same(got[i], expected) or not same(single[i], expected_single):
+                        print("ROUNDING TABLE MISMATCH", spec, "instance", i, "time", times[i], "table", int(table_of[i]), "track", int(wanted[i]), "looping", looping, "normalization", normalization)
+                        return 1
+                checks += 2 * n
             # object space + additive, when the consumers take these settings
             if normalization != 2 and tracks <= 700:
                 parents = np.zeros(tracks, dtype=np.uint32)
