@@ -57,17 +57,6 @@ namespace aclhip
 	};
 	static_assert(sizeof(database_sample_record) == 32, "layout");
 
-	// In front of the sample records of a clip bound to a database (samples[-1] as a database_sample_record): which database, and where
-	// the clip's runtime headers start in it. Read by refresh_database_sample_tiers_kernel only -- not on any decode's path, which is why
-	// it lives here and not in the 128 byte clip record.
-	struct alignas(32) database_binding
-	{
-		const uint8_t* db_headers;			// the database's runtime clip / segment headers (device)
-		uint32_t db_clip_header_offset;		// into db_headers
-		uint32_t reserved[5];
-	};
-	static_assert(sizeof(database_binding) == 32, "layout");
-
 	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
 	// how to expand them, ready to use. Widths: 1..23 = quantized, 0 = constant in the segment (the 16 bit sample is pre-converted into
 	// range_min, range_extent = 0, nothing is read), 32 = raw fp32 (ranges ignored).
@@ -150,7 +139,7 @@ namespace aclhip
 		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
 		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
 		const clip_range_entry* clip_ranges;	// [num_animated]; scalar clips: float[num_tracks][2 * C] range rows
-		uint32_t segment_magic[2];				// k_clip_regular_segments: ceil(2^32 / A), ceil(2^32 / B) (segment_of_key_frame below)
+		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
 		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
 		uint32_t num_tracks;
 		uint32_t num_samples;
@@ -160,7 +149,7 @@ namespace aclhip
 		uint32_t flags;							// k_clip_*
 		uint32_t num_segments;
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
-		uint32_t segment_map;					// k_clip_regular_segments: R | A << 20 | B << 26 -- the clip's first R segments hold A samples each, the others B
+		uint32_t db_clip_header_offset;			// into db_headers
 		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window; behind it,
 												// at the next multiple of 32 bytes: window_span_entry[num_segments][num_windows] (window_spans_of)
 		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: walk schedules for 1 / 2 / 4 / 8 instances per workgroup; or null
@@ -180,7 +169,6 @@ namespace aclhip
 	constexpr uint32_t k_clip_negative_scale = 1u << 11;			// some scale sub-track may decode a negative component: rtm::qvv_mul then composes matrices (pose consumers)
 	constexpr uint32_t k_clip_short_exact_math = 1u << 12;		// no animated rotation of the clip can hand the kernels a square root argument in (0, 2^-96): the short exact forms apply (host_clips.inl)
 	constexpr uint32_t k_clip_raw_rotations = 1u << 13;			// some rotation sub-track is stored raw (fp32) in some segment
-	constexpr uint32_t k_clip_regular_segments = 1u << 14;		// the segment of a sample follows from its index by arithmetic (segment_map, segment_magic): no table needed
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)
@@ -245,13 +233,14 @@ namespace aclhip
 		return params.instance_looping_policies != nullptr ? uint32_t(params.instance_looping_policies[caller_instance]) : uint32_t(params.looping_policy);
 	}
 
-	// The same two for a WAVE UNIFORM instance, on the scalar unit: the dword that holds the instance's byte, always requested -- from
-	// `always_readable` (any 4 byte aligned device address: the clip table) when the launch has no per instance array -- so that the
-	// request has no branch around it and leaves together with its neighbours. Why not the byte itself: the scalar unit of gfx950 has
-	// no byte loads, a global_load_ubyte + readfirstlane puts the byte on the VECTOR memory counter, and the wait the compiler places
-	// where the two paths (array / no array) join is an s_waitcnt vmcnt(0) on BOTH: every wave then waited there for its base pose
-	// DMA -- 5 KiB through the texture unit, 1.7 us of a 4.8 us life (phase stamps, profiles/r05_experiments.md 8) -- before its seek
-	// went on, whether or not the launch had such an array.
+	// The same two for a WAVE UNIFORM instance of the pose kernels, on the scalar unit: the dword that holds the instance's byte, always
+	// requested -- from `always_readable` (any 4 byte aligned device address: the clip table) when the launch has no per instance array --
+	// so that the request has no branch around it. Why not the byte itself: the scalar unit of gfx950 has no byte loads, a
+	// global_load_ubyte + readfirstlane puts the byte on the VECTOR memory counter, and the wait the compiler places where the two paths
+	// (array / no array) join is an s_waitcnt vmcnt(0) on BOTH: every wave of the pose kernels then waited there for its base pose DMA
+	// -- 5 KiB through the texture unit, issued just before: 1.7 us of a 4.8 us life under the phase stamps (profiles/r05_experiments.md 8)
+	// -- before its seek went on, whether or not the launch had such an array. (The pose consumers read their policies BEFORE any vector
+	// memory operation and keep the byte loads: the scalar form costs them registers -- additive1 + object space 143.7 -> 165.9 us, measured.)
 	__device__ __forceinline__ uint32_t uniform_instance_byte(const uint8_t* table, uint32_t index, const void* always_readable, uint32_t otherwise)
 	{
 		const uintptr_t address = table != nullptr ? reinterpret_cast<uintptr_t>(table) + index : reinterpret_cast<uintptr_t>(always_readable);
@@ -426,43 +415,9 @@ namespace aclhip
 		out_alpha = apply_rounding_policy(sample_index - float(key_frame0), rounding_policy);
 	}
 
-	// The segment a key frame belongs to, WITHOUT the sample records. The reference's compressor cuts a clip into segments of 16
-	// samples and spreads what is left over the first segments, or leaves a short last one (compression/impl/segment_streams.h:
-	// split_samples_per_segment): the first R segments hold A samples each, the others B (the last one at most B). Registration checks
-	// that against the clip's segment_start_indices (k_clip_regular_segments; any other cut takes the table) and leaves
-	// ceil(2^32 / A), ceil(2^32 / B): floor(n / d) == mulhi(n, ceil(2^32 / d)) for n < 2^27, 2 <= d <= 32.
-	// Why: the plan rows a wave's lanes fetch are addressed by segment. With the segment from arithmetic those loads leave TOGETHER with
-	// the sample records instead of behind them -- one dependent memory round trip less in every wave's life (five -> four).
-	__device__ __forceinline__ uint32_t segment_of_key_frame(const device_clip& clip, uint32_t key_frame)
-	{
-		const uint32_t leading = clip.segment_map & 0xFFFFFu;					// R
-		const uint32_t leading_size = (clip.segment_map >> 20) & 63u;			// A
-		const uint32_t trailing_size = clip.segment_map >> 26;					// B
-		const uint32_t split = leading * leading_size;							// first sample of segment R
-		const uint32_t shift = split - leading * trailing_size;					// R (A - B)
-		return key_frame < split ? __umulhi(key_frame, clip.segment_magic[0]) : __umulhi(key_frame - shift, clip.segment_magic[1]);
-	}
-
-	// seek_v0 (decompression/impl/decompression.transform.h:206-563) in two halves. Everything here is wave uniform in the pose kernel.
-	// The reference guesses the segment and scans up to 4 start indices (:374-409); the lookup table (or the arithmetic above) gives the
-	// same answer.
-	//   seek_begin:  the two key frames and alpha, their sample records REQUESTED, and the keys' segments -- by arithmetic when the clip
-	//                allows (nothing waits for the records then), from the records otherwise;
-	//   seek_finish: everything that needs the records (where the keys' bits are).
-	// A kernel puts the loads that only need the segments (plan rows) between the two.
-	struct seek_keys
-	{
-		uint32_t key_frame[2];
-		uint32_t segment_index[2];
-		float alpha;
-		sample_record record[2];
-		uint64_t medium[2], low[2];		// clips bound to a database: tier metadata of each key's segment
-	};
-
-	// kSegmentsByArithmetic = false: the keys' segments from the sample records, whatever the clip (kernels that put nothing between
-	// the two halves: the arithmetic would only be instructions)
-	template<bool kSegmentsByArithmetic>
-	__device__ __forceinline__ void seek_begin(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_keys& out)
+	// seek_v0 (decompression/impl/decompression.transform.h:206-563). Everything here is wave uniform in the pose kernel.
+	// The reference guesses the segment and scans up to 4 start indices (:374-409); the lookup table gives the same answer.
+	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
 	{
 		uint32_t key_frame0, key_frame1;
 		float alpha;
@@ -471,53 +426,24 @@ namespace aclhip
 
 		// one scalar load per key: the sample's record, and for clips bound to a database the tier metadata of its segment with it
 		const bool has_database = (clip.flags & k_clip_database_samples) != 0;
-		out.medium[0] = out.medium[1] = out.low[0] = out.low[1] = 0;
+		sample_record segment0, segment1;
+		uint64_t medium0 = 0, medium1 = 0, low0 = 0, low1 = 0;
 		if (has_database)
 		{
 			const database_sample_record record0 = load_database_sample_record(clip.samples, key_frame0);
 			const database_sample_record record1 = load_database_sample_record(clip.samples, key_frame1);
-			out.record[0] = record0.record;
-			out.record[1] = record1.record;
-			out.medium[0] = record0.tier_metadata[0]; out.low[0] = record0.tier_metadata[1];
-			out.medium[1] = record1.tier_metadata[0]; out.low[1] = record1.tier_metadata[1];
+			segment0 = record0.record;
+			segment1 = record1.record;
+			medium0 = record0.tier_metadata[0]; low0 = record0.tier_metadata[1];
+			medium1 = record1.tier_metadata[0]; low1 = record1.tier_metadata[1];
 		}
 		else
 		{
-			out.record[0] = load_sample_record(clip.samples, key_frame0);
-			out.record[1] = load_sample_record(clip.samples, key_frame1);
+			segment0 = load_sample_record(clip.samples, key_frame0);
+			segment1 = load_sample_record(clip.samples, key_frame1);
 		}
-
-		out.key_frame[0] = key_frame0;
-		out.key_frame[1] = key_frame1;
-		out.alpha = alpha;
-		if constexpr (kSegmentsByArithmetic)
-		{
-			out.segment_index[0] = segment_of_key_frame(clip, key_frame0);
-			out.segment_index[1] = segment_of_key_frame(clip, key_frame1);
-			if ((clip.flags & k_clip_regular_segments) == 0)
-			{
-				// (a branch, not a select: a select would make every wave wait for the records here)
-				asm volatile("");
-				out.segment_index[0] = out.record[0].segment_and_local >> 5;
-				out.segment_index[1] = out.record[1].segment_and_local >> 5;
-			}
-		}
-		else
-		{
-			out.segment_index[0] = out.record[0].segment_and_local >> 5;
-			out.segment_index[1] = out.record[1].segment_and_local >> 5;
-		}
-	}
-
-	__device__ __forceinline__ void seek_finish(const device_clip& clip, const seek_keys& keys, seek_state& out)
-	{
-		const bool has_database = (clip.flags & k_clip_database_samples) != 0;
-		const sample_record segment0 = keys.record[0], segment1 = keys.record[1];
-		const uint64_t medium0 = keys.medium[0], medium1 = keys.medium[1], low0 = keys.low[0], low1 = keys.low[1];
-		const uint32_t key_frame0 = keys.key_frame[0], key_frame1 = keys.key_frame[1];
-		float alpha = keys.alpha;
-		const uint32_t segment_index0 = keys.segment_index[0];
-		const uint32_t segment_index1 = keys.segment_index[1];
+		const uint32_t segment_index0 = segment0.segment_and_local >> 5;
+		const uint32_t segment_index1 = segment1.segment_and_local >> 5;
 
 		uint32_t segment_key_frame0 = segment0.segment_and_local & 31u;
 		uint32_t segment_key_frame1 = segment1.segment_and_local & 31u;
@@ -573,13 +499,6 @@ namespace aclhip
 		out.key_frame_bit_offsets[1] = segment_key_frame1 * segment1.pose_bit_size;
 		out.interpolation_alpha = alpha;
 		out.uses_single_segment = segment_index0 == segment_index1;
-	}
-
-	__device__ __forceinline__ void seek(const device_clip& clip, float sample_time, uint32_t rounding_policy, uint32_t looping_policy, seek_state& out)
-	{
-		seek_keys keys;
-		seek_begin<false>(clip, sample_time, rounding_policy, looping_policy, keys);
-		seek_finish(clip, keys, out);
 	}
 
 	// 4 / 8 bytes at any alignment (gfx950 global loads need no alignment)

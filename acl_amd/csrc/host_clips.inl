@@ -338,69 +338,6 @@ namespace
 	}
 }
 
-// The reference's compressor cuts a clip into segments of 16 samples, then either spreads the samples of a short last segment over the
-// first segments or keeps it (compression/impl/segment_streams.h, split_samples_per_segment): the first R segments hold A samples, the
-// others B, the last at most B. Then the segment of sample n is n / A below R A and R + (n - R A) / B from there on, and the kernels
-// need no table to find the plan row of a key (one dependent load less per wave). Any other cut -- nothing in the format forbids one --
-// keeps taking the segment from the sample records. The divisions are multiplications by ceil(2^32 / d): exact for n < 2^27, 2 <= d <= 32.
-struct segment_map_facts
-{
-	bool regular;
-	uint32_t leading, leading_size, trailing_size;		// R, A, B
-	uint32_t magic[2];
-};
-
-static segment_map_facts analyze_segment_starts(const uint32_t* segment_start_indices, uint32_t num_segments, uint32_t num_samples)
-{
-	segment_map_facts facts = { false, 0, 0, 0, { 0, 0 } };
-	static const int off = []() { const char* value = path_knob("ACLHIP_REGULAR_SEGMENTS"); return value != nullptr && value[0] == '0' ? 1 : 0; }();
-	if (off != 0 || num_samples >= (1u << 27) || num_segments >= (1u << 20))
-		return facts;
-	if (num_segments <= 1 || segment_start_indices == nullptr)
-	{
-		// one segment (or none): every key is in segment 0 = mulhi(n, 0)
-		facts.regular = true;
-		return facts;
-	}
-	const auto size_of = [&](uint32_t segment) { return (segment + 1 < num_segments ? segment_start_indices[segment + 1] : num_samples) - segment_start_indices[segment]; };
-	// (the last segment is free to be shorter than its rule says: it is left out of the scan)
-	const uint32_t leading_size = size_of(0);
-	uint32_t leading = 0;
-	while (leading + 1 < num_segments && size_of(leading) == leading_size)
-		leading++;
-	uint32_t trailing_size;
-	if (leading + 1 == num_segments)
-		trailing_size = std::max(size_of(leading), leading_size);		// every segment but the last holds A: the last one may hold anything
-	else
-	{
-		trailing_size = size_of(leading);
-		for (uint32_t segment = leading; segment < num_segments; ++segment)
-			if (segment + 1 < num_segments ? size_of(segment) != trailing_size : size_of(segment) > trailing_size)
-				return facts;
-	}
-	if (leading_size < 2 || leading_size > 32 || trailing_size < 2 || trailing_size > 32)
-		return facts;
-	facts.regular = true;
-	facts.leading = leading;
-	facts.leading_size = leading_size;
-	facts.trailing_size = trailing_size;
-	facts.magic[0] = uint32_t(((uint64_t(1) << 32) + leading_size - 1) / leading_size);
-	facts.magic[1] = uint32_t(((uint64_t(1) << 32) + trailing_size - 1) / trailing_size);
-	// (belt and braces: the arithmetic against the clip's own table, every sample)
-	for (uint32_t segment = 0; segment < num_segments; ++segment)
-		for (uint32_t sample = segment_start_indices[segment]; sample < segment_start_indices[segment] + size_of(segment); ++sample)
-		{
-			const uint32_t split = leading * leading_size, shift = split - leading * trailing_size;
-			const uint32_t computed = sample < split ? uint32_t((uint64_t(sample) * facts.magic[0]) >> 32) : uint32_t((uint64_t(sample - shift) * facts.magic[1]) >> 32);
-			if (computed != segment)
-			{
-				facts.regular = false;
-				return facts;
-			}
-		}
-	return facts;
-}
-
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
 	bool validate_only = false, uint32_t* out_facts = nullptr)
 {
@@ -659,9 +596,6 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 	}
 
-	// ---- do the segments follow from arithmetic? (segment_of_key_frame, aclhip_device.h) ----
-	const segment_map_facts segment_map = analyze_segment_starts(num_tracks != 0 && num_segments > 1 ? reinterpret_cast<const uint32_t*>(tbase + k_segment_start_indices_offset) : nullptr, num_segments, num_samples);
-
 	// ---- animated sub-tracks in POSE order ----
 	// The tables above follow the bitstream (rotations, translations, scales); lanes do not care which sub-track they get, so the
 	// tables are reordered by destination window (and by kind inside a window). The sub-tracks that land in quads [c * k_image_chunk_quads, (c + 1) * ..) are then
@@ -815,11 +749,10 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(packed + 4, record + 4, 12);
 		std::memcpy(packed + 7, record + 8, 12);
 	}
+	const uint64_t samples_offset = (resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31);
 	// clips bound to a database carry a copy of their segments' tier metadata per sample (database_sample_record; zero = not resident
-	// until refresh_database_sample_tiers_kernel has run for the clip, below), and in front of the records which database that is
-	// (database_binding)
+	// until refresh_database_sample_tiers_kernel has run for the clip, below)
 	const bool database_samples = database != ACLHIP_INVALID_HANDLE && num_tracks != 0 && header.has_database();
-	const uint64_t samples_offset = ((resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31)) + (database_samples ? sizeof(database_binding) : 0);
 	const size_t sample_record_size = database_samples ? sizeof(database_sample_record) : sizeof(sample_record);
 	const uint64_t plan_offset = (samples_offset + samples.size() * sample_record_size + 31) & ~uint64_t(31);		// 32 byte entries from here on
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
@@ -854,7 +787,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	// aclhip_analyze_clip: what registration derives about the clip's VALUES (the kernels' variants follow from these)
 	if (out_facts != nullptr)
 		*out_facts = (rotation_facts.short_exact_math ? ACLHIP_CLIP_FACT_SHORT_EXACT_MATH : 0u) | (raw_rotations ? ACLHIP_CLIP_FACT_RAW_ROTATIONS : 0u)		// (the analysis, not what a knob made of it)
-			| (negative_scale_possible ? ACLHIP_CLIP_FACT_NEGATIVE_SCALE : 0u) | (segment_map.regular && num_tracks != 0 ? ACLHIP_CLIP_FACT_REGULAR_SEGMENTS : 0u);
+			| (negative_scale_possible ? ACLHIP_CLIP_FACT_NEGATIVE_SCALE : 0u);
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_clip: everything above is host work
 
@@ -892,7 +825,6 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 	device_clip record;
 	std::memset(&record, 0, sizeof(record));
-	uint32_t db_clip_header_offset = 0;		// clips with a database: where the clip's runtime headers start in the database's
 	record.blob = d_memory;
 	record.base_pose = reinterpret_cast<const float4*>(d_memory + base_pose_offset);
 	record.resolved_pose = reinterpret_cast<const float4*>(d_memory + resolved_pose_offset);
@@ -920,14 +852,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.num_segments = num_segments;
 		record.num_animated = num_animated;
 		if (header.has_database())
-			db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(tbase + th.database_header_offset)->clip_header_offset;
-		if (segment_map.regular)
-		{
-			record.flags |= k_clip_regular_segments;
-			record.segment_map = segment_map.leading | (segment_map.leading_size << 20) | (segment_map.trailing_size << 26);
-			record.segment_magic[0] = segment_map.magic[0];
-			record.segment_magic[1] = segment_map.magic[1];
-		}
+			record.db_clip_header_offset = reinterpret_cast<const tracks_database_header*>(tbase + th.database_header_offset)->clip_header_offset;
 	}
 
 	if (database != ACLHIP_INVALID_HANDLE)
@@ -946,8 +871,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		{
 			contained = false;
 			for (const database_clip_metadata& metadata : db.clip_metadata)
-				contained = contained || (metadata.clip_hash == buffer_header.hash && metadata.clip_header_offset == db_clip_header_offset);
-			contained = contained && uint64_t(db_clip_header_offset) + sizeof(database_runtime_clip_header) + uint64_t(num_segments) * sizeof(database_runtime_segment_header) <= db.runtime_headers_size;
+				contained = contained || (metadata.clip_hash == buffer_header.hash && metadata.clip_header_offset == record.db_clip_header_offset);
+			contained = contained && uint64_t(record.db_clip_header_offset) + sizeof(database_runtime_clip_header) + uint64_t(record.num_segments) * sizeof(database_runtime_segment_header) <= db.runtime_headers_size;
 		}
 		if (!contained)
 		{
@@ -959,7 +884,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		// offset, the size of a keyframe is the clip's (animated_pose_bit_size of the segment)
 		for (uint32_t si = 0; contained && si < num_segments; ++si)
 		{
-			const uint32_t segment_header_offset = db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header));
+			const uint32_t segment_header_offset = record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header));
 			const uint64_t pose_bit_size = segment_pose_bit_sizes[si];
 			for (int tier = 0; tier < 2; ++tier)
 			{
@@ -979,12 +904,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		}
 		if (db.streamed)
 			for (uint32_t si = 0; si < num_segments; ++si)
-				db.segment_pose_bits.emplace_back(db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header)), segment_pose_bit_sizes[si]);
-		database_binding binding;
-		std::memset(&binding, 0, sizeof(binding));
-		binding.db_headers = db.d_runtime_headers;
-		binding.db_clip_header_offset = db_clip_header_offset;
-		std::memcpy(staging.data() + samples_offset - sizeof(database_binding), &binding, sizeof(binding));
+				db.segment_pose_bits.emplace_back(record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header)) + si * uint32_t(sizeof(database_runtime_segment_header)), segment_pose_bit_sizes[si]);
+		record.db_headers = db.d_runtime_headers;
 		record.db_bulk_data[0] = db.d_bulk_data[0];
 		record.db_bulk_data[1] = db.d_bulk_data[1];
 		record.flags |= k_clip_database_samples;
@@ -1036,7 +957,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	entry.database = database;
 	if (database != ACLHIP_INVALID_HANDLE && context->databases[database].streamed)
 	{
-		entry.db_first_segment_header = db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header));
+		entry.db_first_segment_header = record.db_clip_header_offset + uint32_t(sizeof(database_runtime_clip_header));
 		entry.db_num_segments = num_segments;
 	}
 	entry.device_memory = d_memory;

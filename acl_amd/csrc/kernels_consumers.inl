@@ -314,18 +314,10 @@
 				|| (kBase == k_consumer_base_buffer && uint64_t(clip.num_tracks) * 48u > consumers.base_pose_stride_bytes)
 				|| (!kMirrored && multiplies_transforms && !base_is_clip && (clip.flags & k_clip_negative_scale) != 0);
 
-#if defined(ACLHIP_EXP_CONSUMER_VECTOR_POLICY_LOADS)
 			const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(launch_params, instance));
-#else
-			const uint32_t rounding_policy = uniform_instance_rounding_policy_of(launch_params, instance, clips);
-#endif
 			// the instance's own looping policy (decompress.h:149) goes for every clip decoded on its behalf -- its base, its blend partners
 			decode_params params = launch_params;
-#if defined(ACLHIP_EXP_CONSUMER_VECTOR_POLICY_LOADS)
 			params.looping_policy = uint8_t(__builtin_amdgcn_readfirstlane(instance_looping_policy_of(launch_params, instance)));
-#else
-			params.looping_policy = uint8_t(uniform_instance_looping_policy_of(launch_params, instance, clips));
-#endif
 
 			short_exact &= walk_may_use_short_exact_math(clip.flags, params.normalization);
 			device_clip base_clip = clip;

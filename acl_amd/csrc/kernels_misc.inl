@@ -49,14 +49,10 @@
 		if (clip_id >= num_clips)
 			return;
 		const device_clip clip = clips[clip_id];
-		if ((clip.flags & (k_clip_valid | k_clip_database_samples)) != (k_clip_valid | k_clip_database_samples))
+		if ((clip.flags & (k_clip_valid | k_clip_database_samples)) != (k_clip_valid | k_clip_database_samples) || clip.db_headers != runtime_headers)
 			return;
 		database_sample_record* samples = reinterpret_cast<database_sample_record*>(const_cast<sample_record*>(clip.samples));
-		// (which database the clip is bound to is written in front of its sample records: database_binding, aclhip_device.h)
-		const database_binding binding = *(reinterpret_cast<const database_binding*>(samples) - 1);
-		if (binding.db_headers != runtime_headers)
-			return;
-		const uint8_t* segment_headers = runtime_headers + binding.db_clip_header_offset + sizeof(database_runtime_clip_header);
+		const uint8_t* segment_headers = runtime_headers + clip.db_clip_header_offset + sizeof(database_runtime_clip_header);
 		for (uint32_t sample = threadIdx.x; sample < clip.num_samples; sample += blockDim.x)
 		{
 			const uint32_t segment = samples[sample].record.segment_and_local >> 5;

@@ -160,10 +160,12 @@
 	};
 
 	// What an instance brings to the launch: its clip handle and its sample time (wave uniform, scalar unit). A batch's input lists
-	// are read once, by one wave each: these two loads usually miss every cache, and they are the only ones of a wave's prologue that do.
-	// Both are therefore requested TOGETHER, with the kernel arguments beyond the 16 preloaded SGPRs next to them -- left alone the
-	// compiler requests the sample time where the seek first uses it, behind the clip record: two misses in a row in every wave's life.
-	// (Round 5 found this in the ISA, not in a counter: the phase stamps said "seek 2.35 us", three scalar round trips were expected.)
+	// are read once, by one wave each: these two loads are the ones of a wave's prologue that miss the caches. Both are requested
+	// TOGETHER -- left alone the compiler requests the sample time where the seek first uses it, behind the clip record: two misses in a
+	// row in every wave's life (found in the ISA in round 5; the phase stamps, profiles/r05_experiments.md 8, put the prologue's steps at
+	// 0.3 us for the inputs, 0.25 us for the clip record and 1.7 us from there to the end of the seek -- most of that last figure was the
+	// wait for the base pose DMA that uniform_instance_byte, aclhip_device.h, removes). Together with that and the clip range requested
+	// in front of the plan entries: -1.3 .. -2.8 % on every kernel of one-window poses (exp_r5t.sh), nothing on the others.
 	//   Instance lists decode in slot order: the caller's index of a slot's instance is in their order (decode_params::time_indices),
 	//   the sample time that was requested for the slot's own index is thrown away (the index is in bounds: the order is a permutation);
 	//   an attached list's clip handles are in the caller's order as well (one more dependent load, for these launches only).
@@ -193,32 +195,10 @@
 		out.sample_time = sample_time;
 	}
 
-	// The table entries of a window's first pass, requested as soon as the keys' SEGMENTS are known (seek_begin, aclhip_device.h) --
-	// with a clip whose segments follow from arithmetic that is before the sample records have arrived: the two requests share one round trip.
-	struct window_entries
-	{
-		plan_entry entry0, entry1;
-		clip_range_entry clip_range;
-	};
-
-	__device__ __forceinline__ void request_window_entries(const window_tables& tables, uint32_t segment_index0, uint32_t segment_index1,
-		uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, window_entries& out)
-	{
-		if (first_ordinal >= end_ordinal)
-			return;
-		const plan_entry* plan_row0 = tables.plan + size_t(segment_index0) * tables.num_animated;
-		const plan_entry* plan_row1 = tables.plan + size_t(segment_index1) * tables.num_animated;
-		const uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
-		// (the clip range first: the keys' addresses wait for the plan entries, and what is requested behind that wait arrives a round trip later)
-		out.clip_range = load_entry(tables.clip_ranges, ordinal);
-		out.entry0 = load_entry(plan_row0, ordinal);
-		out.entry1 = segment_index0 == segment_index1 ? out.entry0 : load_entry(plan_row1, ordinal);
-	}
-
 	template<bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false, class image_writer_type>
 	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image,
-		bool have_requested = false, window_entries requested = window_entries(), const uint8_t* track_rounding_policies = nullptr)
+		const uint8_t* track_rounding_policies = nullptr)
 	{
 		// track_rounding_policies (kPolicies): the writer's per track policies -- the launch's, or the instance's own table (wave uniform)
 		(void)params;
@@ -232,20 +212,10 @@
 		const plan_entry* plan_row1 = tables.plan + size_t(state.segment_index[1]) * tables.num_animated;
 
 		uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
-		plan_entry entry0, entry1;
-		clip_range_entry clip_range;
-		if (have_requested)
-		{
-			entry0 = requested.entry0;
-			entry1 = requested.entry1;
-			clip_range = requested.clip_range;
-		}
-		else
-		{
-			entry0 = load_entry(plan_row0, ordinal);
-			entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
-			clip_range = load_entry(tables.clip_ranges, ordinal);
-		}
+		// (the clip range first: the keys' addresses wait for the plan entries, and what is requested behind that wait arrives a round trip later)
+		clip_range_entry clip_range = load_entry(tables.clip_ranges, ordinal);
+		plan_entry entry0 = load_entry(plan_row0, ordinal);
+		plan_entry entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
 
 		for (uint32_t base = first_ordinal; base < end_ordinal; base += k_wave_size)
 		{
@@ -291,13 +261,13 @@
 	template<bool kAnySettings, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t window_quads, uint32_t lane, f32x4* image,
-		bool have_requested = false, window_entries requested = window_entries(), const uint8_t* track_rounding_policies = nullptr)
+		const uint8_t* track_rounding_policies = nullptr)
 	{
 		const qvv48_image_writer writer = { image, first_quad, window_quads };
 		if (kAnySettings && params.per_track_rounding != 0)
-			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, have_requested, requested, track_rounding_policies);
+			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, track_rounding_policies);
 		else
-			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, have_requested, requested);
+			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -314,11 +284,7 @@
 	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
 	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
 	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
-	// kRequestEarly: the lanes' table entries are requested between the two halves of the seek (seek_begin, aclhip_device.h) -- what the
-	// kernels of one-window poses, bound by the lives of their waves, gain from; the kernels bound by instruction issue (the items in
-	// turn of poses of several windows: +2 % with it, measured) and the any-settings kernels (24 more live registers across the seek
-	// spill there at 8 waves per SIMD) keep their requests behind the seek.
-	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false, bool kRequestEarly = false>
+	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
@@ -346,8 +312,16 @@
 		const float sample_time = inputs.sample_time;
 		ACLHIP_PROLOGUE_STAMP(1);		// (-DACLHIP_EXP_PHASE_TIMES=2: the prologue's steps instead of the wave's phases)
 		// (the instance's own policies, if the launch has any, are requested with the clip record: uniform_instance_byte, aclhip_device.h)
-		const uint32_t rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);
-		const uint32_t looping_policy = uniform_instance_looping_policy_of(params, caller_instance, clips);
+		// (the generic compact kernels hold more of the launch in scalar registers: there the two are requested in front of the seek,
+		// still on the scalar unit -- requested here they cost those kernels 30 spilled SGPRs)
+		// (so do the items in turn of poses of several windows, bound by instruction issue: +0.6 % with the early requests, measured)
+		uint32_t rounding_policy = 0, looping_policy = 0;
+		const bool policies_with_the_clip_record = !kCompactOutput && image_clip == nullptr;		// (known when the kernel is compiled)
+		if (policies_with_the_clip_record)
+		{
+			rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);
+			looping_policy = uniform_instance_looping_policy_of(params, caller_instance, clips);
+		}
 		const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
 #if defined(ACLHIP_EXP_PHASE_TIMES) && ACLHIP_EXP_PHASE_TIMES == 2
 		asm volatile("" :: "s"(clip.flags));
@@ -405,18 +379,14 @@
 		}
 
 		const uint32_t normalization = params.normalization;
+		if (!policies_with_the_clip_record)
+		{
+			rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);
+			looping_policy = uniform_instance_looping_policy_of(params, caller_instance, clips);
+		}
 
-		// the seek in two halves, the lanes' table entries requested in between (seek_begin, aclhip_device.h)
-		constexpr bool k_request_early = kRequestEarly;
-		static_assert(!(kRequestEarly && kAnySettings), "see above");
-		seek_keys keys;
-		seek_begin<k_request_early>(clip, sample_time, rounding_policy, looping_policy, keys);
-		window_entries requested;
-		if (k_request_early)
-			request_window_entries(window_tables_of(clip), keys.segment_index[0], keys.segment_index[1], first_ordinal, end_ordinal, lane, requested);
-		__builtin_amdgcn_sched_barrier(0);
 		seek_state state;
-		seek_finish(clip, keys, state);
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
 #if defined(ACLHIP_EXP_PHASE_TIMES)
 		asm volatile("" :: "s"(state.key_frame_bit_offsets[0]), "s"(state.key_frame_bit_offsets[1]));		// the seek's loads have arrived
 		ACLHIP_WAVE0_STAMP(1);
@@ -451,7 +421,7 @@
 		const uint8_t* track_rounding_policies = kAnySettings ? params.track_rounding_policies : nullptr;
 		if (kAnySettings && params.instance_rounding_tables != nullptr)
 			track_rounding_policies = params.track_rounding_table + size_t(as_constant(params.instance_rounding_tables)[caller_instance]) * params.track_rounding_stride;
-		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, k_request_early, requested, track_rounding_policies);
+		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, track_rounding_policies);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -737,13 +707,8 @@
 		}
 
 
-		seek_keys keys;
-		seek_begin<true>(clip, sample_time, rounding_policy, looping_policy, keys);
-		window_entries requested;
-		request_window_entries(window_tables_of(clip), keys.segment_index[0], keys.segment_index[1], first_ordinal, end_ordinal, lane, requested);
-		__builtin_amdgcn_sched_barrier(0);
 		seek_state state;
-		seek_finish(clip, keys, state);
+		seek(clip, sample_time, rounding_policy, looping_policy, state);
 #if defined(ACLHIP_EXP_PHASE_TIMES)
 		asm volatile("" :: "s"(state.key_frame_bit_offsets[0]), "s"(state.key_frame_bit_offsets[1]));		// the seek's loads have arrived
 		ACLHIP_WAVE0_STAMP(1);
@@ -752,7 +717,7 @@
 		// the base pose must be in the image before decoded sub-tracks take their places in it (the QVV40 pieces of a decoded sub-track
 		// and of its constant neighbours share 16 byte units: DMA first, then the decode's own writes)
 		const compact_image_writer<kLayout> writer = { reinterpret_cast<float*>(image), first_track, window_tracks };
-		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer, true, requested);
+		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer);
 
 		__builtin_amdgcn_s_waitcnt(0);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -797,14 +762,14 @@
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false, false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+		decompress_tracks_window<false, false>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	// the same for poses of several windows (the 300-bone rig): one dword aligned 16 byte read of the bitstream per key
 	// (unpack_animated_samples_wide, aclhip_device.h)
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_wide_loads_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false, false, true, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+		decompress_tracks_window<false, false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	// Poses of several windows, since round 4: every wave takes params.items_per_wave work items IN TURN and keeps its LDS image from
@@ -854,7 +819,7 @@
 	// the common case with an aclhip_output_desc: compact layouts, skipped sub-track kinds
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_compact_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
-		decompress_tracks_window<false, true, false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+		decompress_tracks_window<false, true>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_qv32_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)

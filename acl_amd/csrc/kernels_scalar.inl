@@ -264,8 +264,8 @@
 		if (first_track >= clip.num_tracks || clip.num_samples == 0)
 			return;		// past the end of this clip's track list / empty track list (:185-186,246-248)
 
-		const uint32_t rounding_policy = uniform_instance_rounding_policy_of(params, instance, clips);
-		const uint32_t looping_policy = uniform_instance_looping_policy_of(params, instance, clips);
+		const uint32_t rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, instance));
+		const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, instance));
 
 		// seek_v0 (:182-240): a frame is num_bits_per_frame bits
 		uint32_t key_frame0, key_frame1;
@@ -451,8 +451,8 @@
 		#pragma unroll
 		for (uint32_t k = 0; k < k_scalar_group; ++k)
 		{
-			rounding_policies[k] = uniform_instance_rounding_policy_of(params, first_instance + min(k, count - 1), clips);
-			const uint32_t looping_policy = uniform_instance_looping_policy_of(params, first_instance + min(k, count - 1), clips);
+			rounding_policies[k] = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, first_instance + min(k, count - 1)));
+			const uint32_t looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, first_instance + min(k, count - 1)));
 			uint32_t key_frame0, key_frame1;
 			find_key_frames(clip.flags, clip.num_samples, clip.sample_rate, clip.duration_clamp, clip.duration_wrap, times[k], rounding_policies[k], looping_policy,
 				key_frame0, key_frame1, alphas[k]);

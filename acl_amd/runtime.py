@@ -243,7 +243,7 @@ def check_clip(blob, check_hash=True):
     return status, message.value.decode()
 
 
-CLIP_FACT_SHORT_EXACT_MATH, CLIP_FACT_RAW_ROTATIONS, CLIP_FACT_NEGATIVE_SCALE, CLIP_FACT_REGULAR_SEGMENTS = 1, 2, 4, 8
+CLIP_FACT_SHORT_EXACT_MATH, CLIP_FACT_RAW_ROTATIONS, CLIP_FACT_NEGATIVE_SCALE = 1, 2, 4
 
 
 def analyze_clip(blob, check_hash=True):

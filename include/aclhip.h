@@ -237,17 +237,11 @@ aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, in
  *                                      (same bits, fewer instructions: DESIGN.md 4.1);
  *   ACLHIP_CLIP_FACT_RAW_ROTATIONS     some rotation sub-track is stored raw (fp32) in some segment;
  *   ACLHIP_CLIP_FACT_NEGATIVE_SCALE    some scale may decode to a negative component: the pose consumers compile rtm::qvv_mul's
- *                                      matrix route in while such a clip is registered;
- *   ACLHIP_CLIP_FACT_REGULAR_SEGMENTS  the clip is cut the way the reference's compressor cuts (the first R segments hold A samples,
- *                                      the others B, the last at most B: compression/impl/segment_streams.h): the kernels find a
- *                                      key's segment by arithmetic and request its table rows together with its sample record
- *                                      instead of behind it (one dependent memory round trip less per wave: DESIGN.md 4.1). Any
- *                                      other cut decodes just the same, through the table.
+ *                                      matrix route in while such a clip is registered.
  * Scalar track lists: 0. No reference counterpart (the reference has one code path). */
 #define ACLHIP_CLIP_FACT_SHORT_EXACT_MATH 1u
 #define ACLHIP_CLIP_FACT_RAW_ROTATIONS 2u
 #define ACLHIP_CLIP_FACT_NEGATIVE_SCALE 4u
-#define ACLHIP_CLIP_FACT_REGULAR_SEGMENTS 8u
 aclhip_status aclhip_analyze_clip(const void* compressed_tracks, uint64_t size, int check_hash, uint32_t* out_facts);
 
 /* Replaces decompression_context::is_bound_to(const compressed_tracks&) (decompress.h:138): true when `clip`

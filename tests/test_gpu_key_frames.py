@@ -1,11 +1,8 @@
-"""A key's segment by arithmetic (k_clip_regular_segments; aclhip_device.h: segment_of_key_frame, seek_begin) against the oracle at every
-key frame and on both sides of it, for clips of many lengths (both of the compressor's cuts), through every pose kernel that requests
-its table rows early; clips cut otherwise (they keep taking the segment from their sample records), and the whole thing once more with
-the arithmetic switched off (ACLHIP_REGULAR_SEGMENTS=0: every clip through the sample records). Needs a GPU."""
-import os
-import subprocess
-import sys
-
+"""The seek at every key frame of a clip and on both sides of it (k / rate, its float neighbours, the middle of every interval, both ends
+from outside) against the oracle, for clips of many lengths -- both of the compressor's cuts (compression/impl/segment_streams.h: the
+samples of a short last segment spread over the first ones, or kept), other segment sizes of the same splitter, and cuts the
+compressor never makes (a segment start moved by hand: the sample records follow the clip's own segment_start_indices) -- through the
+pose kernels of every layout, the kernel of poses of several windows, every rounding policy and single bone requests. Needs a GPU."""
 import numpy as np
 import pytest
 import torch
@@ -13,10 +10,29 @@ import torch
 from acl_amd import runtime, synth
 from oracle import bindings as ob
 import helpers
-from test_segment_map import with_moved_start
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+TRANSFORM_HEADER_OFFSET = 32            # acl_format.h: k_transform_header_offset
+SEGMENT_START_INDICES_OFFSET = 52       # acl_format.h: k_segment_start_indices_offset (relative to the transform header)
+
+
+def segment_starts(blob):
+    """the clip's own segment_start_indices (multi segment clips), as a writable view"""
+    num_segments = int(np.frombuffer(blob, dtype=np.uint32, count=1, offset=TRANSFORM_HEADER_OFFSET)[0])
+    assert num_segments > 1
+    return blob[TRANSFORM_HEADER_OFFSET + SEGMENT_START_INDICES_OFFSET:][: 4 * num_segments].view(np.uint32)
+
+
+def with_moved_start(clip, segment, delta):
+    """the same blob with one segment start moved: a cut the compressor never makes (the bytes stay a valid clip: the keyframes the
+    moved segment now claims lie inside the buffer; what they decode to is whatever bytes are there -- the same for every decoder)"""
+    blob = clip.blob.copy()
+    aligned = synth.aligned_bytes(blob.size)
+    aligned[:] = blob
+    starts = segment_starts(aligned)
+    starts[segment] = int(starts[segment]) + delta
+    return aligned
 
 
 def times_around_every_key_frame(clip, wrap_extra=0):
@@ -69,7 +85,6 @@ def check_clip_everywhere(context, clip, blob=None, check_hash=True, layouts=("q
 def test_every_key_frame_of_clips_of_many_lengths(num_samples):
     with runtime.Context(0) as context:
         clip = synth.build_clip(seed=40 + num_samples, num_tracks=37, num_samples=num_samples, has_scale=num_samples % 2, wrap=int(num_samples % 3 == 0), strip_keyframes=int(num_samples % 5 == 0))
-        assert runtime.analyze_clip(clip.blob) & runtime.CLIP_FACT_REGULAR_SEGMENTS
         check_clip_everywhere(context, clip)
         assert context.rejected_instance_count() == 0
 
@@ -82,18 +97,17 @@ def test_other_segment_sizes(ideal, maximum, num_samples):
 
 
 def test_poses_of_several_windows():
-    """the 300-bone rig's kernel (items in turn, 16 byte key reads) requests its rows early too"""
+    """the 300-bone rig's kernel (items in turn, 16 byte key reads)"""
     with runtime.Context(0) as context:
         clip = synth.build_clip(seed=77, num_tracks=300, num_samples=100, has_scale=1, scale_default=0.4)
         check_clip_everywhere(context, clip)
 
 
-def test_clips_cut_otherwise_take_the_table():
+def test_cuts_the_compressor_never_makes():
     with runtime.Context(0) as context:
         clip = synth.build_clip(seed=5, num_tracks=24, num_samples=100)          # 17 17 17 17 16 16
         for segment, delta in ((1, -1), (2, 1), (4, -1)):
             moved = with_moved_start(clip, segment, delta)
-            assert not runtime.analyze_clip(moved, check_hash=False) & runtime.CLIP_FACT_REGULAR_SEGMENTS
             check_clip_everywhere(context, clip, blob=moved, check_hash=False)
         # both kinds in one batch
         regular = context.register_clip(clip.blob)
@@ -106,27 +120,3 @@ def test_clips_cut_otherwise_take_the_table():
         expected = ob.oracle_decompress_tracks_batch([clip.blob, moved], which.astype(np.uint32), times, clip.num_tracks)
         assert helpers.exact(got, expected)
         assert context.rejected_instance_count() == 0
-
-
-_SCRIPT = r"""
-import sys
-sys.path.insert(0, "tests")
-import torch
-torch.cuda.init()
-from acl_amd import runtime, synth
-import test_gpu_segment_map as t
-with runtime.Context(0) as context:
-    for num_samples in (33, 100, 301):
-        clip = synth.build_clip(seed=40 + num_samples, num_tracks=37, num_samples=num_samples, has_scale=1, strip_keyframes=int(num_samples == 100))
-        t.check_clip_everywhere(context, clip)
-    t.check_clip_everywhere(context, synth.build_clip(seed=77, num_tracks=300, num_samples=100, has_scale=1, scale_default=0.4))
-print("SEGMENTS_OK")
-"""
-
-
-def test_the_same_through_the_sample_records():
-    """ACLHIP_REGULAR_SEGMENTS=0: no clip gets the flag, every wave takes its keys' segments from the sample records (the path
-    clips cut otherwise take) -- the same bits"""
-    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), ACLHIP_REGULAR_SEGMENTS="0")
-    completed = subprocess.run([sys.executable, "-c", _SCRIPT], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert completed.returncode == 0 and "SEGMENTS_OK" in completed.stdout, completed.stderr[-3000:]
