@@ -176,20 +176,33 @@
 		float sample_time;
 	};
 
+	// time_with_the_handle = false (known when the kernel is compiled): the sample time where the compiler puts it -- the kernel of poses
+	// of several windows, bound by instruction issue, not by the lives of its waves, loses 1.2 % to the three changes together (exp_r5u.sh)
 	__device__ __forceinline__ void load_instance_inputs(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const decode_params& params,
-		uint32_t instance, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, instance_inputs& out)
+		uint32_t instance, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, bool time_with_the_handle, instance_inputs& out)
 	{
 		uint32_t clip_id = as_constant(clip_ids)[instance];
-		float sample_time = as_constant(sample_times)[instance];
-		asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id), "s"(__float_as_uint(sample_time)));
+		float sample_time = 0.0f;
+		// (kernel arguments beyond the 16 preloaded SGPRs -- the stride and the LDS slot size the launch shape checks need -- are fetched
+		// next to the instance's clip handle, not behind the clip record where the compiler would put them: one round trip less)
+		if (time_with_the_handle)
+		{
+			sample_time = as_constant(sample_times)[instance];
+			asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id), "s"(__float_as_uint(sample_time)));
+		}
+		else
+			asm volatile("" :: "s"(pose_stride_bytes), "s"(lds_quads_per_wave), "s"(clip_id));
 		uint32_t caller_instance = instance;
 		if (params.time_indices != nullptr)
 		{
 			caller_instance = as_constant(params.time_indices)[instance];
 			if (params.clips_by_caller_instance != 0)
 				clip_id = as_constant(clip_ids)[caller_instance];
-			sample_time = as_constant(sample_times)[caller_instance];
+			if (time_with_the_handle)
+				sample_time = as_constant(sample_times)[caller_instance];
 		}
+		if (!time_with_the_handle)
+			sample_time = as_constant(sample_times)[caller_instance];
 		out.clip_id = clip_id;
 		out.caller_instance = caller_instance;
 		out.sample_time = sample_time;
@@ -198,9 +211,10 @@
 	template<bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false, class image_writer_type>
 	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image,
-		const uint8_t* track_rounding_policies = nullptr)
+		const uint8_t* track_rounding_policies = nullptr, bool clip_range_first = false)
 	{
 		// track_rounding_policies (kPolicies): the writer's per track policies -- the launch's, or the instance's own table (wave uniform)
+		// clip_range_first (known when the kernel is compiled): the first pass's clip range is requested in front of its plan entries
 		(void)params;
 		if (first_ordinal >= end_ordinal)
 			return;
@@ -212,10 +226,15 @@
 		const plan_entry* plan_row1 = tables.plan + size_t(state.segment_index[1]) * tables.num_animated;
 
 		uint32_t ordinal = min(first_ordinal + lane, end_ordinal - 1);
-		// (the clip range first: the keys' addresses wait for the plan entries, and what is requested behind that wait arrives a round trip later)
-		clip_range_entry clip_range = load_entry(tables.clip_ranges, ordinal);
+		// (the clip range first, in the kernels of one-window poses: the keys' addresses wait for the plan entries, and what is requested
+		// behind that wait arrives a round trip later)
+		clip_range_entry clip_range;
+		if (clip_range_first)
+			clip_range = load_entry(tables.clip_ranges, ordinal);
 		plan_entry entry0 = load_entry(plan_row0, ordinal);
 		plan_entry entry1 = single_segment ? entry0 : load_entry(plan_row1, ordinal);
+		if (!clip_range_first)
+			clip_range = load_entry(tables.clip_ranges, ordinal);
 
 		for (uint32_t base = first_ordinal; base < end_ordinal; base += k_wave_size)
 		{
@@ -261,13 +280,13 @@
 	template<bool kAnySettings, bool kWideKeyLoads = false>
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t window_quads, uint32_t lane, f32x4* image,
-		const uint8_t* track_rounding_policies = nullptr)
+		const uint8_t* track_rounding_policies = nullptr, bool clip_range_first = false)
 	{
 		const qvv48_image_writer writer = { image, first_quad, window_quads };
 		if (kAnySettings && params.per_track_rounding != 0)
-			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, track_rounding_policies);
+			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, track_rounding_policies, clip_range_first);
 		else
-			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer);
+			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, nullptr, clip_range_first);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -306,17 +325,18 @@
 			return;
 
 		// wave uniform prologue on the scalar unit: instance -> clip record -> sample records
+		// (items taken in turn -- the kernels of poses of several windows -- keep the prologue they had: see load_instance_inputs)
+		const bool one_shot = image_clip == nullptr;		// known when the kernel is compiled
 		instance_inputs inputs;
-		load_instance_inputs(clip_ids, sample_times, params, instance, pose_stride_bytes, lds_quads_per_wave, inputs);
+		load_instance_inputs(clip_ids, sample_times, params, instance, pose_stride_bytes, lds_quads_per_wave, one_shot, inputs);
 		const uint32_t clip_id = inputs.clip_id, caller_instance = inputs.caller_instance;
 		const float sample_time = inputs.sample_time;
 		ACLHIP_PROLOGUE_STAMP(1);		// (-DACLHIP_EXP_PHASE_TIMES=2: the prologue's steps instead of the wave's phases)
 		// (the instance's own policies, if the launch has any, are requested with the clip record: uniform_instance_byte, aclhip_device.h)
 		// (the generic compact kernels hold more of the launch in scalar registers: there the two are requested in front of the seek,
 		// still on the scalar unit -- requested here they cost those kernels 30 spilled SGPRs)
-		// (so do the items in turn of poses of several windows, bound by instruction issue: +0.6 % with the early requests, measured)
 		uint32_t rounding_policy = 0, looping_policy = 0;
-		const bool policies_with_the_clip_record = !kCompactOutput && image_clip == nullptr;		// (known when the kernel is compiled)
+		const bool policies_with_the_clip_record = !kCompactOutput && one_shot;
 		if (policies_with_the_clip_record)
 		{
 			rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);
@@ -379,10 +399,15 @@
 		}
 
 		const uint32_t normalization = params.normalization;
-		if (!policies_with_the_clip_record)
+		if (!policies_with_the_clip_record && one_shot)
 		{
 			rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);
 			looping_policy = uniform_instance_looping_policy_of(params, caller_instance, clips);
+		}
+		if (!one_shot)
+		{
+			rounding_policy = __builtin_amdgcn_readfirstlane(instance_rounding_policy_of(params, caller_instance));
+			looping_policy = __builtin_amdgcn_readfirstlane(instance_looping_policy_of(params, caller_instance));
 		}
 
 		seek_state state;
@@ -421,7 +446,7 @@
 		const uint8_t* track_rounding_policies = kAnySettings ? params.track_rounding_policies : nullptr;
 		if (kAnySettings && params.instance_rounding_tables != nullptr)
 			track_rounding_policies = params.track_rounding_table + size_t(as_constant(params.instance_rounding_tables)[caller_instance]) * params.track_rounding_stride;
-		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, track_rounding_policies);
+		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, track_rounding_policies, one_shot);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -661,7 +686,7 @@
 			return;
 
 		instance_inputs inputs;
-		load_instance_inputs(clip_ids, sample_times, params, instance, pose_stride_bytes, lds_quads_per_wave, inputs);
+		load_instance_inputs(clip_ids, sample_times, params, instance, pose_stride_bytes, lds_quads_per_wave, true, inputs);
 		const uint32_t clip_id = inputs.clip_id, caller_instance = inputs.caller_instance;
 		const float sample_time = inputs.sample_time;
 		const uint32_t rounding_policy = uniform_instance_rounding_policy_of(params, caller_instance, clips);		// (see decompress_tracks_window)
@@ -717,7 +742,7 @@
 		// the base pose must be in the image before decoded sub-tracks take their places in it (the QVV40 pieces of a decoded sub-track
 		// and of its constant neighbours share 16 byte units: DMA first, then the decode's own writes)
 		const compact_image_writer<kLayout> writer = { reinterpret_cast<float*>(image), first_track, window_tracks };
-		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer);
+		decode_window_sub_tracks_into<false>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, writer, nullptr, true);
 
 		__builtin_amdgcn_s_waitcnt(0);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
