@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: this set ran on commit 5d59a74 / its working tree -- the knobs and variant libraries it names are not part of the shipped tree; results: profiles/r05_experiments.md 8)
 # round 5, set P: a wave's sample time requested next to its clip handle (not behind the clip record), a key's segment by arithmetic
 # (table rows requested with the sample records, not behind them) -- against the library of the commit before (libaclhip_base.so,
 # built from `git archive 4649d62`) and against ACLHIP_REGULAR_SEGMENTS=0 (every clip through its sample records)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: this set ran on commit 5d59a74 / its working tree -- the knobs and variant libraries it names are not part of the shipped tree; results: profiles/r05_experiments.md 8)
 # round 5, set Q: phase stamps (tools/phase_times.py) of the pose kernel before / after the prologue change of set P.
 #   *_phase1: entry | seek done | window decoded | stores issued          (-DACLHIP_EXP_PHASE_TIMES=1)
 #   *_phase2: entry | inputs arrived | clip record arrived | seek done    (-DACLHIP_EXP_PHASE_TIMES=2; printed under phase1's names)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: this set ran on commit 5d59a74 / its working tree -- the knobs and variant libraries it names are not part of the shipped tree; results: profiles/r05_experiments.md 8)
 # round 5, set R: the pose kernels' prologue without its vector memory wait (per instance policies through the scalar unit:
 # uniform_instance_byte) + sets P's changes, against the library of the commit before (libaclhip_base.so); then the phase stamps
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

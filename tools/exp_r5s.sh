@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: this set ran on commit 5d59a74 / its working tree -- the knobs and variant libraries it names are not part of the shipped tree; results: profiles/r05_experiments.md 8)
 # round 5, set S: set R with the early requests / the arithmetic only in the one-shot pose kernels (template parameters), against base;
 # `records` = the same library with ACLHIP_REGULAR_SEGMENTS=0; `cvec` = the consumers with their per lane policy byte loads
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (history: this set ran on commit 5d59a74 / its working tree -- the knobs and variant libraries it names are not part of the shipped tree; results: profiles/r05_experiments.md 8)
 # round 5, set U: the pose consumers without the multi-window loop in the kernel (c1w: a launch of one-window poses never reaches it; its
 # presence makes the compiler wait for the base pose DMA before the table rows are requested), with the instance's sample time requested
 # next to its clip handle (ct), both (c1wt), against the shipped library; cinematic once more against base
