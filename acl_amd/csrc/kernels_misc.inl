@@ -264,6 +264,10 @@
 			if (instance >= num_instances)
 				continue;
 			const uint32_t destination = order_slot_of(layout, table.counts[slot[k]] + rank[k]);
+			// (a position past the list: this launch's counters were written by ANOTHER launch at the same time -- a captured ordering replayed
+			// on another stream than the one whose scratch it holds, next to an ordering of that stream. Nothing is written out of bounds.)
+			if (destination >= num_instances)
+				continue;
 			out_order[destination] = instance;
 			if (out_clip_ids != nullptr)
 				out_clip_ids[destination] = clip_id[k];
@@ -543,6 +547,15 @@
 		{
 			const uint32_t clip_id = clip_ids[instance];
 			const uint32_t destination = order_slot_of(layout, atomicAdd(&cursors[min(clip_id, num_bins - 1)], 1u));
+			// A position past the list: the matrix or the barrier words of this launch were written by ANOTHER launch at the same time --
+			// a captured ordering replayed on another stream than the one whose scratch it holds, next to an ordering of that stream
+			// (include/aclhip.h: aclhip_order_instances_device). Nothing is written out of bounds; the failure is raised like a barrier's.
+			if (destination >= num_instances)
+			{
+				__hip_atomic_store(&control->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(host_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				continue;
+			}
 			out_order[destination] = instance;
 			if (out_clip_ids != nullptr)
 				out_clip_ids[destination] = clip_id;

@@ -381,7 +381,11 @@ aclhip_status aclhip_pose_windows_of_launch(aclhip_context* context, uint32_t la
  * sample_times[out_order[k]] (the arguments of the decode that follows on the same stream; rows = out_order puts the poses back
  * in the caller's rows). Which instance of a clip takes which of the clip's slots is decided by atomics: every call returns a valid
  * order, not the same one. The first call on a stream allocates that stream's scratch: make it before capturing the stream into a
- * hipGraph. An instance list usually outlives a frame (which character plays which clip changes rarely, the
+ * hipGraph. A captured ordering HOLDS the scratch of the stream it was captured on: launch the graph on that stream (or at least never
+ * while that stream, or another replay, orders -- two orderings that share a scratch at the same time write each other's counters; such
+ * a launch places nothing out of bounds and raises the same failure as a barrier that does not open, but its order is not valid).
+ * (PyTorch's CUDAGraph.replay() launches on the CURRENT stream, not on the capture stream: wrap it in `with torch.cuda.stream(s)`.)
+ * An instance list usually outlives a frame (which character plays which clip changes rarely, the
  * sample times every frame): order once, keep the lists in that order. */
 aclhip_status aclhip_order_instances_device(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, uint32_t num_instances,
 	uint32_t* out_order, aclhip_clip* out_clips, float* out_sample_times, void* stream);

@@ -190,7 +190,12 @@ def test_the_one_launch_form_on_two_streams_and_replayed_from_a_graph():
             instance_clips = handles[rng.integers(0, handles.size, size=n)]
             buffers[0][0].copy_(torch.from_numpy(instance_clips.astype(np.int32)))
             torch.cuda.synchronize(device)
-            graph.replay()
+            # (a captured ordering holds the scratch of the stream it was captured on: the graph is launched on THAT stream --
+            # CUDAGraph.replay() launches on the current one. On the default stream the replay and the plain call below ran side by side
+            # on one scratch: fine on an idle device, where the 12 us replay is over before Python gets to the call; a memory fault as soon
+            # as other processes keep the device busy. tools/order_under_load.py)
+            with torch.cuda.stream(streams[0]):
+                graph.replay()
             if replay == 2:
                 call(0)         # a plain call between two replays moves the generation on: the replays do not care
             torch.cuda.synchronize(device)
