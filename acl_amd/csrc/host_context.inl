@@ -603,17 +603,19 @@ namespace
 		const uint64_t tbase = k_transform_header_offset;
 		const bool stripped = header.has_stripped_keyframes() || header.has_database();
 		const uint32_t segment_header_size = stripped ? sizeof(stripped_segment_header) : sizeof(segment_header);
-		const uint32_t num_entries = (header.num_tracks + 15) / 16;
-		const uint32_t num_rotations_padded = align_to_u32(th.num_animated_rotation_sub_tracks, 4);
+		// (64 bit: num_tracks is untrusted, and 0xFFFFFFFF + 15 wraps to 14 -- no sub-track type words at all, the bounds test below passed,
+		// and registration went on to size its tables for 4 G tracks: found with the validators under AddressSanitizer, round 5)
+		const uint64_t num_entries = (uint64_t(header.num_tracks) + 15) / 16;
+		const uint64_t num_rotations_padded = (uint64_t(th.num_animated_rotation_sub_tracks) + 3) & ~uint64_t(3);
 
 		if (th.num_segments == 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
 		if (uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
-		if (th.num_animated_variable_sub_tracks != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
+		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
 		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
-			|| tbase + th.sub_track_types_offset + uint64_t(num_entries) * 4 * (header.has_scale() ? 3 : 2) > blob_size
+			|| tbase + th.sub_track_types_offset + num_entries * 4 * (header.has_scale() ? 3 : 2) > blob_size
 			|| tbase + th.constant_track_data_offset + 12ull * (uint64_t(th.num_constant_rotation_samples) + th.num_constant_translation_samples + th.num_constant_scale_samples) > blob_size
 			|| tbase + th.clip_range_data_offset + 24ull * (uint64_t(th.num_animated_rotation_sub_tracks) + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks) > blob_size)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");

@@ -150,3 +150,26 @@ def test_random_database_corruptions_never_crash_the_host_side(seed):
                     runtime.check_database(database, check_hash=False)
                 else:
                     runtime.check_database(database, medium if medium.size else None, low if low.size else None, check_hash=False)
+
+
+def test_a_track_count_near_2_to_the_32_is_refused():
+    """0xFFFFFFFF tracks: (num_tracks + 15) / 16 sub-track type words wrapped to zero in 32 bit arithmetic, the bounds test passed and
+    registration went on to size its tables for four billion tracks (found with tools/fuzz_host_validators.py under AddressSanitizer)"""
+    clip = synth.build_clip(seed=3, num_tracks=20, num_samples=20)
+    for num_tracks in (0xFFFFFFFF, 0xFFFFFFF1, 0xFFFFFFF0, 0x80000000, 0x10000000):
+        blob = clip.blob.copy()
+        aligned = synth.aligned_bytes(blob.size)
+        aligned[:] = blob
+        aligned[16:20].view(np.uint32)[0] = num_tracks          # tracks_header::num_tracks (core/impl/compressed_headers.h)
+        status, message = runtime.check_clip(aligned, check_hash=False)
+        assert status != 0, (hex(num_tracks), message)
+
+
+def test_mutated_buffers_are_refused_or_accepted_never_worse():
+    """a slice of tools/fuzz_host_validators.py (fixed seed, 3 seconds): clips, inline databases, tier stripping, walk planning"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    result = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_host_validators.py"), "5", "3"], capture_output=True, text=True, timeout=300)
+    assert result.returncode == 0 and "host validator fuzz ok" in result.stdout, result.stdout[-2000:] + result.stderr[-2000:]
