@@ -559,6 +559,8 @@ namespace
 		}
 		if (bits_per_frame != sh.num_bits_per_frame || bits_per_frame > k_quad_ordinal_mask)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Track bit rates add up to %llu bits per frame, header says %u", static_cast<unsigned long long>(bits_per_frame), sh.num_bits_per_frame);
+		if (((sh.track_constant_values | sh.track_range_values) & 3u) != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets are not 4 byte aligned");
 		if (uint64_t(sh.track_constant_values) + num_constant * num_components * 4 > limit
 			|| uint64_t(sh.track_range_values) + num_ranged * num_components * 8 > limit
 			|| uint64_t(sh.track_animated_values) + (bits_per_frame * header.num_samples + 7) / 8 > limit
@@ -619,6 +621,10 @@ namespace
 			|| tbase + th.constant_track_data_offset + 12ull * (uint64_t(th.num_constant_rotation_samples) + th.num_constant_translation_samples + th.num_constant_scale_samples) > blob_size
 			|| tbase + th.clip_range_data_offset + 24ull * (uint64_t(th.num_animated_rotation_sub_tracks) + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks) > blob_size)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+		// (the reference's writer aligns every one of these sections to 4 bytes, and the host reads them as words and floats)
+		if (((th.segment_headers_offset | th.sub_track_types_offset | th.constant_track_data_offset | th.clip_range_data_offset) & 3u) != 0
+			|| (header.has_database() && (th.database_header_offset & 3u) != 0))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets are not 4 byte aligned");
 		if (th.num_segments > 1 && tbase + k_segment_start_indices_offset + 4ull * (th.num_segments + 1) > blob_size)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Segment start indices point outside of the buffer");
 		if (header.has_database() && tbase + th.database_header_offset + sizeof(tracks_database_header) > blob_size)

@@ -58,6 +58,8 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 	if (descriptions_offset + num_descriptions * sizeof(database_chunk_description) > header_limit
 		|| uint64_t(header.clip_metadata_offset) + uint64_t(header.num_clips) * sizeof(database_clip_metadata) > header_limit)
 		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
+	if ((header.clip_metadata_offset & 3u) != 0)
+		return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets are not 4 byte aligned");
 
 	const bool is_inline = (header.misc_packed & 1u) != 0;
 	const uint8_t* bulk_sources[2] = { static_cast<const uint8_t*>(bulk_data_medium), static_cast<const uint8_t*>(bulk_data_low) };
@@ -67,7 +69,8 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 			continue;
 		if (bulk_sources[tier] == nullptr)
 		{
-			if (!is_inline || header.bulk_data_offset[tier] == k_invalid_offset || uint64_t(header.bulk_data_offset[tier]) + header.bulk_data_size[tier] > header_limit)
+			if (!is_inline || header.bulk_data_offset[tier] == k_invalid_offset || uint64_t(header.bulk_data_offset[tier]) + header.bulk_data_size[tier] > header_limit
+				|| (header.bulk_data_offset[tier] & 3u) != 0)
 				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "tier %d has %u bytes of bulk data: pass it in, it is not inline", tier + 1, header.bulk_data_size[tier]);
 			bulk_sources[tier] = hbase + header.bulk_data_offset[tier];
 		}
@@ -91,7 +94,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 	db.runtime_headers_size = runtime_size;
 	for (const database_clip_metadata& metadata : db.clip_metadata)
 	{
-		if (uint64_t(metadata.clip_header_offset) + sizeof(database_runtime_clip_header) > runtime_size)
+		if (uint64_t(metadata.clip_header_offset) + sizeof(database_runtime_clip_header) > runtime_size || (metadata.clip_header_offset & 7u) != 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Clip metadata points outside of the runtime headers");
 		reinterpret_cast<database_runtime_clip_header*>(runtime.data() + metadata.clip_header_offset)->clip_hash = metadata.clip_hash;	// database.impl.h:151-157
 	}
@@ -112,7 +115,8 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 		for (uint32_t chunk_index = 0; chunk_index < num_chunks; ++chunk_index)
 		{
 			const database_chunk_description& description = tier_descriptions[chunk_index];
-			if (uint64_t(description.offset) + description.size > header.bulk_data_size[tier] || description.size < sizeof(database_chunk_header) || description.size > header.max_chunk_size)
+			if (uint64_t(description.offset) + description.size > header.bulk_data_size[tier] || description.size < sizeof(database_chunk_header) || description.size > header.max_chunk_size
+				|| (description.offset & 3u) != 0)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d lies outside of the bulk data", chunk_index, tier + 1);
 			if (streamed)
 				continue;		// its header arrives with the chunk (parse_arrived_chunks)
@@ -128,7 +132,9 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 			const database_chunk_segment_header* segments = reinterpret_cast<const database_chunk_segment_header*>(&chunk + 1);
 			for (uint32_t i = 0; i < chunk.num_segments; ++i)
 			{
-				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > runtime_size || segments[i].samples_offset >= header.bulk_data_size[tier])
+				// (8 byte aligned: the device stores the tier words of a segment header as 64 bit atomics)
+				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > runtime_size || segments[i].samples_offset >= header.bulk_data_size[tier]
+					|| (segments[i].segment_header_offset & 7u) != 0)
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d points outside of the database", chunk_index, tier + 1);
 				patches[tier].push_back(tier_patch{ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
 			}
@@ -399,7 +405,8 @@ namespace
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u lists more segments than the database has", chunk_index, tier_index + 1);
 			for (uint32_t i = 0; i < chunk.num_segments; ++i)
 			{
-				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > db.runtime_headers_size || segments[i].samples_offset >= bulk_size)
+				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > db.runtime_headers_size || segments[i].samples_offset >= bulk_size
+					|| (segments[i].segment_header_offset & 7u) != 0)
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u points outside of the database", chunk_index, tier_index + 1);
 				// keyframes of a clip that is already bound must lie inside the tier (clips bound later are checked when they are bound)
 				for (const std::pair<uint32_t, uint32_t>& bound : db.segment_pose_bits)
