@@ -95,6 +95,14 @@ def main():
                 out = synth.aligned_bytes(out_size.value + 16)
                 status = lib.aclhip_strip_database_tier(m.ctypes.data, size, tier, out.ctypes.data, out_size.value, ctypes.byref(out_size))
             counts["strip ok" if status == 0 else "strip refused"] += 1
+        elif which == 9 and rng.integers(0, 2) == 0:
+            # the host side decode order: any clip handles, any number of wavefronts per pose
+            n = int(rng.integers(0, 3000))
+            handles = rng.integers(0, int(rng.choice([1, 7, 300, 0xFFFFFFFF])) + 1, size=n, dtype=np.uint64).astype(np.uint32)
+            order = np.zeros(max(n, 1), dtype=np.uint32)
+            status = lib.aclhip_order_instances_for_pose_windows(int(rng.choice([0, 1, 2, 3, 8, 17, 0xFFFFFFFF])), handles.ctypes.data, n, order.ctypes.data)
+            assert status != 0 or np.array_equal(np.sort(order[:n]), np.arange(n)), "not a permutation"
+            counts["order ok" if status == 0 else "order refused"] = counts.get("order ok" if status == 0 else "order refused", 0) + 1
         else:
             n = int(rng.integers(1, 300))
             parents = np.array([0xFFFFFFFF if i == 0 else rng.integers(0, i) for i in range(n)], dtype=np.uint32)
