@@ -472,6 +472,10 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 
 		if (animated_counts[0] != num_animated_rotations || animated_counts[1] != num_animated_translations || animated_counts[2] != num_animated_scales)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sub-track types disagree with the animated sub-track counts");
+		// (equal, not "at most": the reference sizes its SOA groups of constant rotations and finds the translations and scales behind them
+		// from the header's counts, decompression.transform.h -- types that name fewer constants than the header decode differently there)
+		if (constant_counts[0] != constant_limits[0] || constant_counts[1] != constant_limits[1] || (has_scale && constant_counts[2] != constant_limits[2]))
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sub-track types disagree with the constant sample counts");
 
 		// clip ranges: rotations are SOA per group of 4 (last group unpadded), translations / scales AOS (write_range_data.h:79-207)
 		{
@@ -589,10 +593,48 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 				}
 
 				bit_offset += num_bits * 3;
+				// The reference finds a keyframe's translations behind animated_rotation_bit_size bits and its scales behind
+				// animated_translation_bit_size more (decompression.transform.h:533-536, animated_track_cache.transform.h): the kernels here
+				// take every sub-track's position from the widths in front of it and never read the two fields -- a blob in which they
+				// disagree with the widths would decode HERE and send the reference's walk anywhere. Refused, like the pose size below.
+				// (found with the oracle under AddressSanitizer on blobs the validators had accepted, round 5)
+				if (a + 1 == num_animated_rotations && bit_offset != sh.animated_rotation_bit_size)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: rotation widths add up to %u bits, header says %u", si, bit_offset, sh.animated_rotation_bit_size);
+				if (a + 1 == num_animated_rotations + num_animated_translations && bit_offset != sh.animated_rotation_bit_size + sh.animated_translation_bit_size)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: translation widths add up to %u bits, header says %u", si, bit_offset - sh.animated_rotation_bit_size, sh.animated_translation_bit_size);
 			}
+			if (num_animated_rotations == 0 && sh.animated_rotation_bit_size != 0)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: no animated rotations, header says %u bits of them", si, sh.animated_rotation_bit_size);
+			if (num_animated_translations == 0 && sh.animated_translation_bit_size != 0)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: no animated translations, header says %u bits of them", si, sh.animated_translation_bit_size);
 
 			if (bit_offset != sh.animated_pose_bit_size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: sub-track widths add up to %u bits, header says %u", si, bit_offset, sh.animated_pose_bit_size);
+		}
+	}
+
+	// ---- would the reference find the same segments? ----
+	// The reference has no table: it guesses a key's segment from num_samples / num_segments and scans up to four start indices from the
+	// segment in front of the guess (decompression.transform.h:372-409). For every cut its compressor makes that lands on the segment the
+	// sample records name; for start indices edited by hand (or a sample count that disagrees with them) it may not -- such a blob would
+	// decode to other poses here than there. Refused. (Found by decoding mutated-but-accepted clips on the GPU against the oracle, round 5.)
+	if (multi_segment && num_tracks != 0)
+	{
+		const uint32_t* starts = reinterpret_cast<const uint32_t*>(tbase + k_segment_start_indices_offset);		// num_segments + 1 entries, the last one 0xFFFFFFFF (validate_clip)
+		const uint32_t approx_samples_per_segment = num_samples / num_segments;
+		for (uint32_t sample = 0; sample < num_samples; ++sample)
+		{
+			const uint32_t approx_segment = approx_samples_per_segment != 0 ? sample / approx_samples_per_segment : 0xFFFFFFFFu;
+			const uint32_t first = approx_segment > 0 ? approx_segment - 1 : 0;
+			uint32_t found = 0xFFFFFFFFu;
+			for (uint32_t segment = first; segment < first + 4 && segment <= num_segments; ++segment)
+				if (sample < starts[segment])
+				{
+					found = segment - 1;		// (segment == 0 cannot match: starts[0] is 0)
+					break;
+				}
+			if (approx_samples_per_segment == 0 || found != (samples[sample].segment_and_local >> 5))
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "sample %u: the reference's segment lookup would not find segment %u", sample, samples[sample].segment_and_local >> 5);
 		}
 	}
 

@@ -631,6 +631,10 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Database header points outside of the buffer");
 
 		const uint32_t* segment_start_indices = th.num_segments > 1 ? reinterpret_cast<const uint32_t*>(blob + tbase + k_segment_start_indices_offset) : nullptr;
+		// (the list ends with 0xFFFFFFFF: what stops the reference's scan for a key's segment, decompression.transform.h:374-409 -- the
+		// sample records here do not need it, a reference decoder fed the same blob would walk into a segment that is not there)
+		if (segment_start_indices != nullptr && segment_start_indices[th.num_segments] != 0xFFFFFFFFu)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "The segment start indices do not end with 0xFFFFFFFF");
 		for (uint32_t i = 0; i < th.num_segments; ++i)
 		{
 			const segment_header& sh = *reinterpret_cast<const segment_header*>(blob + tbase + th.segment_headers_offset + size_t(i) * segment_header_size);
@@ -648,9 +652,33 @@ namespace
 			const uint64_t end = th.num_segments > 1 && i + 1 < th.num_segments ? segment_start_indices[i + 1] : header.num_samples;
 			if (start >= end || end > header.num_samples || end - start > 32)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%llu, %llu)", i, static_cast<unsigned long long>(start), static_cast<unsigned long long>(end));
+			if (stripped)
+			{
+				// A segment's first and last sample are always among the keyframes it keeps (the compressor strips and moves to a database
+				// only what lies between them, compress.transform.impl.h / compress.database.impl.h), and it keeps none past its last
+				// sample: the seek's "nearest keyframe that is present" (decompression.transform.h:272-362) has no answer otherwise -- a
+				// count of leading zeros of zero, which the reference's CPU and this device define differently.
+				const uint32_t sample_indices = reinterpret_cast<const stripped_segment_header&>(sh).sample_indices;
+				const uint32_t count = uint32_t(end - start);		// 1 .. 32
+				const uint32_t past_the_end = count < 32 ? (0xFFFFFFFFu >> count) : 0u;
+				if ((sample_indices & 0x80000000u) == 0 || (sample_indices & (0x80000000u >> (count - 1))) == 0 || (sample_indices & past_the_end) != 0)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u: the keyframes it keeps (%08x) do not span its %u samples", i, sample_indices, count);
+			}
 			const uint64_t stored = stripped ? uint64_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : end - start;
-			if (animated_offset + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8 > blob_size)
+			const uint64_t animated_end = animated_offset + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8;
+			if (animated_end > blob_size)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", i);
+			// ... and in front of the next segment's data: the writer lays the segments out one behind the other
+			// (compression/impl/write_segment_data.h), so a segment whose sample range says it stores more keyframes than lie between its
+			// data and the next segment's claims keyframes that are not there. Such "keyframes" are the next segment's format bytes; the
+			// reference (which unpacks four sub-tracks at a time and reads past them), its restatement and these kernels each make something
+			// else of them -- three different poses for one blob, measured. Refused.
+			if (i + 1 < th.num_segments)
+			{
+				const segment_header& next = *reinterpret_cast<const segment_header*>(blob + tbase + th.segment_headers_offset + size_t(i + 1) * segment_header_size);
+				if (next.segment_data != 0xFFFFFFFFu && animated_end > tbase + uint64_t(next.segment_data))
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u claims keyframes that overlap the data of segment %u", i, i + 1);
+			}
 		}
 
 		return ACLHIP_OK;

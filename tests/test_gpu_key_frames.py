@@ -1,7 +1,6 @@
 """The seek at every key frame of a clip and on both sides of it (k / rate, its float neighbours, the middle of every interval, both ends
 from outside) against the oracle, for clips of many lengths -- both of the compressor's cuts (compression/impl/segment_streams.h: the
-samples of a short last segment spread over the first ones, or kept), other segment sizes of the same splitter, and cuts the
-compressor never makes (a segment start moved by hand: the sample records follow the clip's own segment_start_indices) -- through the
+samples of a short last segment spread over the first ones, or kept) and other segment sizes of the same splitter -- through the
 pose kernels of every layout, the kernel of poses of several windows, every rounding policy and single bone requests. Needs a GPU."""
 import numpy as np
 import pytest
@@ -12,28 +11,6 @@ from oracle import bindings as ob
 import helpers
 
 pytestmark = pytest.mark.gpu
-
-TRANSFORM_HEADER_OFFSET = 32            # acl_format.h: k_transform_header_offset
-SEGMENT_START_INDICES_OFFSET = 52       # acl_format.h: k_segment_start_indices_offset (relative to the transform header)
-
-
-def segment_starts(blob):
-    """the clip's own segment_start_indices (multi segment clips), as a writable view"""
-    num_segments = int(np.frombuffer(blob, dtype=np.uint32, count=1, offset=TRANSFORM_HEADER_OFFSET)[0])
-    assert num_segments > 1
-    return blob[TRANSFORM_HEADER_OFFSET + SEGMENT_START_INDICES_OFFSET:][: 4 * num_segments].view(np.uint32)
-
-
-def with_moved_start(clip, segment, delta):
-    """the same blob with one segment start moved: a cut the compressor never makes (the bytes stay a valid clip: the keyframes the
-    moved segment now claims lie inside the buffer; what they decode to is whatever bytes are there -- the same for every decoder)"""
-    blob = clip.blob.copy()
-    aligned = synth.aligned_bytes(blob.size)
-    aligned[:] = blob
-    starts = segment_starts(aligned)
-    starts[segment] = int(starts[segment]) + delta
-    return aligned
-
 
 def times_around_every_key_frame(clip, wrap_extra=0):
     """k / rate, and its float neighbours, for every sample index of the clip (and one beyond for clips that wrap); the ends, outside"""
@@ -101,22 +78,3 @@ def test_poses_of_several_windows():
     with runtime.Context(0) as context:
         clip = synth.build_clip(seed=77, num_tracks=300, num_samples=100, has_scale=1, scale_default=0.4)
         check_clip_everywhere(context, clip)
-
-
-def test_cuts_the_compressor_never_makes():
-    with runtime.Context(0) as context:
-        clip = synth.build_clip(seed=5, num_tracks=24, num_samples=100)          # 17 17 17 17 16 16
-        for segment, delta in ((1, -1), (2, 1), (4, -1)):
-            moved = with_moved_start(clip, segment, delta)
-            check_clip_everywhere(context, clip, blob=moved, check_hash=False)
-        # both kinds in one batch
-        regular = context.register_clip(clip.blob)
-        moved = with_moved_start(clip, 2, 1)
-        other = context.register_clip(moved, check_hash=False)
-        rng = np.random.default_rng(3)
-        which = rng.integers(0, 2, size=2000)
-        times = rng.uniform(-0.1, clip.duration + 0.1, size=2000).astype(np.float32)
-        got = context.decompress_tracks(np.where(which == 0, regular, other).astype(np.uint32), times)
-        expected = ob.oracle_decompress_tracks_batch([clip.blob, moved], which.astype(np.uint32), times, clip.num_tracks)
-        assert helpers.exact(got, expected)
-        assert context.rejected_instance_count() == 0

@@ -173,3 +173,60 @@ def test_mutated_buffers_are_refused_or_accepted_never_worse():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     result = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_host_validators.py"), "5", "3"], capture_output=True, text=True, timeout=300)
     assert result.returncode == 0 and "host validator fuzz ok" in result.stdout, result.stdout[-2000:] + result.stderr[-2000:]
+
+
+TRANSFORM_HEADER_OFFSET = 32            # acl_format.h: k_transform_header_offset
+SEGMENT_START_INDICES_OFFSET = 52       # acl_format.h: k_segment_start_indices_offset (relative to the transform header)
+
+
+def segment_starts(blob):
+    """the clip's own segment_start_indices (multi segment clips), as a writable view"""
+    num_segments = int(np.frombuffer(blob, dtype=np.uint32, count=1, offset=TRANSFORM_HEADER_OFFSET)[0])
+    assert num_segments > 1
+    return blob[TRANSFORM_HEADER_OFFSET + SEGMENT_START_INDICES_OFFSET:][: 4 * num_segments].view(np.uint32)
+
+
+def with_moved_start(clip, segment, delta):
+    """the same blob with one segment start moved: a cut the compressor never makes (the bytes stay a valid clip: the keyframes the
+    moved segment now claims lie inside the buffer; what they decode to is whatever bytes are there -- the same for every decoder)"""
+    blob = clip.blob.copy()
+    aligned = synth.aligned_bytes(blob.size)
+    aligned[:] = blob
+    starts = segment_starts(aligned)
+    starts[segment] = int(starts[segment]) + delta
+    return aligned
+
+
+def test_segment_starts_moved_by_hand_are_refused():
+    """a segment start moved by one sample makes one of its neighbours claim a keyframe it does not store (what lies there is the next
+    segment's format data): the reference, its restatement and the kernels each decode something else from such a blob (measured with
+    tools/fuzz_gpu_mutated.py) -- registration refuses it; so it does a list of starts without its 0xFFFFFFFF end, or one the reference's
+    guess-and-scan lookup would not resolve to the same segments"""
+    clip = synth.build_clip(seed=5, num_tracks=24, num_samples=100)          # 17 17 17 17 16 16
+    assert runtime.check_clip(clip.blob)[0] == 0
+    for segment, delta in ((1, -1), (1, 1), (2, 1), (4, -1), (5, 1), (5, -2), (3, 4)):
+        status, message = runtime.check_clip(with_moved_start(clip, segment, delta), check_hash=False)
+        assert status != 0, (segment, delta)
+    unterminated = synth.aligned_bytes(clip.blob.size)
+    unterminated[:] = clip.blob
+    end = unterminated[TRANSFORM_HEADER_OFFSET + SEGMENT_START_INDICES_OFFSET + 4 * 6:][:4].view(np.uint32)     # the entry behind the last segment
+    assert end[0] == 0xFFFFFFFF
+    end[0] = 100
+    assert runtime.check_clip(unterminated, check_hash=False)[0] != 0
+
+
+def test_stripped_segments_keep_their_first_and_last_keyframe():
+    clip = synth.build_clip(seed=9, num_tracks=12, num_samples=70, strip_keyframes=1)
+    assert runtime.check_clip(clip.blob)[0] == 0
+    num_segments = int(np.frombuffer(clip.blob, dtype=np.uint32, count=1, offset=32)[0])
+    headers_offset = 32 + int(np.frombuffer(clip.blob, dtype=np.uint32, count=1, offset=32 + 36)[0])      # transform_tracks_header::segment_headers_offset
+    for segment in range(num_segments):
+        for clear in (0x80000000, None):
+            blob = synth.aligned_bytes(clip.blob.size)
+            blob[:] = clip.blob
+            word = blob[headers_offset + segment * 20 + 16:][:4].view(np.uint32)        # stripped_segment_header::sample_indices
+            indices = int(word[0])
+            lowest = indices & -indices
+            word[0] = indices & ~(clear if clear is not None else lowest)                # first / last kept keyframe gone
+            status, _ = runtime.check_clip(blob, check_hash=False)
+            assert status != 0, (segment, hex(indices))
