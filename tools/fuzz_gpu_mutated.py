@@ -52,6 +52,9 @@ def main():
     rng = np.random.default_rng(seed)
     import conftest
     sources = [synth.build_clip(**spec) for spec in conftest.CLIP_SPECS.values() if spec.get("num_tracks", 100) <= 330]
+    if os.environ.get("FUZZ_SCALAR", "0") == "1":
+        import helpers
+        sources = [synth.build_scalar_clip(**spec) for spec in helpers.SCALAR_CLIP_SPECS.values()]
     accepted = refused = decoded = different = 0
     start = time.time()
     with runtime.Context(0) as context:
@@ -70,7 +73,20 @@ def main():
                 refused += 1
                 continue
             info = context.clip_info(handle)
-            if info.track_type != 12 and info.num_components != 12:
+            if info.num_components != 12:
+                # a scalar track list (float1f .. vector4f)
+                duration = float(info.duration) if np.isfinite(info.duration) else 1.0
+                times = np.nan_to_num(np.concatenate([rng.uniform(-0.1, max(duration, 0.0) + 0.1, size=12), [0.0, duration]]).astype(np.float32), nan=0.0, posinf=1.0, neginf=0.0)
+                if info.num_tracks != 0 and info.num_tracks < 100000:
+                    values = context.decompress_scalar_tracks(np.full(times.size, handle, dtype=np.uint32), times)
+                    decoded += times.size
+                    row_floats = values.shape[1] * values.shape[2]
+                    expected = ob.oracle_scalar_decompress_tracks_batch([blob], np.zeros(times.size, dtype=np.uint32), times, row_floats).reshape(values.shape)
+                    if not np.array_equal(np.nan_to_num(values), np.nan_to_num(expected)):
+                        different += 1
+                        print(f"DIFFERENT (scalar): mutation {accepted + refused} of seed {seed}, {info.num_tracks} tracks x {info.num_components}", flush=True)
+                        if different <= 12 and os.environ.get("FUZZ_SAVE_DIR"):
+                            np.savez(os.path.join(os.environ["FUZZ_SAVE_DIR"], f"different_scalar_{seed}_{accepted + refused}.npz"), blob=blob, original=source.blob, times=times, gpu=values, oracle=expected)
                 context.unregister_clip(handle)
                 continue
             duration = float(info.duration) if np.isfinite(info.duration) else 1.0
