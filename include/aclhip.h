@@ -227,7 +227,12 @@ aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip cl
  * no device): everything aclhip_register_clip checks before it uploads -- tag, version, hash, every header offset, sub-track
  * classes against counts, bit widths against the per segment pose size, stored keyframes inside the buffer. `out_message`
  * (optional) receives the reason, like error_result::c_str(). The reference only checks alignment, tag, version and hash; the
- * rest is here because the device reads through these offsets. */
+ * rest is here because the device reads through these offsets -- and, since round 5, because a buffer that is accepted has to decode to
+ * the SAME poses here and in the reference: also refused are blobs the reference's decoder and these kernels would read differently
+ * (a segment whose sample range claims keyframes that overlap the next segment's data; a stripped segment that does not keep its first
+ * and last sample; segment start indices without their 0xFFFFFFFF end or that the reference's guess-and-scan lookup would resolve to
+ * other segments; per segment rotation / translation bit sizes and constant sample counts that disagree with the sub-track types;
+ * section offsets that are not 4 byte aligned). Everything the reference's compressor writes passes. */
 aclhip_status aclhip_check_clip(const void* compressed_tracks, uint64_t size, int check_hash, char* out_message, uint32_t capacity);
 
 /* Host only, like aclhip_check_clip: what registration derives about the VALUES a (valid) clip can decode to, which decides the kernel
