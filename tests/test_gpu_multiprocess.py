@@ -80,17 +80,30 @@ def test_peer_gather_between_processes(tmp_path, world_size):
 
 
 @pytest.mark.parametrize("world_size,workload,instances", [(2, "one_clip", 8192), (8, "cinematic", 1024), (4, "database", 4096)])
-def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, instances):
+def _run_bench(command, env, tmp_path, timeout):
+    """runs bench.py; returns (completed process, the ONE stdout line = the compact headline, the full record from bench_details.json)"""
+    details_path = os.path.join(str(tmp_path), "bench_details.json")
+    completed = subprocess.run(command, cwd=ROOT, env=dict(env, ACLHIP_BENCH_DETAILS=details_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, completed.stdout[-2000:] + completed.stderr[-3000:]
+    assert len(lines[0]) < 4096, len(lines[0])          # the driver's parser gave up on round 5's 26 KB line
+    headline = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in headline, key
+    details = json.load(open(details_path))
+    assert headline["n_gpus"] == details["n_gpus"] and abs(headline["value"] / details["value"] - 1.0) < 1e-4
+    return completed, headline, details
+
+
+def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, instances, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` exactly as the driver launches it, ranks sharing the one
     GPU (ACLHIP_BENCH_BACKEND=gloo): the line must carry the whole-job rate and both gathers, timed separately from the decode."""
     env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_SHARDED_INSTANCES="1024")
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--workload", workload, "--instances", str(instances), "--gather", "both"]
-    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    completed, headline, result = _run_bench(command, env, tmp_path, 600)
     assert completed.returncode == 0, completed.stderr[-3000:]
-    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, completed.stdout[-2000:]
-    result = json.loads(lines[0])
+    assert headline["gather"]["p2p_to_rank0_ms"] > 0 and headline["checks"]["communicator_ranks"] == world_size
     assert result["n_gpus"] == world_size and result["scaling"] == "weak" and result["value"] > 0
     assert result["config"]["instances_per_gpu"] == instances
     gather = result["gather"]
@@ -100,7 +113,17 @@ def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, insta
     assert result["checks"]["communicator_ranks"] == world_size and len(result["checks"]["kernel_ms_per_rank"]) == world_size
 
 
-def test_bench_at_8_ranks_covers_the_8_gpu_configs():
+def test_bench_launches_itself_under_torchrun(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE (how the driver launches its 1-GPU run) becomes a 2-rank torch.distributed.run"""
+    env = {key: value for key, value in os.environ.items() if key not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    command = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--instances", "4096", "--no-extras", "--gather", "none"]
+    completed, headline, result = _run_bench(command, env, tmp_path, 600)
+    assert completed.returncode == 0, completed.stderr[-3000:]
+    assert headline["n_gpus"] == 2 and headline["checks"]["communicator_ranks"] == 2 and headline["self_check"]["bit_exact"] is True
+
+
+def test_bench_at_8_ranks_covers_the_8_gpu_configs(tmp_path):
     """The driver's own launch, `torchrun --nproc-per-node 8 bench.py --gpus 8`, as a dry run on the one test GPU (small shards): after
     the headline the line carries BASELINE.json's 8-GPU configs -- the 300-bone rig shards and the database-bound clips whose tiers
     stream in on all ranks together -- each with its whole-job rate and both gathers."""
@@ -108,11 +131,10 @@ def test_bench_at_8_ranks_covers_the_8_gpu_configs():
     env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_SHARDED_INSTANCES="512")
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--instances", "2048"]
-    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    completed, headline, result = _run_bench(command, env, tmp_path, 900)
     assert completed.returncode == 0, completed.stderr[-3000:]
-    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, completed.stdout[-2000:]
-    result = json.loads(lines[0])
+    assert set(headline["workloads"]) == {"cinematic", "database"} and all(row[0] > 0 for row in headline["workloads"].values()), headline["workloads"]
+    assert headline["gather"]["status"] == "done" and len(headline["roofline"]["kernel_ms_per_rank"]) == world_size
     assert result["n_gpus"] == world_size and result["gather"]["status"] == "done"
     # what the line says about the job itself (bench.py: distributed_checks): the communicator counted every rank, every rank reported
     # its device and its kernel time; the ranks of a dry run share one GPU, which the check of distinct devices is not applied to
@@ -136,7 +158,7 @@ def test_bench_at_8_ranks_covers_the_8_gpu_configs():
     assert workloads["database"]["database_chunks_streamed_in_together"] > 0
 
 
-def test_a_gather_that_does_not_come_back_still_leaves_the_decode_line():
+def test_a_gather_that_does_not_come_back_still_leaves_the_decode_line(tmp_path):
     """the first real N > 1 run must report its decode whatever a collective or a peer mapping does on a node this code has never run on:
     with the gather watchdog set to fire at once, the line still arrives -- the communicator's rank count, every rank's kernel time,
     the whole-job rate -- and says that the gather timed out"""
@@ -144,10 +166,8 @@ def test_a_gather_that_does_not_come_back_still_leaves_the_decode_line():
     env = dict(os.environ, ACLHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", ACLHIP_BENCH_GATHER_TIMEOUT="0.0001")
     command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world_size}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                os.path.join(ROOT, "bench.py"), "--gpus", str(world_size), "--steps", "20", "--warmup", "5", "--instances", "8192", "--no-extras", "--gather", "both"]
-    completed = subprocess.run(command, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    lines = [line for line in completed.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, completed.stdout[-2000:] + completed.stderr[-2000:]
-    result = json.loads(lines[0])
+    completed, headline, result = _run_bench(command, env, tmp_path, 600)
+    assert headline["gather"]["status"] == "timed out" and headline["value"] > 0 and headline["roofline"]["kernel_ms"] > 0
     assert result["gather"]["status"] == "timed out"
     assert result["n_gpus"] == world_size and result["value"] > 0 and result["roofline"]["kernel_ms"] > 0
     checks = result["checks"]
