@@ -79,7 +79,6 @@ def test_peer_gather_between_processes(tmp_path, world_size):
     assert all(os.path.exists(tmp_path / f"peer_ok{rank}") for rank in range(world_size))
 
 
-@pytest.mark.parametrize("world_size,workload,instances", [(2, "one_clip", 8192), (8, "cinematic", 1024), (4, "database", 4096)])
 def _run_bench(command, env, tmp_path, timeout):
     """runs bench.py; returns (completed process, the ONE stdout line = the compact headline, the full record from bench_details.json)"""
     details_path = os.path.join(str(tmp_path), "bench_details.json")
@@ -95,6 +94,7 @@ def _run_bench(command, env, tmp_path, timeout):
     return completed, headline, details
 
 
+@pytest.mark.parametrize("world_size,workload,instances", [(2, "one_clip", 8192), (8, "cinematic", 1024), (4, "database", 4096)])
 def test_bench_dry_run_of_the_multi_gpu_control_flow(world_size, workload, instances, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` exactly as the driver launches it, ranks sharing the one
     GPU (ACLHIP_BENCH_BACKEND=gloo): the line must carry the whole-job rate and both gathers, timed separately from the decode."""
