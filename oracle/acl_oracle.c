@@ -28,6 +28,8 @@ typedef struct
 #define VERSION_V02_01_99_1 9
 #define VERSION_LATEST 10
 #define TRACK_TYPE_QVVF 12
+#define ROTATION_FULL 0
+#define ROTATION_DROP_W_FULL 2
 #define ROTATION_DROP_W_VARIABLE 3
 #define VECTOR_VARIABLE 1
 
@@ -122,10 +124,11 @@ int aclo_is_valid(const void* blob, uint64_t blob_size, int check_hash)
 		return 7;
 	if (check_hash && aclo_hash32((const uint8_t*)blob + 8, buffer_header->size - 8) != buffer_header->hash)
 		return 8;	/* Invalid hash */
-	/* scope of this restatement: qvvf tracks with the variable formats (decompression_settings.h:211-232) */
+	/* scope of this restatement: qvvf tracks in every format the reference's decoder takes (debug_transform_decompression_settings,
+	 * decompression_settings.h:236-262): quatf_full / quatf_drop_w_full / quatf_drop_w_variable, vector3f_full / vector3f_variable */
 	if (header->track_type != TRACK_TYPE_QVVF)
 		return 9;
-	if (header->num_tracks != 0 && (hdr_rotation_format(header) != ROTATION_DROP_W_VARIABLE || hdr_translation_format(header) != VECTOR_VARIABLE || (hdr_has_scale(header) && hdr_scale_format(header) != VECTOR_VARIABLE)))
+	if (header->num_tracks != 0 && hdr_rotation_format(header) != ROTATION_FULL && hdr_rotation_format(header) != ROTATION_DROP_W_FULL && hdr_rotation_format(header) != ROTATION_DROP_W_VARIABLE)
 		return 10;
 	return 0;
 }
@@ -266,6 +269,21 @@ void aclo_unpack_vector3_96(const uint8_t* data, uint32_t bit_offset, float out[
 	const uint32_t shift_offset = bit_offset % 8;
 	int c;
 	for (c = 0; c < 3; ++c)
+	{
+		uint64_t v = bswap64(load_u64(data + byte_offset + 4 * (uint32_t)c));
+		v <<= shift_offset;
+		v >>= 32;
+		out[c] = bits_to_float((uint32_t)v);
+	}
+}
+
+void aclo_unpack_vector4_128(const uint8_t* data, uint32_t bit_offset, float out[4])
+{
+	/* unpack_vector4_128_unsafe, math/vector4_packing.h:59-164: four big-endian IEEE floats starting at an arbitrary bit */
+	const uint32_t byte_offset = bit_offset / 8;
+	const uint32_t shift_offset = bit_offset % 8;
+	int c;
+	for (c = 0; c < 4; ++c)
 	{
 		uint64_t v = bswap64(load_u64(data + byte_offset + 4 * (uint32_t)c));
 		v <<= shift_offset;
@@ -601,6 +619,10 @@ typedef struct
 	const aclo_seek_result* seek;
 	uint32_t raw_num_bits;		/* 31 from v02_01_99_1 on, 32 before (animated_track_cache.transform.h:523) */
 	int has_segments;
+	/* the clip's packed formats (decompression.transform.h:95-116). Only the VARIABLE formats carry per track metadata (one format byte per
+	 * segment), segment ranges and clip ranges; the full formats store every sample as 96 (quatf_drop_w_full, vector3f_full) or 128
+	 * (quatf_full) raw bits and nothing else (animated_track_cache.transform.h:1254-1300) */
+	int rotations_variable, rotations_full, translations_variable, scales_variable;
 } decode_ctx_t;
 
 /* Bits a sub-track occupies per component in the animated pose (count_animated_group_bit_size, animated_track_cache.transform.h:1105-1192) */
@@ -608,7 +630,7 @@ static uint32_t stored_bits(const decode_ctx_t* ctx, uint32_t num_bits) { return
 
 /* One animated rotation sample of one key frame, whole-pose flavour: unpack_animated_quat (:515-687) + remap_segment_range_data4 (:302-350)
  * + remap_clip_range_data4 (:391-466). 'index' is the ordinal among animated rotations, 'bit_offset' the sub-track's bit position. */
-static void unpack_rotation_sample(const decode_ctx_t* ctx, int key, uint32_t index, uint32_t bit_offset, float out_xyz[3])
+static void unpack_rotation_sample(const decode_ctx_t* ctx, int key, uint32_t index, uint32_t bit_offset, float out_xyz[4])
 {
 	const uint32_t group = index / 4, lane = index % 4;
 	const uint32_t num_rotations = ctx->th->num_animated_rotation_sub_tracks;
@@ -616,9 +638,20 @@ static void unpack_rotation_sample(const decode_ctx_t* ctx, int key, uint32_t in
 	const uint8_t* format_per_track_data = ctx->seek->format_per_track_data[key];
 	const uint8_t* segment_range_data = ctx->seek->segment_range_data[key] + (uint64_t)group * 24 + lane;
 	const uint8_t* clip_range_data = (const uint8_t*)ctx->th + ctx->th->clip_range_data_offset + (uint64_t)group * 96 + (uint64_t)lane * 4;
-	const uint32_t num_bits = format_per_track_data[index];
+	uint32_t num_bits;
 	int ignore_segment, ignore_clip, c;
 
+	if (!ctx->rotations_variable)
+	{
+		/* :608-620 / :796-806: raw samples, no metadata, no range reduction (the masks are zero and the remaps are not called, :1384-1412) */
+		if (ctx->rotations_full)
+			aclo_unpack_vector4_128(ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		else
+			aclo_unpack_vector3_96(ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		return;
+	}
+
+	num_bits = format_per_track_data[index];
 	if (num_bits == 0)
 	{
 		/* constant in this segment: 16 bit sample hidden in the segment range bytes, hi/lo split across the SOA rows (:552-588) */
@@ -669,11 +702,19 @@ static void unpack_rotation_sample(const decode_ctx_t* ctx, int key, uint32_t in
 static void unpack_vector3_sample(const decode_ctx_t* ctx, int key, uint32_t format_index, const uint8_t* segment_range_base, const uint8_t* clip_range_base,
 	uint32_t range_index, uint32_t bit_offset, float out_xyz[3])
 {
-	const uint32_t num_bits = ctx->seek->format_per_track_data[key][format_index];
+	uint32_t num_bits;
 	const uint8_t* segment_range_data = segment_range_base + (uint64_t)range_index * 6;
 	const uint8_t* clip_range_data = clip_range_base + (uint64_t)range_index * 24;
 	int ignore_segment, ignore_clip, c;
 
+	if (format_index == 0xFFFFFFFFu)
+	{
+		/* vector3f_full (:921-926, :1071): three raw floats, no ranges */
+		aclo_unpack_vector3_96(ctx->seek->animated_track_data[key], bit_offset, out_xyz);
+		return;
+	}
+
+	num_bits = ctx->seek->format_per_track_data[key][format_index];
 	if (num_bits == 0)
 	{
 		aclo_unpack_vector3_u48(segment_range_data, out_xyz);
@@ -755,13 +796,20 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 	const uint8_t* rotation_types = tbase + th->sub_track_types_offset;
 	const uint8_t* translation_types = rotation_types + 4 * num_entries;
 	const uint8_t* scale_types = translation_types + 4 * num_entries;
+	/* the formats decide what exists per sub-track (constant_track_cache.transform.h:102-110, animated_track_cache.transform.h:1254-1300) */
+	const int rotations_variable = hdr_rotation_format(header) == ROTATION_DROP_W_VARIABLE;
+	const int rotations_full = hdr_rotation_format(header) == ROTATION_FULL;
+	const int translations_variable = hdr_translation_format(header) == VECTOR_VARIABLE;
+	const int scales_variable = hdr_scale_format(header) == VECTOR_VARIABLE;
 	const uint8_t* constant_rotations = tbase + th->constant_track_data_offset;
-	const uint8_t* constant_translations = constant_rotations + 12 * (uint64_t)th->num_constant_rotation_samples;
+	const uint8_t* constant_translations = constant_rotations + (rotations_full ? 16u : 12u) * (uint64_t)th->num_constant_rotation_samples;
 	const uint8_t* constant_scales = constant_translations + 12 * (uint64_t)th->num_constant_translation_samples;
-	const uint32_t num_rotations_padded = (th->num_animated_rotation_sub_tracks + 3) & ~3u;
+	/* entries in front of the translations / scales in the per track format bytes and in the segment range data: only variable sub-tracks have any */
+	const uint32_t num_rotations_padded = rotations_variable ? ((th->num_animated_rotation_sub_tracks + 3) & ~3u) : 0u;
+	const uint32_t num_translation_entries = translations_variable ? th->num_animated_translation_sub_tracks : 0u;
 	const uint8_t* clip_range_rotations = tbase + th->clip_range_data_offset;
-	const uint8_t* clip_range_translations = clip_range_rotations + 24 * (uint64_t)th->num_animated_rotation_sub_tracks;
-	const uint8_t* clip_range_scales = clip_range_translations + 24 * (uint64_t)th->num_animated_translation_sub_tracks;
+	const uint8_t* clip_range_translations = clip_range_rotations + (rotations_variable ? 24u : 0u) * (uint64_t)th->num_animated_rotation_sub_tracks;
+	const uint8_t* clip_range_scales = clip_range_translations + (translations_variable ? 24u : 0u) * (uint64_t)th->num_animated_translation_sub_tracks;
 	const int single = track_filter >= 0;
 	aclo_seek_result seek;
 	decode_ctx_t ctx;
@@ -783,6 +831,10 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 	ctx.seek = &seek;
 	ctx.raw_num_bits = header->version >= VERSION_V02_01_99_1 ? 31u : 32u;
 	ctx.has_segments = th->num_segments > 1;
+	ctx.rotations_variable = rotations_variable;
+	ctx.rotations_full = rotations_full;
+	ctx.translations_variable = translations_variable;
+	ctx.scales_variable = scales_variable;
 
 	/* animated_track_cache_v0::initialize (animated_track_cache.transform.h:1223-1314) */
 	for (key = 0; key < 2; ++key)
@@ -822,12 +874,21 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 					const uint32_t group_size = left < 4 ? left : 4;
 					const uint8_t* group_data = constant_rotations + (uint64_t)group * 48;
 					float q[4];
-					q[0] = load_f32(group_data + 4 * (uint64_t)(group_size * 0 + lane));
-					q[1] = load_f32(group_data + 4 * (uint64_t)(group_size * 1 + lane));
-					q[2] = load_f32(group_data + 4 * (uint64_t)(group_size * 2 + lane));
-					q[3] = quat_from_positive_w(q[0], q[1], q[2]);
-					if (options->normalization == ACLO_NORMALIZE_ALWAYS)
-						quat_normalize(q);
+					if (rotations_full)
+					{
+						/* unpack_quat_128 (:136-149, :220-224): AOS xyzw, stored as is -- never normalized, whatever the policy */
+						const uint8_t* src = constant_rotations + (uint64_t)index * 16;
+						q[0] = load_f32(src + 0); q[1] = load_f32(src + 4); q[2] = load_f32(src + 8); q[3] = load_f32(src + 12);
+					}
+					else
+					{
+						q[0] = load_f32(group_data + 4 * (uint64_t)(group_size * 0 + lane));
+						q[1] = load_f32(group_data + 4 * (uint64_t)(group_size * 1 + lane));
+						q[2] = load_f32(group_data + 4 * (uint64_t)(group_size * 2 + lane));
+						q[3] = quat_from_positive_w(q[0], q[1], q[2]);
+						if (options->normalization == ACLO_NORMALIZE_ALWAYS)
+							quat_normalize(q);
+					}
 					qvv[0] = q[0]; qvv[1] = q[1]; qvv[2] = q[2]; qvv[3] = q[3];
 				}
 				else
@@ -843,7 +904,8 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 			else
 			{
 				const uint32_t index = animated_counts[kind]++;
-				const uint32_t format_index = kind == 0 ? index : (kind == 1 ? num_rotations_padded + index : num_rotations_padded + th->num_animated_translation_sub_tracks + index);
+				const int kind_variable = kind == 0 ? rotations_variable : (kind == 1 ? translations_variable : scales_variable);
+				const uint32_t format_index = !kind_variable ? 0xFFFFFFFFu : (kind == 0 ? index : (kind == 1 ? num_rotations_padded + index : num_rotations_padded + num_translation_entries + index));
 				uint32_t sample_bit_offsets[2];
 				float alpha = seek.interpolation_alpha;
 				int policy = ACLO_ROUND_NONE;
@@ -851,7 +913,8 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 				for (key = 0; key < 2; ++key)
 				{
 					sample_bit_offsets[key] = bit_offsets[kind][key];
-					bit_offsets[kind][key] += stored_bits(&ctx, seek.format_per_track_data[key][format_index]) * 3;
+					/* full formats: 96 bits per sample, 128 for quatf_full (:608-620, skip_rotation_groups :1697-1706) */
+					bit_offsets[kind][key] += kind_variable ? stored_bits(&ctx, seek.format_per_track_data[key][format_index]) * 3 : ((kind == 0 && rotations_full) ? 128u : 96u);
 				}
 
 				if (!wanted)
@@ -877,14 +940,21 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 					float q0[4], q1[4], result[4];
 					unpack_rotation_sample(&ctx, 0, index, sample_bit_offsets[0], q0);
 					unpack_rotation_sample(&ctx, 1, index, sample_bit_offsets[1], q1);
-					q0[3] = quat_from_positive_w(q0[0], q0[1], q0[2]);
-					q1[3] = quat_from_positive_w(q1[0], q1[1], q1[2]);
-
-					/* animated_track_cache.transform.h:1463-1473 (whole pose only) */
-					if (!single && options->normalization == ACLO_NORMALIZE_ALWAYS && options->per_track_rounding)
+					/* :1416-1475: W is reconstructed (and, under 'always', the samples normalized) for the drop-W formats only; quatf_full
+					 * samples carry their W. should_interpolate_samples (decompression_context.transform.h:192-199) is true whenever the
+					 * settings support more than one rotation format -- the only settings that accept a full format besides a raw-only one --
+					 * so the samples are always interpolated here. */
+					if (!rotations_full)
 					{
-						quat_normalize(q0);
-						quat_normalize(q1);
+						q0[3] = quat_from_positive_w(q0[0], q0[1], q0[2]);
+						q1[3] = quat_from_positive_w(q1[0], q1[1], q1[2]);
+
+						/* animated_track_cache.transform.h:1463-1473 (whole pose only) */
+						if (!single && options->normalization == ACLO_NORMALIZE_ALWAYS && options->per_track_rounding)
+						{
+							quat_normalize(q0);
+							quat_normalize(q1);
+						}
 					}
 
 					if (policy == ACLO_ROUND_FLOOR)
@@ -905,7 +975,7 @@ static int decode_pose(const void* blob, float sample_time, int rounding_policy,
 				else
 				{
 					const uint8_t* clip_range_base = kind == 1 ? clip_range_translations : clip_range_scales;
-					const uint32_t range_entries_before = kind == 1 ? num_rotations_padded : num_rotations_padded + th->num_animated_translation_sub_tracks;
+					const uint32_t range_entries_before = kind == 1 ? num_rotations_padded : num_rotations_padded + num_translation_entries;
 					float v0[3], v1[3], result[3];
 					unpack_vector3_sample(&ctx, 0, format_index, seek.segment_range_data[0] + (uint64_t)range_entries_before * 6, clip_range_base, index, sample_bit_offsets[0], v0);
 					unpack_vector3_sample(&ctx, 1, format_index, seek.segment_range_data[1] + (uint64_t)range_entries_before * 6, clip_range_base, index, sample_bit_offsets[1], v1);

@@ -90,6 +90,7 @@ float aclo_apply_rounding_policy(float alpha, int rounding_policy);
 /* Bit unpackers (math/vector4_packing.h) */
 void aclo_unpack_vector3_uXX(uint32_t num_bits, const uint8_t* data, uint32_t bit_offset, float out[3]);	/* :921-1035 */
 void aclo_unpack_vector3_96(const uint8_t* data, uint32_t bit_offset, float out[3]);						/* :479-599 */
+void aclo_unpack_vector4_128(const uint8_t* data, uint32_t bit_offset, float out[4]);						/* :59-164 */
 void aclo_unpack_vector3_u48(const uint8_t* data, float out[3]);												/* :628-653 */
 void aclo_unpack_vector3_u24(const uint8_t* data, float out[3]);												/* :781-818 */
 /* Bit packers, only used by tests to round trip (math/vector4_packing.h:828-858, core/memory_utils.h:295-335) */

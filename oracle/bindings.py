@@ -406,6 +406,55 @@ def ref_compress(raw, sample_rate, parents=None, precision=0.0001, shell_distanc
     return blob
 
 
+class RefCompressSettings(ctypes.Structure):
+    """aclref_compress_settings (oracle/ref_compress_bridge.cpp)"""
+    _fields_ = [("level", ctypes.c_uint32), ("rotation_format", ctypes.c_uint32), ("translation_format", ctypes.c_uint32), ("scale_format", ctypes.c_uint32),
+                ("flags", ctypes.c_uint32), ("strip_proportion", ctypes.c_float), ("strip_threshold", ctypes.c_float), ("precision", ctypes.c_float), ("shell_distance", ctypes.c_float)]
+
+
+LEVELS = {"lowest": 0, "low": 1, "medium": 2, "high": 3, "highest": 4}
+ROTATION_FORMATS = {"quatf_full": 0, "quatf_drop_w_full": 2, "quatf_drop_w_variable": 3}
+VECTOR_FORMATS = {"vector3f_full": 0, "vector3f_variable": 1}
+COMPRESS_FLAGS = {"optimize_loops": 1, "enable_database_support": 2, "include_contributing_error": 4, "include_parent_track_indices": 8, "include_track_descriptions": 16,
+                  "include_track_names": 32, "include_track_list_name": 64, "matrix_error_metric": 128, "strip_trivial": 256}
+_ref_compress_ex = None
+
+
+def ref_compress_ex(raw, sample_rate, parents=None, bind_pose=None, level="medium", rotation_format="quatf_drop_w_variable", translation_format="vector3f_variable",
+                    scale_format="vector3f_variable", precision=0.0001, shell_distance=1.0, strip_proportion=0.0, strip_threshold=0.0, **flags):
+    """compress_track_list with any compression_settings (the reference's regression configs: test_data/configs/*.sjson).
+    raw [num_samples, num_tracks, 12]; bind_pose [num_tracks, 12] = track_desc_transformf::default_value; flags: COMPRESS_FLAGS names = True."""
+    global _ref_compress_ex
+    if _ref_compress_ex is None:
+        if not os.path.exists(REF_COMPRESS_PATH):
+            raise RuntimeError(f"{REF_COMPRESS_PATH} is missing: built from /root/reference by `make -C oracle ref`")
+        lib = ctypes.CDLL(REF_COMPRESS_PATH)
+        lib.aclref_compress_ex.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(RefCompressSettings),
+                                           ctypes.c_void_p, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_uint32]
+        lib.aclref_compress_ex.restype = ctypes.c_uint32
+        _ref_compress_ex = lib
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    num_samples, num_tracks = raw.shape[0], raw.shape[1]
+    if parents is None:
+        parents = np.arange(-1, num_tracks - 1, dtype=np.int32)    # a chain
+    parents = np.ascontiguousarray(parents, dtype=np.int32)
+    if bind_pose is not None:
+        bind_pose = np.ascontiguousarray(bind_pose, dtype=np.float32)
+        assert bind_pose.shape == (num_tracks, 12)
+    settings = RefCompressSettings(LEVELS[level], ROTATION_FORMATS[rotation_format], VECTOR_FORMATS[translation_format], VECTOR_FORMATS[scale_format],
+                                   sum(COMPRESS_FLAGS[name] for name, on in flags.items() if on), strip_proportion, strip_threshold, precision, shell_distance)
+    error = ctypes.create_string_buffer(256)
+    args = [raw.ctypes.data, num_tracks, num_samples, ctypes.c_float(sample_rate), parents.ctypes.data, _ptr(bind_pose), ctypes.byref(settings)]
+    size = _ref_compress_ex.aclref_compress_ex(*args, None, 0, error, 256)
+    if size == 0:
+        raise RuntimeError(f"aclref_compress_ex failed: {error.value.decode()}")
+    from acl_amd.synth import aligned_bytes
+    blob = aligned_bytes(size)
+    written = _ref_compress_ex.aclref_compress_ex(*args, blob.ctypes.data, size, error, 256)
+    assert written == size
+    return blob
+
+
 REF_DB_PATH = os.path.join(_HERE, "_ref", "libaclref_db.so")
 _ref_db = None
 

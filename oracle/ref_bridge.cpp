@@ -49,6 +49,25 @@ namespace
 		static constexpr bool is_per_track_rounding_supported() { return true; }
 	};
 
+	// Default settings that take EVERY packed format (quatf_full / quatf_drop_w_full / vector3f_full next to the variable ones): what a
+	// runtime that loads the reference's raw or mixed regression configs (test_data/configs/uniformly_sampled_raw / _mixed_var_*.config.sjson)
+	// would compile -- normalization lerp_only, no per track rounding
+	struct any_format_settings final : public acl::default_transform_decompression_settings
+	{
+		static constexpr bool is_rotation_format_supported(acl::rotation_format8) { return true; }
+		static constexpr bool is_translation_format_supported(acl::vector_format8) { return true; }
+		static constexpr bool is_scale_format_supported(acl::vector_format8) { return true; }
+	};
+
+	// ... and the same with rotation_normalization_policy_t::never
+	struct any_format_never_normalize_settings final : public acl::default_transform_decompression_settings
+	{
+		static constexpr bool is_rotation_format_supported(acl::rotation_format8) { return true; }
+		static constexpr bool is_translation_format_supported(acl::vector_format8) { return true; }
+		static constexpr bool is_scale_format_supported(acl::vector_format8) { return true; }
+		static constexpr acl::rotation_normalization_policy_t get_rotation_normalization_policy() { return acl::rotation_normalization_policy_t::never; }
+	};
+
 	// 48 bytes per bone: rotation xyzw, translation xyz_, scale xyz_ (core/impl/debug_track_writer.h:61-62,172-192)
 	template<acl::default_sub_track_mode rot_mode, acl::default_sub_track_mode trans_mode, acl::default_sub_track_mode scale_mode>
 	struct qvv_pose_writer final : public acl::track_writer
@@ -174,6 +193,8 @@ extern "C"
 			case 1: return run_one_mode<debug_settings>(tracks, sample_time, rounding, looping, track_index, default_mode, out, defaults, per_track_policies);
 			case 2: return run_one_mode<per_track_settings>(tracks, sample_time, rounding, looping, track_index, default_mode, out, defaults, per_track_policies);
 			case 3: return run_one_mode<benchmark_settings>(tracks, sample_time, rounding, looping, track_index, default_mode, out, defaults, per_track_policies);
+			case 4: return run_one_mode<any_format_settings>(tracks, sample_time, rounding, looping, track_index, default_mode, out, defaults, per_track_policies);
+			case 5: return run_one_mode<any_format_never_normalize_settings>(tracks, sample_time, rounding, looping, track_index, default_mode, out, defaults, per_track_policies);
 			}
 #if defined(ACL_ON_ASSERT_THROW)
 		}

@@ -13,11 +13,106 @@
 #include <acl/compression/transform_error_metrics.h>
 
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <utility>
 
 extern "C"
 {
+	// Everything compress_track_list can be asked for (compression_settings.h:200-250 and the regression configs under
+	// test_data/configs/): what tests/golden/make_corpus.py sweeps.
+	struct aclref_compress_settings
+	{
+		uint32_t level;					// acl::compression_level8 (0 lowest .. 4 highest)
+		uint32_t rotation_format;		// acl::rotation_format8: 0 quatf_full, 2 quatf_drop_w_full, 3 quatf_drop_w_variable
+		uint32_t translation_format;	// acl::vector_format8: 0 vector3f_full, 1 vector3f_variable
+		uint32_t scale_format;
+		uint32_t flags;					// bit 0 optimize_loops, 1 enable_database_support, 2 include_contributing_error, 3 include_parent_track_indices,
+										// 4 include_track_descriptions, 5 include_track_names, 6 include_track_list_name, 7 matrix error metric, 8 strip_trivial
+		float strip_proportion;
+		float strip_threshold;
+		float precision;				// per track: track_desc_transformf::precision / shell_distance
+		float shell_distance;
+	};
+
+	// raw / parents as for aclref_compress; bind_pose: [num_tracks][12] floats = track_desc_transformf::default_value per track, or null (identity)
+	uint32_t aclref_compress_ex(const float* raw, uint32_t num_tracks, uint32_t num_samples, float sample_rate, const int32_t* parents, const float* bind_pose,
+		const aclref_compress_settings* options, void* out, uint32_t capacity, char* error, uint32_t error_capacity)
+	{
+		acl::ansi_allocator allocator;
+		uint32_t size = 0;
+		{
+			acl::track_array_qvvf tracks(allocator, num_tracks);
+			if ((options->flags & 64u) != 0)
+				tracks.set_name(acl::string(allocator, "corpus clip"));
+			for (uint32_t track_index = 0; track_index < num_tracks; ++track_index)
+			{
+				acl::track_desc_transformf desc;
+				desc.output_index = track_index;
+				desc.parent_index = parents != nullptr && parents[track_index] >= 0 ? uint32_t(parents[track_index]) : acl::k_invalid_track_index;
+				desc.precision = options->precision;
+				desc.shell_distance = options->shell_distance;
+				if (bind_pose != nullptr)
+				{
+					const float* qvv = bind_pose + size_t(track_index) * 12;
+					desc.default_value = rtm::qvv_set(rtm::quat_load(qvv + 0), rtm::vector_load3(qvv + 4), rtm::vector_load3(qvv + 8));
+				}
+
+				acl::track_qvvf track = acl::track_qvvf::make_reserve(desc, allocator, num_samples, sample_rate);
+				for (uint32_t sample_index = 0; sample_index < num_samples; ++sample_index)
+				{
+					const float* qvv = raw + (size_t(sample_index) * num_tracks + track_index) * 12;
+					track[sample_index] = rtm::qvv_set(rtm::quat_load(qvv + 0), rtm::vector_load3(qvv + 4), rtm::vector_load3(qvv + 8));
+				}
+				if ((options->flags & 32u) != 0)
+				{
+					char name[32];
+					std::snprintf(name, sizeof(name), "bone_%u", track_index);
+					track.set_name(acl::string(allocator, name));
+				}
+				tracks[track_index] = std::move(track);
+			}
+
+			acl::compression_settings settings;
+			settings.level = static_cast<acl::compression_level8>(options->level);
+			settings.rotation_format = static_cast<acl::rotation_format8>(options->rotation_format);
+			settings.translation_format = static_cast<acl::vector_format8>(options->translation_format);
+			settings.scale_format = static_cast<acl::vector_format8>(options->scale_format);
+			acl::qvvf_transform_error_metric error_metric;
+			acl::qvvf_matrix3x4f_transform_error_metric matrix_error_metric;
+			settings.error_metric = (options->flags & 128u) != 0 ? static_cast<acl::itransform_error_metric*>(&matrix_error_metric) : &error_metric;
+			settings.optimize_loops = (options->flags & 1u) != 0;
+			settings.enable_database_support = (options->flags & 2u) != 0;
+			settings.keyframe_stripping.proportion = options->strip_proportion;
+			settings.keyframe_stripping.threshold = options->strip_threshold;
+			settings.keyframe_stripping.strip_trivial = (options->flags & 256u) != 0;
+			settings.metadata.include_contributing_error = (options->flags & (4u | 2u)) != 0;
+			settings.metadata.include_parent_track_indices = (options->flags & 8u) != 0;
+			settings.metadata.include_track_descriptions = (options->flags & 16u) != 0;
+			settings.metadata.include_track_names = (options->flags & 32u) != 0;
+			settings.metadata.include_track_list_name = (options->flags & 64u) != 0;
+
+			acl::output_stats stats;
+			acl::compressed_tracks* compressed = nullptr;
+			const acl::error_result result = acl::compress_track_list(allocator, tracks, settings, compressed, stats);
+			if (result.any() || compressed == nullptr)
+			{
+				if (error != nullptr && error_capacity != 0)
+				{
+					std::strncpy(error, result.c_str(), error_capacity - 1);
+					error[error_capacity - 1] = '\0';
+				}
+				return 0;
+			}
+
+			size = compressed->get_size();
+			if (out != nullptr && capacity >= size)
+				std::memcpy(out, compressed, size);
+			allocator.deallocate(compressed, size);
+		}
+		return size;
+	}
+
 	// raw: [num_samples][num_tracks][12] floats (rot xyzw | trans xyz_ | scale xyz_). parents: num_tracks entries, -1 = root.
 	// flags: bit 0 optimize_loops, bit 1 keyframe stripping (proportion = strip_proportion), bit 2 include metadata (names etc. none; contributing error)
 	// Returns the blob size (0 on error). The blob is copied into `out` (16 byte aligned, capacity bytes) when it fits.

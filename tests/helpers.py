@@ -45,7 +45,8 @@ def mode_triplet(default_mode):
 
 def settings_pair(settings):
     """reference bridge settings id -> (normalization, per_track_rounding)"""
-    return {0: (ob.NORMALIZE_LERP_ONLY, 0), 1: (ob.NORMALIZE_ALWAYS, 1), 2: (ob.NORMALIZE_LERP_ONLY, 1), 3: (ob.NORMALIZE_LERP_ONLY, 0)}[settings]
+    return {0: (ob.NORMALIZE_LERP_ONLY, 0), 1: (ob.NORMALIZE_ALWAYS, 1), 2: (ob.NORMALIZE_LERP_ONLY, 1), 3: (ob.NORMALIZE_LERP_ONLY, 0),
+            4: (ob.NORMALIZE_LERP_ONLY, 0), 5: (ob.NORMALIZE_NEVER, 0)}[settings]      # 4 / 5: default settings that take every packed format (ref_bridge.cpp)
 
 
 def oracle_options(settings=0, default_mode=0, defaults=None, track_rounding=None, looping=ob.LOOP_AS_COMPRESSED):
