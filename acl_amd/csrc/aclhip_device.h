@@ -39,8 +39,10 @@ namespace aclhip
 	{
 		uint32_t animated_offset;		// first stored keyframe of the sample's segment, from the blob start (4 byte aligned)
 		uint32_t pose_bit_size;			// bits per stored keyframe (segment_header::animated_pose_bit_size)
-		uint32_t sample_indices;		// stored keyframes of the segment, MSB = first sample (0xFFFFFFFF when nothing is stripped)
-		uint32_t segment_and_local;		// segment index << 5 | index of the sample inside its segment (a segment holds at most 32 samples)
+		uint32_t sample_indices;		// clips with stripped keyframes / a database: stored keyframes of the segment, MSB = first sample (a segment then
+										// holds at most 32 samples). Every other clip: the index of the sample inside its segment, whole -- a clip in
+										// the full formats is ONE segment of any length (compress.transform.impl.h:168-176: no segmenting without a variable format)
+		uint32_t segment_and_local;		// segment index << 5 | (index of the sample inside its segment) & 31
 	};
 
 	// Clips bound to a compressed_database keep 32 bytes per sample: the record above and a COPY of the runtime tier metadata of the
@@ -59,7 +61,7 @@ namespace aclhip
 
 	// One per (segment, animated sub-track), 32 bytes: where the sub-track's bits sit inside a keyframe of that segment and
 	// how to expand them, ready to use. Widths: 1..23 = quantized, 0 = constant in the segment (the 16 bit sample is pre-converted into
-	// range_min, range_extent = 0, nothing is read), 32 = raw fp32 (ranges ignored).
+	// range_min, range_extent = 0, nothing is read), 32 / 33 / 34 = raw fp32 (ranges ignored; k_width_raw_* below).
 	// Segment range values are float(u8) * (1/255) exactly as the reference computes them per pose
 	// (animated_track_cache.transform.h:188-196, math/vector4_packing.h:781-818); single segment clips get min 0 / extent 1.
 	// (Round 2 measured the compact alternative -- 8 byte entries expanded in-lane, bit offsets from a wavefront prefix sum over the
@@ -124,11 +126,24 @@ namespace aclhip
 
 	__device__ __forceinline__ bool is_rotation_entry(const clip_range_entry& entry) { return entry.quad_index == entry.track_index * 3u; }
 
-	// Markers in the W lane of a base pose quad (a real W is never negative: sqrt(|..|) for rotations, 0 for vectors)
-	constexpr uint32_t k_quad_special = 0x80000000u;			// sign bit set: not a constant sub-track
-	constexpr uint32_t k_quad_animated = 0x20000000u;			// special + this bit: low 24 bits = animated ordinal
+	// Markers in the W lane of a base pose quad: the bit patterns from 0xFFC00000 up (negative quiet NaNs). A real W is never one of
+	// them: sqrt(|..|) for the drop-W rotation formats, 0 for vectors, and for quatf_full -- whose W is stored and may be NEGATIVE, which is
+	// why the sign bit alone (rounds 1-5) no longer marks anything -- any float but a NaN (registration makes a garbage constant's NaN
+	// positive; the device's own arithmetic produces 0x7FC00000).
+	constexpr uint32_t k_quad_special = 0xFFC00000u;			// bits >= this: not a constant sub-track (is_special_quad)
+	constexpr uint32_t k_quad_animated = 0x00200000u;			// special + this bit: low 21 bits = animated ordinal
 	constexpr uint32_t k_quad_default_w_one = 0x00000001u;		// special, not animated: default sub-track, this bit = its identity W is 1
-	constexpr uint32_t k_quad_ordinal_mask = 0x00FFFFFFu;
+	constexpr uint32_t k_quad_ordinal_mask = 0x001FFFFFu;
+	__host__ __device__ __forceinline__ bool is_special_quad(uint32_t w_bits) { return w_bits >= k_quad_special; }
+
+	// Widths a plan_entry can name beyond the quantized 0..23 (bit_offset_and_width >> 24). The three raw classes store IEEE floats, big
+	// endian, at any bit of the keyframe and skip both range expansions (animated_track_cache.transform.h:589-620,905-926):
+	constexpr uint32_t k_width_raw_variable = 32u;		// the raw bit rate of a VARIABLE format: 3 floats; a rotation still passes through the SOA range
+														// arithmetic as value * 1 + 0 twice (:316-349,420-465: a -0.0 comes out +0.0)
+	constexpr uint32_t k_width_raw_full = 33u;			// quatf_drop_w_full / vector3f_full: 3 floats, no range arithmetic at all (:1384-1412 never runs)
+	constexpr uint32_t k_width_raw_quat = 34u;			// quatf_full: 4 floats, W stored (unpack_vector4_128_unsafe, math/vector4_packing.h:59-164)
+	__host__ __device__ __forceinline__ bool is_raw_width(uint32_t width) { return width >= k_width_raw_variable; }
+	__host__ __device__ __forceinline__ uint32_t stored_sample_bits(uint32_t width) { return width < k_width_raw_variable ? width * 3u : (width == k_width_raw_quat ? 128u : 96u); }
 
 	// Per clip record in HBM, written once at registration; read through the scalar cache by every wave.
 	struct alignas(128) device_clip
@@ -169,6 +184,7 @@ namespace aclhip
 	constexpr uint32_t k_clip_negative_scale = 1u << 11;			// some scale sub-track may decode a negative component: rtm::qvv_mul then composes matrices (pose consumers)
 	constexpr uint32_t k_clip_short_exact_math = 1u << 12;		// no animated rotation of the clip can hand the kernels a square root argument in (0, 2^-96): the short exact forms apply (host_clips.inl)
 	constexpr uint32_t k_clip_raw_rotations = 1u << 13;			// some rotation sub-track is stored raw (fp32) in some segment
+	constexpr uint32_t k_clip_full_rotations = 1u << 14;			// rotation format quatf_full: W is stored, constant rotations are never normalized (constant_track_cache.transform.h:136-149)
 	constexpr uint32_t k_clip_valid = 1u << 31;
 
 	// pose windows of a transform clip, and where its window span table starts (behind image_chunks, 32 byte aligned)
@@ -489,6 +505,12 @@ namespace aclhip
 			segment_key_frame0 = uint32_t(__builtin_popcount(~(0xFFFFFFFFu >> segment_key_frame0) & sample_indices0));
 			segment_key_frame1 = uint32_t(__builtin_popcount(~(0xFFFFFFFFu >> segment_key_frame1) & sample_indices1));
 		}
+		else
+		{
+			// every keyframe is stored: the sample's index inside its segment, which may be longer than 32 samples (sample_record)
+			segment_key_frame0 = segment0.sample_indices;
+			segment_key_frame1 = segment1.sample_indices;
+		}
 
 		// :530-562
 		out.animated_track_data[0] = animated_track_data0;
@@ -585,16 +607,18 @@ namespace aclhip
 			#pragma unroll
 			for (uint32_t key = 0; key < 2; ++key)
 			{
-				if ((key == 0 ? num_bits0 : num_bits1) == 32u)
+				const uint32_t key_bits = key == 0 ? num_bits0 : num_bits1;
+				if (is_raw_width(key_bits))
 				{
 					const uint32_t bit_offset = key == 0 ? bit_offset0 : bit_offset1;
 					const ACLHIP_CONSTANT uint8_t* bytes = (key == 0 ? data0 : data1) + (bit_offset >> 3);
 					const uint32_t shift = bit_offset & 7u;
 					const uint32_t w0 = load_be32(bytes), w1 = load_be32(bytes + 4), w2 = load_be32(bytes + 8), w3 = load_be32(bytes + 12);
 					float raw[3] = { __uint_as_float(__funnelshift_l(w1, w0, shift)), __uint_as_float(__funnelshift_l(w2, w1, shift)), __uint_as_float(__funnelshift_l(w3, w2, shift)) };
+					const bool through_ranges = is_rotation && key_bits == k_width_raw_variable;
 					#pragma unroll
 					for (uint32_t c = 0; c < 3; ++c)
-						v[key][c] = is_rotation ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
+						v[key][c] = through_ranges ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
 				}
 			}
 		}
@@ -670,16 +694,17 @@ namespace aclhip
 				v[key][c] = (segment_value * clip_range.range_extent[c]) + clip_range.range_min[c];
 			}
 
-			if (kHasRaw && num_bits == 32u)
+			if (kHasRaw && is_raw_width(num_bits))
 			{
 				// Raw (fp32) keyframes: three big endian floats starting at an arbitrary bit (math/vector4_packing.h:479-599) -- the same
 				// four dwords. What the code above computed for them is discarded. Raw samples skip both range expansions; in the
 				// reference's SOA rotation path the ignored lanes still see value * 1 + 0 twice
 				// (animated_track_cache.transform.h:316-349,420-465), which only matters for a -0.0.
 				const float raw[3] = { __uint_as_float(bits_from(w0, w1, shift_x)), __uint_as_float(bits_from(w1, w2, shift_x)), __uint_as_float(bits_from(w2, w3, shift_x)) };
+				const bool through_ranges = is_rotation && num_bits == k_width_raw_variable;
 				#pragma unroll
 				for (uint32_t c = 0; c < 3; ++c)
-					v[key][c] = is_rotation ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
+					v[key][c] = through_ranges ? (((raw[c] * 1.0f) + 0.0f) * 1.0f) + 0.0f : raw[c];
 			}
 		}
 
@@ -838,21 +863,54 @@ namespace aclhip
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
 			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+		if constexpr (kHasRaw)
+		{
+			// quatf_full: the sample's W is the fourth float of its 128 bits (unpack_vector4_128_unsafe) -- no reconstruction, no sample
+			// normalization (animated_track_cache.transform.h:1416-1475 covers the drop-W formats only); a clip's rotations all share the
+			// format, so both keys are of this class or neither is
+			const bool stored_w = (plan0.bit_offset_and_width >> 24) == k_width_raw_quat;
+			if (__builtin_amdgcn_ballot_w64(stored_w) != 0)
+			{
+				float w0 = 0.0f, w1 = 0.0f;
+				if (stored_w)
+				{
+					const uint32_t bit_offset0 = state.key_frame_bit_offsets[0] + (plan0.bit_offset_and_width & 0x00FFFFFFu) + 96u;
+					const uint32_t bit_offset1 = state.key_frame_bit_offsets[1] + (plan1.bit_offset_and_width & 0x00FFFFFFu) + 96u;
+					const ACLHIP_CONSTANT uint8_t* bytes0 = as_constant(state.animated_track_data[0]) + (bit_offset0 >> 3);
+					const ACLHIP_CONSTANT uint8_t* bytes1 = as_constant(state.animated_track_data[1]) + (bit_offset1 >> 3);
+					w0 = __uint_as_float(__funnelshift_l(load_be32(bytes0 + 4), load_be32(bytes0), bit_offset0 & 7u));
+					w1 = __uint_as_float(__funnelshift_l(load_be32(bytes1 + 4), load_be32(bytes1), bit_offset1 & 7u));
+				}
+				// (the wave's other lanes -- the vectors of test_data/configs/uniformly_sampled_mixed_var_0, say -- take their usual route)
+				if (is_rotation)
+					return interpolate_animated_rotation<kPolicies, false, true>(state, v0, v1, policy, lerp_alpha, normalization, normalize_samples, stored_w, w0, w1);
+				return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, false, policy, lerp_alpha, normalization, normalize_samples, false);
+			}
+		}
 		// (raw samples are any floats: a wave that meets one keeps the compiler's forms)
 		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples, !kHasRaw && short_exact_math);
 	}
 
 	// What follows the unpack: W reconstruction, interpolation, normalization (rotations) / the stable lerp (translations, scales)
 	// The rotation arithmetic of interpolate_animated_samples, with the compiler's or the short exact square roots / reciprocal
-	template<bool kPolicies, bool kShortExact>
+	// kStoredW (quatf_full, lanes with stored_w set): the samples carry their W (w0, w1) -- no reconstruction and no sample normalization,
+	// which animated_track_cache.transform.h:1416-1475 applies to the drop-W formats only. should_interpolate_samples
+	// (decompression_context.transform.h:192-199) is true for every settings type that supports more than one rotation format, the only
+	// kind this library stands in for: the samples are always interpolated, then normalized under lerp_only / always.
+	template<bool kPolicies, bool kShortExact, bool kStoredW = false>
 	__device__ __forceinline__ float4 interpolate_animated_rotation(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
-		uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples)
+		uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool stored_w = false, float w0 = 0.0f, float w1 = 0.0f)
 	{
 		float4 q0 = make_float4(v0[0], v0[1], v0[2], quat_from_positive_w<kShortExact>(v0[0], v0[1], v0[2]));
 		float4 q1 = make_float4(v1[0], v1[1], v1[2], quat_from_positive_w<kShortExact>(v1[0], v1[1], v1[2]));
+		if (kStoredW)
+		{
+			q0.w = stored_w ? w0 : q0.w;
+			q1.w = stored_w ? w1 : q1.w;
+		}
 
 		// animated_track_cache.transform.h:1463-1473
-		if (kPolicies && normalize_samples)
+		if (kPolicies && normalize_samples && !(kStoredW && stored_w))
 		{
 			q0 = quat_normalize<kShortExact>(q0);
 			q1 = quat_normalize<kShortExact>(q1);

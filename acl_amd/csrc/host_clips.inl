@@ -215,7 +215,7 @@ namespace
 		bool short_exact_math;		// -> k_clip_short_exact_math
 		bool raw_rotations;			// -> k_clip_raw_rotations
 	};
-	rotation_value_facts analyze_rotation_values(const uint8_t* blob, uint32_t blob_size, bool key_frames_in_a_database, uint32_t num_tracks, uint32_t num_samples, uint32_t num_segments,
+	rotation_value_facts analyze_rotation_values(const uint8_t* blob, uint32_t blob_size, bool key_frames_in_a_database, bool key_frames_stripped, uint32_t num_tracks, uint32_t num_samples, uint32_t num_segments,
 		uint32_t num_animated, const std::vector<plan_entry>& plan, const std::vector<clip_range_entry>& clip_ranges, const std::vector<sample_record>& samples, const std::vector<float>& base_pose)
 	{
 		bool short_exact_math = true, raw_rotations = false, grid_has_tiny_values = false;
@@ -239,7 +239,7 @@ namespace
 				{
 					const plan_entry& entry = plan[size_t(si) * num_animated + a];
 					const uint32_t num_bits = entry.bit_offset_and_width >> 24;
-					if (num_bits == 32)
+					if (is_raw_width(num_bits))
 					{
 						// any floats: a wave that meets a raw sample takes the compiler's forms (decode_animated_sub_track<kHasRaw = true>);
 						// the rest of the clip is judged on its quantized samples
@@ -302,10 +302,11 @@ namespace
 				{
 					const sample_record& record = samples[sample];
 					const uint32_t si = record.segment_and_local >> 5, local = record.segment_and_local & 31u;
-					// (stripped key frames: bit `31 - local` of sample_indices says whether this one is stored, the ones in front of it where)
-					if ((record.sample_indices & (0x80000000u >> local)) == 0)
+					// (stripped key frames: bit `31 - local` of sample_indices says whether this one is stored, the ones in front of it where;
+					// nothing stripped: sample_indices IS the sample's index inside its segment)
+					if (key_frames_stripped && (record.sample_indices & (0x80000000u >> local)) == 0)
 						continue;
-					const uint32_t stored_ordinal = uint32_t(__builtin_popcount(record.sample_indices & ~(0xFFFFFFFFu >> local)));
+					const uint32_t stored_ordinal = key_frames_stripped ? uint32_t(__builtin_popcount(record.sample_indices & ~(0xFFFFFFFFu >> local))) : record.sample_indices;
 					const uint64_t key_frame_bit = uint64_t(record.animated_offset) * 8 + uint64_t(stored_ordinal) * record.pose_bit_size;
 					for (uint32_t a = 0; a < num_animated && short_exact_math; ++a)
 					{
@@ -314,7 +315,7 @@ namespace
 							continue;
 						const plan_entry& entry = plan[size_t(si) * num_animated + a];
 						const uint32_t num_bits = entry.bit_offset_and_width >> 24;
-						if (num_bits == 32)
+						if (is_raw_width(num_bits))
 							continue;
 						float value[3];
 						for (uint32_t c = 0; c < 3; ++c)
@@ -330,7 +331,7 @@ namespace
 			{
 				const float* value = &base_pose[size_t(track * 3) * 4];
 				const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
-				if (int32_t(marker) >= 0)		// a constant rotation (W rebuilt above with the host's sqrtf)
+				if (!is_special_quad(marker))		// a constant rotation (W rebuilt above with the host's sqrtf)
 					short_exact_math = std::fabs(value[0]) <= k_huge && std::fabs(value[1]) <= k_huge && std::fabs(value[2]) <= k_huge;
 			}
 		}
@@ -376,7 +377,13 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	const uint32_t num_animated_translations = num_tracks != 0 ? th.num_animated_translation_sub_tracks : 0;
 	const uint32_t num_animated_scales = num_tracks != 0 ? th.num_animated_scale_sub_tracks : 0;
 	const uint32_t num_animated = num_animated_rotations + num_animated_translations + num_animated_scales;
-	const uint32_t num_rotations_padded = align_to_u32(num_animated_rotations, 4);
+	// the packed formats: only the variable ones carry a format byte per segment, segment ranges and a clip range (validate_clip)
+	const bool rotations_variable = num_tracks == 0 || header.rotation_format() == k_rotation_quatf_drop_w_variable;
+	const bool rotations_full = num_tracks != 0 && header.rotation_format() == k_rotation_quatf_full;
+	const bool translations_variable = num_tracks == 0 || header.translation_format() == k_vector_vector3f_variable;
+	const bool scales_variable = num_tracks == 0 || header.scale_format() == k_vector_vector3f_variable;
+	const uint32_t num_rotations_padded = rotations_variable ? align_to_u32(num_animated_rotations, 4) : 0u;
+	const uint32_t num_variable_translations = translations_variable ? num_animated_translations : 0u;
 	if (num_animated > k_quad_ordinal_mask)
 		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "too many animated sub-tracks");
 
@@ -398,7 +405,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		const uint32_t num_entries = (num_tracks + 15) / 16;
 		const uint32_t* types = reinterpret_cast<const uint32_t*>(tbase + th.sub_track_types_offset);
 		const float* constant_rotations = reinterpret_cast<const float*>(tbase + th.constant_track_data_offset);
-		const float* constant_translations = constant_rotations + size_t(th.num_constant_rotation_samples) * 3;
+		const float* constant_translations = constant_rotations + size_t(th.num_constant_rotation_samples) * (rotations_full ? 4 : 3);
 		const float* constant_scales = constant_translations + size_t(th.num_constant_translation_samples) * 3;
 		const float default_scale = float(header.default_scale());
 
@@ -424,7 +431,12 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 					if (index >= constant_limits[kind])
 						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "more constant sub-tracks than constant samples");
 
-					if (kind == 0)
+					if (kind == 0 && rotations_full)
+					{
+						// unpack_quat_128 (constant_track_cache.transform.h:136-149): AOS xyzw, stored whole -- W as written, no reconstruction
+						std::memcpy(value, constant_rotations + size_t(index) * 4, 16);
+					}
+					else if (kind == 0)
 					{
 						// constant_track_cache_v0::unpack_rotation_group (constant_track_cache.transform.h:113-205): SOA groups of 4, last one unpadded
 						const uint32_t group = index / 4, lane = index % 4;
@@ -444,8 +456,8 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 						const float* src = (kind == 1 ? constant_translations : constant_scales) + size_t(index) * 3;
 						value[0] = src[0]; value[1] = src[1]; value[2] = src[2]; value[3] = 0.0f;
 					}
-					if (int32_t(value_bits[3]) < 0)
-						value_bits[3] &= 0x7FFFFFFFu;	// only a garbage (NaN) constant could collide with the marker bit
+					if (is_special_quad(value_bits[3]))
+						value_bits[3] &= 0x7FFFFFFFu;	// only a garbage (NaN) constant could collide with the markers
 				}
 				else if (cls == k_sub_track_animated)
 				{
@@ -480,7 +492,14 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		// clip ranges: rotations are SOA per group of 4 (last group unpadded), translations / scales AOS (write_range_data.h:79-207)
 		{
 			const float* range_data = reinterpret_cast<const float*>(tbase + th.clip_range_data_offset);
-			for (uint32_t i = 0; i < num_animated_rotations; ++i)
+			// (sub-tracks of a full format have no clip range: min 0 / extent 1, never used -- their samples are raw)
+			for (uint32_t i = 0; i < num_animated; ++i)
+				for (uint32_t c = 0; c < 3; ++c)
+				{
+					clip_ranges[i].range_min[c] = 0.0f;
+					clip_ranges[i].range_extent[c] = 1.0f;
+				}
+			for (uint32_t i = 0; rotations_variable && i < num_animated_rotations; ++i)
 			{
 				const uint32_t group = i / 4, lane = i % 4;
 				const uint32_t group_size = std::min<uint32_t>(num_animated_rotations - group * 4, 4);
@@ -491,10 +510,14 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 					clip_ranges[i].range_extent[c] = group_data[group_size * (3 + c) + lane];
 				}
 			}
-			const float* vector_ranges = range_data + size_t(num_animated_rotations) * 6;
+			const float* vector_ranges = range_data + size_t(rotations_variable ? num_animated_rotations : 0u) * 6;
 			for (uint32_t i = num_animated_rotations; i < num_animated; ++i)
 			{
-				const float* entry = vector_ranges + size_t(i - num_animated_rotations) * 6;
+				const bool is_translation = i < num_animated_rotations + num_animated_translations;
+				if (!(is_translation ? translations_variable : scales_variable))
+					continue;
+				const uint32_t range_index = is_translation ? i - num_animated_rotations : num_variable_translations + (i - num_animated_rotations - num_animated_translations);
+				const float* entry = vector_ranges + size_t(range_index) * 6;
 				for (uint32_t c = 0; c < 3; ++c)
 				{
 					clip_ranges[i].range_min[c] = entry[c];
@@ -511,7 +534,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			const segment_header& sh = *reinterpret_cast<const segment_header*>(tbase + th.segment_headers_offset + size_t(si) * segment_header_size);
 			const uint32_t start = multi_segment ? segment_start_indices[si] : 0;
 			const uint32_t end = multi_segment && si + 1 < num_segments ? segment_start_indices[si + 1] : num_samples;
-			if (start >= end || end > num_samples || end - start > 32 || (si == 0 && start != 0))
+			if (start >= end || end > num_samples || (stripped && end - start > 32) || (si == 0 && start != 0))
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%u, %u)", si, start, end);
 			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324)
 			const uint32_t format_offset = k_transform_header_offset + sh.segment_data;
@@ -525,10 +548,11 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			record.animated_offset = animated_offset;
 			record.pose_bit_size = sh.animated_pose_bit_size;
 			segment_pose_bit_sizes[si] = sh.animated_pose_bit_size;
-			record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : 0xFFFFFFFFu;
 			for (uint32_t sample = start; sample < end; ++sample)
 			{
-				record.segment_and_local = (si << 5) | (sample - start);
+				// (sample_record: the keyframes the segment keeps, or -- nothing stripped -- the sample's index inside its segment, of any length)
+				record.sample_indices = stripped ? reinterpret_cast<const stripped_segment_header&>(sh).sample_indices : sample - start;
+				record.segment_and_local = (si << 5) | ((sample - start) & 31u);
 				samples[sample] = record;
 			}
 
@@ -538,9 +562,13 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			for (uint32_t a = 0; a < num_animated; ++a)
 			{
 				const bool is_rotation = a < num_animated_rotations;
-				const uint32_t vector_index = a - num_animated_rotations;
+				const bool is_translation = !is_rotation && a < num_animated_rotations + num_animated_translations;
+				const bool is_variable = is_rotation ? rotations_variable : (is_translation ? translations_variable : scales_variable);
+				// ordinal among the sub-tracks that HAVE metadata, translations and scales behind the (padded) rotations
+				const uint32_t vector_index = is_translation ? a - num_animated_rotations : num_variable_translations + (a - num_animated_rotations - num_animated_translations);
 				const uint32_t format_index = is_rotation ? a : num_rotations_padded + vector_index;
-				const uint32_t stored_bits = format_per_track[format_index];
+				// full formats: every sample raw, 96 bits -- 128 for quatf_full -- and no format byte (animated_track_cache.transform.h:608-620,921-926)
+				const uint32_t stored_bits = is_variable ? format_per_track[format_index] : raw_num_bits;
 				const bool is_raw = stored_bits == raw_num_bits;
 				if (!is_raw && stored_bits > 23)
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u sub-track %u has an invalid bit width %u", si, a, stored_bits);
@@ -548,7 +576,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 					return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "keyframes larger than 2 MiB are not supported");
 
 				plan_entry& entry = plan[size_t(si) * num_animated + a];
-				const uint32_t num_bits = is_raw ? 32u : stored_bits;
+				const uint32_t num_bits = !is_raw ? stored_bits : (is_variable ? k_width_raw_variable : (is_rotation && rotations_full ? k_width_raw_quat : k_width_raw_full));
 				entry.bit_offset_and_width = bit_offset | (num_bits << 24);
 				entry.inv_max_value = num_bits == 0 ? 0.0f : (is_raw ? 1.0f : 1.0f / float((1u << num_bits) - 1u));
 				for (uint32_t c = 0; c < 3; ++c)
@@ -592,7 +620,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 					}
 				}
 
-				bit_offset += num_bits * 3;
+				bit_offset += stored_sample_bits(num_bits);
 				// The reference finds a keyframe's translations behind animated_rotation_bit_size bits and its scales behind
 				// animated_translation_bit_size more (decompression.transform.h:533-536, animated_track_cache.transform.h): the kernels here
 				// take every sub-track's position from the widths in front of it and never read the two fields -- a blob in which they
@@ -709,7 +737,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 				const uint32_t kind = clip_ranges[a].quad_index - clip_ranges[a].track_index * 3;
 				const uint32_t bit = entry.bit_offset_and_width & 0x00FFFFFFu;
 				span.first_bit[kind] = seen[kind] ? std::min(span.first_bit[kind], bit) : bit;
-				span.end_bit[kind] = seen[kind] ? std::max(span.end_bit[kind], bit + width * 3) : bit + width * 3;
+				span.end_bit[kind] = seen[kind] ? std::max(span.end_bit[kind], bit + stored_sample_bits(width)) : bit + stored_sample_bits(width);
 				seen[kind] = true;
 			}
 			uint32_t key_bytes = 0;
@@ -737,7 +765,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		{
 			const float* value = &base_pose[size_t(track * 3 + 2) * 4];
 			const uint32_t marker = reinterpret_cast<const uint32_t*>(value)[3];
-			if (int32_t(marker) >= 0 || (marker & k_quad_animated) == 0)		// constant, or default (the base pose holds the default's xyz)
+			if (!is_special_quad(marker) || (marker & k_quad_animated) == 0)		// constant, or default (the base pose holds the default's xyz)
 				negative_scale_possible = negative_scale_possible || may_be_negative(value[0]) || may_be_negative(value[1]) || may_be_negative(value[2]);
 		}
 		for (uint32_t a = 0; a < num_animated; ++a)
@@ -748,14 +776,15 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			for (uint32_t c = 0; c < 3; ++c)
 				negative_scale_possible = negative_scale_possible || may_be_negative(range.range_min[c]) || may_be_negative(range.range_min[c] + std::min(range.range_extent[c], 0.0f) * 1.01f);
 			for (uint32_t si = 0; si < num_segments; ++si)
-				negative_scale_possible = negative_scale_possible || (plan[size_t(si) * num_animated + a].bit_offset_and_width >> 24) == 32u;
+				negative_scale_possible = negative_scale_possible || is_raw_width(plan[size_t(si) * num_animated + a].bit_offset_and_width >> 24);
 		}
 	}
 
 	// ---- may the kernels use the SHORT correctly rounded square root / reciprocal on this clip's rotations? (analyze_rotation_values above) ----
-	const rotation_value_facts rotation_facts = analyze_rotation_values(blob, blob_size, header.has_database(), num_tracks, num_samples, num_segments, num_animated, plan, clip_ranges, samples, base_pose);
-	bool short_exact_math = rotation_facts.short_exact_math;
-	const bool raw_rotations = rotation_facts.raw_rotations;
+	const rotation_value_facts rotation_facts = analyze_rotation_values(blob, blob_size, header.has_database(), stripped, num_tracks, num_samples, num_segments, num_animated, plan, clip_ranges, samples, base_pose);
+	// (quatf_full: a stored W is any float, constants included -- nothing the analysis proves about x, y, z bounds the norms)
+	bool short_exact_math = rotation_facts.short_exact_math && !rotations_full;
+	const bool raw_rotations = rotation_facts.raw_rotations || rotations_full;
 	// ACLHIP_SHORT_EXACT_MATH = 0: never (A/B measurements; harmless: the compiler's forms are exact everywhere). = 1: ALWAYS, whatever
 	// the analysis says -- it BREAKS bit exactness on the clips the analysis exists for, so only a lab build (-DACLHIP_LAB_KNOBS:
 	// libaclhip_lab.so, what tests/test_gpu_exact_math.py uses to show the analysis has teeth) listens to it.
@@ -774,7 +803,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	for (uint32_t quad = 0; quad < num_quads; ++quad)
 	{
 		uint32_t* value_bits = reinterpret_cast<uint32_t*>(&resolved_pose[size_t(quad) * 4]);
-		if (int32_t(value_bits[3]) < 0)
+		if (is_special_quad(value_bits[3]))
 			resolved_pose[size_t(quad) * 4 + 3] = (value_bits[3] & (k_quad_animated | k_quad_default_w_one)) == k_quad_default_w_one ? 1.0f : 0.0f;
 	}
 
@@ -891,6 +920,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		record.flags |= negative_scale_possible ? k_clip_negative_scale : 0u;
 		record.flags |= short_exact_math ? k_clip_short_exact_math : 0u;
 		record.flags |= raw_rotations ? k_clip_raw_rotations : 0u;
+		record.flags |= rotations_full ? k_clip_full_rotations : 0u;
 		record.num_segments = num_segments;
 		record.num_animated = num_animated;
 		if (header.has_database())

@@ -594,9 +594,10 @@ namespace
 			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "unsupported track type %u", uint32_t(header.track_type));
 		if (header.num_tracks == 0)
 			return ACLHIP_OK;
-		if (header.rotation_format() != k_rotation_quatf_drop_w_variable || header.translation_format() != k_vector_vector3f_variable
-			|| (header.has_scale() && header.scale_format() != k_vector_vector3f_variable))
-			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "only quatf_drop_w_variable + vector3f_variable are supported (default_transform_decompression_settings)");
+		// every packed format the reference's decoder takes (debug_transform_decompression_settings, decompression_settings.h:236-262):
+		// quatf_full, quatf_drop_w_full, quatf_drop_w_variable; vector3f_full, vector3f_variable (one header bit each: always one of the two)
+		if (header.rotation_format() != k_rotation_quatf_full && header.rotation_format() != k_rotation_quatf_drop_w_full && header.rotation_format() != k_rotation_quatf_drop_w_variable)
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "unknown rotation format %u", uint32_t(header.rotation_format()));
 		if (header.num_samples == 0 || !(header.sample_rate > 0.0f))
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid sample count or rate");
 
@@ -608,18 +609,28 @@ namespace
 		// (64 bit: num_tracks is untrusted, and 0xFFFFFFFF + 15 wraps to 14 -- no sub-track type words at all, the bounds test below passed,
 		// and registration went on to size its tables for 4 G tracks: found with the validators under AddressSanitizer, round 5)
 		const uint64_t num_entries = (uint64_t(header.num_tracks) + 15) / 16;
-		const uint64_t num_rotations_padded = (uint64_t(th.num_animated_rotation_sub_tracks) + 3) & ~uint64_t(3);
+		// Only the VARIABLE formats have per sub-track metadata (a format byte and, in multi segment clips, six range bytes per segment;
+		// a clip range entry): animated_track_cache.transform.h:1254-1300, write_stream_data.h:158-197, write_range_data.h:79-207
+		const bool rotations_variable = header.rotation_format() == k_rotation_quatf_drop_w_variable;
+		const bool translations_variable = header.translation_format() == k_vector_vector3f_variable;
+		const bool scales_variable = header.scale_format() == k_vector_vector3f_variable;
+		const uint64_t num_rotations_padded = rotations_variable ? ((uint64_t(th.num_animated_rotation_sub_tracks) + 3) & ~uint64_t(3)) : 0;
+		const uint64_t num_variable_translations = translations_variable ? th.num_animated_translation_sub_tracks : 0;
+		const uint64_t num_variable_scales = scales_variable ? th.num_animated_scale_sub_tracks : 0;
+		const uint64_t constant_rotation_size = header.rotation_format() == k_rotation_quatf_full ? 16 : 12;		// constant_track_cache.transform.h:102-110
 
 		if (th.num_segments == 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
-		if (uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
+		// (a segment of a clip with stripped keyframes or a database names the keyframes it keeps in 32 bits; any other segment can be of any
+		// length -- a clip in the full formats is never segmented, compress.transform.impl.h:168-176)
+		if (stripped && uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
-		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks)
+		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + num_variable_translations + num_variable_scales)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
 		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
 			|| tbase + th.sub_track_types_offset + num_entries * 4 * (header.has_scale() ? 3 : 2) > blob_size
-			|| tbase + th.constant_track_data_offset + 12ull * (uint64_t(th.num_constant_rotation_samples) + th.num_constant_translation_samples + th.num_constant_scale_samples) > blob_size
-			|| tbase + th.clip_range_data_offset + 24ull * (uint64_t(th.num_animated_rotation_sub_tracks) + th.num_animated_translation_sub_tracks + th.num_animated_scale_sub_tracks) > blob_size)
+			|| tbase + th.constant_track_data_offset + constant_rotation_size * th.num_constant_rotation_samples + 12ull * (uint64_t(th.num_constant_translation_samples) + th.num_constant_scale_samples) > blob_size
+			|| tbase + th.clip_range_data_offset + 24ull * ((rotations_variable ? uint64_t(th.num_animated_rotation_sub_tracks) : 0) + num_variable_translations + num_variable_scales) > blob_size)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Header offsets point outside of the buffer");
 		// (the reference's writer aligns every one of these sections to 4 bytes, and the host reads them as words and floats)
 		if (((th.segment_headers_offset | th.sub_track_types_offset | th.constant_track_data_offset | th.clip_range_data_offset) & 3u) != 0
@@ -650,7 +661,7 @@ namespace
 			// moved to a database) must lie inside the buffer
 			const uint64_t start = th.num_segments > 1 ? segment_start_indices[i] : 0;
 			const uint64_t end = th.num_segments > 1 && i + 1 < th.num_segments ? segment_start_indices[i + 1] : header.num_samples;
-			if (start >= end || end > header.num_samples || end - start > 32)
+			if (start >= end || end > header.num_samples || (stripped && end - start > 32))
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%llu, %llu)", i, static_cast<unsigned long long>(start), static_cast<unsigned long long>(end));
 			if (stripped)
 			{
@@ -666,7 +677,8 @@ namespace
 			}
 			const uint64_t stored = stripped ? uint64_t(__builtin_popcount(reinterpret_cast<const stripped_segment_header&>(sh).sample_indices)) : end - start;
 			const uint64_t animated_end = animated_offset + (uint64_t(sh.animated_pose_bit_size) * stored + 7) / 8;
-			if (animated_end > blob_size)
+			// (a keyframe's bit offset inside its segment is a 32 bit product, here and in the reference: decompression.transform.h:533-534)
+			if (animated_end > blob_size || uint64_t(sh.animated_pose_bit_size) * stored > 0xFFFFFFFFull)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u animated data points outside of the buffer", i);
 			// ... and in front of the next segment's data: the writer lays the segments out one behind the other
 			// (compression/impl/write_segment_data.h), so a segment whose sample range says it stores more keyframes than lie between its

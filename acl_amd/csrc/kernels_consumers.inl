@@ -101,7 +101,7 @@
 		{
 			float4 value = load_quad(clip.base_pose, quad);
 			const uint32_t marker = __float_as_uint(value.w);
-			if (int32_t(marker) < 0)
+			if (is_special_quad(marker))
 			{
 				if ((marker & k_quad_animated) != 0)
 					continue;
@@ -161,7 +161,7 @@
 		{
 			float4 value = load_quad(clip.base_pose, quad);
 			const uint32_t marker = __float_as_uint(value.w);
-			if (int32_t(marker) < 0)
+			if (is_special_quad(marker))
 			{
 				if ((marker & k_quad_animated) != 0)
 					continue;

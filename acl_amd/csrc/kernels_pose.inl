@@ -113,7 +113,7 @@
 	{
 		out_store = true;
 		const uint32_t marker = __float_as_uint(value.w);
-		if (int32_t(marker) >= 0)
+		if (!is_special_quad(marker))
 			return value;
 
 		const uint32_t track_index = quad / 3u;
@@ -254,7 +254,7 @@
 			}
 
 			// the raw bit rate is rare: only a wave that actually meets one (in these two segments) pays for its code path
-			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+			const bool has_raw = __any(int(is_raw_width(plan0.bit_offset_and_width >> 24) || is_raw_width(plan1.bit_offset_and_width >> 24))) != 0;
 
 			float4 value;
 			if (!has_raw)
@@ -418,10 +418,11 @@
 		ACLHIP_PROLOGUE_STAMP(3);
 #endif
 
-		if (kAnySettings && normalization == ACLHIP_NORMALIZE_ALWAYS)
+		if (kAnySettings && normalization == ACLHIP_NORMALIZE_ALWAYS && (clip.flags & k_clip_full_rotations) == 0)
 		{
 			// rotation_normalization_policy_t::always also normalizes CONSTANT rotations (constant_track_cache.transform.h:163-175):
-			// done in the image before the animated sub-tracks (normalized by their decode) replace their markers. Rare (debug
+			// done in the image before the animated sub-tracks (normalized by their decode) replace their markers. Not for quatf_full
+			// clips, whose constants are stored whole and left alone (:136-149). Rare (debug
 			// settings): this path waits for the base pose instead of overlapping it with the decode.
 			__builtin_amdgcn_s_waitcnt(0);
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -431,7 +432,7 @@
 			{
 				// (slots of animated rotations hold a tag, or zeros in the resolved pose: whatever this makes of them is overwritten)
 				const f32x4 value = image[quad];
-				if ((first_quad + quad) % 3u == 0 && int32_t(__float_as_uint(value.w)) >= 0)
+				if ((first_quad + quad) % 3u == 0 && !is_special_quad(__float_as_uint(value.w)))
 				{
 					const float4 normalized = quat_normalize(make_float4(value.x, value.y, value.z, value.w));
 					image[quad] = f32x4{ normalized.x, normalized.y, normalized.z, normalized.w };
@@ -551,7 +552,7 @@
 				// default sub-tracks still carry their tag in the W lane (every other quad holds a real W >= +0 by now) and follow the
 				// default sub-track modes (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310,1653-1680)
 				const uint32_t marker = __float_as_uint(value.w);
-				const bool is_default = int32_t(marker) < 0;
+				const bool is_default = is_special_quad(marker);
 				const uint32_t mode = kind == 0 ? params.default_modes[0] : (kind == 1 ? params.default_modes[1] : params.default_modes[2]);
 				store = store && !(is_default && mode == ACLHIP_DEFAULT_SKIPPED);
 				if (is_default)

@@ -106,14 +106,14 @@
 			float4 value = quads[kind];
 			const uint32_t marker = __float_as_uint(value.w);
 			bool store = true;
-			if (int32_t(marker) < 0 && (marker & k_quad_animated) != 0)
+			if (is_special_quad(marker) && (marker & k_quad_animated) != 0)
 			{
 				out_animated |= 1u << kind;
 				out_ordinals[kind] = marker & k_quad_ordinal_mask;
 			}
-			else if (int32_t(marker) < 0)
+			else if (is_special_quad(marker))
 				value = resolve_quad(params, value, track_index * 3u + kind, store);
-			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0)
+			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0 && (clip.flags & k_clip_full_rotations) == 0)
 				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
 			out_quads[kind] = value;
 			out_store[kind] = store;
@@ -271,7 +271,7 @@
 			key_state.uses_single_segment = false;
 
 			// the raw bit rate is rare: only a wave that actually meets one pays for its code path
-			const bool has_raw = __any(int((plan0.bit_offset_and_width >> 24) == 32u || (plan1.bit_offset_and_width >> 24) == 32u)) != 0;
+			const bool has_raw = __any(int(is_raw_width(plan0.bit_offset_and_width >> 24) || is_raw_width(plan1.bit_offset_and_width >> 24))) != 0;
 			const bool short_exact_math = (request.rows[0] & k_track_row_short_exact_math) != 0;
 			float4 value;
 			if (!has_raw)

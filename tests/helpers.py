@@ -170,3 +170,54 @@ def load_consumer_golden(name):
         blob[:] = case[key]
         case[key] = blob
     return case
+
+
+# ---- the real-compressor corpus (tests/golden/corpus/*.npz, see make_corpus.py) ----
+CORPUS_DIR = os.path.join(GOLDEN_DIR, "corpus")
+CORPUS_DATABASES = ("database", "database_4kb", "database_4kb_mixed", "database_mixed")
+_corpus = {}
+
+
+def _aligned_copy(array):
+    from acl_amd import synth
+    out = synth.aligned_bytes(max(array.size, 1))
+    out[: array.size] = array
+    return out[: array.size] if array.size else out[:0]
+
+
+def load_corpus():
+    """The transform clips the reference's compressor wrote for tests/golden/make_corpus.py: a list of dicts
+    {name, spec, blob (16 byte aligned), parents (int32, -1 = root), bind_pose [num_tracks, 12], bind_is_default}"""
+    import json
+    if "transforms" not in _corpus:
+        data = np.load(os.path.join(CORPUS_DIR, "transforms.npz"))
+        specs = json.loads(str(data["specs"]))
+        blobs, offsets, track_offsets = data["blobs"], data["offsets"], data["track_offsets"]
+        parents, bind_poses, bind_is_default = data["parents"], data["bind_poses"], data["bind_is_default"]
+        clips = []
+        for index, spec in enumerate(specs):
+            first, last = int(track_offsets[index]), int(track_offsets[index + 1])
+            clips.append({"name": spec["name"], "spec": spec, "blob": _aligned_copy(blobs[offsets[index]: offsets[index + 1]]), "parents": parents[first:last].copy(),
+                          "bind_pose": bind_poses[first:last].copy(), "bind_is_default": bool(bind_is_default[index])})
+        _corpus["transforms"] = clips
+    return _corpus["transforms"]
+
+
+def load_corpus_database(name):
+    """One of CORPUS_DATABASES: {clips: [blobs], database, bulk_medium, bulk_low, options}"""
+    import json
+    data = np.load(os.path.join(CORPUS_DIR, f"{name}.npz"))
+    offsets = data["clip_offsets"]
+    return {"clips": [_aligned_copy(data["clips"][offsets[i]: offsets[i + 1]]) for i in range(offsets.size - 1)], "database": _aligned_copy(data["database"]),
+            "bulk_medium": _aligned_copy(data["bulk_medium"]), "bulk_low": _aligned_copy(data["bulk_low"]), "options": json.loads(str(data["options"]))}
+
+
+def corpus_sample_times(blob):
+    """validate_accuracy's sample times (tools/acl_compressor/sources/validate_tracks.cpp:125-129,217-219): min(i / rate, duration) for
+    every sample of the clip, the repeating first sample of a wrapping clip included"""
+    lib = ob.oracle()
+    duration = lib.aclo_finite_duration(blob.ctypes.data, ob.LOOP_AS_COMPRESSED)
+    rate = np.float32(lib.aclo_sample_rate(blob.ctypes.data))
+    num_samples = lib.aclo_calculate_num_samples(ctypes.c_float(duration), ctypes.c_float(rate)) if lib.aclo_num_tracks(blob.ctypes.data) != 0 else 0
+    times = np.minimum(np.arange(num_samples, dtype=np.float32) / rate, np.float32(duration)).astype(np.float32)
+    return times, float(duration)

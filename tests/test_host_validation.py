@@ -52,8 +52,12 @@ def test_targeted_corruptions_are_refused_with_a_reason():
     assert runtime.check_clip(_patched(blob, 40, "<I", 1))[1] == "Invalid hash"
     status, message = runtime.check_clip(_patched(blob, 15, "<B", 7), check_hash=False)         # track type: not qvvf, not scalar
     assert status == 3 and "track type" in message
-    status, message = runtime.check_clip(_patched(blob, 28, "<I", 0), check_hash=False)         # formats: quatf_full + vector3f_full
-    assert status == 3
+    # formats rewritten to quatf_full + vector3f_full on a clip laid out for the variable ones: the sections no longer add up (since round 6
+    # the full formats themselves register: tests/test_gpu_corpus.py)
+    assert runtime.check_clip(_patched(blob, 28, "<I", 0), check_hash=False)[0] == 2
+    misc_packed = int(np.frombuffer(bytes(blob[28:32]), dtype=np.uint32)[0])
+    status, message = runtime.check_clip(_patched(blob, 28, "<I", (misc_packed & ~0xF0) | (1 << 4)), check_hash=False)      # rotation_format8 1: no such format
+    assert status == 3 and "rotation format" in message
     assert runtime.check_clip(_patched(blob, 32, "<I", 0), check_hash=False)[0] != 0            # no segments
     assert runtime.check_clip(_patched(blob, 32 + 36, "<I", 0x7FFFFFF0), check_hash=False)[0] != 0      # segment headers offset
     assert runtime.check_clip(_patched(blob, 32 + 4, "<I", 9999), check_hash=False)[0] != 0     # animated sub-track count
