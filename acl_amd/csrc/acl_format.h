@@ -144,6 +144,17 @@ namespace aclhip
 			: (track_type == k_track_type_float4f || track_type == k_track_type_vector4f) ? 4u : 0u;
 	}
 
+	// Optional metadata, the LAST 20 bytes of a blob whose header says has_metadata (core/impl/compressed_headers.h:367-393,
+	// compressed_tracks.impl.h:62-65); every offset is from the START of the blob, 0xFFFFFFFF = not stored
+	struct optional_metadata_header
+	{
+		uint32_t track_list_name;
+		uint32_t track_name_offsets;
+		uint32_t parent_track_indices;		// u32[num_tracks], 0xFFFFFFFF = no parent
+		uint32_t track_descriptions;		// transform tracks: 5 / 15 / 12 floats per track for v02_00 / v02_01_99 / later (compressed_tracks.impl.h:237-271)
+		uint32_t contributing_error;
+	};
+
 	struct tracks_database_header
 	{
 		uint32_t clip_header_offset;		// into the database's runtime clip/segment header block

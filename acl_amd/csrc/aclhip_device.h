@@ -195,6 +195,16 @@ namespace aclhip
 	}
 	__host__ __device__ __forceinline__ uint32_t window_spans_word_offset(uint32_t num_windows) { return (num_windows + 1u + 7u) & ~7u; }
 
+	// Behind a clip's resolved pose: the same pose as 10 packed floats per track (what the QVV40 layout starts from), then the clip's
+	// BIND POSE, 12 floats per track (rotation xyzw | translation xyz 0 | scale xyz 0) -- track_desc_transformf::default_value of every
+	// track from the blob's optional track descriptions, the identity when it carries none: what ACLHIP_DEFAULT_BIND_POSE resolves
+	// default sub-tracks to. No pointer of its own: the 128 byte clip record is full.
+	__host__ __device__ __forceinline__ uint32_t resolved_qvv40_floats(uint32_t num_tracks) { return (num_tracks * 10u + 3u) / 4u * 4u + 4u; }
+	__device__ __forceinline__ const float* bind_pose_of(const device_clip& clip)
+	{
+		return reinterpret_cast<const float*>(clip.resolved_pose + size_t(clip.num_tracks) * 3u) + resolved_qvv40_floats(clip.num_tracks);
+	}
+
 	// LDS bytes that staging a run of `bits` keyframe bits takes: whole 16 byte pieces of the bitstream from the piece that holds the
 	// run's first bit (the keyframe may start at any bit of any byte) to the piece that holds its last one, plus one piece of slack for
 	// the 64 bit windows lanes read

@@ -339,6 +339,62 @@ namespace
 	}
 }
 
+namespace
+{
+	// The optional metadata behind a transform clip's compressed data (optional_metadata_header, acl_format.h): which sections the blob
+	// stores, its parent indices (compressed_tracks::get_parent_track_index, core/impl/compressed_tracks.impl.h:175-190) and track
+	// descriptions (get_track_description, :214-275) as [num_tracks][14] = default_value (12 floats, a row of default_values) | precision |
+	// shell_distance. A section whose offset does not keep it inside the blob counts as not stored: the decode never reads any of this.
+	void parse_clip_metadata(const uint8_t* blob, uint32_t blob_size, const tracks_header& header, aclhip_clip_metadata_info& out_info, std::vector<uint32_t>& out_parents, std::vector<float>& out_descriptions)
+	{
+		out_info = {};
+		out_parents.clear();
+		out_descriptions.clear();
+		if (!header.has_metadata() || blob_size < k_transform_header_offset + sizeof(optional_metadata_header))
+			return;
+		out_info.has_metadata = 1;
+		optional_metadata_header metadata;
+		std::memcpy(&metadata, blob + blob_size - sizeof(metadata), sizeof(metadata));
+		const uint64_t limit = blob_size - sizeof(metadata);
+		const uint32_t num_tracks = header.num_tracks;
+		const auto inside = [&](uint32_t offset, uint64_t bytes, uint32_t alignment) { return offset != k_invalid_offset && offset % alignment == 0 && uint64_t(offset) + bytes <= limit; };
+
+		out_info.has_track_list_name = inside(metadata.track_list_name, 1, 1) ? 1 : 0;
+		out_info.has_track_names = inside(metadata.track_name_offsets, uint64_t(num_tracks) * 4, 4) ? 1 : 0;
+		out_info.has_contributing_error = inside(metadata.contributing_error, 1, 1) ? 1 : 0;
+		if (inside(metadata.parent_track_indices, uint64_t(num_tracks) * 4, 4))
+		{
+			out_info.has_parent_track_indices = 1;
+			out_parents.resize(num_tracks);
+			if (num_tracks != 0)
+				std::memcpy(out_parents.data(), blob + metadata.parent_track_indices, size_t(num_tracks) * 4);
+		}
+		// transform descriptions: precision, shell_distance, [3 constant thresholds, v02_00 .. v02_01_99], [default_value: 10 floats, from v02_01_99 on]
+		const uint32_t floats = 5u + (header.version >= k_version_v02_01_99 ? 10u : 0u) - (header.version >= k_version_v02_01_99_1 ? 3u : 0u);
+		if (header.track_type == k_track_type_qvvf && out_info.has_parent_track_indices != 0 && inside(metadata.track_descriptions, uint64_t(num_tracks) * floats * 4, 4))
+		{
+			out_info.has_track_descriptions = 1;
+			out_descriptions.assign(size_t(num_tracks) * 14, 0.0f);
+			for (uint32_t track = 0; track < num_tracks; ++track)
+			{
+				float data[15];
+				std::memcpy(data, blob + metadata.track_descriptions + size_t(track) * floats * 4, size_t(floats) * 4);
+				float* row = &out_descriptions[size_t(track) * 14];
+				row[3] = 1.0f; row[8] = 1.0f; row[9] = 1.0f; row[10] = 1.0f;		// qvv_identity (before v02_01_99 there is no default_value)
+				if (header.version >= k_version_v02_01_99)
+				{
+					const float* value = data + 2 + (header.version < k_version_v02_01_99_1 ? 3 : 0);
+					std::memcpy(row + 0, value + 0, 16);		// rotation xyzw
+					std::memcpy(row + 4, value + 4, 12);		// translation xyz
+					std::memcpy(row + 8, value + 7, 12);		// scale xyz
+				}
+				row[12] = data[0];
+				row[13] = data[1];
+			}
+		}
+	}
+}
+
 static aclhip_status register_clip_impl(aclhip_context* context, const void* compressed_tracks, uint64_t size, int check_hash, aclhip_database database, aclhip_clip* out_clip,
 	bool validate_only = false, uint32_t* out_facts = nullptr)
 {
@@ -820,7 +876,29 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 		std::memcpy(packed + 4, record + 4, 12);
 		std::memcpy(packed + 7, record + 8, 12);
 	}
-	const uint64_t samples_offset = (resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float) + 31) & ~uint64_t(31);
+	// ... and behind that the clip's bind pose, 12 floats per track (bind_pose_of, aclhip_device.h): ACLHIP_DEFAULT_BIND_POSE
+	aclhip_clip_metadata_info metadata_info;
+	std::vector<uint32_t> metadata_parents;
+	std::vector<float> metadata_descriptions;
+	parse_clip_metadata(blob, blob_size, header, metadata_info, metadata_parents, metadata_descriptions);
+	static_assert(sizeof(float) == 4, "layout");
+	if (resolved_qvv40.size() != resolved_qvv40_floats(num_tracks))
+		return fail(context, ACLHIP_ERROR_DEVICE, "internal: packed pose size");
+	const uint64_t bind_pose_offset = resolved_qvv40_offset + resolved_qvv40.size() * sizeof(float);
+	std::vector<float> bind_pose(std::max<size_t>(size_t(num_tracks) * 12, 4), 0.0f);
+	for (uint32_t track = 0; track < num_tracks; ++track)
+	{
+		float* row = &bind_pose[size_t(track) * 12];
+		if (metadata_info.has_track_descriptions != 0)
+			std::memcpy(row, &metadata_descriptions[size_t(track) * 14], 48);
+		else
+		{
+			row[3] = 1.0f; row[8] = 1.0f; row[9] = 1.0f; row[10] = 1.0f;		// track_desc_transformf::default_value = qvv_identity (core/track_desc.h:103)
+		}
+		row[7] = 0.0f;
+		row[11] = 0.0f;
+	}
+	const uint64_t samples_offset = (bind_pose_offset + bind_pose.size() * sizeof(float) + 31) & ~uint64_t(31);
 	// clips bound to a database carry a copy of their segments' tier metadata per sample (database_sample_record; zero = not resident
 	// until refresh_database_sample_tiers_kernel has run for the clip, below)
 	const bool database_samples = database != ACLHIP_INVALID_HANDLE && num_tracks != 0 && header.has_database();
@@ -844,6 +922,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	if (num_quads != 0)
 		std::memcpy(staging.data() + resolved_pose_offset, resolved_pose.data(), size_t(num_quads) * 16);
 	std::memcpy(staging.data() + resolved_qvv40_offset, resolved_qvv40.data(), resolved_qvv40.size() * sizeof(float));
+	std::memcpy(staging.data() + bind_pose_offset, bind_pose.data(), bind_pose.size() * sizeof(float));
 	if (database_samples)
 		for (size_t sample = 0; sample < samples.size(); ++sample)
 			std::memcpy(staging.data() + samples_offset + sample * sizeof(database_sample_record), &samples[sample], sizeof(sample_record));		// (tier metadata: the staging bytes are zero)
@@ -1057,6 +1136,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	context->max_window_animated = std::max(context->max_window_animated, window_animated_max);
 	context->max_window_key_bytes = std::max(context->max_window_key_bytes, window_key_bytes_max);
 #endif
+	entry.metadata = metadata_info;
+	entry.metadata_parents = std::move(metadata_parents);
+	entry.metadata_descriptions = std::move(metadata_descriptions);
 	entry.scaled = num_tracks != 0 && (has_scale || float(header.default_scale()) != 1.0f);
 	context->num_scaled_clips += entry.scaled ? 1u : 0u;
 	entry.negative_scale = negative_scale_possible;

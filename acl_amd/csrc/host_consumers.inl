@@ -116,6 +116,25 @@ extern "C" aclhip_status aclhip_plan_hierarchy_walk(const uint32_t* parent_indic
 	});
 }
 
+extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks);
+
+// aclhip_set_clip_hierarchy with the parent indices the blob carried (read at registration: parse_clip_metadata)
+extern "C" aclhip_status aclhip_set_clip_hierarchy_from_metadata(aclhip_context* context, aclhip_clip clip)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::vector<uint32_t> parents;
+	{
+		std::shared_lock<std::shared_mutex> lock(context->mutex);
+		if (clip >= context->clips.size() || !context->clips[clip].in_use)
+			return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+		if (context->clips[clip].metadata.has_parent_track_indices == 0)
+			return fail(context, ACLHIP_ERROR_NO_METADATA, "clip %u was compressed without include_parent_track_indices: pass the hierarchy to aclhip_set_clip_hierarchy", clip);
+		parents = context->clips[clip].metadata_parents;
+	}
+	return aclhip_set_clip_hierarchy(context, clip, parents.data(), uint32_t(parents.size()));
+}
+
 extern "C" aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks)
 {
 	if (context == nullptr)

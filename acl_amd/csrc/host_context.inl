@@ -19,6 +19,10 @@ namespace
 		bool negative_scale = false;		// some scale sub-track may decode a negative component (mirrored rigs): rtm::qvv_mul then goes through matrices
 		bool wide_scalar = false;			// scalar track list of more than one float per track
 		uint32_t db_first_segment_header = 0, db_num_segments = 0;	// bound to a streamed database: its runtime segment headers (host_database::segment_pose_bits)
+		// the blob's optional metadata, read at registration (parse_clip_metadata, host_clips.inl)
+		aclhip_clip_metadata_info metadata = {};
+		std::vector<uint32_t> metadata_parents;			// [num_tracks] when has_parent_track_indices
+		std::vector<float> metadata_descriptions;		// [num_tracks][14]: default_value as 12 floats, precision, shell_distance, when has_track_descriptions
 	};
 }
 
@@ -623,6 +627,9 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
 		// (a segment of a clip with stripped keyframes or a database names the keyframes it keeps in 32 bits; any other segment can be of any
 		// length -- a clip in the full formats is never segmented, compress.transform.impl.h:168-176)
+		// (registration keeps 16 bytes per sample: a blob without animated sub-tracks could otherwise name any count -- 2^24 samples are 155 hours at 30 Hz)
+		if (header.num_samples > (1u << 24))
+			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "%u samples: clips of more than 16 777 216 samples are not supported", header.num_samples);
 		if (stripped && uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
 		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + num_variable_translations + num_variable_scales)
@@ -783,7 +790,8 @@ namespace
 
 		if (params->rounding_policy > ACLHIP_ROUND_PER_TRACK || params->looping_policy > ACLHIP_LOOP_AS_COMPRESSED || params->normalization > ACLHIP_NORMALIZE_ALWAYS)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid rounding / looping / normalization policy");
-		if (params->default_rotation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_translation_mode > ACLHIP_DEFAULT_VARIABLE || params->default_scale_mode > ACLHIP_DEFAULT_LEGACY)
+		const auto valid_mode = [](uint32_t mode, bool scale) { return mode <= ACLHIP_DEFAULT_VARIABLE || mode == ACLHIP_DEFAULT_BIND_POSE || (scale && mode == ACLHIP_DEFAULT_LEGACY); };
+		if (!valid_mode(params->default_rotation_mode, false) || !valid_mode(params->default_translation_mode, false) || !valid_mode(params->default_scale_mode, true))
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "invalid default sub-track mode (legacy is only valid for scale)");
 		if (params->rounding_policy == ACLHIP_ROUND_PER_TRACK && params->per_track_rounding == 0)
 			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "sample_rounding_policy::per_track needs per_track_rounding enabled (decompression_settings::is_per_track_rounding_supported)");
@@ -843,6 +851,7 @@ extern "C" const char* aclhip_status_string(aclhip_status status)
 	case ACLHIP_ERROR_NO_DEVICE: return "no HIP device";
 	case ACLHIP_ERROR_UNKNOWN_DATABASE: return "unknown database handle";
 	case ACLHIP_ERROR_NOT_IN_DATABASE: return "clip is not contained in the database";
+	case ACLHIP_ERROR_NO_METADATA: return "the clip does not carry that optional metadata";
 	}
 	return "unknown status";
 }

@@ -585,6 +585,102 @@ extern "C" aclhip_status aclhip_get_clip_info(const aclhip_context* context, acl
 	return ACLHIP_OK;
 }
 
+// Host only: compressed_tracks::get_parent_track_index / get_track_description on a blob that need not be registered
+extern "C" aclhip_status aclhip_read_clip_metadata(const void* compressed_tracks, uint64_t size, aclhip_clip_metadata_info* out_info, uint32_t* out_parent_indices,
+	float* out_default_values, float* out_precisions, float* out_shell_distances, uint32_t capacity)
+{
+	if (compressed_tracks == nullptr || out_info == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	try
+	{
+		const uint8_t* blob = static_cast<const uint8_t*>(compressed_tracks);
+		const aclhip_status status = validate_clip(nullptr, blob, size, 0);
+		if (status != ACLHIP_OK)
+			return status;
+		const raw_buffer_header& buffer_header = *reinterpret_cast<const raw_buffer_header*>(blob);
+		const tracks_header& header = *reinterpret_cast<const tracks_header*>(blob + k_tracks_header_offset);
+		std::vector<uint32_t> parents;
+		std::vector<float> descriptions;
+		parse_clip_metadata(blob, buffer_header.size, header, *out_info, parents, descriptions);
+		if ((out_parent_indices != nullptr && out_info->has_parent_track_indices != 0) || ((out_default_values != nullptr || out_precisions != nullptr || out_shell_distances != nullptr) && out_info->has_track_descriptions != 0))
+			if (capacity < header.num_tracks)
+				return fail(nullptr, ACLHIP_ERROR_INVALID_ARGUMENT, "room for %u tracks, the clip has %u", capacity, header.num_tracks);
+		if (out_parent_indices != nullptr && !parents.empty())
+			std::memcpy(out_parent_indices, parents.data(), parents.size() * sizeof(uint32_t));
+		for (size_t track = 0; track < descriptions.size() / 14; ++track)
+		{
+			const float* row = &descriptions[track * 14];
+			if (out_default_values != nullptr)
+				std::memcpy(out_default_values + track * 12, row, 48);
+			if (out_precisions != nullptr)
+				out_precisions[track] = row[12];
+			if (out_shell_distances != nullptr)
+				out_shell_distances[track] = row[13];
+		}
+		return ACLHIP_OK;
+	}
+	catch (const std::bad_alloc&)
+	{
+		return ACLHIP_ERROR_OUT_OF_MEMORY;
+	}
+}
+
+extern "C" aclhip_status aclhip_get_clip_metadata_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_metadata_info* out_info)
+{
+	if (context == nullptr || out_info == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	*out_info = context->clips[clip].metadata;
+	return ACLHIP_OK;
+}
+
+// compressed_tracks::get_parent_track_index (core/impl/compressed_tracks.impl.h:175-190) for every track
+extern "C" aclhip_status aclhip_get_clip_parent_indices(const aclhip_context* context, aclhip_clip clip, uint32_t* out_parent_indices, uint32_t capacity)
+{
+	if (context == nullptr || (out_parent_indices == nullptr && capacity != 0))
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	const host_clip& entry = context->clips[clip];
+	if (entry.metadata.has_parent_track_indices == 0)
+		return fail(context, ACLHIP_ERROR_NO_METADATA, "clip %u was compressed without include_parent_track_indices", clip);
+	if (capacity < entry.metadata_parents.size())
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "room for %u parent indices, the clip has %zu tracks", capacity, entry.metadata_parents.size());
+	if (!entry.metadata_parents.empty())
+		std::memcpy(out_parent_indices, entry.metadata_parents.data(), entry.metadata_parents.size() * sizeof(uint32_t));
+	return ACLHIP_OK;
+}
+
+// compressed_tracks::get_track_description(track, track_desc_transformf&) (core/impl/compressed_tracks.impl.h:214-275) for every track
+extern "C" aclhip_status aclhip_get_clip_track_descriptions(const aclhip_context* context, aclhip_clip clip, float* out_default_values, float* out_precisions, float* out_shell_distances, uint32_t capacity)
+{
+	if (context == nullptr)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	std::lock_guard<std::shared_mutex> lock(const_cast<aclhip_context*>(context)->mutex);
+	if (clip >= context->clips.size() || !context->clips[clip].in_use)
+		return fail(context, ACLHIP_ERROR_UNKNOWN_CLIP, "unknown clip handle %u", clip);
+	const host_clip& entry = context->clips[clip];
+	if (entry.metadata.has_track_descriptions == 0)
+		return fail(context, ACLHIP_ERROR_NO_METADATA, "clip %u was compressed without include_track_descriptions", clip);
+	const size_t num_tracks = entry.metadata_descriptions.size() / 14;
+	if (capacity < num_tracks)
+		return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "room for %u track descriptions, the clip has %zu tracks", capacity, num_tracks);
+	for (size_t track = 0; track < num_tracks; ++track)
+	{
+		const float* row = &entry.metadata_descriptions[track * 14];
+		if (out_default_values != nullptr)
+			std::memcpy(out_default_values + track * 12, row, 48);
+		if (out_precisions != nullptr)
+			out_precisions[track] = row[12];
+		if (out_shell_distances != nullptr)
+			out_shell_distances[track] = row[13];
+	}
+	return ACLHIP_OK;
+}
+
 extern "C" aclhip_status aclhip_clip_matches(const aclhip_context* context, aclhip_clip clip, const void* compressed_tracks, int* out_matches)
 {
 	if (context == nullptr || compressed_tracks == nullptr || out_matches == nullptr)

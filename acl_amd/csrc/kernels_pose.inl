@@ -30,11 +30,17 @@
 
 	// Value of a default sub-track (unpack_default_*_sub_tracks, decompression.transform.h:575-675,883-985,1203-1310, and the
 	// "no scale" loop :1653-1680). `identity` is the track_writer default for the kind (identity / zero / legacy scale).
-	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 identity, bool& out_store)
+	__device__ __forceinline__ float4 default_quad(const decode_params& params, uint32_t kind, uint32_t track_index, float4 identity, bool& out_store, const float* clip_bind_pose)
 	{
 		const uint32_t mode = params.default_modes[kind];
 		out_store = mode != ACLHIP_DEFAULT_SKIPPED;
 
+		if (mode == ACLHIP_DEFAULT_BIND_POSE)
+		{
+			// the clip's own table (aclhip_device.h: bind_pose_of)
+			const float* src = clip_bind_pose + size_t(track_index) * 12 + kind * 4;
+			return make_float4(src[0], src[1], src[2], kind == 0 ? src[3] : 0.0f);
+		}
 		if (params.default_values != nullptr && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
 		{
 			const float* src = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
@@ -109,7 +115,7 @@
 
 	// What the any-settings pose kernel stores for a quad of the LDS image: default sub-tracks -- still tagged in their W lane, every
 	// other quad holds a real W >= +0 by now -- follow the default sub-track modes, the rest passes through.
-	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, bool& out_store)
+	__device__ __forceinline__ float4 resolve_quad(const decode_params& params, float4 value, uint32_t quad, bool& out_store, const float* clip_bind_pose)
 	{
 		out_store = true;
 		const uint32_t marker = __float_as_uint(value.w);
@@ -119,7 +125,7 @@
 		const uint32_t track_index = quad / 3u;
 		const uint32_t kind = quad - track_index * 3u;
 		value.w = (marker & k_quad_default_w_one) != 0 ? 1.0f : 0.0f;
-		return default_quad(params, kind, track_index, value, out_store);
+		return default_quad(params, kind, track_index, value, out_store, clip_bind_pose);
 	}
 
 	// Where the tables of a pose window's animated sub-tracks are
@@ -540,7 +546,9 @@
 		const uint32_t lane_quad = first_quad + lane;
 		const uint32_t lane_track = lane_quad / 3u;
 		uint32_t kind = lane_quad - lane_track * 3u;
-		const bool user_defaults = kAnySettings && params.default_values != nullptr;		// wave uniform
+		const bool bind_pose_defaults = kAnySettings && (params.default_modes[0] == ACLHIP_DEFAULT_BIND_POSE || params.default_modes[1] == ACLHIP_DEFAULT_BIND_POSE || params.default_modes[2] == ACLHIP_DEFAULT_BIND_POSE);
+		const bool user_defaults = kAnySettings && (params.default_values != nullptr || bind_pose_defaults);		// wave uniform
+		const float* clip_bind_pose = bind_pose_defaults ? bind_pose_of(clip) : nullptr;
 
 		#pragma unroll
 		for (uint32_t r = 0; r < k_rows; ++r)
@@ -562,10 +570,11 @@
 					if (kind == 2 && mode != ACLHIP_DEFAULT_LEGACY)
 						value = f32x4{ 1.0f, 1.0f, 1.0f, 0.0f };		// track_writer::get_constant_default_scale (core/track_writer.h:169)
 				}
-				if (user_defaults && is_default && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE))
+				if (user_defaults && is_default && ((params.default_values != nullptr && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE)) || mode == ACLHIP_DEFAULT_BIND_POSE))
 				{
 					const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
-					const float* source = params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+					const float* source = mode == ACLHIP_DEFAULT_BIND_POSE ? clip_bind_pose + size_t(track_index) * 12 + kind * 4
+						: params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
 					value = f32x4{ source[0], source[1], source[2], kind == 0 ? source[3] : 0.0f };
 				}
 			}

@@ -112,7 +112,7 @@
 				out_ordinals[kind] = marker & k_quad_ordinal_mask;
 			}
 			else if (is_special_quad(marker))
-				value = resolve_quad(params, value, track_index * 3u + kind, store);
+				value = resolve_quad(params, value, track_index * 3u + kind, store, bind_pose_of(clip));
 			else if (params.normalization == ACLHIP_NORMALIZE_ALWAYS && kind == 0 && (clip.flags & k_clip_full_rotations) == 0)
 				value = quat_normalize(value);		// constant_track_cache.transform.h:163-175
 			out_quads[kind] = value;

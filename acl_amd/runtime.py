@@ -17,10 +17,10 @@ _LIB_PATH = os.environ.get("ACLHIP_LIBRARY") or os.path.join(os.path.dirname(os.
 ROUND_NONE, ROUND_FLOOR, ROUND_CEIL, ROUND_NEAREST, ROUND_PER_TRACK = 0, 1, 2, 3, 4
 LOOP_CLAMP, LOOP_WRAP, LOOP_AS_COMPRESSED = 0, 1, 2
 NORMALIZE_NEVER, NORMALIZE_LERP_ONLY, NORMALIZE_ALWAYS = 0, 1, 2
-DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY = 0, 1, 2, 3
+DEFAULT_SKIPPED, DEFAULT_CONSTANT, DEFAULT_VARIABLE, DEFAULT_LEGACY, DEFAULT_BIND_POSE = 0, 1, 2, 3, 4
 # aclhip_status
 (OK, ERROR_INVALID_ARGUMENT, ERROR_INVALID_CLIP, ERROR_UNSUPPORTED_FORMAT, ERROR_UNKNOWN_CLIP, ERROR_OUT_OF_MEMORY, ERROR_DEVICE, ERROR_NO_DEVICE,
- ERROR_UNKNOWN_DATABASE, ERROR_NOT_IN_DATABASE) = range(10)
+ ERROR_UNKNOWN_DATABASE, ERROR_NOT_IN_DATABASE, ERROR_NO_METADATA) = range(11)
 INVALID_HANDLE = 0xFFFFFFFF
 
 EXPORTED_SYMBOLS = [
@@ -40,6 +40,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_decompress_tracks_list", "aclhip_instance_list_get_order", "aclhip_instance_list_attach", "aclhip_instance_list_note_changes",
     "aclhip_strip_database_tier", "aclhip_plan_hierarchy_walk", "aclhip_set_clip_hierarchy", "aclhip_decompress_poses_batch", "aclhip_decompress_poses_host", "aclhip_time_decompress_poses_batch",
     "aclhip_pose_windows_of_launch", "aclhip_order_instances_device_for_windows", "aclhip_describe_tracks_launch", "aclhip_analyze_clip",
+    "aclhip_get_clip_metadata_info", "aclhip_get_clip_parent_indices", "aclhip_get_clip_track_descriptions", "aclhip_set_clip_hierarchy_from_metadata", "aclhip_read_clip_metadata",
 ]
 
 
@@ -73,7 +74,7 @@ class OutputDesc(ctypes.Structure):
     ]
 
 
-ABI_VERSION = 5             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
+ABI_VERSION = 6             # ACLHIP_ABI_VERSION: the struct layouts mirrored above
 PEER_HANDLE_BYTES = 72      # ACLHIP_PEER_HANDLE_BYTES
 LAYOUT_QVV48, LAYOUT_QVV40, LAYOUT_QV32 = 0, 1, 2  # aclhip_pose_layout
 LAYOUTS = {"qvv48": (LAYOUT_QVV48, 48), "qvv40": (LAYOUT_QVV40, 40), "qv32": (LAYOUT_QV32, 32)}     # name -> (aclhip_pose_layout, bytes per track)
@@ -108,6 +109,12 @@ class ClipInfo(ctypes.Structure):
         ("hash", ctypes.c_uint32), ("num_animated_sub_tracks", ctypes.c_uint32), ("has_database", ctypes.c_uint32), ("has_stripped_keyframes", ctypes.c_uint32),
         ("track_type", ctypes.c_uint32), ("num_components", ctypes.c_uint32),
     ]
+
+
+class ClipMetadataInfo(ctypes.Structure):
+    """aclhip_clip_metadata_info"""
+    _fields_ = [("has_metadata", ctypes.c_uint32), ("has_parent_track_indices", ctypes.c_uint32), ("has_track_descriptions", ctypes.c_uint32),
+                ("has_track_names", ctypes.c_uint32), ("has_track_list_name", ctypes.c_uint32), ("has_contributing_error", ctypes.c_uint32)]
 
 
 class DatabaseInfo(ctypes.Structure):
@@ -221,6 +228,11 @@ def load_library():
     lib.aclhip_pose_windows_of_launch.argtypes = [vp, u32, u64, ctypes.POINTER(u32)]
     lib.aclhip_order_instances_device_for_windows.argtypes = [vp, u32, vp, vp, u32, vp, vp, vp, vp]
     lib.aclhip_describe_tracks_launch.argtypes = [vp, pparams, poutput, u64, ctypes.c_char_p, u32, ctypes.POINTER(u32)]
+    lib.aclhip_get_clip_metadata_info.argtypes = [vp, u32, ctypes.POINTER(ClipMetadataInfo)]
+    lib.aclhip_get_clip_parent_indices.argtypes = [vp, u32, vp, u32]
+    lib.aclhip_get_clip_track_descriptions.argtypes = [vp, u32, vp, vp, vp, u32]
+    lib.aclhip_set_clip_hierarchy_from_metadata.argtypes = [vp, u32]
+    lib.aclhip_read_clip_metadata.argtypes = [vp, u64, ctypes.POINTER(ClipMetadataInfo), vp, vp, vp, vp, u32]
     _lib = lib
     return lib
 
@@ -244,6 +256,20 @@ def check_clip(blob, check_hash=True):
 
 
 CLIP_FACT_SHORT_EXACT_MATH, CLIP_FACT_RAW_ROTATIONS, CLIP_FACT_NEGATIVE_SCALE = 1, 2, 4
+
+
+def read_clip_metadata(blob):
+    """aclhip_read_clip_metadata (host only): (ClipMetadataInfo, parents or None, (default_values [n, 12], precisions, shell_distances) or None)"""
+    lib = load_library()
+    num_tracks = int(np.frombuffer(bytes(blob[16:20]), dtype=np.uint32)[0])
+    info = ClipMetadataInfo()
+    parents = np.zeros(max(num_tracks, 1), dtype=np.uint32)
+    defaults, precisions, shells = np.zeros((max(num_tracks, 1), 12), dtype=np.float32), np.zeros(max(num_tracks, 1), dtype=np.float32), np.zeros(max(num_tracks, 1), dtype=np.float32)
+    status = lib.aclhip_read_clip_metadata(blob.ctypes.data, blob.size, ctypes.byref(info), parents.ctypes.data, defaults.ctypes.data, precisions.ctypes.data, shells.ctypes.data, max(num_tracks, 1))
+    if status != 0:
+        raise AclHipError(status, lib.aclhip_last_error_message(None).decode())
+    return (info, parents[:num_tracks] if info.has_parent_track_indices else None,
+            (defaults[:num_tracks], precisions[:num_tracks], shells[:num_tracks]) if info.has_track_descriptions else None)
 
 
 def analyze_clip(blob, check_hash=True):
@@ -402,6 +428,27 @@ class Context:
         info = ClipInfo()
         self._check(self._lib.aclhip_get_clip_info(self._handle, clip, ctypes.byref(info)))
         return info
+
+    def clip_metadata_info(self, clip):
+        info = ClipMetadataInfo()
+        self._check(self._lib.aclhip_get_clip_metadata_info(self._handle, clip, ctypes.byref(info)))
+        return info
+
+    def clip_parent_indices(self, clip):
+        """compressed_tracks::get_parent_track_index of every track (NO_PARENT for roots); AclHipError(ERROR_NO_METADATA) when not stored"""
+        parents = np.zeros(self.clip_info(clip).num_tracks, dtype=np.uint32)
+        self._check(self._lib.aclhip_get_clip_parent_indices(self._handle, clip, parents.ctypes.data, parents.size))
+        return parents
+
+    def clip_track_descriptions(self, clip):
+        """(default_values [num_tracks, 12], precisions, shell_distances) from the blob's track descriptions"""
+        num_tracks = self.clip_info(clip).num_tracks
+        defaults, precisions, shells = np.zeros((num_tracks, 12), dtype=np.float32), np.zeros(num_tracks, dtype=np.float32), np.zeros(num_tracks, dtype=np.float32)
+        self._check(self._lib.aclhip_get_clip_track_descriptions(self._handle, clip, defaults.ctypes.data, precisions.ctypes.data, shells.ctypes.data, num_tracks))
+        return defaults, precisions, shells
+
+    def set_clip_hierarchy_from_metadata(self, clip):
+        self._check(self._lib.aclhip_set_clip_hierarchy_from_metadata(self._handle, clip))
 
     def clip_matches(self, clip, blob):
         matches = ctypes.c_int(0)

@@ -32,13 +32,14 @@ typedef enum aclhip_status
 	ACLHIP_OK = 0,
 	ACLHIP_ERROR_INVALID_ARGUMENT = 1,
 	ACLHIP_ERROR_INVALID_CLIP = 2,			/* compressed_tracks::is_valid() would fail (core/impl/compressed_tracks.impl.h:278-301) */
-	ACLHIP_ERROR_UNSUPPORTED_FORMAT = 3,	/* a transform clip that is not quatf_drop_w_variable + vector3f_variable, an unknown track type */
+	ACLHIP_ERROR_UNSUPPORTED_FORMAT = 3,	/* an unknown track type or rotation format; tables beyond the limits registration states */
 	ACLHIP_ERROR_UNKNOWN_CLIP = 4,
 	ACLHIP_ERROR_OUT_OF_MEMORY = 5,
 	ACLHIP_ERROR_DEVICE = 6,				/* a HIP call failed, see aclhip_last_error_message */
 	ACLHIP_ERROR_NO_DEVICE = 7,
 	ACLHIP_ERROR_UNKNOWN_DATABASE = 8,
-	ACLHIP_ERROR_NOT_IN_DATABASE = 9
+	ACLHIP_ERROR_NOT_IN_DATABASE = 9,
+	ACLHIP_ERROR_NO_METADATA = 10			/* the blob does not carry the optional metadata that was asked for */
 } aclhip_status;
 
 /* acl::sample_rounding_policy (core/sample_rounding_policy.h) */
@@ -73,7 +74,11 @@ typedef enum aclhip_default_mode
 	ACLHIP_DEFAULT_SKIPPED = 0,				/* default sub-tracks are not written, the caller pre-filled the pose buffer */
 	ACLHIP_DEFAULT_CONSTANT = 1,			/* one value for every default sub-track (identity / 0 / 1 when no value is given) */
 	ACLHIP_DEFAULT_VARIABLE = 2,			/* per track value, e.g. the bind pose */
-	ACLHIP_DEFAULT_LEGACY = 3				/* scale only: the clip's default scale bit (ACL 2.0 behaviour) */
+	ACLHIP_DEFAULT_LEGACY = 3,				/* scale only: the clip's default scale bit (ACL 2.0 behaviour) */
+	ACLHIP_DEFAULT_BIND_POSE = 4			/* not in the reference: variable, with every clip's OWN table -- track_desc_transformf::default_value of each track,
+											 * read from the blob's optional track descriptions at registration (compressed_tracks::get_track_description,
+											 * core/impl/compressed_tracks.impl.h:214-275); the identity for clips that carry none. What a caller of the
+											 * reference does by hand: get_track_description() per track into a debug_track_writer_variable_defaults */
 } aclhip_default_mode;
 
 typedef struct aclhip_context aclhip_context;
@@ -180,10 +185,11 @@ const char* aclhip_last_error_message(const aclhip_context* context);
 
 /* The layouts of the structs in this header as a number: bumped whenever one of them changes (3: aclhip_output_desc::skip_tracks;
  * 4: aclhip_pose_consumers::num_blend_clips, flags, blend_clips, blend_sample_times, blend_weights;
- * 5: aclhip_decompress_params::instance_looping_policies, track_rounding_table, instance_rounding_tables, track_rounding_stride, aclhip_output_desc::mask_table, instance_masks, instance_track_counts, mask_stride).
+ * 5: aclhip_decompress_params::instance_looping_policies, track_rounding_table, instance_rounding_tables, track_rounding_stride, aclhip_output_desc::mask_table, instance_masks, instance_track_counts, mask_stride;
+ * 6: ACLHIP_DEFAULT_BIND_POSE, aclhip_clip_metadata_info; ACLHIP_ERROR_UNSUPPORTED_FORMAT no longer covers the full-precision formats).
  * A caller compiled against another header would hand over structs of another shape; aclhip_abi_version() says what the LIBRARY was
  * built with, and the C++ mirror (aclhip.hpp) refuses to create a context when the two differ. */
-#define ACLHIP_ABI_VERSION 5u
+#define ACLHIP_ABI_VERSION 6u
 uint32_t aclhip_abi_version(void);
 
 /* Creates a context bound to HIP device `device_index` (replaces nothing in the reference: contexts there are
@@ -222,6 +228,35 @@ aclhip_status aclhip_forget_stream(aclhip_context* context, void* stream);
 aclhip_status aclhip_get_lifetime_stats(aclhip_context* context, uint64_t* out_stats);
 
 aclhip_status aclhip_get_clip_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_info* out_info);
+
+/* The optional metadata a blob may carry behind its compressed data (compression_metadata_settings, compression_settings.h:84-120): read and
+ * bounds checked once, at registration. Replaces compressed_tracks::get_parent_track_index / get_track_description
+ * (core/impl/compressed_tracks.impl.h:175-275) for registered clips. */
+typedef struct aclhip_clip_metadata_info
+{
+	uint32_t has_metadata;					/* tracks_header::get_has_metadata() */
+	uint32_t has_parent_track_indices;		/* ... and the section is stored (and lies inside the blob) */
+	uint32_t has_track_descriptions;
+	uint32_t has_track_names;
+	uint32_t has_track_list_name;
+	uint32_t has_contributing_error;
+} aclhip_clip_metadata_info;
+aclhip_status aclhip_get_clip_metadata_info(const aclhip_context* context, aclhip_clip clip, aclhip_clip_metadata_info* out_info);
+
+/* Host only (no context, no device), on a blob that need not be registered -- where the reference's accessors live: which optional sections
+ * the blob stores and, for the arrays that are not null (capacity = the tracks they hold), get_parent_track_index / get_track_description of
+ * every track as the two calls below return them. Sections that are not stored leave their arrays untouched. */
+aclhip_status aclhip_read_clip_metadata(const void* compressed_tracks, uint64_t size, aclhip_clip_metadata_info* out_info, uint32_t* out_parent_indices,
+	float* out_default_values, float* out_precisions, float* out_shell_distances, uint32_t capacity);
+
+/* compressed_tracks::get_parent_track_index for every track (ACLHIP_NO_PARENT = k_invalid_track_index); `capacity` entries are available at
+ * out_parent_indices and must cover the clip's tracks. ACLHIP_ERROR_NO_METADATA when the blob does not store them. */
+aclhip_status aclhip_get_clip_parent_indices(const aclhip_context* context, aclhip_clip clip, uint32_t* out_parent_indices, uint32_t capacity);
+
+/* compressed_tracks::get_track_description(track, track_desc_transformf&) for every track: default_value as 12 floats per track (rotation
+ * xyzw | translation xyz 0 | scale xyz 0: a row of aclhip_decompress_params::default_values), and -- both optional -- precision and
+ * shell_distance. `capacity` = tracks the arrays hold. ACLHIP_ERROR_NO_METADATA when the blob does not store descriptions. */
+aclhip_status aclhip_get_clip_track_descriptions(const aclhip_context* context, aclhip_clip clip, float* out_default_values, float* out_precisions, float* out_shell_distances, uint32_t capacity);
 
 /* Replaces compressed_tracks::is_valid(check_hash) (core/impl/compressed_tracks.impl.h:278-301) as a host only call (no context,
  * no device): everything aclhip_register_clip checks before it uploads -- tag, version, hash, every header offset, sub-track
@@ -520,6 +555,11 @@ typedef enum aclhip_additive_format
  * num_tracks must be the clip's. Replaces a previous hierarchy of the clip (stream ordered like aclhip_unregister_clip: the old walk
  * schedule is recycled once the launches already enqueued have completed). */
 aclhip_status aclhip_set_clip_hierarchy(aclhip_context* context, aclhip_clip clip, const uint32_t* parent_indices, uint32_t num_tracks);
+
+/* The same with the parent indices the blob itself carries (compression_metadata_settings::include_parent_track_indices /
+ * include_track_descriptions; compressed_tracks::get_parent_track_index, core/impl/compressed_tracks.impl.h:175-190): the caller passes
+ * nothing. ACLHIP_ERROR_NO_METADATA when the clip was registered from a blob without them. */
+aclhip_status aclhip_set_clip_hierarchy_from_metadata(aclhip_context* context, aclhip_clip clip);
 
 /* Host only (no GPU work): how aclhip_set_clip_hierarchy schedules the object space walk of a hierarchy when up to
  * `transforms_per_step` transforms can be computed at once (64 / 32 / 16 / 8 for 1 / 2 / 4 / 8 instances per workgroup): every

@@ -151,6 +151,8 @@ def ref(asserting=False):
         lib.aclref_bench.restype = ctypes.c_double
         lib.aclref_bench_timed.argtypes = [vp, vp, vp, u32, u32, u32, ctypes.c_double, i32, vp]
         lib.aclref_bench_timed.restype = ctypes.c_double
+        if hasattr(lib, "aclref_get_metadata"):
+            lib.aclref_get_metadata.argtypes = [vp, vp, vp, vp, vp]
         if hasattr(lib, "aclref_bench_cold"):
             lib.aclref_bench_cold.argtypes = [vp, u32, vp, u32, u32, u32, ctypes.c_uint64, ctypes.c_double]
             lib.aclref_bench_cold.restype = ctypes.c_double
@@ -363,6 +365,19 @@ def ref_decompress(blob, sample_time, rounding=ROUND_NONE, looping=-1, settings=
     if result != 0:
         raise RuntimeError(f"aclref_decompress failed: {result}")
     return out
+
+
+def ref_get_metadata(blob):
+    """compressed_tracks::get_parent_track_index / get_track_description of every track through the reference's own accessors:
+    (parents, (default_values [n, 12], precisions, shell_distances) or None when the blob stores no descriptions)"""
+    lib = ref()
+    num_tracks = lib.aclref_get_num_tracks(blob.ctypes.data)
+    parents = np.zeros(max(num_tracks, 1), dtype=np.uint32)
+    defaults, precisions, shells = np.zeros((max(num_tracks, 1), 12), dtype=np.float32), np.zeros(max(num_tracks, 1), dtype=np.float32), np.zeros(max(num_tracks, 1), dtype=np.float32)
+    result = lib.aclref_get_metadata(blob.ctypes.data, parents.ctypes.data, defaults.ctypes.data, precisions.ctypes.data, shells.ctypes.data)
+    if result < 0:
+        raise RuntimeError("the description's parent index differs from get_parent_track_index")
+    return parents[:num_tracks], ((defaults[:num_tracks], precisions[:num_tracks], shells[:num_tracks]) if result == 1 else None)
 
 
 _ref_compress = None

@@ -150,6 +150,34 @@ extern "C"
 		return tracks->is_valid(check_hash != 0).any() ? 1 : 0;
 	}
 
+	// compressed_tracks::get_parent_track_index and get_track_description(track_desc_transformf&) for every track
+	// (core/impl/compressed_tracks.impl.h:175-275): returns bit 0 = descriptions are stored. out_parents [n]; out_defaults [n][12]
+	// (rotation xyzw | translation xyz 0 | scale xyz 0); out_precisions / out_shell_distances [n]
+	int aclref_get_metadata(const void* blob, uint32_t* out_parents, float* out_defaults, float* out_precisions, float* out_shell_distances)
+	{
+		const acl::compressed_tracks* tracks = static_cast<const acl::compressed_tracks*>(blob);
+		int result = 0;
+		for (uint32_t track_index = 0; track_index < tracks->get_num_tracks(); ++track_index)
+		{
+			out_parents[track_index] = tracks->get_parent_track_index(track_index);
+			acl::track_desc_transformf desc;
+			if (tracks->get_track_description(track_index, desc))
+			{
+				result = 1;
+				float* row = out_defaults + size_t(track_index) * 12;
+				std::memset(row, 0, 48);
+				rtm::quat_store(desc.default_value.rotation, row + 0);
+				rtm::vector_store3(desc.default_value.translation, row + 4);
+				rtm::vector_store3(desc.default_value.scale, row + 8);
+				out_precisions[track_index] = desc.precision;
+				out_shell_distances[track_index] = desc.shell_distance;
+				if (desc.parent_index != out_parents[track_index])
+					return -1;
+			}
+		}
+		return result;
+	}
+
 	// Writes the error string (or "") into 'message'.
 	int aclref_is_valid_msg(const void* blob, int check_hash, char* message, int message_capacity)
 	{

@@ -100,3 +100,53 @@ def test_oracle_single_track_is_the_reference_single_track(name):
             actual = ob.oracle_decompress_track(blob, float(t), track, ob.ROUND_NONE, options)
             assert helpers.max_abs_diff(actual, full[track]) <= 1e-6
             assert np.array_equal(actual[[4, 5, 6, 8, 9, 10]].view(np.uint32), full[track][[4, 5, 6, 8, 9, 10]].view(np.uint32))
+
+
+def test_optional_metadata_is_read_like_the_reference_reads_it():
+    """aclhip_read_clip_metadata (host only) against the corpus' own sources -- the skeleton and bind pose every clip was compressed with --
+    and, where oracle/_ref exists, against compressed_tracks::get_parent_track_index / get_track_description themselves
+    (core/impl/compressed_tracks.impl.h:175-275)"""
+    with_parents = with_descriptions = 0
+    for clip in CORPUS:
+        spec, blob = clip["spec"], clip["blob"]
+        info, parents, descriptions = runtime.read_clip_metadata(blob)
+        wants_descriptions = bool(spec.get("include_track_descriptions"))
+        wants_parents = wants_descriptions or bool(spec.get("include_parent_track_indices"))       # (descriptions bring the parents along, compress.transform.impl.h:182-183)
+        assert bool(info.has_parent_track_indices) == wants_parents and bool(info.has_track_descriptions) == wants_descriptions, clip["name"]
+        assert bool(info.has_track_names) == bool(spec.get("include_track_names")) and bool(info.has_track_list_name) == bool(spec.get("include_track_list_name"))
+        if wants_parents:
+            with_parents += 1
+            assert np.array_equal(parents, clip["parents"].astype(np.uint32))                        # (-1 = 0xFFFFFFFF = k_invalid_track_index)
+        if wants_descriptions:
+            with_descriptions += 1
+            defaults, precisions, shells = descriptions
+            expected = clip["bind_pose"].copy() if clip["bind_is_default"] else np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0], dtype=np.float32), (spec["bones"], 1))
+            expected[:, 7] = 0.0
+            expected[:, 11] = 0.0
+            assert np.array_equal(defaults.view(np.uint32), expected.view(np.uint32)), clip["name"]
+            assert np.all(precisions == np.float32(spec.get("precision", 0.01))) and np.all(shells == np.float32(spec.get("shell_distance", 3.0)))
+        if ob.have_ref() and hasattr(ob.ref(), "aclref_get_metadata"):
+            ref_parents, ref_descriptions = ob.ref_get_metadata(blob)
+            assert (ref_descriptions is not None) == wants_descriptions
+            if wants_parents:
+                assert np.array_equal(parents, ref_parents)
+            else:
+                assert np.all(ref_parents == 0xFFFFFFFF)
+            if wants_descriptions:
+                for ours, theirs in zip(descriptions, ref_descriptions):
+                    assert np.array_equal(ours.view(np.uint32), theirs.view(np.uint32)), clip["name"]
+    assert with_parents >= 3 and with_descriptions >= 3
+
+
+def test_metadata_offsets_that_leave_the_blob_count_as_not_stored():
+    clip = next(clip for clip in CORPUS if clip["spec"].get("include_track_descriptions") and clip["spec"].get("include_track_names"))
+    blob = clip["blob"]
+    for field in range(5):
+        for value in (blob.size - 8, 0x7FFFFFF0, 0xFFFFFFFE):
+            broken = blob.copy()
+            broken[blob.size - 20 + 4 * field: blob.size - 16 + 4 * field] = np.frombuffer(np.uint32(value).tobytes(), dtype=np.uint8)
+            info, parents, descriptions = runtime.read_clip_metadata(broken)
+            stored = [info.has_track_list_name, info.has_track_names, info.has_parent_track_indices, info.has_track_descriptions, info.has_contributing_error]
+            assert info.has_metadata == 1 and (stored[field] == 0 or value == blob.size - 8 and field in (0, 4))
+            if field == 2:
+                assert parents is None and descriptions is None       # (descriptions come with the parent indices, compressed_tracks.impl.h:229-230)
