@@ -244,6 +244,8 @@ namespace aclhip
 		uint8_t skip_mask;				// bit k: sub-tracks of kind k (rotation / translation / scale) are not stored
 		uint8_t items_per_wave;			// decompress_tracks_in_turn_kernel: work items a wave takes in turn
 		uint8_t clips_by_caller_instance;	// pose kernels: 1 when the clip list is in the CALLER's instance order although the launch decodes in slot order (attached instance lists: clip = clips[time_indices[slot]])
+		uint8_t fast_math;					// aclhip_decompress_params::flags & ACLHIP_DECODE_FAST (the host picks the kernels compiled for it)
+		uint8_t user_defaults;				// some default sub-track takes a value from a table: default_values (constant / variable modes) or the clip's bind pose
 	};
 
 	// Per instance settings. `caller_instance`: the instance's index in the CALLER's lists -- instance lists decode in slot order and find
@@ -859,12 +861,14 @@ namespace aclhip
 	// `policy` is the effective rounding policy of the track (none unless per track rounding is enabled);
 	// `lerp_alpha` the alpha handed to the interpolation.
 	// kHasRaw = false compiles the raw bit rate out, kPolicies = false the per track rounding policies.
-	template<bool kPolicies, bool kFastMath = false>
+	// kFastMath: 0 = the reference's arithmetic, bit for bit; 1 = ACLHIP_CONSUMERS_FAST (rotations and vectors in the hardware's cheapest
+	// forms); 2 = ACLHIP_DECODE_FAST (rotations only: translations and scales stay bit identical)
+	template<bool kPolicies, uint32_t kFastMath = 0>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
 		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math);
 
 	// short_exact_math (WAVE UNIFORM): the clip's k_clip_short_exact_math -- its rotations may take sqrt_rn_short / rcp_rn_short
-	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false>
+	template<bool kHasRaw, bool kPolicies, bool kWideKeyLoads = false, uint32_t kFastMath = 0>
 	__device__ __forceinline__ float4 decode_animated_sub_track(const seek_state& state, const plan_entry& plan0, const plan_entry& plan1,
 		const clip_range_entry& clip_range, bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math = false)
 	{
@@ -943,11 +947,11 @@ namespace aclhip
 		return result;
 	}
 
-	template<bool kPolicies, bool kFastMath>
+	template<bool kPolicies, uint32_t kFastMath>
 	__device__ __forceinline__ float4 interpolate_animated_samples(const seek_state& state, const float (&v0)[3], const float (&v1)[3],
 		bool is_rotation, uint32_t policy, float lerp_alpha, uint32_t normalization, bool normalize_samples, bool short_exact_math)
 	{
-		if constexpr (kFastMath && !kPolicies)
+		if constexpr (kFastMath != 0 && !kPolicies)
 		{
 			// ACLHIP_CONSUMERS_FAST: the same formulas, 1 ulp square roots and fused multiply-adds (see quat_normalize_fast above)
 			if (is_rotation && __builtin_amdgcn_ballot_w64(is_rotation) != 0)
@@ -959,8 +963,13 @@ namespace aclhip
 					result = quat_normalize_fast(result);
 				return result;
 			}
-			const float beta = 1.0f - lerp_alpha;
-			return make_float4(__builtin_fmaf(v1[0], lerp_alpha, v0[0] * beta), __builtin_fmaf(v1[1], lerp_alpha, v0[1] * beta), __builtin_fmaf(v1[2], lerp_alpha, v0[2] * beta), 0.0f);
+			// ACLHIP_DECODE_FAST keeps translations and scales exact: their error would scale with the rig's size, a rotation's does not
+			if constexpr (kFastMath == 1)
+			{
+				const float beta = 1.0f - lerp_alpha;
+				return make_float4(__builtin_fmaf(v1[0], lerp_alpha, v0[0] * beta), __builtin_fmaf(v1[1], lerp_alpha, v0[1] * beta), __builtin_fmaf(v1[2], lerp_alpha, v0[2] * beta), 0.0f);
+			}
+			return make_float4(lerp_stable(v0[0], v1[0], lerp_alpha), lerp_stable(v0[1], v1[1], lerp_alpha), lerp_stable(v0[2], v1[2], lerp_alpha), 0.0f);
 		}
 
 		// (the rotation arithmetic -- three square roots and a division, ~90 instructions -- sits behind a branch the WAVE takes: the

@@ -904,6 +904,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 	const bool database_samples = database != ACLHIP_INVALID_HANDLE && num_tracks != 0 && header.has_database();
 	const size_t sample_record_size = database_samples ? sizeof(database_sample_record) : sizeof(sample_record);
 	const uint64_t plan_offset = (samples_offset + samples.size() * sample_record_size + 31) & ~uint64_t(31);		// 32 byte entries from here on
+	// (the clip range table DIRECTLY behind the plan: decompress_track_kernel addresses a request's plan rows backwards from it, kernels_track.inl)
 	const uint64_t clip_ranges_offset = plan_offset + plan.size() * sizeof(plan_entry);
 	const uint64_t image_chunks_offset = clip_ranges_offset + clip_ranges.size() * sizeof(clip_range_entry);
 #if defined(ACLHIP_EXPERIMENTS)

@@ -821,6 +821,11 @@ namespace
 		out.skip_mask = 0;
 		out.items_per_wave = 1;
 		out.clips_by_caller_instance = 0;
+		if ((params->flags & ~uint32_t(ACLHIP_DECODE_FAST)) != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "unknown aclhip_decompress_params::flags %#x", params->flags);
+		out.fast_math = (params->flags & ACLHIP_DECODE_FAST) != 0 ? 1 : 0;
+		out.user_defaults = (params->default_values != nullptr || params->default_rotation_mode == ACLHIP_DEFAULT_BIND_POSE || params->default_translation_mode == ACLHIP_DEFAULT_BIND_POSE
+			|| params->default_scale_mode == ACLHIP_DEFAULT_BIND_POSE) ? 1 : 0;
 		out.rounding_policy = params->rounding_policy;
 		out.looping_policy = params->looping_policy;
 		out.normalization = params->normalization;

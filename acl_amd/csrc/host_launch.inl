@@ -62,6 +62,11 @@ namespace
 		else if (any_settings && compact) { kernel = decompress_tracks_any_settings_compact_kernel; name = "decompress_tracks_any_settings_compact_kernel"; }
 		else if (any_settings) { kernel = decompress_tracks_any_settings_kernel; name = "decompress_tracks_any_settings_kernel"; }
 		else if (compact) { kernel = decompress_tracks_compact_kernel; name = "decompress_tracks_compact_kernel"; }
+		// ACLHIP_DECODE_FAST: the plain kernels compiled with the 1 ulp rotation arithmetic (kernels_pose.inl)
+		else if (params.fast_math != 0 && shape.wide_key_loads && shape.items_per_wave > 1 && shape.adjacent_items) { kernel = decompress_tracks_in_turn_adjacent_fast_kernel; name = "decompress_tracks_in_turn_adjacent_fast_kernel"; }
+		else if (params.fast_math != 0 && shape.wide_key_loads && shape.items_per_wave > 1) { kernel = decompress_tracks_in_turn_fast_kernel; name = "decompress_tracks_in_turn_fast_kernel"; }
+		else if (params.fast_math != 0 && shape.wide_key_loads) { kernel = decompress_tracks_wide_loads_fast_kernel; name = "decompress_tracks_wide_loads_fast_kernel"; }
+		else if (params.fast_math != 0) { kernel = decompress_tracks_fast_kernel; name = "decompress_tracks_fast_kernel"; }
 		else if (shape.wide_key_loads && shape.items_per_wave > 1 && shape.adjacent_items) { kernel = decompress_tracks_in_turn_adjacent_kernel; name = "decompress_tracks_in_turn_adjacent_kernel"; }
 		else if (shape.wide_key_loads && shape.items_per_wave > 1) { kernel = decompress_tracks_in_turn_kernel; name = "decompress_tracks_in_turn_kernel"; }
 		else if (shape.wide_key_loads) { kernel = decompress_tracks_wide_loads_kernel; name = "decompress_tracks_wide_loads_kernel"; }
@@ -107,7 +112,7 @@ namespace
 #endif
 		const char* kernel_name = nullptr;
 		const pose_kernel kernel = pose_kernel_of(context, params, shape, &kernel_name);
-		if (kernel == decompress_tracks_in_turn_kernel || kernel == decompress_tracks_in_turn_adjacent_kernel)
+		if (kernel == decompress_tracks_in_turn_kernel || kernel == decompress_tracks_in_turn_adjacent_kernel || kernel == decompress_tracks_in_turn_fast_kernel || kernel == decompress_tracks_in_turn_adjacent_fast_kernel)
 		{
 			// every wave takes items_per_wave work items in turn (kernels_pose.inl): a K-th of the workgroups
 			decode_params turn_params = params;
@@ -549,7 +554,9 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 	device_guard guard(context->device);
 	note_launch_stream(context, static_cast<hipStream_t>(stream));
 	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
-	hipLaunchKernelGGL(decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+	// (ACLHIP_DECODE_FAST with the track_writer's own settings; a request's per track rounding policy folds into its alpha either way)
+	const bool fast = device_params.fast_math != 0 && device_params.per_track_rounding == 0;
+	hipLaunchKernelGGL(fast ? decompress_track_fast_kernel : decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
 		context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,
 		static_cast<float4*>(transforms), context->d_rejected);
 	ACLHIP_CHECK_HIP(context, hipGetLastError());

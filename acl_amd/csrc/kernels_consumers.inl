@@ -13,7 +13,7 @@
 
 		const uint32_t num_quads = clip.num_tracks * 3u;
 		if (num_quads <= k_image_chunk_quads)
-			decode_window_sub_tracks_into<false, false, kFastMath>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, lane, write_to_image);
+			decode_window_sub_tracks_into<false, false, (kFastMath ? 1u : 0u)>(window_tables_of(clip), state, params, rounding_policy, params.normalization, 0, clip.num_animated, lane, write_to_image);
 		else
 		{
 			const uint32_t num_windows = (num_quads + k_image_chunk_quads - 1) / k_image_chunk_quads;
@@ -21,7 +21,7 @@
 			{
 				const uint32_t first_ordinal = as_constant(clip.image_chunks)[window];
 				const uint32_t end_ordinal = as_constant(clip.image_chunks)[window + 1];
-				decode_window_sub_tracks_into<false, false, kFastMath>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, write_to_image);
+				decode_window_sub_tracks_into<false, false, (kFastMath ? 1u : 0u)>(window_tables_of(clip), state, params, rounding_policy, params.normalization, first_ordinal, end_ordinal, lane, write_to_image);
 			}
 		}
 	}

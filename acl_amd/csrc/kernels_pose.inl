@@ -214,7 +214,7 @@
 		out.sample_time = sample_time;
 	}
 
-	template<bool kPolicies, bool kWideKeyLoads = false, bool kFastMath = false, class image_writer_type>
+	template<bool kPolicies, bool kWideKeyLoads = false, uint32_t kFastMath = 0, class image_writer_type>
 	__device__ __forceinline__ void decode_window_sub_tracks_into(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t lane, image_writer_type write_to_image,
 		const uint8_t* track_rounding_policies = nullptr, bool clip_range_first = false)
@@ -266,7 +266,7 @@
 			if (!has_raw)
 				value = decode_animated_sub_track<false, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples, tables.short_exact_math);
 			else
-				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads, kFastMath>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples, tables.short_exact_math);
+				value = decode_animated_sub_track<true, kPolicies, kWideKeyLoads, (kFastMath == 2 ? 0u : kFastMath)>(state, plan0, plan1, current_range, is_rotation, policy, state.interpolation_alpha, normalization, normalize_samples, tables.short_exact_math);		// (ACLHIP_DECODE_FAST: a wave that meets a raw sample keeps the exact forms)
 
 			// a decoded W is never negative (a square root, or +0): the marker the base pose carried in this quad is gone
 			if (valid)
@@ -283,7 +283,7 @@
 		}
 	}
 
-	template<bool kAnySettings, bool kWideKeyLoads = false>
+	template<bool kAnySettings, bool kWideKeyLoads = false, uint32_t kFastMath = 0>
 	__device__ __forceinline__ void decode_window_sub_tracks(const window_tables& tables, const seek_state& state, const decode_params& params,
 		uint32_t rounding_policy, uint32_t normalization, uint32_t first_ordinal, uint32_t end_ordinal, uint32_t first_quad, uint32_t window_quads, uint32_t lane, f32x4* image,
 		const uint8_t* track_rounding_policies = nullptr, bool clip_range_first = false)
@@ -292,7 +292,7 @@
 		if (kAnySettings && params.per_track_rounding != 0)
 			decode_window_sub_tracks_into<true, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, track_rounding_policies, clip_range_first);
 		else
-			decode_window_sub_tracks_into<false, kWideKeyLoads>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, nullptr, clip_range_first);
+			decode_window_sub_tracks_into<false, kWideKeyLoads, kFastMath>(tables, state, params, rounding_policy, normalization, first_ordinal, end_ordinal, lane, writer, nullptr, clip_range_first);
 	}
 
 	// The pose kernels. One wave64 per (instance, pose window): a window is k_image_chunk_quads consecutive quads of the pose (a
@@ -309,7 +309,10 @@
 	// is the clip's RESOLVED pose (defaults written out) and step 4 is a plain copy. kAnySettings = true takes every settings
 	// combination: the DMA source is the marker tagged base pose, the decode honours per track rounding, and step 4 resolves what
 	// is not animated (default sub-track modes, caller supplied defaults, always-normalize).
-	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false>
+	// kFastMath = 2: ACLHIP_DECODE_FAST (aclhip_decompress_params::flags) -- rotations through v_sqrt_f32 / v_rsq_f32 and fused
+	// multiply-adds (within 2e-6 of the default's; x, y, z of every sample, translations and scales bit identical), for the launches
+	// whose time is VALU issue: poses of several windows
+	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false, uint32_t kFastMath = 0>
 	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
@@ -453,7 +456,7 @@
 		const uint8_t* track_rounding_policies = kAnySettings ? params.track_rounding_policies : nullptr;
 		if (kAnySettings && params.instance_rounding_tables != nullptr)
 			track_rounding_policies = params.track_rounding_table + size_t(as_constant(params.instance_rounding_tables)[caller_instance]) * params.track_rounding_stride;
-		decode_window_sub_tracks<kAnySettings, kWideKeyLoads>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, track_rounding_policies, one_shot);
+		decode_window_sub_tracks<kAnySettings, kWideKeyLoads, kFastMath>(window_tables_of(clip), state, params, rounding_policy, normalization, first_ordinal, end_ordinal, first_quad, window_quads, lane, image, track_rounding_policies, one_shot);
 
 		// DMA and the wave's own LDS writes must have landed before lanes read each other's quads
 		__builtin_amdgcn_s_waitcnt(0);
@@ -546,9 +549,8 @@
 		const uint32_t lane_quad = first_quad + lane;
 		const uint32_t lane_track = lane_quad / 3u;
 		uint32_t kind = lane_quad - lane_track * 3u;
-		const bool bind_pose_defaults = kAnySettings && (params.default_modes[0] == ACLHIP_DEFAULT_BIND_POSE || params.default_modes[1] == ACLHIP_DEFAULT_BIND_POSE || params.default_modes[2] == ACLHIP_DEFAULT_BIND_POSE);
-		const bool user_defaults = kAnySettings && (params.default_values != nullptr || bind_pose_defaults);		// wave uniform
-		const float* clip_bind_pose = bind_pose_defaults ? bind_pose_of(clip) : nullptr;
+		// (ACLHIP_DEFAULT_BIND_POSE reads the clip's own table: params.user_defaults is set for it as well, resolve_params)
+		const bool user_defaults = kAnySettings && params.user_defaults != 0;		// wave uniform
 
 		#pragma unroll
 		for (uint32_t r = 0; r < k_rows; ++r)
@@ -573,8 +575,8 @@
 				if (user_defaults && is_default && ((params.default_values != nullptr && (mode == ACLHIP_DEFAULT_CONSTANT || mode == ACLHIP_DEFAULT_VARIABLE)) || mode == ACLHIP_DEFAULT_BIND_POSE))
 				{
 					const uint32_t track_index = (lane_quad + r * k_wave_size) / 3u;
-					const float* source = mode == ACLHIP_DEFAULT_BIND_POSE ? clip_bind_pose + size_t(track_index) * 12 + kind * 4
-						: params.default_values + (mode == ACLHIP_DEFAULT_VARIABLE ? size_t(track_index) * 12 : 0) + kind * 4;
+					const float* table = mode == ACLHIP_DEFAULT_BIND_POSE ? bind_pose_of(clip) : params.default_values;
+					const float* source = table + (mode != ACLHIP_DEFAULT_CONSTANT ? size_t(track_index) * 12 : 0) + kind * 4;
 					value = f32x4{ source[0], source[1], source[2], kind == 0 ? source[3] : 0.0f };
 				}
 			}
@@ -818,7 +820,7 @@
 	//                           like the one-shot grid does (the host sizes the grid so that a wave keeps its window index);
 	//   kAdjacentItems = true:  wave g takes window g % W of instances (g / W) K .. (g / W) K + K - 1: consecutive instances, which in a
 	//                           list bucketed by clip are of one clip.
-	template<bool kAdjacentItems, bool kWideKeyLoads = true>
+	template<bool kAdjacentItems, bool kWideKeyLoads = true, uint32_t kFastMath = 0>
 	__device__ __forceinline__ void decompress_tracks_windows_in_turn(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		const uint32_t wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x / k_wave_size);
@@ -831,7 +833,7 @@
 		{
 			const uint32_t work_item = kAdjacentItems ? (group * items_per_wave + turn) * windows_per_instance + window
 				: (turn * gridDim.x + blockIdx.x) * k_waves_per_block + wave_in_block;
-			decompress_tracks_window<false, false, kWideKeyLoads>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
+			decompress_tracks_window<false, false, kWideKeyLoads, kFastMath>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
 			// (the window's LDS reads completed before its stores were issued: the next turn's DMA may overwrite the image)
 		}
 	}
@@ -844,6 +846,29 @@
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<true>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	// ACLHIP_DECODE_FAST (opt in, aclhip_decompress_params::flags): the three plain kernels with the rotation arithmetic in the hardware's
+	// 1 ulp forms. The one-window kernel sits on its write stream and gains little; the kernels of poses of several windows are bound by
+	// VALU issue and get their instructions back.
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_window<false, false, false, 2>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(8, 8))) void decompress_tracks_wide_loads_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_window<false, false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_adjacent_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	{
+		decompress_tracks_windows_in_turn<true, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
 	// (One-window poses gain nothing from taking items in turn -- measured in round 5 with the byte-window key reads of the one-shot kernel,

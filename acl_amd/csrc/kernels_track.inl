@@ -22,14 +22,17 @@
 // that prefix sum.
 
 	// what a decode lane needs to know about the request its sub-track belongs to: 32 bytes in LDS, as two 16 byte parts [part][request]
-	// (the interpolation alpha comes over ds_bpermute, the clip's tables from the scalar clip record or -- waves of mixed clips -- from
-	// the clip handle, over ds_bpermute as well: 5 KiB of LDS per wave all told, so that registers, not LDS, decide how many waves a
+	// (the interpolation alpha comes over ds_bpermute, the clip's tables from the scalar clip record or -- waves of mixed clips -- as ONE
+	// pointer per request, the clip's clip range table, over ds_bpermute as well: the plan sits directly in front of it in the clip's
+	// allocation (host_clips.inl), so the rows are kept as distances back from there. Until round 6 the decode lane fetched its request's
+	// clip record again for the two pointers: one more dependent load in every pass of a mixed wave. 5 KiB of LDS per wave all told, so that registers, not LDS, decide how many waves a
 	// CU holds. Measured, 4 M requests on one clip: 64 bytes of state per request and the list beside the image (7.75 KiB, 20 waves per
 	// CU) 74.3 us; this form at 70 registers = 7 waves per SIMD 64.3 us; squeezed into 64 registers for 8 (15 spilled) 85.4 us.)
 	struct track_request_state
 	{
 		const uint8_t* data[2];					// first stored keyframe of each key's data source (seek_state::animated_track_data)
-		uint32_t rows[2];						// first plan entry of each key's segment (segment index x animated sub-tracks); bit 31 of rows[0]: the clip's k_clip_short_exact_math
+		uint32_t rows[2];						// plan entries from the first entry of each key's segment to the END of the plan = the clip range table
+												// ((segments - segment index) x animated sub-tracks); bit 31 of rows[0]: the clip's k_clip_short_exact_math
 		uint32_t bit_offsets[2];				// seek_state::key_frame_bit_offsets
 	};
 	static_assert(sizeof(track_request_state) == 32, "two 16 byte parts");
@@ -89,8 +92,8 @@
 
 		out_state.data[0] = state.animated_track_data[0];
 		out_state.data[1] = state.animated_track_data[1];
-		out_state.rows[0] = (state.segment_index[0] * clip.num_animated) | ((clip.flags & k_clip_short_exact_math) != 0 ? k_track_row_short_exact_math : 0u);
-		out_state.rows[1] = state.segment_index[1] * clip.num_animated;
+		out_state.rows[0] = ((clip.num_segments - state.segment_index[0]) * clip.num_animated) | ((clip.flags & k_clip_short_exact_math) != 0 ? k_track_row_short_exact_math : 0u);
+		out_state.rows[1] = (clip.num_segments - state.segment_index[1]) * clip.num_animated;
 		out_state.bit_offsets[0] = state.key_frame_bit_offsets[0];
 		out_state.bit_offsets[1] = state.key_frame_bit_offsets[1];
 
@@ -128,9 +131,10 @@
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_TRACK_WAVES_PER_EU, ACLHIP_TRACK_WAVES_PER_EU))) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+	template<uint32_t kFastMath>
+	__device__ __forceinline__ void decompress_track_requests(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
-		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+		const decode_params& params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
 	{
 		__shared__ __attribute__((aligned(16))) uint8_t track_lds[k_waves_per_block * k_track_lds_bytes_per_wave];
 
@@ -167,13 +171,13 @@
 		uint32_t animated = 0;
 		uint32_t ordinals[3] = { 0, 0, 0 };
 		bool accepted = false;
-		// the tables of the shared clip, for the decode lanes (wave uniform)
-		const plan_entry* shared_plan = nullptr;
+		// the clip range table of the request's clip (the plan ends where it starts): the shared clip's for the decode lanes (wave uniform),
+		// or every lane's own
 		const clip_range_entry* shared_clip_ranges = nullptr;
+		const clip_range_entry* own_clip_ranges = nullptr;
 		if (shared_clip)
 		{
 			const device_clip clip = load_clip(clips, first_clip_id);
-			shared_plan = clip.plan;
 			shared_clip_ranges = clip.clip_ranges;
 			if (in_batch)
 				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
@@ -181,6 +185,7 @@
 		else if (known_clip)
 		{
 			const device_clip clip = load_clip_per_lane(clips, clip_id);
+			own_clip_ranges = clip.clip_ranges;
 			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 
@@ -245,20 +250,22 @@
 			__builtin_memcpy(&request, parts, sizeof(request));
 			const float request_alpha = __uint_as_float(uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(__float_as_uint(lerp_alpha)))));
 
-			// the clip's tables: the wave's one clip, or -- a wave of mixed clips -- each request's own
-			const plan_entry* plan = shared_plan;
+			// the clip's tables: the wave's one clip, or -- a wave of mixed clips -- each request's own, from the lane that prepared it
 			const clip_range_entry* clip_ranges = shared_clip_ranges;
 			if (!shared_clip)
 			{
-				const uint32_t request_clip_id = uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(clip_id)));
-				const device_clip clip = load_clip_per_lane(clips, request_clip_id);		// (an accepted request's: a known clip)
-				plan = clip.plan;
-				clip_ranges = clip.clip_ranges;
+				const uint64_t own = reinterpret_cast<uint64_t>(own_clip_ranges);
+				const uint32_t low = uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(uint32_t(own))));
+				const uint32_t high = uint32_t(__builtin_amdgcn_ds_bpermute(int(source_lane * 4u), int(uint32_t(own >> 32))));
+				clip_ranges = reinterpret_cast<const clip_range_entry*>((uint64_t(high) << 32) | low);
 			}
 
+			// (plan_entry and clip_range_entry are both 32 bytes: the plan's last entry is clip_ranges[-1])
+			static_assert(sizeof(plan_entry) == sizeof(clip_range_entry), "the plan is addressed from the clip range table");
+			const plan_entry* plan_end = reinterpret_cast<const plan_entry*>(clip_ranges);
 			const uint32_t row0 = request.rows[0] & ~k_track_row_short_exact_math, row1 = request.rows[1];
-			const plan_entry plan0 = load_entry(plan, row0 + ordinal);
-			const plan_entry plan1 = row1 == row0 ? plan0 : load_entry(plan, row1 + ordinal);
+			const plan_entry plan0 = load_entry(plan_end - row0, ordinal);
+			const plan_entry plan1 = row1 == row0 ? plan0 : load_entry(plan_end - row1, ordinal);
 			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
 
 			seek_state key_state;
@@ -275,7 +282,7 @@
 			const bool short_exact_math = (request.rows[0] & k_track_row_short_exact_math) != 0;
 			float4 value;
 			if (!has_raw)
-				value = decode_animated_sub_track<false, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request_alpha, params.normalization, false, short_exact_math);
+				value = decode_animated_sub_track<false, false, k_track_wide_key_loads, kFastMath>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request_alpha, params.normalization, false, short_exact_math);
 			else
 				value = decode_animated_sub_track<true, false, k_track_wide_key_loads>(key_state, plan0, plan1, clip_range, kind == 0, k_round_none, request_alpha, params.normalization, false, false);
 			if (valid)
@@ -308,4 +315,22 @@
 				if (store[kind])
 					store_streaming(&transforms[size_t(instance) * 3u + kind], image[lane * 3u + kind]);
 		}
+	}
+
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_TRACK_WAVES_PER_EU, ACLHIP_TRACK_WAVES_PER_EU))) void decompress_track_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
+		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_track_requests<0>(clips, num_clips, clip_ids, sample_times, track_indices, num_instances, params, transforms, rejected_count);
+	}
+
+	// ACLHIP_DECODE_FAST (aclhip_decompress_params::flags): rotations in the hardware's 1 ulp forms, translations and scales bit identical
+#if !defined(ACLHIP_TRACK_FAST_WAVES_PER_EU)
+	#define ACLHIP_TRACK_FAST_WAVES_PER_EU 7
+#endif
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_TRACK_FAST_WAVES_PER_EU, ACLHIP_TRACK_FAST_WAVES_PER_EU))) void decompress_track_fast_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
+		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
+		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
+	{
+		decompress_track_requests<2>(clips, num_clips, clip_ids, sample_times, track_indices, num_instances, params, transforms, rejected_count);
 	}

@@ -51,7 +51,7 @@ class DecompressParams(ctypes.Structure):
         ("default_rotation_mode", ctypes.c_uint8), ("default_translation_mode", ctypes.c_uint8), ("default_scale_mode", ctypes.c_uint8), ("reserved0", ctypes.c_uint8),
         ("default_values", ctypes.c_void_p), ("track_rounding_policies", ctypes.c_void_p), ("instance_rounding_policies", ctypes.c_void_p),
         ("instance_looping_policies", ctypes.c_void_p),
-        ("track_rounding_table", ctypes.c_void_p), ("instance_rounding_tables", ctypes.c_void_p), ("track_rounding_stride", ctypes.c_uint32), ("reserved1", ctypes.c_uint32),
+        ("track_rounding_table", ctypes.c_void_p), ("instance_rounding_tables", ctypes.c_void_p), ("track_rounding_stride", ctypes.c_uint32), ("flags", ctypes.c_uint32),
     ]
 
 
@@ -98,6 +98,7 @@ def relayout_pose(pose, layout, skip=(False, False, False), into=None):
 
 ADDITIVE_NONE, ADDITIVE_RELATIVE, ADDITIVE_ADDITIVE0, ADDITIVE_ADDITIVE1 = 0, 1, 2, 3  # aclhip_additive_format
 CONSUMERS_FAST = 1          # ACLHIP_CONSUMERS_FAST (aclhip_pose_consumers::flags)
+DECODE_FAST = 1             # ACLHIP_DECODE_FAST (aclhip_decompress_params::flags)
 NO_PARENT = 0xFFFFFFFF
 
 

@@ -177,11 +177,11 @@ class Job:
     aclhip_instance_list_note_changes counts them, the list is decoded: the caller's kernel, the decode and the re-orders are all part of the step).
     layout: output layout name of runtime.LAYOUTS ("qvv48" = rtm::qvvf records, the default)."""
 
-    def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48", paging="decode_stream"):
+    def __init__(self, name, rank, device_index, num_instances=INSTANCES_PER_GPU, order="random", keep_rows=False, layout="qvv48", paging="decode_stream", fast=False):
         import torch
         from acl_amd import runtime, synth
 
-        self.name, self.order, self.layout, self.keep_rows = name, order, layout, keep_rows
+        self.name, self.order, self.layout, self.keep_rows, self.fast = name, order, layout, keep_rows, fast
         self.torch, self.runtime = torch, runtime
         self.device = torch.device("cuda", device_index)
         self.lib = runtime.load_library()
@@ -233,7 +233,7 @@ class Job:
         self.d_clips = torch.from_numpy(self.handles[clip_indices].astype(np.int32)).to(self.device)
         self.d_times = torch.from_numpy(times).to(self.device)
         self._order_args = None
-        if order == "device":
+        if order in ("device", "device_pipelined"):
             # the caller's lists stay as drawn; every step orders them into the lists the decode reads
             self.d_source_clips, self.d_source_times = self.d_clips.clone(), self.d_times.clone()
             self.d_order = torch.zeros((self.num_instances,), dtype=torch.int32, device=self.device)
@@ -245,7 +245,8 @@ class Job:
         # (copies overlap the launches: database_streamer.h:87-93 lets a stream-in run concurrently with decompression)
         self.paging = paging
         self.paging_stream = torch.cuda.Stream(self.device) if paging == "second_stream" else self.stream
-        self.params = runtime.default_params()
+        # fast: ACLHIP_DECODE_FAST (opt in: rotations within 2e-6 of the bit exact kernels', everything else bit identical)
+        self.params = runtime.default_params(flags=runtime.DECODE_FAST if fast else 0)
         self.consumers = None
         self.output = None
 
@@ -304,6 +305,22 @@ class Job:
 
         if order == "device":
             self._order_args = (handle, self.d_source_clips.data_ptr(), self.d_source_times.data_ptr(), n, self.d_order.data_ptr(), clips_ptr, times_ptr, stream_ptr)
+        self._pipeline = None
+        if order == "device_pipelined":
+            # a frame loop knows next frame's clip list before this frame's poses are consumed: the ordering of step k + 1 runs on a SECOND
+            # stream while step k decodes -- two sets of ordered lists, an event each way (ordered -> decode may start; decoded -> the set
+            # may be overwritten)
+            self.order_stream = torch.cuda.Stream(self.device)
+            sets = []
+            for _ in range(2):
+                ordered_clips, ordered_times, order_out = torch.zeros_like(self.d_clips), torch.zeros_like(self.d_times), torch.zeros_like(self.d_order)
+                sets.append({"clips": ordered_clips, "times": ordered_times, "order": order_out, "ordered": torch.cuda.Event(), "decoded": torch.cuda.Event(),
+                             "order_args": (handle, self.d_source_clips.data_ptr(), self.d_source_times.data_ptr(), n, order_out.data_ptr(), ordered_clips.data_ptr(), ordered_times.data_ptr(), self.order_stream.cuda_stream),
+                             "decode_args": (handle, ordered_clips.data_ptr(), ordered_times.data_ptr(), n, ctypes.byref(self.params), poses_ptr, self.pose_stride, stream_ptr)})
+            self._pipeline = {"sets": sets, "step": 0}
+            self._enqueue_ordering(sets[0])                    # the first step's list (setup)
+            for item in sets:
+                item["decoded"].record(self.stream)
         self.instance_list = None
         if order in ("list", "attached"):
             # 16 pre-drawn update sets (1 % of the instances each, new clips drawn like the old ones), cycled through by the steps
@@ -323,6 +340,13 @@ class Job:
                 context.instance_list_set_clips(self.instance_list, clips_ptr, stream=stream_ptr)
             self.stream.synchronize()
 
+    def _enqueue_ordering(self, item):
+        self.order_stream.wait_event(item["decoded"])          # the decode that read this set last has finished
+        status = self.lib.aclhip_order_instances_device(*item["order_args"])
+        if status != 0:
+            raise SystemExit(f"the device side ordering failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
+        item["ordered"].record(self.order_stream)
+
     def order_step(self):
         status = self.lib.aclhip_order_instances_device(*self._order_args)
         if status != 0:
@@ -338,6 +362,17 @@ class Job:
             else:
                 self.context.instance_list_update(self.instance_list, instances.data_ptr(), new_clips.data_ptr(), count, stream=self.stream.cuda_stream)
             self.context.decompress_tracks_list(self.instance_list, self.d_times.data_ptr(), self.d_poses.data_ptr(), self.pose_stride, params=self.params, stream=self.stream.cuda_stream)
+            return
+        if self._pipeline is not None:
+            sets, k = self._pipeline["sets"], self._pipeline["step"]
+            self._pipeline["step"] = k + 1
+            self._enqueue_ordering(sets[(k + 1) % 2])           # next step's list, on the second stream
+            current = sets[k % 2]
+            self.stream.wait_event(current["ordered"])
+            status = self.lib.aclhip_decompress_tracks_batch(*current["decode_args"])
+            if status != 0:
+                raise SystemExit(f"the batch launch failed: {status} {self.lib.aclhip_last_error_message(self.context._handle).decode()}")
+            current["decoded"].record(self.stream)
             return
         if self._order_args is not None:
             self.order_step()
@@ -388,7 +423,7 @@ class Job:
         if self.consumers is not None:
             return "decompress_poses_consumer_kernel"
         if self.track_requests:
-            return "decompress_track_kernel"
+            return "decompress_track_fast_kernel" if self.fast else "decompress_track_kernel"
         # the library's own answer for this launch (rows of pose_stride bytes, this output descriptor): aclhip_describe_tracks_launch
         return self.context.tracks_kernel_name(self.params, pose_stride_bytes=self.pose_stride, output=self.output)
 
@@ -457,14 +492,17 @@ def default_run_specs():
         ("256_clips", {}, 300),
         ("256_clips", {"order": "locality"}, 300),
         ("256_clips", {"order": "device"}, 300),                    # ordered on the GPU in front of every launch: the ordering is in kernel_ms
+        ("256_clips", {"order": "device_pipelined"}, 300),          # ... the ordering of step k + 1 on a second stream while step k decodes
         ("256_clips", {"order": "list"}, 300),                      # persistent instance list: 1 % of the instances change clip per step, inside the step
         ("256_clips", {"order": "attached"}, 300),                  # ... attached to the caller's clip array: the caller's own kernel writes the 1 %, no update launch
         ("cinematic", {}, 150),
+        ("cinematic", {"fast": True}, 150),                         # ACLHIP_DECODE_FAST: rotations within 2e-6, the rest bit identical (opt in)
         ("database", {}, 300),
         ("database", {"order": "locality"}, 300),                   # the same instances laid out in aclhip_order_instances_for_locality order
         ("database", {"order": "list"}, 300),                       # ... kept in a persistent instance list, 1 % changing clip per step
         # single bone requests, scalar track lists, the pose consumers fused into the decode
         ("track_requests", {"num_instances": TRACK_REQUESTS}, 100),
+        ("track_requests", {"num_instances": TRACK_REQUESTS, "fast": True}, 100),
         ("scalar", {}, 300),
         ("object_space", {}, 150),
         ("additive_object_space", {}, 100),
@@ -477,7 +515,7 @@ def default_run_specs():
 
 
 def spec_key(name, options):
-    return traffic_key_of(name, options.get("order", "random"), options.get("layout", "qvv48"))
+    return traffic_key_of(name, options.get("order", "random"), options.get("layout", "qvv48"), fast=options.get("fast", False))
 
 
 def run_steps(job, steps):
@@ -561,7 +599,7 @@ def live_traffic(timeout_s=120):
             for key, value in means.items() if "FETCH_SIZE" in value and "WRITE_SIZE" in value}
 
 
-def traffic_key_of(workload, order, layout, keep_rows=False):
+def traffic_key_of(workload, order, layout, keep_rows=False, fast=False):
     if keep_rows:
         return None
     key = workload
@@ -569,6 +607,8 @@ def traffic_key_of(workload, order, layout, keep_rows=False):
         key += f", {order} order"
     if layout != "qvv48":
         key += f", {layout}"
+    if fast:
+        key += ", fast"
     return key
 
 
@@ -607,7 +647,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
         if not job.is_scalar and not job.track_requests and job.layout == "qvv48":
             achievable = job.context.measure_pose_store_bandwidth(job.d_poses.data_ptr(), job.pose_stride, job.num_instances, job.max_tracks, repeats=10, stream=job.stream.cuda_stream)[0]
         return {
-            "workload": traffic_key_of(name, job.order, job.layout, job.keep_rows) or f"{name}, {job.order} order, rows kept",
+            "workload": traffic_key_of(name, job.order, job.layout, job.keep_rows, job.fast) or f"{name}, {job.order} order, rows kept",
             "config": WORKLOAD_TEXT[name],
             "order": job.order,
             "layout": job.layout,
@@ -623,7 +663,7 @@ def measure_job(name, rank, device_index, repeats=300, **job_options):
             "frac": achieved / HBM_PEAK_GBPS,
             "best_store_only_gbps": achievable,        # this batch's own write stream alone, best of thirteen shapes (aclhip_measure_pose_store_bandwidth): a second denominator, not a bound
             "frac_of_best_store_only": None if not achievable else achieved / achievable,
-            "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows), kernel),
+            "traffic": measured_traffic(traffic_key_of(name, job.order, job.layout, job.keep_rows, job.fast), kernel),
             "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes)",
             "ordering_ms_host": None if job.ordering_ms is None else round(job.ordering_ms, 3),
             "ordering_ms_device": ordering_ms_device,          # inside kernel_ms when the order is "device"
@@ -732,7 +772,7 @@ def self_check(job, count=256):
     tools/acl_compressor/sources/validate_tracks.cpp:92-260). Pose batches in a caller-visible row order, single track requests and scalar
     lists; None for what has no oracle on this side (database tiers, consumers) or no fixed rows (device / list orders)."""
     from oracle import bindings as ob      # the checker, never the thing measured
-    if job.database is not None or job.consumers is not None or job.order in ("device", "list", "attached") or job.d_rows is not None or job.name == "one_clip_lods":
+    if job.database is not None or job.consumers is not None or job.order in ("device", "device_pipelined", "list", "attached") or job.d_rows is not None or job.name == "one_clip_lods" or job.fast:
         return None
     torch = job.torch
     torch.cuda.synchronize(job.device)
@@ -1150,12 +1190,13 @@ def main():
     parser.add_argument("--warmup", type=int, default=500)
     parser.add_argument("--workload", default="one_clip", choices=sorted(WORKLOAD_TEXT))
     parser.add_argument("--instances", type=int, default=INSTANCES_PER_GPU, help="instances per GPU")
-    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "list", "attached"],
+    parser.add_argument("--order", default="random", choices=["random", "by_clip", "locality", "device", "device_pipelined", "list", "attached"],
                         help="instance order: as drawn; bucketed by clip on the host; aclhip_order_instances_for_locality (host, setup); "
                              "aclhip_order_instances_device in front of every launch (part of the step)")
     parser.add_argument("--no-live-traffic", action="store_true", help="default run: keep roofline.traffic from profiles/traffic.json instead of measuring it with two rocprofv3 --pmc passes")
     parser.add_argument("--keep-rows", action="store_true", help="with --order locality: store every pose in its instance's ORIGINAL row")
     parser.add_argument("--layout", default="qvv48", choices=["qvv48", "qvv40", "qv32"], help="output layout (aclhip_output_desc)")
+    parser.add_argument("--fast", action="store_true", help="ACLHIP_DECODE_FAST: the opt in tolerance mode (rotations within 2e-6 of the bit exact kernels')")
     parser.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline leg")
     parser.add_argument("--no-extras", action="store_true", help="only the headline workload: no other workloads, footprint sweep, layouts")
     parser.add_argument("--gather", default="both", choices=["none", "rccl", "p2p", "both"], help="N > 1: time the pose gather after the decode (reported separately)")
@@ -1204,7 +1245,7 @@ def main():
         traffic_pass(device_index, args.traffic_pass)
         return
     instances = TRACK_REQUESTS if args.workload == "track_requests" and args.instances == INSTANCES_PER_GPU else args.instances
-    job = Job(args.workload, rank, device_index, num_instances=instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout)
+    job = Job(args.workload, rank, device_index, num_instances=instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout, fast=args.fast)
 
     # device pre-warm (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)
     prewarm_launches = 0 if profiling else job.prewarm(0.15)
@@ -1273,6 +1314,7 @@ def main():
         if args.order != "random":
             workload_text += {"by_clip": ", bucketed by clip", "locality": ", decoded in aclhip_order_instances_for_locality order",
                               "device": ", ordered by aclhip_order_instances_device in front of every launch (inside the step)",
+                              "device_pipelined": ", ordered by aclhip_order_instances_device on a second stream while the previous step decodes (inside the step)",
                               "list": ", kept in a persistent aclhip_instance_list: 1 % of the instances change clip in every step (inside the step), the library re-orders when 1/8 has changed",
                               "attached": ", kept in an aclhip_instance_list ATTACHED to the caller's clip array: every step a caller side kernel (torch index_copy_) writes 1 % of the clips there (inside the step), no update launch, the library re-orders when 1/8 has changed"}[args.order]
             workload_text += ", poses scattered back to their original rows" if args.keep_rows else ""
@@ -1370,7 +1412,7 @@ def main():
     if distributed and args.gather != "none":
         finished.set()
 
-    extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU
+    extras = world_size == 1 and not args.no_extras and not profiling and args.workload == "one_clip" and args.order == "random" and args.layout == "qvv48" and args.instances == INSTANCES_PER_GPU and not args.fast
     if rank == 0 and extras:
         # the other north-star configs, measured in this process outside the timed region (about 0.2 s of launches each)
         specs = default_run_specs()

@@ -112,8 +112,19 @@ typedef struct aclhip_decompress_params
 	const uint8_t* track_rounding_table;		/* DEVICE pointer or NULL */
 	const uint8_t* instance_rounding_tables;	/* DEVICE pointer or NULL: one table index per instance */
 	uint32_t track_rounding_stride;				/* bytes from one table to the next (>= tracks of the largest clip of the batch) */
-	uint32_t reserved1;
+	uint32_t flags;								/* ACLHIP_DECODE_* (reserved1 until ABI 6: aclhip_default_params has always zeroed it) */
 } aclhip_decompress_params;
+
+/* aclhip_decompress_params::flags.
+ * ACLHIP_DECODE_FAST: opt in, per launch. The default kernels follow the reference's x86 arithmetic one IEEE operation at a time and are bit
+ * exact with it (math/quatf.h:135-211); north_star's bar is 1e-5. With this flag an animated ROTATION is computed with the hardware's 1 ulp
+ * square root / reciprocal square root and fused multiply-adds: every rotation component stays within 2e-6 of the default kernels'
+ * (tests/test_gpu_fast_decode.py asserts it over every instance of the BASELINE.json batches and the corpus); the x, y, z of every sample
+ * (the range expansions are never fused), constant and default sub-tracks, translations and scales are bit identical. Taken by the plain
+ * decode (aclhip_decompress_tracks_batch / _rows / _list with the QVV48 layout and the track_writer defaults) and by aclhip_decompress_track_batch;
+ * launches with other settings or an output descriptor keep the exact kernels, as do per track rounding policies. What it buys is VALU
+ * issue: poses of several windows (the 300-bone rig) and single track requests; a one-window batch sits on its write stream either way. */
+#define ACLHIP_DECODE_FAST 1u
 
 /* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
  * (core/track_writer.h:161-216). A writer decides per sub-track kind whether it wants it at all -- skip_all_rotations /

@@ -12,15 +12,19 @@ import torch  # noqa: E402
 from acl_amd import runtime, synth  # noqa: E402
 
 
+FAST = os.environ.get("TRACK_SWEEP_FAST", "0") == "1"       # ACLHIP_DECODE_FAST: rotations within 2e-6, the rest bit identical
+
+
 def time_requests(ctx, ids, times, tracks, out, repeats=100):
     n = ids.numel()
     stream = torch.cuda.current_stream()
+    params = runtime.default_params(flags=runtime.DECODE_FAST if FAST else 0)
     for _ in range(30):
-        ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), n, out.data_ptr(), stream=stream.cuda_stream)
+        ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), n, out.data_ptr(), params=params, stream=stream.cuda_stream)
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record(stream)
     for _ in range(repeats):
-        ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), n, out.data_ptr(), stream=stream.cuda_stream)
+        ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), n, out.data_ptr(), params=params, stream=stream.cuda_stream)
     stop.record(stream)
     stop.synchronize()
     return start.elapsed_time(stop) / repeats * 1000
@@ -33,10 +37,13 @@ def check_against_poses(ctx, ids, times, tracks, out, num_tracks, sample=8192):
     poses = torch.zeros((n, num_tracks, 12), dtype=torch.float32, device="cuda")
     ctx.decompress_tracks_batch(ids.data_ptr(), times.data_ptr(), n, poses.data_ptr(), num_tracks * 48, stream=stream.cuda_stream)
     out.zero_()
-    ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), ids.numel(), out.data_ptr(), stream=stream.cuda_stream)
+    ctx.decompress_track_batch(ids.data_ptr(), times.data_ptr(), tracks.data_ptr(), ids.numel(), out.data_ptr(), params=runtime.default_params(flags=runtime.DECODE_FAST if FAST else 0), stream=stream.cuda_stream)
     stream.synchronize()
     expected = poses[torch.arange(n, device="cuda"), tracks[:n].long()]
     same = torch.equal(expected.view(torch.int32), out[:n].view(torch.int32))
+    if FAST:
+        lanes = torch.tensor([4, 5, 6, 8, 9, 10], device="cuda")
+        same = bool((expected[:, :4] - out[:n, :4]).abs().max() <= 2e-6) and torch.equal(expected[:, lanes].view(torch.int32), out[:n][:, lanes].view(torch.int32))
     nonzero = bool((out.view(torch.int32) != 0).any(dim=1).all())      # every request wrote something (rotations are never all zero)
     return same and nonzero
 
