@@ -38,6 +38,10 @@ namespace aclhip
 	// reference: core/additive_utils.h:43-68
 	enum class additive_clip_format8 : uint8_t { none = 0, relative = 1, additive0 = 2, additive1 = 3 };
 
+	// acl::rotation_format8 / vector_format8 (core/track_formats.h:48-71)
+	enum class rotation_format8 : uint8_t { quatf_full = 0, quatf_drop_w_full = 2, quatf_drop_w_variable = 3 };
+	enum class vector_format8 : uint8_t { vector3f_full = 0, vector3f_variable = 1 };
+
 	struct quatf { float x, y, z, w; };
 	struct vector4f { float x, y, z, w; };
 	struct qvvf { quatf rotation; vector4f translation; vector4f scale; };		// 48 bytes, the layout of a pose row
@@ -50,6 +54,11 @@ namespace aclhip
 		static constexpr bool skip_initialize_safety_checks() { return false; }
 		static constexpr bool is_wrapping_supported() { return true; }
 		static constexpr bool is_per_track_rounding_supported() { return true; }
+		// which packed formats the settings take (decompression_settings.h:108-112): a context whose settings do not take a clip's formats
+		// does not initialize (the reference asserts, decompression.transform.h:102-104)
+		static constexpr bool is_rotation_format_supported(rotation_format8 /*format*/) { return true; }
+		static constexpr bool is_translation_format_supported(vector_format8 /*format*/) { return true; }
+		static constexpr bool is_scale_format_supported(vector_format8 /*format*/) { return true; }
 	};
 
 	// acl::debug_transform_decompression_settings (decompression_settings.h:186-191)
@@ -60,7 +69,61 @@ namespace aclhip
 	{
 		static constexpr rotation_normalization_policy_t get_rotation_normalization_policy() { return rotation_normalization_policy_t::lerp_only; }
 		static constexpr bool is_per_track_rounding_supported() { return false; }
+		static constexpr bool is_rotation_format_supported(rotation_format8 format) { return format == rotation_format8::quatf_drop_w_variable; }
+		static constexpr bool is_translation_format_supported(vector_format8 format) { return format == vector_format8::vector3f_variable; }
+		static constexpr bool is_scale_format_supported(vector_format8 format) { return format == vector_format8::vector3f_variable; }
 	};
+
+	// The optional metadata of a blob, as compressed_tracks hands it out (core/impl/compressed_tracks.impl.h:175-275). Host only.
+	static constexpr uint32_t k_invalid_track_index = 0xFFFFFFFFu;
+	struct track_desc_transformf			// core/track_desc.h:86-158, what a compressed blob keeps of it
+	{
+		qvvf default_value = qvvf{ quatf{ 0.0f, 0.0f, 0.0f, 1.0f }, vector4f{ 0.0f, 0.0f, 0.0f, 0.0f }, vector4f{ 1.0f, 1.0f, 1.0f, 0.0f } };
+		uint32_t output_index = k_invalid_track_index;
+		uint32_t parent_index = k_invalid_track_index;
+		float precision = 0.01f;
+		float shell_distance = 3.0f;
+	};
+
+	// compressed_tracks::get_parent_track_index (compressed_tracks.impl.h:175-190): k_invalid_track_index for a root, and when the blob
+	// does not store parent indices
+	inline uint32_t get_parent_track_index(const void* compressed_tracks, uint64_t size, uint32_t track_index)
+	{
+		aclhip_clip_metadata_info info = {};
+		uint32_t num_tracks = 0;
+		if (compressed_tracks == nullptr || size < 32)
+			return k_invalid_track_index;
+		memcpy(&num_tracks, static_cast<const uint8_t*>(compressed_tracks) + 16, 4);
+		if (track_index >= num_tracks)
+			return k_invalid_track_index;
+		std::vector<uint32_t> parents(num_tracks, k_invalid_track_index);
+		if (aclhip_read_clip_metadata(compressed_tracks, size, &info, parents.data(), nullptr, nullptr, nullptr, num_tracks) != ACLHIP_OK || info.has_parent_track_indices == 0)
+			return k_invalid_track_index;
+		return parents[track_index];
+	}
+
+	// compressed_tracks::get_track_description(track_index, track_desc_transformf&) (compressed_tracks.impl.h:214-275)
+	inline bool get_track_description(const void* compressed_tracks, uint64_t size, uint32_t track_index, track_desc_transformf& out_description)
+	{
+		aclhip_clip_metadata_info info = {};
+		uint32_t num_tracks = 0;
+		if (compressed_tracks == nullptr || size < 32)
+			return false;
+		memcpy(&num_tracks, static_cast<const uint8_t*>(compressed_tracks) + 16, 4);
+		if (track_index >= num_tracks)
+			return false;
+		std::vector<uint32_t> parents(num_tracks, k_invalid_track_index);
+		std::vector<float> defaults(size_t(num_tracks) * 12), precisions(num_tracks), shells(num_tracks);
+		if (aclhip_read_clip_metadata(compressed_tracks, size, &info, parents.data(), defaults.data(), precisions.data(), shells.data(), num_tracks) != ACLHIP_OK
+			|| info.has_track_descriptions == 0)
+			return false;
+		memcpy(&out_description.default_value, &defaults[size_t(track_index) * 12], sizeof(qvvf));
+		out_description.output_index = track_index;
+		out_description.parent_index = parents[track_index];
+		out_description.precision = precisions[track_index];
+		out_description.shell_distance = shells[track_index];
+		return true;
+	}
 
 	// acl::track_writer (core/track_writer.h:82-216), transform part. Derive and override what you need.
 	struct track_writer
@@ -326,6 +389,8 @@ namespace aclhip
 			if (!gpu.is_valid() || compressed_tracks == nullptr)
 				return false;
 
+			if (!formats_are_supported(compressed_tracks, size))
+				return false;
 			aclhip_clip clip = ACLHIP_INVALID_HANDLE;
 			// is_valid(false): the reference does not check the hash on initialize (impl/decompress.impl.h:70)
 			if (aclhip_register_clip(gpu.get(), compressed_tracks, size, 0, &clip) != ACLHIP_OK)
@@ -346,7 +411,7 @@ namespace aclhip
 		bool initialize(const void* compressed_tracks, uint64_t size, const database_context<database_settings_type>& database)
 		{
 			reset();
-			if (compressed_tracks == nullptr || !database.is_initialized() || !database.contains(compressed_tracks))
+			if (compressed_tracks == nullptr || !database.is_initialized() || !database.contains(compressed_tracks) || !formats_are_supported(compressed_tracks, size))
 				return false;
 
 			device& gpu = *database.get_device();
@@ -364,6 +429,23 @@ namespace aclhip
 		}
 
 		bool is_initialized() const { return m_device != nullptr; }
+
+		// the settings' is_*_format_supported against the blob's packed formats (transform clips; decompression.transform.h:95-104)
+		static bool formats_are_supported(const void* compressed_tracks, uint64_t size)
+		{
+			if (size < 32)
+				return true;		// (registration refuses it with its own message)
+			const uint8_t* blob = static_cast<const uint8_t*>(compressed_tracks);
+			uint32_t num_tracks, misc_packed;
+			memcpy(&num_tracks, blob + 16, 4);
+			memcpy(&misc_packed, blob + 28, 4);
+			if (blob[15] != 12 || num_tracks == 0)
+				return true;		// scalar track lists have no packed formats
+			const bool has_scale = (misc_packed & 1u) != 0;
+			return settings_type::is_rotation_format_supported(static_cast<rotation_format8>((misc_packed >> 4) & 15u))
+				&& settings_type::is_translation_format_supported(static_cast<vector_format8>((misc_packed >> 3) & 1u))
+				&& (!has_scale || settings_type::is_scale_format_supported(static_cast<vector_format8>((misc_packed >> 2) & 1u)));
+		}
 
 		void reset()
 		{
@@ -415,6 +497,11 @@ namespace aclhip
 		bool set_parent_indices(const uint32_t* parent_indices, uint32_t num_transforms)
 		{
 			return is_initialized() && aclhip_set_clip_hierarchy(m_device->get(), m_clip, parent_indices, num_transforms) == ACLHIP_OK;
+		}
+		// ... the parent indices the blob itself carries (compressed_tracks::get_parent_track_index); false when it carries none
+		bool set_parent_indices_from_metadata()
+		{
+			return is_initialized() && aclhip_set_clip_hierarchy_from_metadata(m_device->get(), m_clip) == ACLHIP_OK;
 		}
 
 		// The pose at the last seek() as a caller of the reference would have it after

@@ -877,6 +877,7 @@ namespace aclhip
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
 			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
+#if !defined(ACLHIP_AB_NO_STORED_W)
 		if constexpr (kHasRaw)
 		{
 			// quatf_full: the sample's W is the fourth float of its 128 bits (unpack_vector4_128_unsafe) -- no reconstruction, no sample
@@ -901,6 +902,7 @@ namespace aclhip
 				return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, false, policy, lerp_alpha, normalization, normalize_samples, false);
 			}
 		}
+#endif
 		// (raw samples are any floats: a wave that meets one keeps the compiler's forms)
 		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples, !kHasRaw && short_exact_math);
 	}

@@ -590,7 +590,7 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			const segment_header& sh = *reinterpret_cast<const segment_header*>(tbase + th.segment_headers_offset + size_t(si) * segment_header_size);
 			const uint32_t start = multi_segment ? segment_start_indices[si] : 0;
 			const uint32_t end = multi_segment && si + 1 < num_segments ? segment_start_indices[si + 1] : num_samples;
-			if (start >= end || end > num_samples || (stripped && end - start > 32) || (si == 0 && start != 0))
+			if (start >= end || end > num_samples || (si == 0 && start != 0))		// (validate_clip bounds a segment's length)
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%u, %u)", si, start, end);
 			// transform_tracks_header::get_segment_data (core/impl/compressed_headers.h:309-324)
 			const uint32_t format_offset = k_transform_header_offset + sh.segment_data;

@@ -476,6 +476,18 @@ namespace
 		aclhip_output_desc local_output = {};
 		if (output != nullptr)
 		{
+			// (the same refusals apply_output_desc makes for the device entry points, BEFORE anything is uploaded: a descriptor with one of
+			// the two mask arrays used to be decoded here without masks)
+			if ((output->instance_masks != nullptr) != (output->mask_table != nullptr))
+			{
+				release();
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "instance_masks and mask_table come together");
+			}
+			if (output->instance_masks != nullptr && output->mask_stride == 0)
+			{
+				release();
+				return fail(context, ACLHIP_ERROR_INVALID_ARGUMENT, "mask_stride: the bytes of one mask of mask_table (at least the tracks of the largest clip of the batch)");
+			}
 			local_output = *output;
 			void* d_rows = nullptr;
 			if (ok && output->rows != nullptr)

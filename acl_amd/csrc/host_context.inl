@@ -625,12 +625,16 @@ namespace
 
 		if (th.num_segments == 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Invalid segment count");
-		// (a segment of a clip with stripped keyframes or a database names the keyframes it keeps in 32 bits; any other segment can be of any
-		// length -- a clip in the full formats is never segmented, compress.transform.impl.h:168-176)
 		// (registration keeps 16 bytes per sample: a blob without animated sub-tracks could otherwise name any count -- 2^24 samples are 155 hours at 30 Hz)
 		if (header.num_samples > (1u << 24))
 			return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "%u samples: clips of more than 16 777 216 samples are not supported", header.num_samples);
-		if (stripped && uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
+		// A segment holds at most 32 samples (the compressor cuts at 31, segment_context.h:55-66; stripped keyframes and database tiers name a
+		// segment's keyframes in 32 bits) -- unless EVERY format is a full one: such a clip is never segmented and is one segment of any length
+		// (compress.transform.impl.h:168-176). (Round 6 first lifted the limit for every clip without stripped keyframes: a multi segment clip
+		// whose segment count was edited to 1 then registered, and the reference, its restatement and these kernels each read the bytes behind
+		// segment 0 their own way -- three poses for one blob, found by tools/fuzz_gpu_mutated.py.)
+		const bool segments_of_any_length = !stripped && !rotations_variable && !translations_variable && (!header.has_scale() || !scales_variable);
+		if (!segments_of_any_length && uint64_t(header.num_samples) > uint64_t(th.num_segments) * 32)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
 		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + num_variable_translations + num_variable_scales)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
@@ -668,7 +672,7 @@ namespace
 			// moved to a database) must lie inside the buffer
 			const uint64_t start = th.num_segments > 1 ? segment_start_indices[i] : 0;
 			const uint64_t end = th.num_segments > 1 && i + 1 < th.num_segments ? segment_start_indices[i + 1] : header.num_samples;
-			if (start >= end || end > header.num_samples || (stripped && end - start > 32))
+			if (start >= end || end > header.num_samples || (!segments_of_any_length && end - start > 32))
 				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "segment %u has an invalid sample range [%llu, %llu)", i, static_cast<unsigned long long>(start), static_cast<unsigned long long>(end));
 			if (stripped)
 			{

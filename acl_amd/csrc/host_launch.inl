@@ -444,9 +444,11 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 	{
 		__atomic_store_n(scratch->host_failed, 0u, __ATOMIC_RELAXED);
 		scratch->one_launch_form_disabled = true;
-		(void)hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), stream);
+		if (scratch->barrier != nullptr)
+			(void)hipMemsetAsync(scratch->barrier, 0, sizeof(order_control), stream);
 		return fail(context, ACLHIP_ERROR_DEVICE, "an earlier aclhip_order_instances_device on this stream did not complete (its workgroups could not all become resident "
-			"within seconds): the order it was to write is invalid. This stream orders with three launches from now on; order again");
+			"within seconds, or -- three launch form -- another ordering wrote this stream's counters at the same time: a captured ordering replayed next to one of "
+			"the stream whose scratch it holds): the order it was to write is invalid. This stream orders with three launches from now on; order again");
 	}
 	if (num_bins <= k_order_direct_bins && forced_form != 3 && !scratch->one_launch_form_disabled)
 	{
@@ -524,11 +526,17 @@ aclhip_status order_instances_on_device(aclhip_context* context, uint32_t window
 	}
 	uint32_t* counters = scratch->bins;
 	uint32_t* cursors = scratch->bins + padded_bins;
+	// (the three launch form reports a corrupted ordering through the same host word as the one launch form's barrier give-up)
+	if (scratch->host_failed == nullptr)
+	{
+		ACLHIP_CHECK_HIP(context, hipHostMalloc(reinterpret_cast<void**>(&scratch->host_failed), sizeof(uint32_t), hipHostMallocMapped));
+		*scratch->host_failed = 0;
+	}
 
 	const uint32_t num_blocks = (num_instances + k_order_instances_per_block - 1) / k_order_instances_per_block;
 	hipLaunchKernelGGL(order_count_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, num_instances, num_bins, counters);
 	hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(1024), 0, stream, counters, cursors, num_bins);
-	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times, out_positions);
+	hipLaunchKernelGGL(order_scatter_kernel, dim3(num_blocks), dim3(k_order_block_size), 0, stream, clips, sample_times, num_instances, num_bins, cursors, layout, out_order, out_clips, out_sample_times, out_positions, scratch->host_failed);
 	ACLHIP_CHECK_HIP(context, hipGetLastError());
 	return ACLHIP_OK;
 }

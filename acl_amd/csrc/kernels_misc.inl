@@ -234,7 +234,7 @@
 	// every instance takes the next position of its clip and lands in the slot that position maps to
 	__global__ __launch_bounds__(k_order_block_size) void order_scatter_kernel(const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances,
 		uint32_t num_bins, uint32_t* __restrict__ bins, order_layout layout_argument, uint32_t* __restrict__ out_order, uint32_t* __restrict__ out_clip_ids, float* __restrict__ out_sample_times,
-		uint32_t* __restrict__ out_positions)
+		uint32_t* __restrict__ out_positions, uint32_t* __restrict__ host_failed)
 	{
 		__shared__ order_table table;
 		__shared__ order_layout layout;
@@ -265,9 +265,14 @@
 				continue;
 			const uint32_t destination = order_slot_of(layout, table.counts[slot[k]] + rank[k]);
 			// (a position past the list: this launch's counters were written by ANOTHER launch at the same time -- a captured ordering replayed
-			// on another stream than the one whose scratch it holds, next to an ordering of that stream. Nothing is written out of bounds.)
+			// on another stream than the one whose scratch it holds, next to an ordering of that stream. Nothing is written out of bounds, and
+			// the host hears about it like about a barrier that gave up: the order this launch leaves is not a permutation.)
 			if (destination >= num_instances)
+			{
+				if (host_failed != nullptr)
+					__hip_atomic_store(host_failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				continue;
+			}
 			out_order[destination] = instance;
 			if (out_clip_ids != nullptr)
 				out_clip_ids[destination] = clip_id[k];

@@ -166,7 +166,7 @@
 
 		track_request_state state;
 		float lerp_alpha = 0.0f;
-		float4 quads[3];
+		float4 quads[3] = { make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f), make_float4(0.0f, 0.0f, 0.0f, 0.0f) };		// (refused requests write these to LDS, never to memory)
 		bool store[3] = { false, false, false };
 		uint32_t animated = 0;
 		uint32_t ordinals[3] = { 0, 0, 0 };
@@ -175,10 +175,16 @@
 		// or every lane's own
 		const clip_range_entry* shared_clip_ranges = nullptr;
 		const clip_range_entry* own_clip_ranges = nullptr;
+#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
+		uint32_t ab_total_rows = 0;
+#endif
 		if (shared_clip)
 		{
 			const device_clip clip = load_clip(clips, first_clip_id);
 			shared_clip_ranges = clip.clip_ranges;
+#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
+			ab_total_rows = clip.num_segments * clip.num_animated;
+#endif
 			if (in_batch)
 				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
@@ -260,6 +266,14 @@
 				clip_ranges = reinterpret_cast<const clip_range_entry*>((uint64_t(high) << 32) | low);
 			}
 
+#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
+			// A/B: the shared clip's plan addressed forwards from a scalar base
+			const uint32_t ab_row0 = request.rows[0] & ~k_track_row_short_exact_math, ab_row1 = request.rows[1];
+			const plan_entry* ab_plan = reinterpret_cast<const plan_entry*>(clip_ranges) - ab_total_rows;
+			const plan_entry plan0 = load_entry(ab_plan, (ab_total_rows - ab_row0) + ordinal);
+			const plan_entry plan1 = ab_row1 == ab_row0 ? plan0 : load_entry(ab_plan, (ab_total_rows - ab_row1) + ordinal);
+			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
+#else
 			// (plan_entry and clip_range_entry are both 32 bytes: the plan's last entry is clip_ranges[-1])
 			static_assert(sizeof(plan_entry) == sizeof(clip_range_entry), "the plan is addressed from the clip range table");
 			const plan_entry* plan_end = reinterpret_cast<const plan_entry*>(clip_ranges);
@@ -267,6 +281,7 @@
 			const plan_entry plan0 = load_entry(plan_end - row0, ordinal);
 			const plan_entry plan1 = row1 == row0 ? plan0 : load_entry(plan_end - row1, ordinal);
 			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
+#endif
 
 			seek_state key_state;
 			key_state.animated_track_data[0] = request.data[0];

@@ -310,7 +310,8 @@ class Job:
             # a frame loop knows next frame's clip list before this frame's poses are consumed: the ordering of step k + 1 runs on a SECOND
             # stream while step k decodes -- two sets of ordered lists, an event each way (ordered -> decode may start; decoded -> the set
             # may be overwritten)
-            self.order_stream = torch.cuda.Stream(self.device)
+            # (ACLHIP_BENCH_ORDER_PRIORITY=1: the ordering's stream at high priority, so that its workgroups are dispatched ahead of the decode's)
+            self.order_stream = torch.cuda.Stream(self.device, priority=-1 if os.environ.get("ACLHIP_BENCH_ORDER_PRIORITY", "0") == "1" else 0)
             sets = []
             for _ in range(2):
                 ordered_clips, ordered_times, order_out = torch.zeros_like(self.d_clips), torch.zeros_like(self.d_times), torch.zeros_like(self.d_order)

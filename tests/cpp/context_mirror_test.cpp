@@ -145,5 +145,63 @@ int main(int argc, char** argv)
 		return run<pose_writer<default_sub_track_mode::skipped, default_sub_track_mode::skipped>>(gpu, storage, blob, blob_size, times, argv[3]);
 	if (mode == "variable")
 		return run<pose_writer<default_sub_track_mode::variable, default_sub_track_mode::variable>>(gpu, storage, blob, blob_size, times, argv[3]);
+	if (mode == "formats")
+	{
+		// a clip in a full-precision format (test_data/configs/uniformly_sampled_raw.config.sjson) that carries track descriptions: the default
+		// settings do not take it (decompression_settings.h:221-223; the reference asserts), settings that support its formats do; its metadata reads like
+		// compressed_tracks::get_parent_track_index / get_track_description; the object space pose needs no skeleton from the caller
+		aclhip::decompression_context<aclhip::default_transform_decompression_settings> refusing;
+		if (refusing.initialize(gpu, blob, blob_size))
+			return 20;
+		// (what a runtime that loads the raw / mixed configurations compiles: the default settings with every packed format switched on)
+		struct any_format_settings : public aclhip::default_transform_decompression_settings
+		{
+			static constexpr bool is_rotation_format_supported(aclhip::rotation_format8) { return true; }
+			static constexpr bool is_translation_format_supported(aclhip::vector_format8) { return true; }
+			static constexpr bool is_scale_format_supported(aclhip::vector_format8) { return true; }
+		};
+		aclhip::decompression_context<aclhip::debug_transform_decompression_settings> debug_context;
+		if (!debug_context.initialize(gpu, blob, blob_size))
+			return 25;
+		aclhip::decompression_context<any_format_settings> context;
+		if (!context.initialize(gpu, blob, blob_size) || !context.set_parent_indices_from_metadata())
+			return 21;
+		uint32_t num_tracks;
+		std::memcpy(&num_tracks, blob + 16, 4);
+		FILE* out = std::fopen(argv[3], "wb");
+		if (out == nullptr)
+			return 14;
+		// [num_tracks] parents, [num_tracks][12] default values, then per time: the local pose and the object space pose
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			const uint32_t parent = aclhip::get_parent_track_index(blob, blob_size, track);
+			std::fwrite(&parent, 4, 1, out);
+		}
+		for (uint32_t track = 0; track < num_tracks; ++track)
+		{
+			aclhip::track_desc_transformf desc;
+			if (!aclhip::get_track_description(blob, blob_size, track, desc) || desc.parent_index != aclhip::get_parent_track_index(blob, blob_size, track) || desc.output_index != track)
+				return 22;
+			std::fwrite(&desc.default_value, sizeof(aclhip::qvvf), 1, out);
+		}
+		if (aclhip::get_parent_track_index(blob, blob_size, num_tracks) != aclhip::k_invalid_track_index)
+			return 23;
+		pose_writer<default_sub_track_mode::constant, default_sub_track_mode::legacy> writer;
+		std::vector<float> pose(size_t(num_tracks) * 12);
+		std::vector<aclhip::qvvf> object_pose(num_tracks);
+		for (float t : times)
+		{
+			std::fill(pose.begin(), pose.end(), 0.0f);
+			writer.pose = pose.data();
+			context.seek(t, aclhip::sample_rounding_policy::none);
+			context.decompress_tracks(writer);
+			if (!context.decompress_pose(object_pose.data(), true))
+				return 24;
+			std::fwrite(pose.data(), sizeof(float), pose.size(), out);
+			std::fwrite(object_pose.data(), sizeof(aclhip::qvvf), object_pose.size(), out);
+		}
+		std::fclose(out);
+		return 0;
+	}
 	return 6;
 }

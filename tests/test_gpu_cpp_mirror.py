@@ -55,6 +55,38 @@ def test_cpp_context_matches_oracle(mirror_binary, tmp_path, mode):
         assert np.array_equal(poses[i][:, lanes].view(np.uint32), expected[:, lanes].view(np.uint32))
 
 
+def test_cpp_context_full_formats_and_metadata(mirror_binary, tmp_path):
+    """a quatf_full + vector3f_full clip with track descriptions from the reference's compressor (tests/golden/corpus): the default settings
+    refuse it, settings that support every format decode it to the oracle's bits, its metadata reads like the reference's accessors
+    return it, and decompress_pose(object space) takes the skeleton from the blob"""
+    import helpers
+    clip = next(clip for clip in helpers.load_corpus() if clip["name"].endswith("metadata_raw"))
+    blob_path, times_path, out_path = tmp_path / "clip.acl", tmp_path / "times.txt", tmp_path / "poses.bin"
+    clip["blob"].tofile(blob_path)
+    times, _ = helpers.corpus_sample_times(clip["blob"])
+    times = times[::3]
+    times_path.write_text("\n".join(repr(float(t)) for t in times))
+    result = subprocess.run([mirror_binary, str(blob_path), str(times_path), str(out_path), "formats"])
+    assert result.returncode == 0
+    bones = clip["spec"]["bones"]
+    raw = np.fromfile(out_path, dtype=np.float32)
+    parents = raw[:bones].view(np.uint32)
+    assert np.array_equal(parents, clip["parents"].astype(np.uint32))
+    defaults = raw[bones: bones + bones * 12].reshape(bones, 12)
+    expected_defaults = clip["bind_pose"].copy()
+    expected_defaults[:, 7] = 0.0
+    expected_defaults[:, 11] = 0.0
+    assert np.array_equal(defaults.view(np.uint32), expected_defaults.view(np.uint32))
+    poses = raw[bones + bones * 12:].reshape(times.size, 2, bones, 12)
+    options = helpers.oracle_options(4)         # default settings that take every packed format (oracle/ref_bridge.cpp: any_format_settings)
+    lanes = [0, 1, 2, 3, 4, 5, 6, 8, 9, 10]
+    for i, t in enumerate(times):
+        local = ob.oracle_decompress_tracks(clip["blob"], float(t), 0, options)
+        assert np.array_equal(poses[i, 0][:, lanes].view(np.uint32), local[:, lanes].view(np.uint32))
+        in_object_space = ob.oracle_local_to_object_space(clip["parents"].astype(np.uint32), local)
+        assert np.array_equal(poses[i, 1][:, lanes].view(np.uint32), in_object_space[:, lanes].view(np.uint32))
+
+
 @pytest.fixture(scope="module")
 def database_mirror_binary(tmp_path_factory):
     out = tmp_path_factory.mktemp("cpp") / "database_mirror_test"

@@ -52,8 +52,13 @@ def main():
     rng = np.random.default_rng(seed)
     import conftest
     sources = [synth.build_clip(**spec) for spec in conftest.CLIP_SPECS.values() if spec.get("num_tracks", 100) <= 330]
+    # ... and what the reference's own compressor writes in the full-precision and mixed formats (round 6: quatf_full, quatf_drop_w_full,
+    # vector3f_full; one segment of any length when nothing is variable), with and without optional metadata
+    import helpers
+    import types
+    sources += [types.SimpleNamespace(blob=clip["blob"]) for clip in helpers.load_corpus()
+                if (clip["spec"]["config"] in ("raw", "mixed_var_0", "mixed_var_1", "drop_w_full") or clip["name"].split("_", 1)[1].startswith("metadata")) and clip["spec"]["bones"] <= 105]
     if os.environ.get("FUZZ_SCALAR", "0") == "1":
-        import helpers
         sources = [synth.build_scalar_clip(**spec) for spec in helpers.SCALAR_CLIP_SPECS.values()]
     accepted = refused = decoded = different = 0
     start = time.time()
