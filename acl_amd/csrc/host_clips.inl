@@ -341,6 +341,8 @@ namespace
 
 namespace
 {
+	uint32_t database_clip_segments(const host_database& db, uint32_t clip_header_offset);		// host_databases.inl
+
 	// The optional metadata behind a transform clip's compressed data (optional_metadata_header, acl_format.h): which sections the blob
 	// stores, its parent indices (compressed_tracks::get_parent_track_index, core/impl/compressed_tracks.impl.h:175-190) and track
 	// descriptions (get_track_description, :214-275) as [num_tracks][14] = default_value (12 floats, a row of default_values) | precision |
@@ -1025,6 +1027,9 @@ static aclhip_status register_clip_impl(aclhip_context* context, const void* com
 			for (const database_clip_metadata& metadata : db.clip_metadata)
 				contained = contained || (metadata.clip_hash == buffer_header.hash && metadata.clip_header_offset == record.db_clip_header_offset);
 			contained = contained && uint64_t(record.db_clip_header_offset) + sizeof(database_runtime_clip_header) + uint64_t(record.num_segments) * sizeof(database_runtime_segment_header) <= db.runtime_headers_size;
+			// ... and the database keeps exactly this clip's segments behind its runtime clip header (a metadata offset moved by one
+			// segment header leaves the clip in front one header short: its last segment's tier words would be the next clip's hash)
+			contained = contained && database_clip_segments(db, record.db_clip_header_offset) == record.num_segments;
 		}
 		if (!contained)
 		{

@@ -638,6 +638,12 @@ namespace
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "%u samples cannot fit in %u segments of at most 32", header.num_samples, th.num_segments);
 		if (uint64_t(th.num_animated_variable_sub_tracks) != num_rotations_padded + num_variable_translations + num_variable_scales)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Inconsistent animated sub-track counts");
+		// (a track has one sub-track of each kind: no count exceeds the track count. The sum above bounded the three counts while every
+		// format was variable; a full format's count appears in no sum -- 0xFFFFFFFF animated rotations + 2 translations wrapped to ONE
+		// table entry at registration: found by the mutated-clip fuzz under AddressSanitizer, round 6)
+		if (th.num_animated_rotation_sub_tracks > header.num_tracks || th.num_animated_translation_sub_tracks > header.num_tracks || th.num_animated_scale_sub_tracks > header.num_tracks
+			|| th.num_constant_rotation_samples > header.num_tracks || th.num_constant_translation_samples > header.num_tracks || th.num_constant_scale_samples > header.num_tracks)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "More sub-tracks of a kind than tracks");
 		if (tbase + th.segment_headers_offset + uint64_t(segment_header_size) * th.num_segments > blob_size
 			|| tbase + th.sub_track_types_offset + num_entries * 4 * (header.has_scale() ? 3 : 2) > blob_size
 			|| tbase + th.constant_track_data_offset + constant_rotation_size * th.num_constant_rotation_samples + 12ull * (uint64_t(th.num_constant_translation_samples) + th.num_constant_scale_samples) > blob_size

@@ -29,6 +29,31 @@ namespace
 	}
 }
 
+
+namespace
+{
+	// segments of the clip whose runtime clip header sits at `clip_header_offset` (the clip metadata tile the block: register_database_impl);
+	// 0 when no clip's does
+	uint32_t database_clip_segments(const host_database& db, uint32_t clip_header_offset)
+	{
+		const auto found = std::lower_bound(db.clip_metadata.begin(), db.clip_metadata.end(), clip_header_offset,
+			[](const database_clip_metadata& metadata, uint32_t offset) { return metadata.clip_header_offset < offset; });
+		if (found == db.clip_metadata.end() || found->clip_header_offset != clip_header_offset)
+			return 0;
+		const uint64_t end = found + 1 != db.clip_metadata.end() ? (found + 1)->clip_header_offset : db.runtime_headers_size;
+		return uint32_t((end - clip_header_offset - sizeof(database_runtime_clip_header)) / sizeof(database_runtime_segment_header));
+	}
+
+	// a chunk segment header must name one of the segment headers of the clip it names
+	bool names_a_segment_header(const host_database& db, uint32_t clip_header_offset, uint32_t segment_header_offset)
+	{
+		const uint32_t segments = database_clip_segments(db, clip_header_offset);
+		const uint64_t first = uint64_t(clip_header_offset) + sizeof(database_runtime_clip_header);
+		return segments != 0 && segment_header_offset >= first && (segment_header_offset - first) % sizeof(database_runtime_segment_header) == 0
+			&& (segment_header_offset - first) / sizeof(database_runtime_segment_header) < segments;
+	}
+}
+
 static aclhip_status register_database_impl(aclhip_context* context, const void* compressed_database, uint64_t size,
 	const void* bulk_data_medium, const void* bulk_data_low, int check_hash, aclhip_database* out_database, bool validate_only, bool streamed = false)
 {
@@ -92,10 +117,20 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 		return fail(context, ACLHIP_ERROR_UNSUPPORTED_FORMAT, "%u clips / %u segments: runtime headers beyond 256 MiB are not supported", header.num_clips, header.num_segments);
 	std::vector<uint8_t> runtime(std::max<uint64_t>(runtime_size, 16), 0);
 	db.runtime_headers_size = runtime_size;
-	for (const database_clip_metadata& metadata : db.clip_metadata)
+	// The runtime block is [clip header, one segment header per segment of the clip] per clip, in clip order (build_database,
+	// compress.database.impl.h): the clip metadata's offsets start at 0, ascend, leave room for whole segment headers between them and
+	// use the block up. A database whose offsets overlap has clip hashes written INTO segment headers by initialize
+	// (database.impl.h:151-157) -- the reference, its restatement and this library then each decode the tiers of that segment their own
+	// way. Refused. (Found by tools/fuzz_gpu_mutated_db.py, round 6.)
+	for (size_t i = 0; i < db.clip_metadata.size(); ++i)
 	{
+		const database_clip_metadata& metadata = db.clip_metadata[i];
 		if (uint64_t(metadata.clip_header_offset) + sizeof(database_runtime_clip_header) > runtime_size || (metadata.clip_header_offset & 7u) != 0)
 			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Clip metadata points outside of the runtime headers");
+		const uint64_t end = i + 1 < db.clip_metadata.size() ? db.clip_metadata[i + 1].clip_header_offset : runtime_size;
+		const uint64_t first_segment = uint64_t(metadata.clip_header_offset) + sizeof(database_runtime_clip_header);
+		if ((i == 0 && metadata.clip_header_offset != 0) || end < first_segment + sizeof(database_runtime_segment_header) || (end - first_segment) % sizeof(database_runtime_segment_header) != 0)
+			return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Clip metadata: the runtime headers of clip %zu do not tile the block", i);
 		reinterpret_cast<database_runtime_clip_header*>(runtime.data() + metadata.clip_header_offset)->clip_hash = metadata.clip_hash;	// database.impl.h:151-157
 	}
 
@@ -134,7 +169,7 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 			{
 				// (8 byte aligned: the device stores the tier words of a segment header as 64 bit atomics)
 				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > runtime_size || segments[i].samples_offset >= header.bulk_data_size[tier]
-					|| (segments[i].segment_header_offset & 7u) != 0)
+					|| (segments[i].segment_header_offset & 7u) != 0 || !names_a_segment_header(db, segments[i].clip_header_offset, segments[i].segment_header_offset))
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %d points outside of the database", chunk_index, tier + 1);
 				patches[tier].push_back(tier_patch{ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
 			}
@@ -406,7 +441,7 @@ namespace
 			for (uint32_t i = 0; i < chunk.num_segments; ++i)
 			{
 				if (uint64_t(segments[i].segment_header_offset) + sizeof(database_runtime_segment_header) > db.runtime_headers_size || segments[i].samples_offset >= bulk_size
-					|| (segments[i].segment_header_offset & 7u) != 0)
+					|| (segments[i].segment_header_offset & 7u) != 0 || !names_a_segment_header(db, segments[i].clip_header_offset, segments[i].segment_header_offset))
 					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u points outside of the database", chunk_index, tier_index + 1);
 				// keyframes of a clip that is already bound must lie inside the tier (clips bound later are checked when they are bound)
 				for (const std::pair<uint32_t, uint32_t>& bound : db.segment_pose_bits)

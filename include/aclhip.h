@@ -314,6 +314,9 @@ typedef struct aclhip_database_info
 /* Replaces database_context::initialize(allocator, database, medium_streamer, low_streamer)
  * (decompression/database/database.h:116; impl/database.impl.h): registers a compressed_database (HOST pointer, `size` bytes).
  * Bulk data of the two tiers is given separately (split_database_bulk_data) or may be null when it is inline in the database.
+ * A bulk data pointer given separately must address compressed_database::get_bulk_data_size(tier) bytes (database_header::
+ * bulk_data_size, aclhip_database_info::bulk_data_size after aclhip_check_database): like the reference's streamers, the call takes
+ * no size for it and trusts the header the caller paired it with.
  * The bulk data is copied once into PINNED host memory -- the streamer's backing store -- and HBM buffers of the same size are
  * reserved; nothing is resident on the GPU until aclhip_database_stream_in. The runtime tier metadata the decoder reads
  * (database_runtime_segment_header::tier_metadata, core/impl/compressed_headers.h:404-422) lives in HBM. */

@@ -234,3 +234,44 @@ def test_stripped_segments_keep_their_first_and_last_keyframe():
             word[0] = indices & ~(clear if clear is not None else lowest)                # first / last kept keyframe gone
             status, _ = runtime.check_clip(blob, check_hash=False)
             assert status != 0, (segment, hex(indices))
+
+
+def test_more_sub_tracks_of_a_kind_than_tracks_are_refused():
+    """a full format's sub-track count appears in no sum the validator checked: 0xFFFFFFFF animated rotations (+ 2 translations) wrapped
+    the table sizes at registration (found by tools/fuzz_gpu_mutated.py with full-format corpus sources under AddressSanitizer, round 6)"""
+    raw = [clip for clip in helpers.load_corpus() if clip["spec"]["config"] == "raw"]
+    assert raw
+    blob = raw[0]["blob"]
+    assert runtime.check_clip(blob)[0] == 0
+    num_tracks = int(np.frombuffer(blob, dtype=np.uint32, count=1, offset=16)[0])
+    # transform_tracks_header (acl_format.h): words 2 .. 7 = animated rotation / translation / scale sub-tracks, constant rotation / translation / scale samples
+    for word in range(2, 8):
+        for value in (0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, num_tracks + 1):
+            status, message = runtime.check_clip(_patched(blob, TRANSFORM_HEADER_OFFSET + 4 * word, "<I", value), check_hash=False)
+            assert status != 0, (word, hex(value), message)
+
+
+def test_database_runtime_headers_must_tile_their_block():
+    """clip metadata whose runtime header offsets overlap (or leave a partial segment header) make database_context::initialize write a
+    clip hash into another clip's segment header (database.impl.h:151-157); chunk segment headers must name a segment header of the clip
+    they name (found by tools/fuzz_gpu_mutated_db.py, round 6)"""
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    database, medium, low = case["database"], case["bulk_medium"], case["bulk_low"]
+    assert runtime.check_database(database, medium, low)[0] == 0
+    words = np.frombuffer(database, dtype=np.uint32)
+    num_clips, metadata_offset = int(words[7]), 8 + int(words[9])          # (raw_buffer_header of 8 bytes, then database_header)
+    assert num_clips == 3
+    for clip in range(num_clips):
+        at = metadata_offset + 8 * clip + 4         # database_clip_metadata::clip_header_offset
+        original = int(np.frombuffer(database, dtype=np.uint32, count=1, offset=at)[0])
+        for delta in (-16, -8, 8, 16, 24):
+            status, _ = runtime.check_database(_patched(database, at, "<I", (original + delta) & 0xFFFFFFFF), medium, low, check_hash=False)
+            assert status != 0, (clip, delta)
+    # a chunk segment header that names the header of ANOTHER segment slot than any of its clip's (first chunk of the medium tier:
+    # database_chunk_header {index, size, num_segments} then database_chunk_segment_header {clip_hash, sample_indices, samples_offset, clip_header_offset, segment_header_offset})
+    if medium.size:
+        at = 12 + 16
+        original = int(np.frombuffer(medium, dtype=np.uint32, count=1, offset=at)[0])
+        for delta in (-8, 4, 8, 0x10000):
+            status, _ = runtime.check_database(database, _patched(medium, at, "<I", (original + delta) & 0xFFFFFFFF), low, check_hash=False)
+            assert status != 0, delta

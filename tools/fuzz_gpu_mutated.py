@@ -4,6 +4,7 @@ reading outside the clip's memory (a GPU memory fault ends the process: the run 
 oracle walks the same bytes, to the oracle's bits. The mutations are the ones of tools/fuzz_host_validators.py (header words to
 extremes, byte flips in headers and data, swapped words; no truncations -- a registered blob is whole).
 usage: fuzz_gpu_mutated.py [seed] [seconds]"""
+import faulthandler
 import os
 import sys
 import time
@@ -47,6 +48,7 @@ def mutate(rng, blob):
 
 
 def main():
+    faulthandler.enable()       # a host side crash names the call it was in
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
     rng = np.random.default_rng(seed)

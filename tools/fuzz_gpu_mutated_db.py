@@ -8,6 +8,7 @@ Sources: the four corpus databases (tests/golden/corpus) and the committed datab
 changes of counts and offsets, byte flips in the chunk descriptions / clip metadata, byte flips and word edits in the chunk headers and
 chunk segment headers of the bulk data, swapped words.
 usage: fuzz_gpu_mutated_db.py [seed] [seconds]"""
+import faulthandler
 import os
 import sys
 import time
@@ -29,6 +30,16 @@ def aligned_copy(array):
     out = synth.aligned_bytes(max(array.size, 1))
     out[: array.size] = array
     return out[: array.size] if array.size else out[:0]
+
+
+def grown(buffer, size):
+    """buffer, or a zero padded aligned copy of at least `size` bytes"""
+    if buffer.size >= size:
+        return buffer
+    out = synth.aligned_bytes(size)
+    out[:] = 0
+    out[: buffer.size] = buffer
+    return out
 
 
 def mutate_words(rng, buffer, first, last):
@@ -71,6 +82,7 @@ def mutate(rng, case):
 
 
 def main():
+    faulthandler.enable()       # a host side crash names the call it was in
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seconds = float(sys.argv[2]) if len(sys.argv) > 2 else 60.0
     rng = np.random.default_rng(seed)
@@ -84,6 +96,14 @@ def main():
             iteration += 1
             case = cases[int(rng.integers(0, len(cases)))]
             database, medium, low = mutate(rng, case)
+            # The caller's side of the contract: the bulk data buffers hold database_header::bulk_data_size bytes (the entry points take
+            # pointers without sizes, like database_context::initialize with its streamers). A mutated size that claims more gets a buffer
+            # that long (zeros behind the real data) while that is reasonable, and is not a case otherwise.
+            claimed = [int(v) for v in database[40:48].view(np.uint32)] if database.size >= 48 else [0, 0]
+            if max(claimed) > (16 << 20):
+                refused += 1
+                continue
+            medium, low = (grown(buffer, size) for buffer, size in zip((medium, low), claimed))
             bulk = (medium if medium.size else None, low if low.size else None)
             status, _ = runtime.check_database(database, bulk[0], bulk[1], check_hash=False)
             if status != 0:
