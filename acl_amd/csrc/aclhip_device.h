@@ -145,17 +145,15 @@ namespace aclhip
 	__host__ __device__ __forceinline__ bool is_raw_width(uint32_t width) { return width >= k_width_raw_variable; }
 	__host__ __device__ __forceinline__ uint32_t stored_sample_bits(uint32_t width) { return width < k_width_raw_variable ? width * 3u : (width == k_width_raw_quat ? 128u : 96u); }
 
-	// Per clip record in HBM, written once at registration; read through the scalar cache by every wave.
+	// Per clip record in HBM, written once at registration; read through the scalar cache by every wave. The FIRST 64 bytes hold what a
+	// seek and a single track request need (k_clip_head_bytes: waves of mixed clips in decompress_track_kernel gather just these, four
+	// lanes per record); the second half what only whole poses, databases and the table defaults read.
 	struct alignas(128) device_clip
 	{
 		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding
 		const float4* base_pose;				// [3 * num_tracks] rotation | translation | scale per track: constants expanded, defaults = identity, animated = marker
 		const sample_record* samples;			// [num_samples]; database_sample_record[num_samples] for clips bound to a database (k_clip_database_samples)
-		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
-		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
 		const clip_range_entry* clip_ranges;	// [num_animated]; scalar clips: float[num_tracks][2 * C] range rows
-		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
-		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
 		uint32_t num_tracks;
 		uint32_t num_samples;
 		float sample_rate;
@@ -164,13 +162,20 @@ namespace aclhip
 		uint32_t flags;							// k_clip_*
 		uint32_t num_segments;
 		uint32_t num_animated;					// rotations + translations + scales; scalar clips: bits per frame
-		uint32_t db_clip_header_offset;			// into db_headers
+		// ---- 64 bytes ----
+		const float4* resolved_pose;			// [3 * num_tracks] like base_pose but final: defaults hold the track_writer defaults, no markers
+		const plan_entry* plan;					// [num_segments][num_animated]; scalar clips: scalar_track_header[num_tracks]
+		const uint8_t* db_headers;				// database runtime clip/segment headers (device) or null
+		const uint8_t* db_bulk_data[2];			// database bulk data, medium / low importance tier (device) or null
 		const uint32_t* image_chunks;			// [ceil(3 * num_tracks / k_image_chunk_quads) + 1] first animated ordinal of every pose window; behind it,
 												// at the next multiple of 32 bytes: window_span_entry[num_segments][num_windows] (window_spans_of)
 		const uint32_t* hierarchy;				// aclhip_set_clip_hierarchy: walk schedules for 1 / 2 / 4 / 8 instances per workgroup; or null
+		uint32_t db_clip_header_offset;			// into db_headers
+		uint32_t reserved;
 	};
 
-	static_assert(sizeof(device_clip) == 128, "layout");
+	constexpr uint32_t k_clip_head_bytes = 64;
+	static_assert(sizeof(device_clip) == 128 && offsetof(device_clip, num_animated) + 4 == k_clip_head_bytes && offsetof(device_clip, resolved_pose) == k_clip_head_bytes, "layout");
 
 	constexpr uint32_t k_clip_has_scale = 1u << 0;
 	constexpr uint32_t k_clip_has_stripped_keyframes = 1u << 1;	// stripped keyframes or database: sample_indices matter
@@ -877,7 +882,6 @@ namespace aclhip
 			unpack_animated_samples_wide<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
 		else
 			unpack_animated_samples<kHasRaw>(state, plan0, plan1, clip_range, is_rotation, v0, v1);
-#if !defined(ACLHIP_AB_NO_STORED_W)
 		if constexpr (kHasRaw)
 		{
 			// quatf_full: the sample's W is the fourth float of its 128 bits (unpack_vector4_128_unsafe) -- no reconstruction, no sample
@@ -902,7 +906,6 @@ namespace aclhip
 				return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, false, policy, lerp_alpha, normalization, normalize_samples, false);
 			}
 		}
-#endif
 		// (raw samples are any floats: a wave that meets one keeps the compiler's forms)
 		return interpolate_animated_samples<kPolicies, kFastMath>(state, v0, v1, is_rotation, policy, lerp_alpha, normalization, normalize_samples, !kHasRaw && short_exact_math);
 	}

@@ -182,6 +182,13 @@ static aclhip_status register_database_impl(aclhip_context* context, const void*
 		db.patches_by_header[tier] = patches[tier];
 		std::sort(db.patches_by_header[tier].begin(), db.patches_by_header[tier].end(),
 			[](const tier_patch& lhs, const tier_patch& rhs) { return lhs.segment_header_offset < rhs.segment_header_offset; });
+		// A segment's keyframes of one tier sit in ONE chunk (build_database writes a segment's tier whole): two chunk segment headers
+		// that name the same runtime segment header would have the later stream-in overwrite the earlier one's tier words in the
+		// reference (database.impl.h:520-535, chunk order) and race here, where the patches of a request are applied in parallel.
+		// Refused. (Found by tools/fuzz_gpu_mutated_db.py, round 6: a segment_header_offset moved onto its neighbour's.)
+		for (size_t i = 1; i < db.patches_by_header[tier].size(); ++i)
+			if (db.patches_by_header[tier][i].segment_header_offset == db.patches_by_header[tier][i - 1].segment_header_offset)
+				return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Tier %d: two chunks hold keyframes of the same segment", tier + 1);
 	}
 	if (validate_only)
 		return ACLHIP_OK;		// aclhip_check_database: everything above is host work
@@ -422,6 +429,7 @@ namespace
 		uint32_t next_chunk = db.num_parsed_chunks[tier_index];
 		uint32_t next_patch = db.chunk_first_patch[tier_index][next_chunk];
 		std::vector<tier_patch> new_patches;
+		std::unordered_set<uint32_t> new_headers;	// segment headers the new patches name
 		std::vector<uint32_t> new_chunk_ends;		// patches up to and including every newly parsed chunk
 		for (uint32_t chunk_index = first_chunk_index; chunk_index <= last_chunk_index; ++chunk_index)
 		{
@@ -448,6 +456,14 @@ namespace
 					if (bound.first == segments[i].segment_header_offset
 						&& uint64_t(segments[i].samples_offset) + (uint64_t(__builtin_popcount(segments[i].sample_indices)) * bound.second + 7) / 8 > bulk_size)
 						return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u: keyframes lie outside of the bulk data", chunk_index, tier_index + 1);
+				// ... and a segment has its keyframes of this tier in one chunk (see register_database_impl)
+				const std::vector<tier_patch>& known = db.patches_by_header[tier_index];
+				const auto same_header = std::lower_bound(known.begin(), known.end(), segments[i].segment_header_offset,
+					[](const tier_patch& patch, uint32_t offset) { return patch.segment_header_offset < offset; });
+				bool repeated = same_header != known.end() && same_header->segment_header_offset == segments[i].segment_header_offset;
+				repeated = repeated || !new_headers.insert(segments[i].segment_header_offset).second;
+				if (repeated)
+					return fail(context, ACLHIP_ERROR_INVALID_CLIP, "Chunk %u of tier %u: another chunk holds keyframes of the same segment", chunk_index, tier_index + 1);
 				new_patches.push_back({ segments[i].segment_header_offset, segments[i].sample_indices, segments[i].samples_offset });
 			}
 			next_patch += chunk.num_segments;

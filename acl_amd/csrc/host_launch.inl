@@ -562,9 +562,8 @@ extern "C" aclhip_status aclhip_decompress_track_batch(aclhip_context* context, 
 	device_guard guard(context->device);
 	note_launch_stream(context, static_cast<hipStream_t>(stream));
 	const uint32_t num_blocks = (num_instances + k_block_size - 1) / k_block_size;
-	// (ACLHIP_DECODE_FAST with the track_writer's own settings; a request's per track rounding policy folds into its alpha either way)
-	const bool fast = device_params.fast_math != 0 && device_params.per_track_rounding == 0;
-	hipLaunchKernelGGL(fast ? decompress_track_fast_kernel : decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
+	// (ACLHIP_DECODE_FAST changes nothing here: the variant compiled for it never measured faster than the bit exact kernel, kernels_track.inl)
+	hipLaunchKernelGGL(decompress_track_kernel, dim3(num_blocks), dim3(k_block_size), 0, static_cast<hipStream_t>(stream),
 		context->d_clips, context->d_clips_capacity, clips, sample_times, track_indices, num_instances, device_params,
 		static_cast<float4*>(transforms), context->d_rejected);
 	ACLHIP_CHECK_HIP(context, hipGetLastError());

@@ -6,7 +6,8 @@
 // WRITE_SIZE 2.0 x the transforms, the texture unit 80 % busy, 226.6 us for 4 M requests, profiles/r04_track_requests_pmc_*.txt):
 //   1. lanes <-> requests: clip handle, sample time, track index in; when every request of the wave names the SAME clip -- a crowd of one
 //      rig, the bones of one character -- the clip record and everything derived from it live on the scalar unit (two s_loads instead of
-//      eight vector loads per lane); a wave of mixed clips reads its records per lane. The seek is per lane either way (sample times
+//      eight vector loads per lane); a wave of mixed clips gathers the 64 byte heads of its records four lanes per record and hands them
+//      out through LDS (gather_clip_records, round 6). The seek is per lane either way (sample times
 //      differ): two 16 byte sample records. The track's three base pose quads tell what each sub-track is: constant (the value itself),
 //      default, or animated (marker + ordinal).
 //   2. the wave's ANIMATED (request, kind) pairs -- about 0.4 per request on CMU-shaped clips, not 3 -- are counted with three ballots and
@@ -51,16 +52,56 @@
 	constexpr uint32_t k_track_lds_bytes_per_wave = k_track_image_bytes + k_track_state_bytes;
 	static_assert(k_wave_size * 3 * 4 <= k_track_image_bytes, "the list fits where the image will be");
 
-	// all 128 bytes of a clip record, per lane; what the caller does not use is never loaded
-	__device__ __forceinline__ device_clip load_clip_per_lane(const device_clip* clips, uint32_t clip_id)
+	__device__ __forceinline__ void track_wave_barrier()
 	{
-		const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(clips + clip_id);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+
+	// A wave of mixed clips: every lane's own clip record. Left to itself a lane fetches the seven 16 byte pieces of its record it uses --
+	// seven load instructions that touch 64 different cache lines each, and the texture unit takes a line per cycle: 450 of the wave's
+	// ~1 500 cycles there (round 6; 4 M requests of 256 clips as drawn: 198 us against 77 us for one clip). Instead FOUR lanes fetch the
+	// 64 byte head of one record (k_clip_head_bytes: everything a seek and a track request read from it) -- four load instructions over
+	// 16 lines each, 64 contiguous bytes per line -- and the records change hands in LDS (4 KiB of the wave's 5, before the list and the
+	// image use them). The second half of a record -- database tiers, the table defaults' bind pose -- is fetched per lane, and only by a
+	// wave that has such a request.
+	__device__ __forceinline__ device_clip gather_clip_records(const device_clip* clips, uint32_t num_clips, uint32_t clip_id, bool known_clip, uint32_t lane, uint8_t* wave_lds, bool wants_tail)
+	{
+		static_assert(k_clip_head_bytes == 64 && k_track_image_bytes + k_track_state_bytes >= k_wave_size * k_clip_head_bytes, "64 heads fit in the wave's LDS");
+		u32x4* staging = reinterpret_cast<u32x4*>(wave_lds);			// [request][piece]
+		const uint32_t safe_id = known_clip ? clip_id : 0u;			// (entry 0 always exists; its bytes are not used)
+		const uint32_t piece = lane & 3u;
+		#pragma unroll
+		for (uint32_t round = 0; round < 4; ++round)
+		{
+			const uint32_t request = round * 16u + (lane >> 2);
+			const uint32_t id = uint32_t(__builtin_amdgcn_ds_bpermute(int(request * 4u), int(safe_id)));
+			// (piece p of request r in slot (p + r / 4) % 4 of the request's four: the lanes that read a piece back -- 64 bytes apart --
+			// then start on different banks)
+			staging[request * 4u + ((piece + (request >> 2)) & 3u)] = ((const ACLHIP_CONSTANT u32x4*)(clips + id))[piece];
+		}
+		track_wave_barrier();
 		u32x4 raw[8];
 		#pragma unroll
-		for (uint32_t i = 0; i < 8; ++i)
-			raw[i] = source[i];
+		for (uint32_t i = 0; i < 4; ++i)
+			raw[i] = staging[lane * 4u + ((i + (lane >> 2)) & 3u)];
+		const u32x4 zero = { 0u, 0u, 0u, 0u };
+		#pragma unroll
+		for (uint32_t i = 4; i < 8; ++i)
+			raw[i] = zero;
+		track_wave_barrier();		// the staging area is the list's and the image's from here on
 		device_clip clip;
 		__builtin_memcpy(&clip, raw, sizeof(clip));
+		// the tail: a clip bound to a database reads its tiers, a table default the clip's bind pose (wave uniform)
+		if (wants_tail || __builtin_amdgcn_ballot_w64(known_clip && (clip.flags & k_clip_has_database) != 0) != 0)
+		{
+			const ACLHIP_CONSTANT u32x4* source = (const ACLHIP_CONSTANT u32x4*)(clips + safe_id);
+			#pragma unroll
+			for (uint32_t i = 4; i < 8; ++i)
+				raw[i] = source[i];
+			__builtin_memcpy(&clip, raw, sizeof(clip));
+		}
 		return clip;
 	}
 
@@ -124,13 +165,6 @@
 		return true;
 	}
 
-	__device__ __forceinline__ void track_wave_barrier()
-	{
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	}
-
 	template<uint32_t kFastMath>
 	__device__ __forceinline__ void decompress_track_requests(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
@@ -175,24 +209,19 @@
 		// or every lane's own
 		const clip_range_entry* shared_clip_ranges = nullptr;
 		const clip_range_entry* own_clip_ranges = nullptr;
-#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
-		uint32_t ab_total_rows = 0;
-#endif
 		if (shared_clip)
 		{
 			const device_clip clip = load_clip(clips, first_clip_id);
 			shared_clip_ranges = clip.clip_ranges;
-#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
-			ab_total_rows = clip.num_segments * clip.num_animated;
-#endif
 			if (in_batch)
 				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
-		else if (known_clip)
+		else
 		{
-			const device_clip clip = load_clip_per_lane(clips, clip_id);
+			const device_clip clip = gather_clip_records(clips, num_clips, clip_id, known_clip, lane, wave_lds, params.user_defaults != 0);
 			own_clip_ranges = clip.clip_ranges;
-			accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
+			if (known_clip)
+				accepted = prepare_track_request(clip, sample_time, track_index, rounding_policy, looping_policy, track_rounding_policies, params, state, lerp_alpha, quads, store, animated, ordinals);
 		}
 
 		// refused requests are counted, one atomic per wave
@@ -266,14 +295,6 @@
 				clip_ranges = reinterpret_cast<const clip_range_entry*>((uint64_t(high) << 32) | low);
 			}
 
-#if defined(ACLHIP_AB_TRACK_SCALAR_PLAN)
-			// A/B: the shared clip's plan addressed forwards from a scalar base
-			const uint32_t ab_row0 = request.rows[0] & ~k_track_row_short_exact_math, ab_row1 = request.rows[1];
-			const plan_entry* ab_plan = reinterpret_cast<const plan_entry*>(clip_ranges) - ab_total_rows;
-			const plan_entry plan0 = load_entry(ab_plan, (ab_total_rows - ab_row0) + ordinal);
-			const plan_entry plan1 = ab_row1 == ab_row0 ? plan0 : load_entry(ab_plan, (ab_total_rows - ab_row1) + ordinal);
-			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
-#else
 			// (plan_entry and clip_range_entry are both 32 bytes: the plan's last entry is clip_ranges[-1])
 			static_assert(sizeof(plan_entry) == sizeof(clip_range_entry), "the plan is addressed from the clip range table");
 			const plan_entry* plan_end = reinterpret_cast<const plan_entry*>(clip_ranges);
@@ -281,7 +302,6 @@
 			const plan_entry plan0 = load_entry(plan_end - row0, ordinal);
 			const plan_entry plan1 = row1 == row0 ? plan0 : load_entry(plan_end - row1, ordinal);
 			const clip_range_entry clip_range = load_entry(clip_ranges, ordinal);
-#endif
 
 			seek_state key_state;
 			key_state.animated_track_data[0] = request.data[0];
@@ -339,13 +359,7 @@
 		decompress_track_requests<0>(clips, num_clips, clip_ids, sample_times, track_indices, num_instances, params, transforms, rejected_count);
 	}
 
-	// ACLHIP_DECODE_FAST (aclhip_decompress_params::flags): rotations in the hardware's 1 ulp forms, translations and scales bit identical
-#if !defined(ACLHIP_TRACK_FAST_WAVES_PER_EU)
-	#define ACLHIP_TRACK_FAST_WAVES_PER_EU 7
-#endif
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_TRACK_FAST_WAVES_PER_EU, ACLHIP_TRACK_FAST_WAVES_PER_EU))) void decompress_track_fast_kernel(const device_clip* __restrict__ clips, uint32_t num_clips,
-		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, const uint32_t* __restrict__ track_indices, uint32_t num_instances,
-		decode_params params, float4* __restrict__ transforms, unsigned long long* __restrict__ rejected_count)
-	{
-		decompress_track_requests<2>(clips, num_clips, clip_ids, sample_times, track_indices, num_instances, params, transforms, rejected_count);
-	}
+	// (ACLHIP_DECODE_FAST: single track requests are served by the kernel above. A variant with the hardware's 1 ulp square root and
+	// fused multiply-adds existed for half of round 6: the arithmetic it saves is 18 of the 460 vector instructions of a wave, and it
+	// never measured faster -- 79.3 against 76.7 us on 4 M requests, 107.6 against 78.2 us once the record gather took its registers
+	// (24 spilled at 7 waves per SIMD; 86.1 us at 6) -- profiles/r06_experiments.md 4.)

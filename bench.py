@@ -424,7 +424,7 @@ class Job:
         if self.consumers is not None:
             return "decompress_poses_consumer_kernel"
         if self.track_requests:
-            return "decompress_track_fast_kernel" if self.fast else "decompress_track_kernel"
+            return "decompress_track_kernel"          # (ACLHIP_DECODE_FAST changes nothing for single track requests)
         # the library's own answer for this launch (rows of pose_stride bytes, this output descriptor): aclhip_describe_tracks_launch
         return self.context.tracks_kernel_name(self.params, pose_stride_bytes=self.pose_stride, output=self.output)
 
@@ -503,7 +503,6 @@ def default_run_specs():
         ("database", {"order": "list"}, 300),                       # ... kept in a persistent instance list, 1 % changing clip per step
         # single bone requests, scalar track lists, the pose consumers fused into the decode
         ("track_requests", {"num_instances": TRACK_REQUESTS}, 100),
-        ("track_requests", {"num_instances": TRACK_REQUESTS, "fast": True}, 100),
         ("scalar", {}, 300),
         ("object_space", {}, 150),
         ("additive_object_space", {}, 100),

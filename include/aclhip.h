@@ -121,9 +121,10 @@ typedef struct aclhip_decompress_params
  * square root / reciprocal square root and fused multiply-adds: every rotation component stays within 2e-6 of the default kernels'
  * (tests/test_gpu_fast_decode.py asserts it over every instance of the BASELINE.json batches and the corpus); the x, y, z of every sample
  * (the range expansions are never fused), constant and default sub-tracks, translations and scales are bit identical. Taken by the plain
- * decode (aclhip_decompress_tracks_batch / _rows / _list with the QVV48 layout and the track_writer defaults) and by aclhip_decompress_track_batch;
- * launches with other settings or an output descriptor keep the exact kernels, as do per track rounding policies. What it buys is VALU
- * issue: poses of several windows (the 300-bone rig) and single track requests; a one-window batch sits on its write stream either way. */
+ * decode (aclhip_decompress_tracks_batch / _rows / _list with the QVV48 layout and the track_writer defaults); launches with other settings
+ * or an output descriptor keep the exact kernels, as do per track rounding policies and aclhip_decompress_track_batch (its variant never
+ * measured faster than the exact kernel and was removed: the flag is accepted there and changes nothing). What it buys is VALU issue on
+ * poses of several windows (the 300-bone rig: 2 %); a one-window batch sits on its write stream either way. */
 #define ACLHIP_DECODE_FAST 1u
 
 /* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
@@ -493,7 +494,10 @@ aclhip_status aclhip_decompress_tracks_list(aclhip_context* context, aclhip_inst
 aclhip_status aclhip_instance_list_get_order(aclhip_context* context, aclhip_instance_list list, const uint32_t** out_order, uint64_t* out_num_orderings);
 
 /* Replaces seek() + decompress_track(track_indices[i], writer) (decompress.h:172; decompress_track_v0 :1753-2050):
- * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers. */
+ * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers.
+ * Any order of requests is decoded; the ORDER decides what the launch fetches: 64 consecutive requests share a wavefront, and requests
+ * of many clips are best sorted by clip (4 M requests over 256 clips: 173 us as drawn, 77 us sorted by clip = the time of one clip;
+ * profiles/r06_experiments.md 5b). */
 aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, void* transforms, void* stream);
 

@@ -95,6 +95,37 @@ def test_single_track_requests_follow_the_tiers(context):
     _release(context, database, clips)
 
 
+def test_single_track_requests_of_mixed_waves_follow_the_tiers(context):
+    """waves whose requests name DIFFERENT clips -- database bound ones next to plain ones -- gather their clip records four lanes per
+    record and fetch the records' second halves (the tiers) only when some request of the wave is bound to a database
+    (kernels_track.inl: gather_clip_records): every request against the restated database_context / the oracle, in every residency"""
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    database, clips = _register(context, case, False)
+    oracle_db = OracleDatabase(case["database"], case["bulk_medium"], case["bulk_low"])
+    plain = [synth.build_clip(seed=40 + i, num_tracks=9 + 7 * i, num_samples=25 + 20 * i, strip_keyframes=i % 2) for i in range(3)]
+    plain_handles = [context.register_clip(clip.blob) for clip in plain]
+    blobs = list(case["clips"]) + [clip.blob for clip in plain]
+    handles = np.array(list(clips) + plain_handles, dtype=np.uint32)
+    num_tracks = np.array([ob.oracle().aclo_num_tracks(blob.ctypes.data) for blob in blobs])
+    durations = np.array([ob.oracle().aclo_finite_duration(blob.ctypes.data, ob.LOOP_AS_COMPRESSED) for blob in blobs], dtype=np.float32)
+    rng = np.random.default_rng(11)
+    for tier, num_chunks in ((None, 0), (1, 1), (2, 2), (1, 0xFFFFFFFF), (2, 0xFFFFFFFF)):
+        if tier is not None:
+            assert context.database_stream_in(database, tier, num_chunks) == oracle_db.stream_in(tier, num_chunks)
+        for which in (rng.integers(0, handles.size, size=333), rng.integers(3, handles.size, size=130), np.repeat(rng.integers(0, handles.size, size=5), 64)):
+            times = (rng.uniform(0.0, 1.0, size=which.size) * durations[which]).astype(np.float32)
+            tracks = (rng.uniform(0.0, 1.0, size=which.size) * num_tracks[which]).astype(np.uint32)
+            out = context.decompress_track(handles[which], times, tracks)
+            for i in range(which.size):
+                blob = blobs[which[i]]
+                expected = oracle_db.decompress_tracks(blob, float(times[i])) if which[i] < len(clips) else ob.oracle_decompress_tracks_batch([blob], np.zeros(1, dtype=np.uint32), times[i: i + 1], int(num_tracks[which[i]]))[0]
+                assert helpers.bit_equal(out[i], expected[tracks[i]]), (tier, i, which[i])
+    assert context.rejected_instance_count() == 0
+    for handle in plain_handles:
+        context.unregister_clip(handle)
+    _release(context, database, clips)
+
+
 def test_database_bound_clip_without_database_uses_only_its_own_keyframes(context):
     """decompression_context::initialize(tracks) of a clip that was split into a database: legal, lowest quality
     (impl/decompress.impl.h:58-83 leaves db = nullptr; seek falls back to the clip's sample_indices)."""
@@ -299,6 +330,38 @@ def test_a_streamed_request_that_fails_half_way_leaves_nothing_behind():
             oracle_db.stream_in(tier, num_chunks)
             check()
         assert context.rejected_instance_count() == 0
+        for clip in clips:
+            context.unregister_clip(clip)
+        context.unregister_database(database)
+
+
+def test_a_streamed_chunk_that_repeats_another_chunks_segment_is_refused():
+    """the arrival side of tests/test_host_validation.py::test_two_chunks_with_keyframes_of_the_same_segment_are_refused: the second
+    chunk of the medium tier names a segment header the chunks in front of it (or it) already patch -> the request is refused whole,
+    the good bytes then stream in and decode to the restated database_context"""
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    bulk = case["bulk_medium"]
+    assert bulk[4284] == 8
+    with runtime.Context(0) as context:
+        database = context.register_database_streamed(case["database"])
+        clips = [context.register_clip_with_database(clip, database) for clip in case["clips"]]
+        corrupt = synth.aligned_bytes(bulk.size)
+        corrupt[:] = bulk
+        corrupt[4284] = 24
+        with pytest.raises(runtime.AclHipError, match="same segment"):
+            context.database_stream_in_from(database, runtime.TIER_MEDIUM_IMPORTANCE, corrupt)
+        good = synth.aligned_bytes(bulk.size)
+        good[:] = bulk
+        num_chunks = int(context.database_info(database).num_chunks[0])
+        assert context.database_stream_in_from(database, runtime.TIER_MEDIUM_IMPORTANCE, good) == num_chunks
+        oracle_db = OracleDatabase(case["database"], case["bulk_medium"], case["bulk_low"])
+        oracle_db.stream_in(runtime.TIER_MEDIUM_IMPORTANCE, num_chunks)
+        for blob, clip in zip(case["clips"], clips):
+            duration = float(context.clip_info(clip).duration)
+            times = np.linspace(0.0, duration, 9).astype(np.float32)
+            poses = context.decompress_tracks(np.full(times.size, clip, dtype=np.uint32), times)
+            for row, t in enumerate(times):
+                assert helpers.bit_equal(poses[row], oracle_db.decompress_tracks(blob, float(t))), (row, t)
         for clip in clips:
             context.unregister_clip(clip)
         context.unregister_database(database)

@@ -275,3 +275,13 @@ def test_database_runtime_headers_must_tile_their_block():
         for delta in (-8, 4, 8, 0x10000):
             status, _ = runtime.check_database(database, _patched(medium, at, "<I", (original + delta) & 0xFFFFFFFF), low, check_hash=False)
             assert status != 0, delta
+
+
+def test_two_chunks_with_keyframes_of_the_same_segment_are_refused():
+    """mutation 10915 of seed 72 (tools/fuzz_gpu_mutated_db.py, round 6): a chunk segment header's segment_header_offset moved onto its
+    neighbour's -- the later stream-in overwrites the earlier one's tier words in the reference, the patches race on the device"""
+    case = helpers.load_database_golden("three_clips_4k_chunks")
+    database, medium, low = case["database"], case["bulk_medium"], case["bulk_low"]
+    assert medium[4284] == 8
+    status, message = runtime.check_database(database, _patched(medium, 4284, "<B", 24), low, check_hash=False)
+    assert status != 0 and "same segment" in message, message

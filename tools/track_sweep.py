@@ -71,15 +71,24 @@ def main():
         patterns["256 clips as drawn, random bones"] = (crowd_handles[which], (rng.uniform(0, 1, size=n).astype(np.float32) * crowd_durations[which]).astype(np.float32), rng.integers(0, 100, size=n).astype(np.int32))
         runs = np.repeat(rng.integers(0, 256, size=(n + 63) // 64), 64)[:n]
         patterns["256 clips in runs of 64, random bones"] = (crowd_handles[runs], (rng.uniform(0, 1, size=n).astype(np.float32) * crowd_durations[runs]).astype(np.float32), rng.integers(0, 100, size=n).astype(np.int32))
+        # ... and what a caller who can reorder its requests does: the library's own locality order (the permutation it computes for instance lists)
+        permutation = ctx.order_instances_for_locality(crowd_handles[which].astype(np.uint32))
+        drawn = patterns["256 clips as drawn, random bones"]
+        patterns["256 clips as drawn, requests in aclhip_order_instances_for_locality order"] = tuple(column[permutation] for column in drawn)
+        by_clip = np.argsort(which, kind="stable")
+        patterns["256 clips as drawn, requests sorted by clip"] = tuple(column[by_clip] for column in drawn)
         patterns["256 clips as drawn, root bone"] = (crowd_handles[which], (rng.uniform(0, 1, size=n).astype(np.float32) * crowd_durations[which]).astype(np.float32), np.zeros(n, dtype=np.int32))
         same_time = np.repeat(rng.uniform(0, one.duration, size=(n + 99) // 100).astype(np.float32), 100)[:n]
         patterns["one clip, all 100 bones of each instance"] = (np.full(n, one_handle, dtype=np.int32), same_time, (np.arange(n) % 100).astype(np.int32))
+        only = os.environ.get("TRACK_SWEEP_ONLY")           # one pattern per process (counter passes)
         for name, (ids, times, tracks) in patterns.items():
+            if only and name != only:
+                continue
             d_ids, d_times, d_tracks = torch.from_numpy(ids).cuda(), torch.from_numpy(times).cuda(), torch.from_numpy(tracks).cuda()
             out = torch.empty((n, 12), dtype=torch.float32, device="cuda")
             ok = check_against_poses(ctx, d_ids, d_times, d_tracks, out, 100)
-            us = time_requests(ctx, d_ids, d_times, d_tracks, out)
-            print(f"decompress_track {n:8d} requests  {name:42s} {us:8.1f} us  {n / us / 1e3:7.2f} G bones/s  {n * 60 / us / 1e3:7.0f} GB/s algorithmic  {'== whole pose' if ok else 'DIFFERS FROM THE WHOLE POSE'}", flush=True)
+            us = time_requests(ctx, d_ids, d_times, d_tracks, out, repeats=int(os.environ.get("TRACK_SWEEP_REPEATS", "100")))
+            print(f"decompress_track {n:8d} requests  {name:74s} {us:8.1f} us  {n / us / 1e3:7.2f} G bones/s  {n * 60 / us / 1e3:7.0f} GB/s algorithmic  {'== whole pose' if ok else 'DIFFERS FROM THE WHOLE POSE'}", flush=True)
     if ctx.rejected_instance_count() != 0:
         print("REJECTED", ctx.rejected_instance_count())
     ctx.close()
