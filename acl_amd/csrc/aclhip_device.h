@@ -148,6 +148,8 @@ namespace aclhip
 	// Per clip record in HBM, written once at registration; read through the scalar cache by every wave. The FIRST 64 bytes hold what a
 	// seek and a single track request need (k_clip_head_bytes: waves of mixed clips in decompress_track_kernel gather just these, four
 	// lanes per record); the second half what only whole poses, databases and the table defaults read.
+	// (Kernels that hold two or three records -- the pose consumers -- pass theirs through load_clip_fields, kernels_pose.inl: loaded as
+	// two 16 register blocks, a record otherwise stays two blocks that live as long as any of their fields.)
 	struct alignas(128) device_clip
 	{
 		const uint8_t* blob;					// the compressed_tracks bytes, unchanged, 16 byte aligned, >= 64 bytes of tail padding

@@ -298,7 +298,8 @@
 		if (instance < num_instances)
 		{
 			const uint32_t clip_id = as_constant(clip_ids)[instance];
-			const device_clip clip = load_clip(clips, clip_id < num_clips ? clip_id : 0);
+			// (every field in registers of its own: load_clip_fields, kernels_pose.inl)
+			const device_clip clip = load_clip_fields(clips, clip_id < num_clips ? clip_id : 0);
 
 			// refused: unknown / scalar clips, object space without a hierarchy, poses larger than the launch's LDS images, bases that
 			// are unknown or describe another number of transforms (the reference asserts matching track counts where it combines them).
@@ -324,7 +325,7 @@
 			if (base_is_clip)
 			{
 				const uint32_t base_clip_id = as_constant(consumers.base_clip_ids)[instance];
-				base_clip = load_clip(clips, base_clip_id < num_clips ? base_clip_id : 0);
+				base_clip = load_clip_fields(clips, base_clip_id < num_clips ? base_clip_id : 0);
 				refused = refused || base_clip_id >= num_clips || !is_transform_clip(base_clip.flags) || base_clip.num_tracks != clip.num_tracks
 					|| (!kMirrored && multiplies_transforms && ((clip.flags | base_clip.flags) & k_clip_negative_scale) != 0);
 				short_exact &= walk_may_use_short_exact_math(base_clip.flags, params.normalization);
@@ -398,7 +399,7 @@
 						for (uint32_t k = 1; k < num_blend_clips; ++k)
 						{
 							const size_t entry = size_t(instance) * (num_blend_clips - 1u) + (k - 1u);
-							const device_clip blend_clip = load_clip(clips, as_constant(consumers.blend_clip_ids)[entry]);
+							const device_clip blend_clip = load_clip_fields(clips, as_constant(consumers.blend_clip_ids)[entry]);
 							wave_lds_barrier();		// every quad has its sum so far
 							blend_clip_onto_image(blend_clip, as_constant(consumers.blend_sample_times)[entry], rounding_policy, params, weights[k], lane, image);
 						}

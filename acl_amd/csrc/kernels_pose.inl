@@ -70,6 +70,19 @@
 		return clip;
 	}
 
+	// The same record with every field in registers of its own. load_clip hands back two 16 register blocks and the fields stay
+	// sub-registers of them: a block lives as long as ANY of its fields, and when the scalar registers run out it is spilled and
+	// reloaded whole. Kernels that hold two or three records (the pose consumers: clip, base, blend partners) pass theirs through here
+	// -- the copies are free where the allocator can leave a field where it was loaded.
+	__device__ __forceinline__ device_clip load_clip_fields(const device_clip* clips, uint32_t clip_id)
+	{
+		device_clip clip = load_clip(clips, clip_id);
+		asm volatile("" : "+s"(clip.blob), "+s"(clip.base_pose), "+s"(clip.samples), "+s"(clip.resolved_pose), "+s"(clip.plan), "+s"(clip.clip_ranges), "+s"(clip.image_chunks), "+s"(clip.hierarchy));
+		asm volatile("" : "+s"(clip.db_headers), "+s"(clip.db_bulk_data[0]), "+s"(clip.db_bulk_data[1]), "+s"(clip.db_clip_header_offset));
+		asm volatile("" : "+s"(clip.num_tracks), "+s"(clip.num_samples), "+s"(clip.sample_rate), "+s"(clip.duration_clamp), "+s"(clip.duration_wrap), "+s"(clip.flags), "+s"(clip.num_segments), "+s"(clip.num_animated));
+		return clip;
+	}
+
 	// A 32 byte table entry (plan_entry / clip_range_entry) in two 16 byte loads
 	template<class entry_t>
 	__device__ __forceinline__ entry_t load_entry(const entry_t* table, uint32_t index)
