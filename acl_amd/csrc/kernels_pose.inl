@@ -851,12 +851,15 @@
 		}
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+#if !defined(ACLHIP_IN_TURN_WAVES_PER_EU)
+	#define ACLHIP_IN_TURN_WAVES_PER_EU 7		// (6: 80 VGPRs and 102 SGPRs, nothing spilled -- measured: profiles/r06_experiments.md 11)
+#endif
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<false>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
@@ -874,12 +877,12 @@
 		decompress_tracks_window<false, false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(7, 7))) void decompress_tracks_in_turn_adjacent_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<true, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
 	}

@@ -2,7 +2,7 @@
 # Evidence for profiles/ (round 5: round 4's recipe + the LOD and attached-list workloads; the default run now checks itself against the oracle and carries every entry's VALU issue floor): for every workload of the default run the bench line, the rocprofv3 --kernel-trace --stats summary of the
 # same command, FETCH_SIZE / WRITE_SIZE in their own --pmc passes (-> traffic.json) and, for the workloads named in SQ_WORKLOADS, the SQ /
 # texture unit counters of the shipped kernel; then the default bench.py run (which measures every entry's traffic itself).
-# usage (on the GPU box): tools/profile_round4.sh <tag> [workload file names ...]   -> gpurun_out/<tag>_*
+# usage (on the GPU box): tools/history/profile_round4.sh <tag> [workload file names ...]   -> gpurun_out/<tag>_*
 set -u
 tag=${1:-r05}
 shift
