@@ -13,7 +13,11 @@ def main():
     head_floor = max(r.get("hbm_floor_ms") or 0.0, r.get("valu_issue_floor_ms") or 0.0) * 1e3
     print(f"| **headline: {d['config']['workload'][:60]}** | `{r['kernel']}` | **{r['kernel_ms'] * 1e3:.1f}** | **{r['frac']:.3f}** | hbm {r['hbm_floor_ms'] * 1e3:.1f} (valu {r['valu_issue_floor_ms'] * 1e3:.1f}) -> {r['frac_of_bound']:.2f} | {r['traffic'] / 1e6:.1f} / {r['algorithmic_bytes_per_launch'] / 1e6:.1f} |")
     for e in d["workloads"]:
-        name = e["workload"] + ("" if e.get("order", "random") == "random" else f", {e['order']} order") + ("" if e.get("layout", "qvv48") == "qvv48" else f", {e['layout']}")
+        name = e["workload"]
+        if e.get("order", "random") != "random" and "order" not in name:
+            name += f", {e['order']} order"
+        if e.get("layout", "qvv48") != "qvv48" and e["layout"] not in name:
+            name += f", {e['layout']}"
         floors = ""
         if e.get("bound"):
             floor = (e.get("valu_issue_floor_ms") if e["bound"] == "valu" else e.get("hbm_floor_ms")) or 0.0
