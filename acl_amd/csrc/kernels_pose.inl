@@ -325,11 +325,30 @@
 	// kFastMath = 2: ACLHIP_DECODE_FAST (aclhip_decompress_params::flags) -- rotations through v_sqrt_f32 / v_rsq_f32 and fused
 	// multiply-adds (within 2e-6 of the default's; x, y, z of every sample, translations and scales bit identical), for the launches
 	// whose time is VALU issue: poses of several windows
+	// The pose kernels' arguments as they lie in the kernarg segment (ACLHIP_POSE_KERNEL_ARGUMENTS below: in order, each at its natural
+	// alignment). The kernels that take work items in turn read their arguments THERE, per item and where they are used, instead of
+	// holding them in scalar registers across the decode: their launch does not fit the 94 SGPRs of 7 waves per SIMD, and what the
+	// compiler spills it reloads with v_readlane -- vector instructions, ~30 per window on a kernel bound by vector issue (round 6).
+	struct pose_kernel_args
+	{
+		const device_clip* clips;
+		uint32_t num_clips;
+		const uint32_t* clip_ids;
+		const float* sample_times;
+		uint32_t num_instances;
+		uint32_t windows_per_instance;
+		decode_params params;
+		uint8_t* poses;
+		uint64_t pose_stride_bytes;
+		uint32_t lds_quads_per_wave;
+		unsigned long long* rejected_count;
+	};
+
 	template<bool kAnySettings, bool kCompactOutput, bool kWideKeyLoads = false, uint32_t kFastMath = 0>
 	__device__ __forceinline__ void decompress_tracks_window(const device_clip* __restrict__ clips, uint32_t num_clips,
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance,
 		const decode_params& params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave,
-		unsigned long long* __restrict__ rejected_count, uint32_t work_item, uint32_t* image_clip = nullptr)
+		unsigned long long* __restrict__ rejected_count, uint32_t work_item, uint32_t* image_clip = nullptr, const ACLHIP_CONSTANT pose_kernel_args* late_args = nullptr)
 	{
 		extern __shared__ __attribute__((aligned(16))) uint8_t dynamic_lds[];
 		ACLHIP_WAVE0_STAMP(0);
@@ -375,7 +394,7 @@
 			|| launch_refuses_clip(stored_tracks, windows_per_instance, lds_quads_per_wave, kCompactOutput ? layout_bytes_per_track(params.layout) : 48u, pose_stride_bytes))
 		{
 			if (lane == 0 && window == 0)
-				atomicAdd(rejected_count, 1ull);
+				atomicAdd(late_args != nullptr ? late_args->rejected_count : rejected_count, 1ull);
 			return;
 		}
 
@@ -553,8 +572,20 @@
 		for (uint32_t r = 0; r < k_rows; ++r)
 			staged[r] = image[min(r * k_wave_size + lane, lds_quads_per_wave - 1)];
 
-		// (the row is read here, not in the prologue: one SGPR pair less across the decode)
-		const uint32_t row = params.instance_rows != nullptr ? as_constant(params.instance_rows)[instance] : instance;
+		// (the row is read here, not in the prologue: one SGPR pair less across the decode; items taken in turn read where their pose goes
+		// from the kernarg segment here, see pose_kernel_args)
+		const uint32_t* instance_rows = params.instance_rows;
+#if defined(__HIP_DEVICE_COMPILE__)
+		if (late_args != nullptr)
+		{
+			const ACLHIP_CONSTANT pose_kernel_args* args = late_args;
+			asm volatile("" : "+s"(args));
+			instance_rows = args->params.instance_rows;
+			poses = args->poses;
+			pose_stride_bytes = args->pose_stride_bytes;
+		}
+#endif
+		const uint32_t row = instance_rows != nullptr ? as_constant(instance_rows)[instance] : instance;
 		uint8_t* pose_bytes = poses + uint64_t(row) * pose_stride_bytes;
 		f32x4* pose = reinterpret_cast<f32x4*>(pose_bytes) + first_quad + lane;
 
@@ -827,8 +858,9 @@
 	// rig: BASELINE.json configs[3]) the image already holds the clip's resolved pose window -- the animated quads are about to be
 	// overwritten, the others are this clip's constants -- and the base pose copy, the largest single item through the CU's texture
 	// unit (11 % of the launch, profiles/r03_experiments.md), is skipped from the second turn on. The next item's scalar seek also
-	// hides the store acknowledgement of the item before. With the 16 byte key reads the loop needs 71 registers: compiled for 7 waves
-	// per SIMD (at 64 it spills and loses 10 %; the launch is LDS limited to 32 waves per CU either way).
+	// hides the store acknowledgement of the item before. Until round 6 the loop needed 72 vector registers (one of them for 22 spilled
+	// SGPRs) and ran at 7 waves per SIMD; with its arguments read from the kernarg segment per item it needs 64: 8 waves, what the
+	// launch's LDS allows (32 waves per CU).
 	//   kAdjacentItems = false: item k of workgroup b is work item 4 (k gridDim + b) + wave -- every turn sweeps the batch front to back
 	//                           like the one-shot grid does (the host sizes the grid so that a wave keeps its window index);
 	//   kAdjacentItems = true:  wave g takes window g % W of instances (g / W) K .. (g / W) K + K - 1: consecutive instances, which in a
@@ -842,24 +874,41 @@
 		const uint32_t wave = blockIdx.x * k_waves_per_block + wave_in_block;
 		const uint32_t group = wave / windows_per_instance;
 		const uint32_t window = wave - group * windows_per_instance;
+		const ACLHIP_CONSTANT pose_kernel_args* kernel_args = (const ACLHIP_CONSTANT pose_kernel_args*)__builtin_amdgcn_kernarg_segment_ptr();
 		for (uint32_t turn = 0; turn < items_per_wave; ++turn)
 		{
 			const uint32_t work_item = kAdjacentItems ? (group * items_per_wave + turn) * windows_per_instance + window
 				: (turn * gridDim.x + blockIdx.x) * k_waves_per_block + wave_in_block;
-			decompress_tracks_window<false, false, kWideKeyLoads, kFastMath>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip);
+			// (this item's arguments, read from the kernarg segment now: opaque per turn, so that they are not hoisted out of the loop
+			// and kept -- spilled -- across the decodes; see pose_kernel_args)
+#if defined(__HIP_DEVICE_COMPILE__)
+			const ACLHIP_CONSTANT pose_kernel_args* args = kernel_args;
+			asm volatile("" : "+s"(args));
+			decompress_tracks_window<false, false, kWideKeyLoads, kFastMath>(args->clips, args->num_clips, args->clip_ids, args->sample_times, args->num_instances, args->windows_per_instance,
+				args->params, nullptr, args->pose_stride_bytes, args->lds_quads_per_wave, nullptr, work_item, &image_clip, kernel_args);
+#else
+			decompress_tracks_window<false, false, kWideKeyLoads, kFastMath>(ACLHIP_POSE_KERNEL_FORWARD, work_item, &image_clip, kernel_args);		// (the host pass only has to compile)
+#endif
 			// (the window's LDS reads completed before its stores were issued: the next turn's DMA may overwrite the image)
 		}
 	}
 
+	// Waves per SIMD. With the arguments read from the kernarg segment per item (pose_kernel_args) the exact kernel needs 64 VGPRs and
+	// fits 8 waves (2 spilled SGPRs): 191.3 us on the rig against 194.6 at 7 (65 VGPRs, nothing spilled; before the kernarg reads: 72
+	// VGPRs, 22 spilled SGPRs, 194.6 us as well -- the 30 spill instructions per window were not what the launch waits for) and 201 at 6
+	// (profiles/r06_experiments.md 11). The ACLHIP_DECODE_FAST variant spills vector registers at 8 (194.4 us) and stays at 7 (191.5).
 #if !defined(ACLHIP_IN_TURN_WAVES_PER_EU)
-	#define ACLHIP_IN_TURN_WAVES_PER_EU 7		// (6: 80 VGPRs and 102 SGPRs, nothing spilled -- measured: profiles/r06_experiments.md 11)
+	#define ACLHIP_IN_TURN_WAVES_PER_EU 8
+#endif
+#if !defined(ACLHIP_IN_TURN_OTHER_WAVES_PER_EU)
+	#define ACLHIP_IN_TURN_OTHER_WAVES_PER_EU 7
 #endif
 	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<false>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_OTHER_WAVES_PER_EU, ACLHIP_IN_TURN_OTHER_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<true>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
@@ -877,12 +926,12 @@
 		decompress_tracks_window<false, false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD, one_shot_work_item());
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_OTHER_WAVES_PER_EU, ACLHIP_IN_TURN_OTHER_WAVES_PER_EU))) void decompress_tracks_in_turn_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<false, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
 	}
 
-	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_WAVES_PER_EU, ACLHIP_IN_TURN_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
+	__global__ __launch_bounds__(k_block_size) __attribute__((amdgpu_waves_per_eu(ACLHIP_IN_TURN_OTHER_WAVES_PER_EU, ACLHIP_IN_TURN_OTHER_WAVES_PER_EU))) void decompress_tracks_in_turn_adjacent_fast_kernel(ACLHIP_POSE_KERNEL_ARGUMENTS)
 	{
 		decompress_tracks_windows_in_turn<true, true, 2>(ACLHIP_POSE_KERNEL_FORWARD);
 	}

@@ -123,8 +123,9 @@ typedef struct aclhip_decompress_params
  * (the range expansions are never fused), constant and default sub-tracks, translations and scales are bit identical. Taken by the plain
  * decode (aclhip_decompress_tracks_batch / _rows / _list with the QVV48 layout and the track_writer defaults); launches with other settings
  * or an output descriptor keep the exact kernels, as do per track rounding policies and aclhip_decompress_track_batch (its variant never
- * measured faster than the exact kernel and was removed: the flag is accepted there and changes nothing). What it buys is VALU issue on
- * poses of several windows (the 300-bone rig: 2 %); a one-window batch sits on its write stream either way. */
+ * measured faster than the exact kernel and was removed: the flag is accepted there and changes nothing). What it removes is vector
+ * instructions of poses of several windows (the 300-bone rig: 4 % of them) -- worth 2 % of the launch while both kernels ran at 7 waves
+ * per SIMD and nothing since the exact kernel fits 8 (190.7 against 190.8 us); a one-window batch sits on its write stream either way. */
 #define ACLHIP_DECODE_FAST 1u
 
 /* Where a decoded pose goes and what of it: the run time form of the OUTPUT side of the track_writer protocol
