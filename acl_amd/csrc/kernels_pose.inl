@@ -830,6 +830,8 @@
 		ACLHIP_WAVE0_STAMP(3);
 	}
 
+	// (pose_kernel_args above mirrors this list as it lies in the kernarg segment: change both together -- tests/test_gpu_full_size.py's rig
+	// batches decode garbage at once if they disagree)
 	#define ACLHIP_POSE_KERNEL_ARGUMENTS const device_clip* __restrict__ clips, uint32_t num_clips, \
 		const uint32_t* __restrict__ clip_ids, const float* __restrict__ sample_times, uint32_t num_instances, uint32_t windows_per_instance, \
 		decode_params params, uint8_t* __restrict__ poses, uint64_t pose_stride_bytes, uint32_t lds_quads_per_wave, unsigned long long* __restrict__ rejected_count
