@@ -307,3 +307,30 @@ def test_bind_pose_default_mode_takes_the_blobs_own_track_descriptions(registere
         single = context.decompress_track(clips, times, tracks, params=runtime.default_params(default_rotation_mode=bind, default_translation_mode=bind, default_scale_mode=bind))
         whole = context.decompress_tracks(clips, times, params=runtime.default_params(default_rotation_mode=bind, default_translation_mode=bind, default_scale_mode=bind))
         assert helpers.bit_equal(single, whole[np.arange(times.size), tracks])
+
+
+def test_bind_pose_defaults_in_single_track_requests_of_mixed_waves(registered):
+    """waves of requests that name DIFFERENT clips gather their clip records four lanes per record and fetch the records' second halves
+    -- where the bind pose hangs -- only for launches with table defaults (kernels_track.inl: gather_clip_records): every request
+    == its row of the clip's whole pose under ACLHIP_DEFAULT_BIND_POSE, and under the variable mode with one caller table"""
+    context, handles = registered
+    bind = runtime.DEFAULT_BIND_POSE
+    described = [index for index, clip in enumerate(CORPUS) if clip["spec"].get("include_track_descriptions")]
+    others = [index for index, clip in enumerate(CORPUS) if index not in described and clip["spec"]["bones"] >= 4][:6]
+    chosen = described[:6] + others
+    rng = np.random.default_rng(17)
+    which = rng.integers(0, len(chosen), size=700)
+    bones = np.array([CORPUS[index]["spec"]["bones"] for index in chosen])
+    durations = np.array([ob.oracle().aclo_finite_duration(CORPUS[index]["blob"].ctypes.data, ob.LOOP_AS_COMPRESSED) for index in chosen], dtype=np.float32)
+    times = (rng.uniform(0.0, 1.0, size=which.size) * durations[which]).astype(np.float32)
+    tracks = (rng.uniform(0.0, 1.0, size=which.size) * bones[which]).astype(np.uint32)
+    clips = np.array([handles[index] for index in chosen], dtype=np.uint32)[which]
+    table = rng.uniform(-1.0, 1.0, size=(int(bones.max()), 12)).astype(np.float32)
+    for params, defaults in ((runtime.default_params(default_rotation_mode=bind, default_translation_mode=bind, default_scale_mode=bind), None),
+                             (helpers.gpu_params(runtime, settings=0, default_mode=3), table)):
+        single = context.decompress_track(clips, times, tracks, params=params, **({"default_values": defaults} if defaults is not None else {}))
+        for k, index in enumerate(chosen):
+            rows = np.flatnonzero(which == k)
+            whole = context.decompress_tracks(np.full(rows.size, handles[index], dtype=np.uint32), times[rows], params=params, **({"default_values": defaults} if defaults is not None else {}))
+            assert helpers.bit_equal(single[rows], whole[np.arange(rows.size), tracks[rows]]), CORPUS[index]["name"]
+    assert context.rejected_instance_count() == 0
