@@ -61,7 +61,6 @@ run_workload database_list "database, list order" --workload database --order li
 run_workload one_clip_qv32 "one_clip, qv32" --workload one_clip --layout qv32
 run_workload one_clip_qvv40 "one_clip, qvv40" --workload one_clip --layout qvv40
 run_workload track_requests "track_requests" --workload track_requests
-run_workload "track_requests, fast" --workload track_requests --fast
 run_workload scalar "scalar" --workload scalar
 run_workload object_space "object_space" --workload object_space
 run_workload object_space_fast "object_space_fast" --workload object_space_fast
