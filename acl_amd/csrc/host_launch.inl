@@ -350,6 +350,59 @@ extern "C" aclhip_status aclhip_order_instances_for_pose_windows(uint32_t window
 	});
 }
 
+// Single track requests (decompress_track_kernel): workgroup b takes requests k_block_size b .. k_block_size b + k_block_size - 1 and runs on
+// XCD b % 8. The requests bucketed by clip, XCD x serving one contiguous range of that sequence through the workgroups that run on it.
+extern "C" aclhip_status aclhip_order_track_requests_for_locality(const aclhip_clip* clips, uint32_t num_requests, uint32_t* out_order)
+{
+	if ((clips == nullptr || out_order == nullptr) && num_requests != 0)
+		return ACLHIP_ERROR_INVALID_ARGUMENT;
+	if (num_requests == 0)
+		return ACLHIP_OK;
+	return guarded(static_cast<aclhip_context*>(nullptr), [&]() -> aclhip_status
+	{
+		// bucketed by clip, stable (a counting sort when the handles are small numbers -- they are slots of the registry)
+		std::vector<uint32_t> sorted(num_requests);
+		uint32_t max_clip = 0;
+		for (uint32_t i = 0; i < num_requests; ++i)
+			max_clip = std::max(max_clip, clips[i]);
+		if (uint64_t(max_clip) < uint64_t(num_requests) * 4 + 1024)
+		{
+			std::vector<uint32_t> position(size_t(max_clip) + 2, 0);
+			for (uint32_t i = 0; i < num_requests; ++i)
+				position[size_t(clips[i]) + 1]++;
+			for (size_t clip = 0; clip <= max_clip; ++clip)
+				position[clip + 1] += position[clip];
+			for (uint32_t i = 0; i < num_requests; ++i)
+				sorted[position[clips[i]]++] = i;
+		}
+		else
+		{
+			for (uint32_t i = 0; i < num_requests; ++i)
+				sorted[i] = i;
+			std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) { return clips[a] < clips[b]; });
+		}
+
+		// how many request slots of the launch run on each XCD, and where each XCD's range of the sorted sequence starts
+		const uint64_t whole_blocks = num_requests / k_block_size, tail = num_requests % k_block_size;
+		uint64_t cursor[k_num_xcds + 1] = {};
+		for (uint32_t x = 0; x < k_num_xcds; ++x)
+		{
+			uint64_t slots = (whole_blocks / k_num_xcds + (x < whole_blocks % k_num_xcds ? 1 : 0)) * k_block_size;
+			if (tail != 0 && whole_blocks % k_num_xcds == x)
+				slots += tail;
+			cursor[x + 1] = cursor[x] + slots;
+		}
+		for (uint64_t block = 0; block * k_block_size < num_requests; ++block)
+		{
+			const uint32_t xcd = uint32_t(block % k_num_xcds);
+			const uint64_t first = block * k_block_size, count = std::min<uint64_t>(k_block_size, num_requests - first);
+			for (uint64_t k = 0; k < count; ++k)
+				out_order[first + k] = sorted[cursor[xcd]++];
+		}
+		return ACLHIP_OK;
+	});
+}
+
 // The same order computed on the device, stream ordered: count per clip, scan, scatter (three small kernels on `stream`, counters
 // kept per stream by the context). Which instance of a clip takes which of the clip's slots is decided by atomics: a valid order,
 // not a reproducible one.

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "aclhip_database_stream_in", "aclhip_database_stream_out",
     "aclhip_all_gather_poses", "aclhip_probe_rccl", "aclhip_decompress_all_samples", "aclhip_check_clip", "aclhip_check_database",
     "aclhip_decompress_scalar_tracks_batch", "aclhip_decompress_scalar_track_batch", "aclhip_decompress_scalar_tracks_host", "aclhip_decompress_scalar_track_host",
-    "aclhip_decompress_tracks_batch_rows", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
+    "aclhip_decompress_tracks_batch_rows", "aclhip_order_track_requests_for_locality", "aclhip_order_instances_for_locality", "aclhip_order_instances_device", "aclhip_order_instances_for_pose_windows",
     "aclhip_get_negative_scale_count", "aclhip_register_database_streamed", "aclhip_database_stream_in_from", "aclhip_get_lifetime_stats", "aclhip_peer_export_buffer", "aclhip_peer_open_buffer", "aclhip_peer_close_buffer", "aclhip_push_poses_to_peer",
     "aclhip_decompress_tracks_batch_out", "aclhip_decompress_tracks_host_out", "aclhip_layout_bytes_per_track",
     "aclhip_forget_stream", "aclhip_instance_list_create", "aclhip_instance_list_destroy", "aclhip_instance_list_set_clips", "aclhip_instance_list_update",
@@ -205,6 +205,7 @@ def load_library():
     lib.aclhip_decompress_tracks_batch_rows.argtypes = [vp, vp, vp, vp, u32, pparams, vp, u64, vp]
     lib.aclhip_order_instances_for_locality.argtypes = [vp, vp, u32, vp]
     lib.aclhip_order_instances_for_pose_windows.argtypes = [u32, vp, u32, vp]
+    lib.aclhip_order_track_requests_for_locality.argtypes = [vp, u32, vp]
     lib.aclhip_order_instances_device.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     pconsumers = ctypes.POINTER(PoseConsumers)
     poutput = ctypes.POINTER(OutputDesc)
@@ -299,6 +300,16 @@ def order_instances_for_locality(clips, windows_per_instance=1):
     status = load_library().aclhip_order_instances_for_pose_windows(windows_per_instance, clips.ctypes.data, clips.size, order.ctypes.data)
     if status != 0:
         raise AclHipError(status, "aclhip_order_instances_for_pose_windows failed")
+    return order
+
+
+def order_track_requests_for_locality(clips):
+    """aclhip_order_track_requests_for_locality: host only, no GPU needed."""
+    clips = np.ascontiguousarray(clips, dtype=np.uint32)
+    order = np.empty(clips.size, dtype=np.uint32)
+    status = load_library().aclhip_order_track_requests_for_locality(clips.ctypes.data, clips.size, order.ctypes.data)
+    if status != 0:
+        raise AclHipError(status, "aclhip_order_track_requests_for_locality failed")
     return order
 
 

@@ -53,6 +53,7 @@ WORKLOAD_TEXT = {
     "cinematic_16": "64k instances per GPU drawn from 16 distinct 300-bone rigs with scale (measurement aid: poses of several windows over several clips)",
     "one_clip_mixed_registry": "the one_clip batch (4 800 byte rows) while the context ALSO holds a 300-bone rig and a 551-bone clip: the launch is shaped by the batch, not by the registry",
     "track_requests": "4 M random (instance, bone) requests on the 100-bone clip: seek + decompress_track, one 48 byte qvv per request (SURVEY 8 a15)",
+    "track_requests_256_clips": "4 M random (instance, bone) requests, every request's clip drawn from 256 distinct 100-bone clips: waves of mixed clips (--order locality: the same requests in aclhip_order_track_requests_for_locality order; --order by_clip: sorted by clip)",
     "one_clip_lods": "the one_clip batch with a per character LOD: every instance stores its first 100 / 60 / 30 bones (a third of the crowd each, "
                      "aclhip_output_desc::instance_track_counts): one launch, 63 % of the bytes",
 }
@@ -91,7 +92,7 @@ def _build_workload(name, rank, num_instances):
         clips = [synth.build_clip(seed=2, num_tracks=100, num_samples=301, sample_rate=30.0),
                  synth.build_clip(seed=12, num_tracks=100, num_samples=121, sample_rate=30.0, rotation_constant=0.5, translation_constant=0.8)]
         clip_indices = np.ones(num_instances, dtype=np.uint32)
-    elif name == "256_clips":
+    elif name in ("256_clips", "track_requests_256_clips"):
         clips = []
         spec_rng = np.random.default_rng(3)
         for i in range(256):
@@ -209,7 +210,7 @@ class Job:
 
         self.max_tracks = max(c.num_tracks for c in self.clips)
         self.num_instances = int(clip_indices.size)
-        self.track_requests = name == "track_requests"
+        self.track_requests = name in ("track_requests", "track_requests_256_clips")
         # bytes of one instance's output row: 48 / 40 / 32 per transform track by layout, 4 per component of a scalar track
         bytes_per_track = 4 * self.clips[0].num_components if self.is_scalar else runtime.LAYOUTS[layout][1]
         # rows start on 64 byte HBM access granules: a stride that is only a multiple of 16 (QVV40: 4000 bytes for 100 bones) leaves every
@@ -223,7 +224,8 @@ class Job:
             clip_indices, times = clip_indices[permutation], times[permutation]
         elif order == "locality":
             t0 = time.perf_counter()
-            permutation = context.order_instances_for_locality(self.handles[clip_indices])
+            # (single track requests: 256 of them per workgroup -- aclhip_order_track_requests_for_locality; poses: aclhip_order_instances_for_locality)
+            permutation = runtime.order_track_requests_for_locality(self.handles[clip_indices]) if self.track_requests else context.order_instances_for_locality(self.handles[clip_indices])
             self.ordering_ms = (time.perf_counter() - t0) * 1e3
             clip_indices, times = clip_indices[permutation], times[permutation]
             if keep_rows:
@@ -503,6 +505,8 @@ def default_run_specs():
         ("database", {"order": "list"}, 300),                       # ... kept in a persistent instance list, 1 % changing clip per step
         # single bone requests, scalar track lists, the pose consumers fused into the decode
         ("track_requests", {"num_instances": TRACK_REQUESTS}, 100),
+        ("track_requests_256_clips", {"num_instances": TRACK_REQUESTS}, 60),                          # every request its own clip: waves of mixed clips (record heads gathered, round 6)
+        ("track_requests_256_clips", {"num_instances": TRACK_REQUESTS, "order": "locality"}, 100),   # ... the same requests in aclhip_order_track_requests_for_locality order: what a caller with a persistent request list does
         ("scalar", {}, 300),
         ("object_space", {}, 150),
         ("additive_object_space", {}, 100),
@@ -1244,7 +1248,7 @@ def main():
     if args.traffic_pass is not None:
         traffic_pass(device_index, args.traffic_pass)
         return
-    instances = TRACK_REQUESTS if args.workload == "track_requests" and args.instances == INSTANCES_PER_GPU else args.instances
+    instances = TRACK_REQUESTS if args.workload in ("track_requests", "track_requests_256_clips") and args.instances == INSTANCES_PER_GPU else args.instances
     job = Job(args.workload, rank, device_index, num_instances=instances, order=args.order, keep_rows=args.keep_rows, layout=args.layout, fast=args.fast)
 
     # device pre-warm (skipped under a counter-collecting profiler, where every launch is serialized and slow: ACLHIP_BENCH_PROFILING=1)

@@ -497,8 +497,17 @@ aclhip_status aclhip_instance_list_get_order(aclhip_context* context, aclhip_ins
 /* Replaces seek() + decompress_track(track_indices[i], writer) (decompress.h:172; decompress_track_v0 :1753-2050):
  * one 48 byte qvv per instance at (char*)transforms + i * 48. All pointers are DEVICE pointers.
  * Any order of requests is decoded; the ORDER decides what the launch fetches: 64 consecutive requests share a wavefront, and requests
- * of many clips are best sorted by clip (4 M requests over 256 clips: 173 us as drawn, 77 us sorted by clip = the time of one clip;
- * profiles/r06_experiments.md 5b). */
+ * of many clips are best bucketed by clip -- aclhip_order_track_requests_for_locality above gives the order (4 M requests over 256
+ * clips: 173 us as drawn, 77 us sorted by clip = the time of one clip, 68 - 74 us in the library's order; profiles/r06_experiments.md 5b). */
+/* Host only (no GPU work): the order of a single track request list that draws on many clips -- a permutation of [0, num_requests)
+ * for the request list `clips` (HOST array: the clip of every request) under which the requests are bucketed by clip (stable) and every
+ * clip's requests run on ONE XCD (workgroup b of aclhip_decompress_track_batch takes requests 256 b .. 256 b + 255 and runs on XCD
+ * b % 8; each XCD has its own L2). Use: clips'[k] = clips[out_order[k]], likewise sample times and track indices; transform k of the
+ * launch belongs to request out_order[k]. For request lists that persist across frames (the same bones of the same characters, new
+ * sample times): 4 M requests over 256 clips, 173 us as drawn, 77 us sorted by clip, 68 - 74 us in this order (HBM traffic 4.0 x the
+ * algorithmic bytes as drawn, 0.98 x in this order). */
+aclhip_status aclhip_order_track_requests_for_locality(const aclhip_clip* clips, uint32_t num_requests, uint32_t* out_order);
+
 aclhip_status aclhip_decompress_track_batch(aclhip_context* context, const aclhip_clip* clips, const float* sample_times, const uint32_t* track_indices,
 	uint32_t num_instances, const aclhip_decompress_params* params, void* transforms, void* stream);
 

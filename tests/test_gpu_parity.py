@@ -291,3 +291,24 @@ def test_track_requests_with_refused_and_skipped_lanes_inside_full_waves(context
             assert context.rejected_instance_count() == before + int(refused.sum())
     for handle in handles + [scalar_handle]:
         context.unregister_clip(handle)
+
+
+@pytest.mark.parametrize("num_requests", [300, 5000])
+def test_track_requests_in_the_librarys_locality_order_decode_to_the_same_transforms(context, num_requests):
+    """aclhip_order_track_requests_for_locality permutes a request list (clips bucketed, every clip on one XCD): request k of the ordered
+    launch is request order[k] of the caller's list -- the same bits, wherever a request sits in a wave"""
+    rng = np.random.default_rng(num_requests)
+    clips = [synth.build_clip(**CLIP_SPECS[name]) for name in ("cmu_100", "scale_37", "stripped_wrap_scale", "two_segments_32", "cmu_70_default")]
+    handles = np.array([context.register_clip(c.blob) for c in clips], dtype=np.uint32)
+    which = rng.integers(0, len(clips), size=num_requests)
+    times = np.array([rng.uniform(0.0, clips[w].duration) for w in which], dtype=np.float32)
+    tracks = np.array([rng.integers(0, clips[w].num_tracks) for w in which], dtype=np.uint32)
+    as_drawn = context.decompress_track(handles[which], times, tracks)
+    order = runtime.order_track_requests_for_locality(handles[which])
+    assert np.array_equal(np.sort(order), np.arange(num_requests))
+    ordered = context.decompress_track(handles[which][order], times[order], tracks[order])
+    assert helpers.bit_equal(ordered, as_drawn[order])
+    for i in rng.integers(0, num_requests, size=40):
+        assert helpers.bit_equal(as_drawn[i], ob.oracle_decompress_track(clips[which[i]].blob, float(times[i]), int(tracks[i])))
+    for handle in handles:
+        context.unregister_clip(int(handle))

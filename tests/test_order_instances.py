@@ -86,3 +86,38 @@ def test_null_arguments():
     assert lib.aclhip_order_instances_for_locality(None, None, 4, None) == runtime.ERROR_INVALID_ARGUMENT
     assert lib.aclhip_order_instances_for_locality(None, None, 0, None) == runtime.OK
     assert lib.aclhip_order_instances_for_pose_windows(0, None, 0, None) == runtime.ERROR_INVALID_ARGUMENT
+
+
+@pytest.mark.parametrize("num_requests", [1, 5, 255, 256, 257, 2047, 2048, 4099, 70001])
+def test_track_request_order_is_a_stable_bucketing_by_clip_with_one_xcd_per_clip(num_requests):
+    """aclhip_order_track_requests_for_locality: workgroup b of aclhip_decompress_track_batch takes requests 256 b .. 256 b + 255 and runs
+    on XCD b % 8 -- a permutation; every XCD serves ONE contiguous range of the requests bucketed by clip (so the XCDs' clip sets overlap
+    in at most the seven clips that straddle two ranges); requests of a clip keep their relative order"""
+    rng = np.random.default_rng(num_requests)
+    clips = rng.integers(3, 3 + 200, size=num_requests).astype(np.uint32)
+    order = runtime.order_track_requests_for_locality(clips)
+    assert np.array_equal(np.sort(order), np.arange(num_requests))
+    ordered = clips[order]
+    xcd_of = (np.arange(num_requests) // 256) % 8
+    served = [ordered[xcd_of == x] for x in range(8)]
+    for x in range(8):
+        assert np.all(np.diff(served[x].astype(np.int64)) >= 0)                     # bucketed by clip inside its range
+        where = order[xcd_of == x]
+        for clip in np.unique(served[x]):
+            mine = where[served[x] == clip]
+            assert np.all(np.diff(mine.astype(np.int64)) > 0)                       # stable
+    for x in range(7):
+        if served[x].size and served[x + 1].size:
+            assert served[x].max() <= served[x + 1].min()                           # the ranges follow one another in the bucketed sequence
+    distinct = sum(np.unique(s).size for s in served)
+    assert distinct <= np.unique(clips).size + 7
+
+
+def test_track_request_order_takes_any_handles_and_refuses_null_lists():
+    clips = (np.random.default_rng(1).integers(0, 5, size=3000) * 900000007 % (1 << 32)).astype(np.uint32)      # (not small numbers: the comparison sort)
+    order = runtime.order_track_requests_for_locality(clips)
+    assert np.array_equal(np.sort(order), np.arange(clips.size))
+    assert np.array_equal(np.sort(clips[order][: 256]), clips[order][: 256])
+    lib = runtime.load_library()
+    assert lib.aclhip_order_track_requests_for_locality(None, 5, None) != 0
+    assert lib.aclhip_order_track_requests_for_locality(None, 0, None) == 0

@@ -7,7 +7,7 @@ set -u
 tag=${1:-r06}
 shift
 only="$*"
-SQ_WORKLOADS=" one_clip one_clip_lods 256_clips 256_clips_attached cinematic cinematic_fast database scalar object_space object_space_fast additive_object_space additive_object_space_fast blend_object_space track_requests "
+SQ_WORKLOADS=" one_clip one_clip_lods 256_clips 256_clips_attached cinematic cinematic_fast database scalar object_space object_space_fast additive_object_space additive_object_space_fast blend_object_space track_requests track_requests_256_clips track_requests_256_clips_locality "
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 rm -f gpurun_out/traffic.json
@@ -61,6 +61,8 @@ run_workload database_list "database, list order" --workload database --order li
 run_workload one_clip_qv32 "one_clip, qv32" --workload one_clip --layout qv32
 run_workload one_clip_qvv40 "one_clip, qvv40" --workload one_clip --layout qvv40
 run_workload track_requests "track_requests" --workload track_requests
+run_workload track_requests_256_clips "track_requests_256_clips" --workload track_requests_256_clips
+run_workload track_requests_256_clips_locality "track_requests_256_clips, locality order" --workload track_requests_256_clips --order locality
 run_workload scalar "scalar" --workload scalar
 run_workload object_space "object_space" --workload object_space
 run_workload object_space_fast "object_space_fast" --workload object_space_fast

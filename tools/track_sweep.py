@@ -77,6 +77,16 @@ def main():
         patterns["256 clips as drawn, requests in aclhip_order_instances_for_locality order"] = tuple(column[permutation] for column in drawn)
         by_clip = np.argsort(which, kind="stable")
         patterns["256 clips as drawn, requests sorted by clip"] = tuple(column[by_clip] for column in drawn)
+        # ... sorted by clip AND laid out for the XCDs: workgroup b (256 requests) runs on XCD b % 8, so clip c's requests go to the workgroups
+        # of XCD c % 8 -- every clip is fetched by ONE L2 instead of all eight
+        streams = [by_clip[(which[by_clip] % 8) == xcd] for xcd in range(8)]
+        blocks = min(len(stream) // 256 for stream in streams)
+        interleaved = [stream[block * 256: (block + 1) * 256] for block in range(blocks) for stream in streams]
+        interleaved = np.concatenate(interleaved + [stream[blocks * 256:] for stream in streams])      # (what is left over, still sorted by clip, at the end)
+        assert interleaved.size == n
+        patterns["256 clips as drawn, requests sorted by clip, clip c on XCD c % 8"] = tuple(column[interleaved] for column in drawn)
+        library_order = runtime.order_track_requests_for_locality(crowd_handles[which].astype(np.uint32))
+        patterns["256 clips as drawn, requests in aclhip_order_track_requests_for_locality order"] = tuple(column[library_order] for column in drawn)
         patterns["256 clips as drawn, root bone"] = (crowd_handles[which], (rng.uniform(0, 1, size=n).astype(np.float32) * crowd_durations[which]).astype(np.float32), np.zeros(n, dtype=np.int32))
         same_time = np.repeat(rng.uniform(0, one.duration, size=(n + 99) // 100).astype(np.float32), 100)[:n]
         patterns["one clip, all 100 bones of each instance"] = (np.full(n, one_handle, dtype=np.int32), same_time, (np.arange(n) % 100).astype(np.int32))
